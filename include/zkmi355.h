@@ -1,0 +1,130 @@
+/*
+ * zkmi355 -- C ABI of the MI355X-native Halo2/KZG proving hot path (BN254).
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b): a thin Rust shim crate that keeps the
+ * `halo2_proofs` API (create_proof / keygen_* / ParamsKZG, transcript + RNG + Circuit::synthesize
+ * stay in Rust) binds exactly these symbols; see INTEGRATION.md for the `extern "C"` block.
+ * The reference has no FFI for this path today; the interfaces each entry point replaces live in
+ * the external crates pinned by the reference (`[REF Cargo.lock:2214-2216]` halo2_proofs 1.1.0 @
+ * scroll-tech/halo2 e5ddf67, `[REF Cargo.lock:2239-2241]` halo2curves 0.1.0 @ a495a7b) and are
+ * reached from the reference call sites listed per function below.
+ *
+ * Conventions
+ *   - every function returns 0 (ZK_OK) or a negative zk_status; nothing unwinds across the ABI;
+ *     zk_last_error(ctx) returns a human-readable message for the last failure on that ctx.
+ *   - Fr / Fq element: 32 bytes = 4 x u64 little-endian limbs, MONTGOMERY form (R = 2^256):
+ *     byte-identical to halo2curves' in-memory layout and to SerdeFormat::RawBytes.
+ *   - G1Affine: 64 bytes {x, y}; identity = all zero.   G1 (Jacobian): 96 bytes {x, y, z}.
+ *   - pointers named d_* are DEVICE pointers (from zk_buf_alloc or any hipMalloc / torch tensor);
+ *     pointers named h_* are host pointers.  The caller owns every buffer it passes.
+ *   - a zk_ctx is used by one host thread at a time; different contexts are independent.
+ *   - all device work is enqueued on the context's stream (zk_ctx_set_stream); functions that
+ *     return host results synchronise that stream before returning.
+ */
+#ifndef ZKMI355_H
+#define ZKMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_srs zk_srs;
+
+typedef enum zk_status {
+    ZK_OK = 0,
+    ZK_ERR_INVALID_ARG = -1,  /* null pointer, n not a power of two, k > 28 (Fr two-adicity) ... */
+    ZK_ERR_HIP = -2,          /* a HIP runtime call failed (message has the HIP error string)   */
+    ZK_ERR_OOM = -3,          /* device allocation failed                                       */
+    ZK_ERR_NO_DEVICE = -4,    /* no gfx950 device visible: there is NO CPU fallback            */
+    ZK_ERR_UNSUPPORTED = -5
+} zk_status;
+
+enum { ZK_FIELD_FR = 0, ZK_FIELD_FQ = 1 };
+enum { ZK_OP_ADD = 0, ZK_OP_SUB = 1, ZK_OP_MUL = 2 };
+
+/* ---- context / memory ----------------------------------------------------------------------- */
+int zk_ctx_create(int device, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_last_error(const zk_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
+int zk_ctx_sync(zk_ctx* ctx);
+int zk_buf_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr);
+int zk_buf_free(zk_ctx* ctx, void* d_ptr);
+int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int zk_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int zk_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py's roofline leg) */
+int zk_timer_start(zk_ctx* ctx);
+int zk_timer_stop_ms(zk_ctx* ctx, float* ms);   /* synchronises on the stop event */
+
+/* ---- field vectors (halo2curves Fr/Fq Add/Sub/Mul, element-wise)  -- SURVEY 8a K4/K10 ---------- */
+int zk_field_vec_op(zk_ctx* ctx, int field, int op, const void* d_a, const void* d_b, void* d_out, size_t n);
+/* out[i] = a[i] * s  (s: host pointer to one element) */
+int zk_fr_scale(zk_ctx* ctx, void* d_a, const void* h_s, size_t n);
+/* ff::BatchInvert semantics (zeros stay zero), in place -- SURVEY 8a K12 */
+int zk_fr_batch_invert(zk_ctx* ctx, void* d_a, size_t n);
+
+/* ---- NTT: halo2_proofs::arithmetic::best_fft / poly::EvaluationDomain  -- SURVEY 8a K2, K3 ---- */
+/* In-place size-2^log_n transform over <omega>, natural order in and out:
+ *   out[i] = sum_j a[j] * omega^(i*j),   omega = ROOT_OF_UNITY^(2^(28-log_n))   (inverse = 0)
+ *   inverse = 1: omega^-1 and the 1/n scale, i.e. EvaluationDomain::lagrange_to_coeff.          */
+int zk_ntt(zk_ctx* ctx, void* d_data, uint32_t log_n, int inverse);
+/* best_fft with an arbitrary primitive 2^log_n-th root (h_omega: one Fr), no scaling.            */
+int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega);
+/* EvaluationDomain::coeff_to_extended: d_coeffs (2^k) -> d_out (2^ext_k): scale by zeta^i,
+ * zero-pad, NTT over the extended domain.                                                       */
+int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out);
+/* EvaluationDomain::extended_to_coeff: inverse NTT over the extended domain, unscale by zeta^-i;
+ * in place on d_ext (2^ext_k); the caller truncates to n*(deg-1).                               */
+int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k);
+
+/* ---- polynomial helpers: halo2_proofs::arithmetic  -- SURVEY 8a K9, K10 ------------------------ */
+/* eval_polynomial(coeffs, x) -> one Fr on the host */
+int zk_poly_eval(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_x, void* h_out);
+/* kate_division(coeffs, z): d_q receives n-1 coefficients of (f(X) - f(z)) / (X - z)             */
+int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_z, void* d_q);
+/* z[0] = 1 (product) / 0 (sum); z[i+1] = z[i] (*|+) a[i]: the permutation / lookup grand product
+ * and grand sum.  d_z may not alias d_a.                                      */
+int zk_fr_prefix_product(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
+int zk_fr_prefix_sum(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
+
+/* ---- SRS: halo2_proofs::poly::kzg::commitment::ParamsKZG  -- SURVEY 8a A5 ---------------------- */
+/* Upload g (n = 2^k G1Affine) and optionally g_lagrange (may be NULL); host pointers.            */
+int zk_srs_create(zk_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagrange, zk_srs** out);
+/* ParamsKZG::unsafe_setup_with_s(k, s): g[i] = s^i * G, g_lagrange[i] = L_i(s) * G, on device.    */
+int zk_srs_setup_with_s(zk_ctx* ctx, uint32_t k, const void* h_s, zk_srs** out);
+void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs);
+uint32_t zk_srs_k(const zk_srs* srs);
+const void* zk_srs_g(const zk_srs* srs);          /* device pointer, n G1Affine */
+const void* zk_srs_g_lagrange(const zk_srs* srs); /* device pointer or NULL     */
+
+/* ---- MSM: halo2_proofs::arithmetic::best_multiexp  -- SURVEY 8a K1 ----------------------------- */
+/* sum_i scalars[i] * bases[i] over device buffers; the affine result (64 B) is written to the
+ * host.  Scalars are Montgomery-form Fr exactly as halo2 holds them.                             */
+int zk_msm_g1(zk_ctx* ctx, const void* d_scalars, const void* d_bases, size_t n, void* h_out_affine);
+/* ParamsKZG::commit (basis = 0, over g) / commit_lagrange (basis = 1, over g_lagrange).          */
+int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, size_t n, void* h_out_affine);
+/* best_multiexp over HOST slices, exactly the reference signature (copies in, computes, copies
+ * the affine result out).                                                                        */
+int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine);
+
+/* ---- G1 element-wise (tests of the group law; halo2curves G1 Add / Double / Mul) --------------- */
+/* out[i] = a[i] + b[i], all affine (n x 64 B) */
+int zk_g1_affine_add_vec(zk_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);
+/* out[i] = scalars[i] * bases[i], affine out */
+int zk_g1_mul_vec(zk_ctx* ctx, const void* d_bases, const void* d_scalars, void* d_out, size_t n);
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+const char* zk_version(void);
+/* fills name (<= len) with the device name, CU count and HBM bytes of the ctx device */
+int zk_device_info(zk_ctx* ctx, char* name, size_t len, int* cu_count, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI355_H */

@@ -1,0 +1,73 @@
+"""GPU parity: Fr / Fq element-wise arithmetic, batch inversion and scans vs the C oracle.
+Bit-exact (integer arithmetic).  Calls go through the C ABI (ctypes)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bn254
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge_values(mod):
+    return [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (mod + 1) // 2, (1 << 253), (1 << 128) - 1]
+
+
+@pytest.mark.parametrize("field,mod", [(0, bn254.R_MOD), (1, bn254.P_MOD)])
+def test_vec_ops_match_oracle(zk, ctx, cref, field, mod):
+    rng = random.Random(1234 + field)
+    n = 4096 + 37
+    xs = _edge_values(mod) + [rng.randrange(mod) for _ in range(n - 9)]
+    ys = list(reversed(_edge_values(mod))) + [rng.randrange(mod) for _ in range(n - 9)]
+    A, B = cref.to_mont(xs, field), cref.to_mont(ys, field)
+    dA, dB, dO = ctx.to_device(A), ctx.to_device(B), ctx.alloc(A.nbytes)
+    for op, name in ((zk.OP_ADD, "add"), (zk.OP_SUB, "sub"), (zk.OP_MUL, "mul")):
+        ctx.field_vec_op(field, op, dA, dB, dO, n)
+        got = dO.download(A.shape)
+        want = cref.fe_binop(name, field, A, B)
+        assert np.array_equal(got, want), name
+
+
+def test_large_random_mul_million(zk, ctx, cref):
+    n = 1 << 20
+    A, B = cref.rand_fr_stream(11, n), cref.rand_fr_stream(12, n)
+    dA, dB, dO = ctx.to_device(A), ctx.to_device(B), ctx.alloc(A.nbytes)
+    ctx.field_vec_op(zk.FIELD_FR, zk.OP_MUL, dA, dB, dO, n)
+    assert np.array_equal(dO.download(A.shape), cref.fe_binop("mul", 0, A, B))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 5000, (1 << 16) + 3])
+def test_batch_invert(ctx, cref, n):
+    A = cref.rand_fr_stream(100 + n, n)
+    if n > 4:
+        A[1] = 0
+        A[n - 1] = 0
+    dA = ctx.to_device(A)
+    ctx.fr_batch_invert(dA, n)
+    assert np.array_equal(dA.download(A.shape), cref.batch_invert(A))
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 2048, 2049, 70000, 1 << 18])
+def test_prefix_product_and_sum(ctx, cref, n):
+    A = cref.rand_fr_stream(7 + n, n)
+    dA, dZ = ctx.to_device(A), ctx.alloc(A.nbytes)
+    ctx.fr_prefix_product(dA, dZ, n)
+    assert np.array_equal(dZ.download(A.shape), cref.prefix_product(A))
+    ctx.fr_prefix_sum(dA, dZ, n)
+    assert np.array_equal(dZ.download(A.shape), cref.prefix_sum(A))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 100, 4096, 100000])
+def test_eval_polynomial_and_kate_division(ctx, cref, n):
+    rng = random.Random(n)
+    C = cref.rand_fr_stream(900 + n, n)
+    dC = ctx.to_device(C)
+    for x in (rng.randrange(bn254.R_MOD), 0, 1, bn254.R_MOD - 1):
+        xm = cref.fr_const(x)
+        got = ctx.poly_eval(dC, n, xm)
+        assert cref.from_mont(got.reshape(1, 4))[0] == cref.eval_polynomial(C, x)
+        if n >= 2:
+            dQ = ctx.alloc((n - 1) * 32)
+            ctx.kate_division(dC, n, xm, dQ)
+            assert np.array_equal(dQ.download((n - 1, 4)), cref.kate_division(C, x))

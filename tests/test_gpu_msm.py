@@ -1,0 +1,114 @@
+"""GPU parity: G1 group law, SRS generation and MSM (halo2 best_multiexp / ParamsKZG) vs the
+oracle.  Bit-exact on the affine result."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bn254
+
+pytestmark = pytest.mark.gpu
+
+R = bn254.R_MOD
+
+
+def _rand_points(cref, n, seed):
+    sc = cref.rand_fr_stream(seed, n)
+    gen = cref.affine_to_mont([bn254.G1_GEN] * n)
+    return cref.g1_mul(gen, sc)
+
+
+def test_g1_add_and_mul_vec(ctx, cref):
+    n = 300
+    P, Q = _rand_points(cref, n, 5), _rand_points(cref, n, 6)
+    Q[0] = P[0]                                   # doubling
+    Q[1] = P[1]; Q[1, 4:] = cref.to_mont([bn254.P_MOD - cref.from_mont(P[1, 4:].reshape(1, 4), 1)[0]], 1)[0]  # P + (-P)
+    P[2] = 0                                      # identity + Q
+    Q[3] = 0                                      # P + identity
+    dP, dQ, dO = ctx.to_device(P), ctx.to_device(Q), ctx.alloc(P.nbytes)
+    ctx.g1_affine_add(dP, dQ, dO, n)
+    got = cref.affine_from_mont(dO.download(P.shape))
+    pp, qq = cref.affine_from_mont(P), cref.affine_from_mont(Q)
+    assert got == [bn254.g1_add(a, b) for a, b in zip(pp, qq)]
+    assert got[1] is None
+    S = cref.rand_fr_stream(77, n)
+    S[0] = 0
+    S[1] = cref.fr_const(1)[0]
+    S[2] = cref.fr_const(R - 1)[0]
+    dS = ctx.to_device(S)
+    ctx.g1_mul(dQ, dS, dO, n)
+    assert np.array_equal(dO.download(P.shape), cref.g1_mul(Q, S))
+
+
+@pytest.mark.parametrize("k", [1, 4, 9])
+def test_srs_setup_with_s(ctx, cref, k):
+    s = 0x1234
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(s))
+    n = 1 << k
+    assert np.array_equal(srs.download_g(), cref.srs_powers(s, n))
+    om = bn254.omega_for_k(k)
+    sn = pow(s, n, R)
+    lag = [pow(om, i, R) * (sn - 1) % R * bn254.fr_inv(n * (s - pow(om, i, R)) % R) % R for i in range(n)]
+    gen = cref.affine_to_mont([bn254.G1_GEN] * n)
+    assert np.array_equal(srs.download_g_lagrange(), cref.g1_mul(gen, cref.to_mont(lag)))
+    srs.destroy()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 100, 1000, 4097])
+def test_msm_small_matches_best_multiexp(ctx, cref, n):
+    if n == 0:
+        out = ctx.best_multiexp(np.zeros((0, 4), np.uint64), np.zeros((0, 8), np.uint64))
+        assert not out.any()
+        return
+    S, P = cref.rand_fr_stream(40 + n, n), _rand_points(cref, n, 50 + n)
+    got = ctx.best_multiexp(S, P)
+    assert np.array_equal(got, cref.best_multiexp(S, P))
+    if n <= 33:
+        assert cref.affine_from_mont(got) == [bn254.msm_naive(cref.from_mont(S), cref.affine_from_mont(P))]
+
+
+def test_msm_edge_cases(ctx, cref):
+    n = 2048
+    P = _rand_points(cref, n, 9)
+    P[5] = 0                      # identity base
+    P[7] = P[6]                   # repeated point
+    P[9] = P[8]; P[9, 4:] = cref.to_mont([bn254.P_MOD - cref.from_mont(P[8, 4:].reshape(1, 4), 1)[0]], 1)[0]
+    cases = {
+        "zeros": np.zeros((n, 4), np.uint64),
+        "ones": np.tile(cref.fr_const(1)[0], (n, 1)),
+        "r_minus_1": np.tile(cref.fr_const(R - 1)[0], (n, 1)),
+        "same_small": np.tile(cref.fr_const(0xFFFF)[0], (n, 1)),
+    }
+    rng = random.Random(3)
+    witness_like = [0 if rng.random() < 0.6 else (rng.randrange(1 << 16) if rng.random() < 0.75 else rng.randrange(R)) for _ in range(n)]
+    cases["witness_like"] = cref.to_mont(witness_like)
+    for name, S in cases.items():
+        assert np.array_equal(ctx.best_multiexp(S, P), cref.best_multiexp(S, P)), name
+
+
+def test_msm_2_16_matches_oracle_pippenger(ctx, cref):
+    n = 1 << 16
+    S, P = cref.rand_fr_stream(1, n), cref.srs_powers(1234, n)
+    assert np.array_equal(ctx.best_multiexp(S, P), cref.best_multiexp(S, P))
+
+
+def test_msm_2_20_closed_form_over_srs(zk, ctx, cref):
+    """BASELINE config 2 size: MSM(a, g) with g[i] = s^i G equals (sum a_i s^i) * G, and
+    commit_lagrange of the evaluations of the same polynomial gives the same point."""
+    k, n, s = 20, 1 << 20, 0xC0FFEE
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(s))
+    A = cref.rand_fr_stream(2020, n)
+    dA = ctx.to_device(A)
+    got = ctx.commit(srs, dA, n)
+    acc = cref.eval_polynomial(A, s)
+    want = cref.g1_mul(cref.affine_to_mont([bn254.G1_GEN]), cref.to_mont([acc]))[0]
+    assert np.array_equal(got, want)
+    ctx.ntt(dA, k)                      # coefficients -> evaluations
+    assert np.array_equal(ctx.commit(srs, dA, n, lagrange=True), want)
+    # splitting identity: MSM over halves adds up
+    h = n // 2
+    lo = ctx.msm(dA.ptr, srs.g_lagrange_ptr, h)
+    hi = ctx.msm(dA.ptr + 32 * h, srs.g_lagrange_ptr + 64 * h, h)
+    both = bn254.g1_add(cref.affine_from_mont(lo)[0], cref.affine_from_mont(hi)[0])
+    assert both == cref.affine_from_mont(want)[0]
+    srs.destroy()

@@ -1,0 +1,79 @@
+"""GPU parity: NTT (halo2 best_fft / EvaluationDomain) vs the C oracle restatement, bit-exact.
+Small sizes are also checked against the O(n^2) definition in the Python oracle."""
+import numpy as np
+import pytest
+
+from oracle import bn254
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 18, 20, 21, 22])
+def test_forward_matches_best_fft(ctx, cref, k):
+    n = 1 << k
+    A = cref.rand_fr_stream(1000 + k, n)
+    got = ctx.best_fft(A, k)
+    want = cref.best_fft(A, bn254.omega_for_k(k), k) if k > 0 else A
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8])
+def test_forward_matches_definition(ctx, cref, k):
+    n = 1 << k
+    A = cref.rand_fr_stream(55 + k, n)
+    got = cref.from_mont(ctx.best_fft(A, k))
+    assert got == bn254.ntt_naive(cref.from_mont(A), bn254.omega_for_k(k))
+
+
+@pytest.mark.parametrize("k", [1, 4, 10, 11, 13, 17, 20, 21])
+def test_inverse_is_lagrange_to_coeff_and_round_trips(ctx, cref, k):
+    n = 1 << k
+    A = cref.rand_fr_stream(2000 + k, n)
+    coeff = ctx.best_fft(A, k, inverse=True)
+    assert np.array_equal(coeff, cref.ifft(A, k))
+    assert np.array_equal(ctx.best_fft(coeff, k), A)
+
+
+def test_closed_forms_at_2_20(ctx, cref):
+    """delta -> all ones; all ones -> n * delta (SURVEY 8d config 2 closed-form vectors)."""
+    k, n = 20, 1 << 20
+    one = cref.fr_const(1)[0]
+    delta = np.zeros((n, 4), dtype=np.uint64)
+    delta[0] = one
+    ones = np.tile(one, (n, 1))
+    assert np.array_equal(ctx.best_fft(delta, k), ones)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    want[0] = cref.fr_const(n)[0]
+    assert np.array_equal(ctx.best_fft(ones, k), want)
+
+
+def test_linearity_at_2_20(zk, ctx, cref):
+    k, n = 20, 1 << 20
+    A, B = cref.rand_fr_stream(1, n), cref.rand_fr_stream(2, n)
+    fa, fb = ctx.best_fft(A, k), ctx.best_fft(B, k)
+    fab = ctx.best_fft(cref.fe_binop("add", 0, A, B), k)
+    assert np.array_equal(fab, cref.fe_binop("add", 0, fa, fb))
+
+
+@pytest.mark.parametrize("k,ext_k", [(3, 5), (6, 9), (10, 12), (12, 15), (16, 19)])
+def test_coset_extended_domain(ctx, cref, k, ext_k):
+    """EvaluationDomain::coeff_to_extended / extended_to_coeff."""
+    n, ne = 1 << k, 1 << ext_k
+    A = cref.rand_fr_stream(3000 + k, n)
+    dA, dE = ctx.to_device(A), ctx.alloc(ne * 32)
+    ctx.coeff_to_extended(dA, k, ext_k, dE)
+    got = dE.download((ne, 4))
+    padded = np.zeros((ne, 4), dtype=np.uint64)
+    padded[:n] = cref.distribute_powers(A, bn254.FR_ZETA)
+    want = cref.best_fft(padded, bn254.omega_for_k(ext_k), ext_k)
+    assert np.array_equal(got, want)
+    ctx.extended_to_coeff(dE, ext_k)
+    back = dE.download((ne, 4))
+    assert np.array_equal(back[:n], A)
+    assert not back[n:].any()
+
+
+def test_ntt_rejects_bad_sizes(zk, ctx):
+    buf = ctx.alloc(64)
+    with pytest.raises(zk.ZkError):
+        ctx.ntt(buf, 29)

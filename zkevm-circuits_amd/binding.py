@@ -1,0 +1,264 @@
+"""ctypes binding of libzkmi355.so (the C ABI in include/zkmi355.h) for tests and bench.py.
+
+This is test/bench plumbing over the product library: the reference's host language (Rust) is not
+available in this image, so the production host side is the C++ layer in ``csrc/``; see
+INTEGRATION.md for the Rust ``extern "C"`` block a maintainer would add.
+
+There is NO CPU fallback: if the shared library or a gfx950 device is missing, loading /
+context creation raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzkmi355.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "zkmi355.h")
+
+FIELD_FR, FIELD_FQ = 0, 1
+OP_ADD, OP_SUB, OP_MUL = 0, 1, 2
+
+_lib = None
+
+
+class ZkError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into lib/libzkmi355.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _HERE, "-j8", "-s"]
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.zk_last_error.restype = ctypes.c_char_p
+        _lib.zk_version.restype = ctypes.c_char_p
+        _lib.zk_srs_g.restype = ctypes.c_void_p
+        _lib.zk_srs_g_lagrange.restype = ctypes.c_void_p
+        _lib.zk_srs_k.restype = ctypes.c_uint32
+        _lib.zk_ctx_destroy.restype = None
+        _lib.zk_srs_destroy.restype = None
+    return _lib
+
+
+def _host_ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class DeviceBuffer:
+    """Owning handle of a device allocation made through the C ABI."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        ctx._ck(lib().zk_buf_alloc(ctx.h, ctypes.c_size_t(nbytes), ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            lib().zk_buf_free(self.ctx.h, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        self.ctx._ck(lib().zk_h2d(self.ctx.h, ctypes.c_void_p(self.ptr), _host_ptr(a), ctypes.c_size_t(a.nbytes)))
+        return self
+
+    def download(self, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._ck(lib().zk_d2h(self.ctx.h, _host_ptr(out), ctypes.c_void_p(self.ptr), ctypes.c_size_t(out.nbytes)))
+        return out
+
+
+class Srs:
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def k(self) -> int:
+        return lib().zk_srs_k(self.h)
+
+    @property
+    def g_ptr(self) -> int:
+        return lib().zk_srs_g(self.h)
+
+    @property
+    def g_lagrange_ptr(self) -> Optional[int]:
+        return lib().zk_srs_g_lagrange(self.h)
+
+    def download_g(self) -> np.ndarray:
+        n = 1 << self.k
+        out = np.empty((n, 8), dtype=np.uint64)
+        self.ctx._ck(lib().zk_d2h(self.ctx.h, _host_ptr(out), ctypes.c_void_p(self.g_ptr), ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def download_g_lagrange(self) -> np.ndarray:
+        n = 1 << self.k
+        out = np.empty((n, 8), dtype=np.uint64)
+        self.ctx._ck(lib().zk_d2h(self.ctx.h, _host_ptr(out), ctypes.c_void_p(self.g_lagrange_ptr), ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def destroy(self):
+        if self.h:
+            lib().zk_srs_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One zk_ctx: one GPU, one stream, one host thread."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        h = ctypes.c_void_p()
+        rc = lib().zk_ctx_create(ctypes.c_int(device), ctypes.byref(h))
+        if rc != 0:
+            raise ZkError(f"zk_ctx_create failed with status {rc} (no gfx950 device? there is no CPU fallback)")
+        self.h = h
+        if stream is not None:
+            self._ck(lib().zk_ctx_set_stream(self.h, ctypes.c_void_p(stream)))
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise ZkError(f"zkmi355 status {rc}: {lib().zk_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            lib().zk_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._ck(lib().zk_ctx_sync(self.h))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int()
+        hbm = ctypes.c_size_t()
+        self._ck(lib().zk_device_info(self.h, name, ctypes.c_size_t(256), ctypes.byref(cu), ctypes.byref(hbm)))
+        return name.value.decode(), cu.value, hbm.value
+
+    # ---- memory
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, a: np.ndarray) -> DeviceBuffer:
+        a = np.ascontiguousarray(a)
+        return DeviceBuffer(self, max(a.nbytes, 1)).upload(a)
+
+    def timer_start(self):
+        self._ck(lib().zk_timer_start(self.h))
+
+    def timer_stop_ms(self) -> float:
+        ms = ctypes.c_float()
+        self._ck(lib().zk_timer_stop_ms(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- field vectors
+    def field_vec_op(self, field: int, op: int, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):
+        self._ck(lib().zk_field_vec_op(self.h, field, op, ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
+
+    def fr_scale(self, a: DeviceBuffer, s: np.ndarray, n: int):
+        self._ck(lib().zk_fr_scale(self.h, ctypes.c_void_p(a.ptr), _host_ptr(np.ascontiguousarray(s)), ctypes.c_size_t(n)))
+
+    def fr_batch_invert(self, a: DeviceBuffer, n: int):
+        self._ck(lib().zk_fr_batch_invert(self.h, ctypes.c_void_p(a.ptr), ctypes.c_size_t(n)))
+
+    def fr_prefix_product(self, a: DeviceBuffer, z: DeviceBuffer, n: int):
+        self._ck(lib().zk_fr_prefix_product(self.h, ctypes.c_void_p(a.ptr), ctypes.c_void_p(z.ptr), ctypes.c_size_t(n)))
+
+    def fr_prefix_sum(self, a: DeviceBuffer, z: DeviceBuffer, n: int):
+        self._ck(lib().zk_fr_prefix_sum(self.h, ctypes.c_void_p(a.ptr), ctypes.c_void_p(z.ptr), ctypes.c_size_t(n)))
+
+    # ---- NTT (halo2 best_fft / EvaluationDomain)
+    def ntt(self, data: DeviceBuffer, log_n: int, inverse: bool = False):
+        self._ck(lib().zk_ntt(self.h, ctypes.c_void_p(data.ptr), ctypes.c_uint32(log_n), ctypes.c_int(1 if inverse else 0)))
+
+    def ntt_omega(self, data: DeviceBuffer, log_n: int, omega_mont: np.ndarray):
+        self._ck(lib().zk_ntt_omega(self.h, ctypes.c_void_p(data.ptr), ctypes.c_uint32(log_n), _host_ptr(np.ascontiguousarray(omega_mont))))
+
+    def coeff_to_extended(self, coeffs: DeviceBuffer, k: int, ext_k: int, out: DeviceBuffer):
+        self._ck(lib().zk_coeff_to_extended(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_uint32(k), ctypes.c_uint32(ext_k), ctypes.c_void_p(out.ptr)))
+
+    def extended_to_coeff(self, ext: DeviceBuffer, ext_k: int):
+        self._ck(lib().zk_extended_to_coeff(self.h, ctypes.c_void_p(ext.ptr), ctypes.c_uint32(ext_k)))
+
+    # ---- polynomial helpers
+    def poly_eval(self, coeffs: DeviceBuffer, n: int, x_mont: np.ndarray) -> np.ndarray:
+        out = np.empty(4, dtype=np.uint64)
+        self._ck(lib().zk_poly_eval(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(x_mont)), _host_ptr(out)))
+        return out
+
+    def kate_division(self, coeffs: DeviceBuffer, n: int, z_mont: np.ndarray, q: DeviceBuffer):
+        self._ck(lib().zk_kate_division(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(z_mont)), ctypes.c_void_p(q.ptr)))
+
+    # ---- SRS / MSM (halo2 ParamsKZG / best_multiexp)
+    def srs_create(self, k: int, g: np.ndarray, g_lagrange: Optional[np.ndarray] = None) -> Srs:
+        h = ctypes.c_void_p()
+        gl = _host_ptr(np.ascontiguousarray(g_lagrange)) if g_lagrange is not None else None
+        self._ck(lib().zk_srs_create(self.h, ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(g)), gl, ctypes.byref(h)))
+        return Srs(self, h)
+
+    def srs_setup_with_s(self, k: int, s_mont: np.ndarray) -> Srs:
+        h = ctypes.c_void_p()
+        self._ck(lib().zk_srs_setup_with_s(self.h, ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(s_mont)), ctypes.byref(h)))
+        return Srs(self, h)
+
+    def msm(self, scalars_ptr: int, bases_ptr: int, n: int) -> np.ndarray:
+        out = np.empty(8, dtype=np.uint64)
+        self._ck(lib().zk_msm_g1(self.h, ctypes.c_void_p(scalars_ptr), ctypes.c_void_p(bases_ptr), ctypes.c_size_t(n), _host_ptr(out)))
+        return out
+
+    def commit(self, srs: Srs, scalars: DeviceBuffer, n: int, lagrange: bool = False) -> np.ndarray:
+        out = np.empty(8, dtype=np.uint64)
+        self._ck(lib().zk_commit(self.h, srs.h, ctypes.c_int(1 if lagrange else 0), ctypes.c_void_p(scalars.ptr), ctypes.c_size_t(n), _host_ptr(out)))
+        return out
+
+    def best_multiexp(self, scalars: np.ndarray, bases: np.ndarray) -> np.ndarray:
+        """halo2 ``best_multiexp(coeffs, bases)`` over host slices."""
+        scalars = np.ascontiguousarray(scalars)
+        bases = np.ascontiguousarray(bases)
+        n = scalars.shape[0] if scalars.size else 0
+        out = np.empty(8, dtype=np.uint64)
+        self._ck(lib().zk_msm_g1_host(self.h, _host_ptr(scalars), _host_ptr(bases), ctypes.c_size_t(n), _host_ptr(out)))
+        return out
+
+    def best_fft(self, a: np.ndarray, log_n: int, inverse: bool = False) -> np.ndarray:
+        """halo2 ``best_fft`` over a host slice (copy in, transform, copy out)."""
+        buf = self.to_device(a)
+        self.ntt(buf, log_n, inverse)
+        out = buf.download(a.shape)
+        buf.free()
+        return out
+
+    # ---- G1 element-wise
+    def g1_affine_add(self, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):
+        self._ck(lib().zk_g1_affine_add_vec(self.h, ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
+
+    def g1_mul(self, bases: DeviceBuffer, scalars: DeviceBuffer, out: DeviceBuffer, n: int):
+        self._ck(lib().zk_g1_mul_vec(self.h, ctypes.c_void_p(bases.ptr), ctypes.c_void_p(scalars.ptr), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
+
+
+def version() -> str:
+    return lib().zk_version().decode()

@@ -1,0 +1,208 @@
+// C ABI glue (include/zkmi355.h): context, device memory, timers, and the NTT / MSM entry points.
+#include "ctx.hpp"
+
+namespace zk {
+
+// ---- host-side constants (slow 32-bit-limb path; used only to derive roots and tables) --------
+Fr fr_from_u64(uint64_t v) {
+    Fr a = Fr::zero();
+    a.l[0] = (uint32_t)v;
+    a.l[1] = (uint32_t)(v >> 32);
+    return to_mont(a);
+}
+Fr fr_pow(Fr base, uint64_t e) { return pow_u64(base, e); }
+Fr fr_inv_host(const Fr& a) { return inv(a); }
+// halo2curves Fr::ROOT_OF_UNITY = 7^((r-1)/2^28), canonical value, converted once
+static Fr root_of_unity_28() {
+    Fr c = Fr{{0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u}};
+    return to_mont(c);
+}
+Fr fr_root_of_unity(uint32_t log_n) {
+    Fr w = root_of_unity_28();
+    for (uint32_t i = log_n; i < 28; ++i) w = sqr(w);
+    return w;
+}
+// halo2curves Fr::ZETA (cube root of unity used as the extended-coset generator)
+Fr fr_zeta() {
+    Fr c = Fr{{0x36636f23u, 0xb8ca0b2du, 0xec2bc5e9u, 0xcc37a73fu, 0x3fd84104u, 0x048b6e19u, 0xe131a029u, 0x30644e72u}};
+    return to_mont(c);
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+const char* zk_version(void) { return "zkmi355 0.1.0 (gfx950)"; }
+
+int zk_ctx_create(int device, zk_ctx** out) {
+    if (!out) return ZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return ZK_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count) return ZK_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ZK_ERR_HIP;
+    zk_ctx* c = new zk_ctx();
+    c->device = device;
+    if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) { delete c; return ZK_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }
+    c->own_stream = true;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return ZK_ERR_HIP; }
+    *out = c;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->domains.clear();
+    for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return ZK_OK;
+}
+int zk_ctx_sync(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+int zk_buf_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_ptr, "null out pointer");
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); *d_ptr = nullptr; return ctx->fail(ZK_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return ZK_OK;
+}
+int zk_buf_free(zk_ctx* ctx, void* d_ptr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    if (!d_ptr) return ZK_OK;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipFree(d_ptr));
+    return ZK_OK;
+}
+int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_dst && h_src) || !bytes, "null pointer");
+    ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+int zk_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (h_dst && d_src) || !bytes, "null pointer");
+    ZK_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+int zk_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_dst && d_src) || !bytes, "null pointer");
+    ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZK_OK;
+}
+int zk_timer_start(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return ZK_OK;
+}
+int zk_timer_stop_ms(zk_ctx* ctx, float* ms) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, ms, "null pointer");
+    ZK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ZK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return ZK_OK;
+}
+int zk_device_info(zk_ctx* ctx, char* name, size_t len, int* cu_count, size_t* hbm_bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    if (name && len) { snprintf(name, len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName); }
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return ZK_OK;
+}
+
+// ---- NTT ---------------------------------------------------------------------------------------
+int zk_ntt(zk_ctx* ctx, void* d_data, uint32_t log_n, int inverse) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_data, "null pointer");
+    ZK_REQUIRE(ctx, log_n <= 28, "log_n exceeds the two-adicity of Fr (28)");
+    Fr omega = fr_root_of_unity(log_n);
+    if (!inverse) return ntt_run(ctx, (Fr*)d_data, log_n, omega, nullptr, nullptr, nullptr);
+    Fr omega_inv = fr_inv_host(omega);
+    Fr ninv = fr_inv_host(fr_from_u64(1ull << log_n));
+    return ntt_run(ctx, (Fr*)d_data, log_n, omega_inv, &ninv, nullptr, nullptr);
+}
+int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_data && h_omega, "null pointer");
+    ZK_REQUIRE(ctx, log_n <= 28, "log_n exceeds the two-adicity of Fr (28)");
+    return ntt_run(ctx, (Fr*)d_data, log_n, *(const Fr*)h_omega, nullptr, nullptr, nullptr);
+}
+int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_coeffs && d_out && d_coeffs != d_out, "null or aliased pointer");
+    ZK_REQUIRE(ctx, k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
+    ZK_HIP(ctx, hipMemcpyAsync(d_out, d_coeffs, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ne > n) ZK_HIP(ctx, hipMemsetAsync((char*)d_out + n * sizeof(Fr), 0, (ne - n) * sizeof(Fr), ctx->stream));
+    // distribute_powers_zeta over the first n coefficients only, then the extended NTT
+    Fr zeta = fr_zeta();
+    int rc = ntt_run(ctx, (Fr*)d_out, ext_k, fr_root_of_unity(ext_k), nullptr, &zeta, nullptr);
+    return rc;
+}
+int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_ext, "null pointer");
+    ZK_REQUIRE(ctx, ext_k <= 28, "ext_k exceeds 28");
+    Fr omega_inv = fr_inv_host(fr_root_of_unity(ext_k));
+    Fr ninv = fr_inv_host(fr_from_u64(1ull << ext_k));
+    Fr zeta_inv = sqr(fr_zeta());   // zeta^3 = 1
+    return ntt_run(ctx, (Fr*)d_ext, ext_k, omega_inv, &ninv, nullptr, &zeta_inv);
+}
+
+// ---- MSM ---------------------------------------------------------------------------------------
+int zk_msm_g1(zk_ctx* ctx, const void* d_scalars, const void* d_bases, size_t n, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, h_out_affine && ((d_scalars && d_bases) || n == 0), "null pointer");
+    return msm_run(ctx, (const Fr*)d_scalars, (const G1Affine*)d_bases, n, (G1Affine*)h_out_affine);
+}
+int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, size_t n, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, srs && h_out_affine, "null pointer");
+    ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
+    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
+    ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
+    return msm_run(ctx, (const Fr*)d_scalars, b, n, (G1Affine*)h_out_affine);
+}
+int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, h_out_affine && ((h_scalars && h_bases) || n == 0), "null pointer");
+    if (n == 0) { memset(h_out_affine, 0, sizeof(G1Affine)); return ZK_OK; }
+    char* d = (char*)ctx->get_scratch(SC_TMP2, n * (sizeof(Fr) + sizeof(G1Affine)));
+    if (!d) return ZK_ERR_OOM;
+    G1Affine* db = (G1Affine*)d;
+    Fr* ds = (Fr*)(d + n * sizeof(G1Affine));
+    ZK_HIP(ctx, hipMemcpyAsync(db, h_bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(ds, h_scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    return msm_run(ctx, ds, db, n, (G1Affine*)h_out_affine);
+}
+
+}  // extern "C"

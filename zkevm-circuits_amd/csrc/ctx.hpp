@@ -1,0 +1,100 @@
+// Context object behind the C ABI (include/zkmi355.h): device, stream, cached NTT domains,
+// a growable scratch arena, and the error string.  One host thread per context.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/zkmi355.h"
+#include "ec.cuh"
+#include "ff.cuh"
+
+namespace zk {
+
+struct NttDomain;   // ntt.hip
+
+struct Scratch {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace zk
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop{};
+    // scratch arenas, grown on demand (never shrunk): index = purpose
+    zk::Scratch scratch[8];
+    std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
+    std::vector<void*> pinned;   // small pinned host staging buffers
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    // returns nullptr on failure (err set)
+    void* get_scratch(int slot, size_t bytes) {
+        zk::Scratch& s = scratch[slot];
+        if (s.cap >= bytes) return s.ptr;
+        if (s.ptr) { (void)hipStreamSynchronize(stream); (void)hipFree(s.ptr); s.ptr = nullptr; s.cap = 0; }
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&s.ptr, bytes); want = bytes; }
+        if (e != hipSuccess) { s.ptr = nullptr; fail(ZK_ERR_OOM, "scratch alloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+        s.cap = want;
+        return s.ptr;
+    }
+};
+
+struct zk_srs {
+    uint32_t k = 0;
+    zk::G1Affine* g = nullptr;
+    zk::G1Affine* g_lagrange = nullptr;
+};
+
+#define ZK_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) return (ctx)->fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define ZK_CHECK_LAUNCH(ctx)                                                                       \
+    do {                                                                                           \
+        hipError_t e__ = hipGetLastError();                                                        \
+        if (e__ != hipSuccess) return (ctx)->fail(ZK_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define ZK_REQUIRE(ctx, cond, msg)                                                                 \
+    do {                                                                                           \
+        if (!(cond)) return (ctx)->fail(ZK_ERR_INVALID_ARG, "invalid argument: %s (%s:%d)", msg, __FILE__, __LINE__); \
+    } while (0)
+
+namespace zk {
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7 };
+
+// host-side field helpers (slow path, used for constants / tables only)
+Fr fr_from_u64(uint64_t v);
+Fr fr_pow(Fr base, uint64_t e);
+Fr fr_inv_host(const Fr& a);
+Fr fr_root_of_unity(uint32_t log_n);   // ROOT_OF_UNITY^(2^(28-log_n))
+Fr fr_zeta();
+
+// internal entry points shared between translation units
+int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale /*nullable*/, const Fr* coset_pre /*nullable: a[i] *= g^i before*/, const Fr* coset_post /*nullable: out[i] *= g^i after*/);
+int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);
+int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out);
+}  // namespace zk

@@ -1,0 +1,210 @@
+// BN254 G1 multi-scalar multiplication for gfx950: halo2_proofs::arithmetic::best_multiexp
+// (external crate; reached from ParamsKZG::commit / commit_lagrange, reference
+// call sites A1-A4).  result = sum_i scalars[i] * bases[i].
+//
+// Pippenger, MI355X layout:
+//   1. digits    scalars leave Montgomery form (one Montgomery product by 1) and are recoded into
+//                W = ceil(256/c) signed c-bit digits; every non-zero digit is a (bucket, point)
+//                pair, bucket = window * 2^(c-1) + |d| - 1, the sign travels with the point index.
+//   2. sort      counting sort of the pairs by bucket: histogram (device atomics) -> exclusive scan
+//                -> scatter.  The scalars are re-recoded in the scatter pass instead of storing
+//                n*W digit words (ALU is cheaper than 4*n*W bytes of HBM traffic twice).
+//   3. buckets   one lane per bucket walks its contiguous run of point indices, gathers the affine
+//                base (64 B, coalescing is per-point not per-lane: the gather is the HBM-side cost)
+//                and accumulates with mixed XYZZ additions (8M + 2S, no inversions).
+//   4. reduce    per window: sum_b (b+1) * B_b.  Each lane folds G consecutive buckets with the
+//                running-sum trick, lifts its partial by its group offset with a short
+//                double-and-add, and a block tree-sum in LDS produces one point per window.
+//   5. tail      W window sums (2 KiB) go to the host, which runs the c doublings per window
+//                (Horner) -- 256 dependent doublings are latency-bound on a GPU lane and take
+//                ~100 us on one CPU core.
+#include "ctx.hpp"
+#include "host_fq.hpp"
+
+namespace zk {
+
+constexpr int MSM_MAX_C = 16;
+constexpr uint32_t NEG_BIT = 0x80000000u;
+
+struct MsmPlan {
+    int c;          // window bits
+    int W;          // windows
+    uint32_t B;     // buckets per window = 2^(c-1)
+};
+
+static MsmPlan make_plan(size_t n) {
+    int lg = 0;
+    while ((1ull << (lg + 1)) <= n) ++lg;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > MSM_MAX_C) c = MSM_MAX_C;
+    MsmPlan p;
+    p.c = c;
+    p.W = (256 + c - 1) / c;
+    p.B = 1u << (c - 1);
+    return p;
+}
+
+// signed-digit recoding of a canonical 256-bit scalar; calls f(window, bucket_in_window, negative)
+template <class Fn>
+__device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * c, limb = bit >> 5, sh = bit & 31;
+        uint32_t d = limb < 8 ? (s.l[limb] >> sh) : 0u;
+        if (sh + c > 32 && limb + 1 < 8) d |= s.l[limb + 1] << (32 - sh);
+        d = (d & mask) + carry;
+        if (d > half) { carry = 1; const uint32_t mag = (1u << c) - d; if (mag) f(w, mag - 1, true); }
+        else { carry = 0; if (d) f(w, d - 1, false); }
+    }
+}
+
+__global__ void k_msm_count(const Fr* __restrict__ scalars, uint64_t n, int c, int W, uint32_t B, uint32_t* __restrict__ counts) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr s = from_mont(ldg(scalars + i));
+    recode(s, c, W, [&](int w, uint32_t b, bool) { atomicAdd(counts + (uint64_t)w * B + b, 1u); });
+}
+
+__global__ void k_msm_scatter(const Fr* __restrict__ scalars, uint64_t n, int c, int W, uint32_t B, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr s = from_mont(ldg(scalars + i));
+    recode(s, c, W, [&](int w, uint32_t b, bool neg) {
+        const uint32_t pos = atomicAdd(cursor + (uint64_t)w * B + b, 1u);
+        idx[pos] = (uint32_t)i | (neg ? NEG_BIT : 0u);
+    });
+}
+
+// exclusive scan of u32 counts (single block, 1024 threads, contiguous chunk per thread);
+// writes offsets[0..cnt] (cnt+1 entries) and a copy into cursor[0..cnt)
+__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t sh[1024];
+    const uint32_t per = (cnt + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, cnt);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += counts[i];
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = sh[threadIdx.x];
+        if ((int)threadIdx.x >= off) v += sh[threadIdx.x - off];
+        __syncthreads();
+        sh[threadIdx.x] = v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; cursor[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) offsets[cnt] = sh[1023];
+}
+
+__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx, uint32_t nbuckets, G1Xyzz* __restrict__ buckets) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    G1Xyzz acc = G1Xyzz::identity();
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t v = idx[j];
+        G1Affine p = ldg(bases + (v & ~NEG_BIT));
+        if (v & NEG_BIT) p.y = neg(p.y);
+        acc = madd(acc, p);
+    }
+    stg(buckets + b, acc);
+}
+
+// k * P for small k (< 2^16), MSB-first double-and-add
+__device__ __forceinline__ G1Xyzz mul_small(const G1Xyzz& p, uint32_t k) {
+    G1Xyzz acc = G1Xyzz::identity();
+    for (int bit = 31 - __clz(k | 1); bit >= 0; --bit) {
+        acc = dbl(acc);
+        if ((k >> bit) & 1) acc = add(acc, p);
+    }
+    return k ? acc : G1Xyzz::identity();
+}
+
+constexpr int RED_G = 8;          // buckets folded per lane
+constexpr int RED_THREADS = 256;
+// grid: (groups_per_window / RED_THREADS, W); each block writes one partial per (window, block)
+__global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1Xyzz* __restrict__ buckets, uint32_t B, G1Xyzz* __restrict__ partial) {
+    __shared__ G1Xyzz sh[RED_THREADS];
+    const uint32_t w = blockIdx.y;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;     // group index in window
+    const uint32_t groups = (B + RED_G - 1) / RED_G;
+    G1Xyzz acc = G1Xyzz::identity();
+    if (g < groups) {
+        const uint32_t b0 = g * RED_G, b1 = min(b0 + RED_G, B);
+        G1Xyzz running = G1Xyzz::identity();
+        for (uint32_t b = b1; b-- > b0;) {
+            running = add(running, ldg(buckets + (uint64_t)w * B + b));
+            acc = add(acc, running);
+        }
+        // acc = sum (b - b0 + 1) * B_b ; lift by b0: + b0 * running
+        if (b0) acc = add(acc, mul_small(running, b0));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(uint64_t)w * gridDim.x + blockIdx.x] = sh[0];
+}
+// one block per window sums `cnt` partials
+__global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz* __restrict__ partial, uint32_t cnt, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz sh[RED_THREADS];
+    const uint32_t w = blockIdx.x;
+    G1Xyzz acc = G1Xyzz::identity();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add(acc, ldg(partial + (uint64_t)w * cnt + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[w] = sh[0];
+}
+
+int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out) {
+    if (n == 0) { memset(h_out, 0, sizeof(G1Affine)); return ZK_OK; }
+    if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
+    const MsmPlan pl = make_plan(n);
+    const uint32_t nb = (uint32_t)pl.W * pl.B;
+
+    // u32 workspace: counts[nb] | offsets[nb+1] | cursor[nb] | idx[n*W]
+    const size_t words = (size_t)nb * 3 + 1 + (size_t)n * pl.W;
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
+    if (!ws) return ZK_ERR_OOM;
+    uint32_t* counts = ws;
+    uint32_t* offsets = counts + nb;
+    uint32_t* cursor = offsets + nb + 1;
+    uint32_t* idx = cursor + nb;
+    const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
+    G1Xyzz* buckets = (G1Xyzz*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz) * ((size_t)nb + (size_t)pl.W * red_blocks + pl.W));
+    if (!buckets) return ZK_ERR_OOM;
+    G1Xyzz* partial = buckets + nb;
+    G1Xyzz* wsum = partial + (size_t)pl.W * red_blocks;
+
+    ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)nb * 4, ctx->stream));
+    const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
+    hipLaunchKernelGGL(k_msm_count, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, counts);
+    ZK_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, cursor);
+    ZK_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_msm_scatter, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, cursor, idx);
+    ZK_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, nb, buckets);
+    ZK_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)buckets, pl.B, partial);
+    ZK_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)partial, red_blocks, wsum);
+    ZK_CHECK_LAUNCH(ctx);
+
+    std::vector<G1Xyzz> hw(pl.W);
+    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, sizeof(G1Xyzz) * pl.W, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    host::msm_tail(hw.data(), pl.W, pl.c, h_out);
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,349 @@
+// BN254 Fr NTT for gfx950: halo2_proofs::arithmetic::best_fft / poly::EvaluationDomain
+// (external crate; reference call sites A1-A4).
+//
+// Definition (natural order in -> natural order out):  out[i] = sum_j a[j] * omega^(i*j).
+//
+// MI355X design: mixed-radix Cooley-Tukey in P <= 3 passes of <= 2^10 points each.  A pass stages
+// a [digit x T] tile in LDS (T consecutive elements of the fastest-varying remaining index, so
+// every global access is a T*32-byte contiguous run), runs all log2(n_p) radix-2 stages out of
+// LDS, applies the inter-pass twiddle omega^(j''*i_p) on the way out (two-level table, also carries
+// the 1/n scale of the inverse transform for free) and writes back.  Input index is read big-endian
+// in the digits, output little-endian; the last pass writes to the digit-reversed position, so
+// no separate transpose / bit-reversal kernel exists.  LDS is laid out as four u64 planes so a
+// wave's accesses are 8-byte strided (ds_read_b64 / ds_write_b64, bank-conflict-free on
+// contiguous runs).
+#include "ctx.hpp"
+
+namespace zk {
+
+constexpr int NTT_MAX_DIGIT = 10;
+constexpr int NTT_TILE = 4096;         // elements staged per workgroup (128 KiB of LDS)
+constexpr int NTT_THREADS = 1024;
+
+struct NttPass {
+    int log_np;     // digit size
+    int log_t;      // tile columns
+    int log_m;      // stride of the digit (non-last) / unused (last)
+    const Fr* tw;   // n_p/2 butterfly twiddles: (omega^(n/n_p))^x
+};
+
+struct NttDomain {
+    uint32_t log_n = 0;
+    Fr omega;
+    bool has_scale = false;
+    Fr scale;
+    int npass = 0;
+    NttPass pass[3];
+    int h = 0;                // two-level split: omega^e = lo[e & (2^h-1)] * hi[e >> h]
+    Fr* d_lo = nullptr;       // 2^h entries
+    Fr* d_hi = nullptr;       // 2^(log_n-h) entries
+    Fr* d_hi_scaled = nullptr; // same, pre-multiplied by `scale` (used by pass 0 only); == d_hi if no scale
+    Fr* d_tw[3] = {nullptr, nullptr, nullptr};
+    ~NttDomain() {
+        if (d_lo) (void)hipFree(d_lo);
+        if (d_hi_scaled && d_hi_scaled != d_hi) (void)hipFree(d_hi_scaled);
+        if (d_hi) (void)hipFree(d_hi);
+        for (auto p : d_tw) if (p) (void)hipFree(p);
+    }
+};
+
+// ------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+struct LdsPlanes {
+    uint64_t* p;     // 4 planes of `stride` u64
+    int stride;
+    __device__ __forceinline__ Fr load(int idx) const {
+        Fr r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { uint64_t v = p[k * stride + idx]; r.l[2 * k] = (uint32_t)v; r.l[2 * k + 1] = (uint32_t)(v >> 32); }
+        return r;
+    }
+    __device__ __forceinline__ void store(int idx, const Fr& v) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k * stride + idx] = (uint64_t)v.l[2 * k] | ((uint64_t)v.l[2 * k + 1] << 32);
+    }
+};
+
+// out[j] = base^j * mul   (table builder; one thread per entry, square-and-multiply)
+__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr r = mul, b = base;
+    uint32_t e = j;
+    while (e) {
+        if (e & 1) r = r * b;
+        b = sqr(b);
+        e >>= 1;
+    }
+    stg(out + j, r);
+}
+
+__device__ __forceinline__ Fr two_level(const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint32_t e) {
+    return ldg(lo + (e & ((1u << h) - 1))) * ldg(hi + (e >> h));
+}
+
+// ------------------------------------------------------------------------------ non-last pass
+// Tile = [n_p digits][T columns], element (d, c) lives at base + d*m + c with
+// base = hi_idx * (n_p*m) + blk*T.  DIT: loaded bit-reversed in d, leaves in natural d = i_p.
+// On the way out: multiply by omega^((j'' * i_p) << tw_shift) * [scale], j'' = blk*T + c.
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
+           const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+    const int tile = 1 << (log_np + log_t);
+    LdsPlanes L{smem, tile};
+    const int T = 1 << log_t, np = 1 << log_np;
+    const uint64_t m = 1ull << log_m;
+    const uint32_t tiles_per_hi = (uint32_t)(m >> log_t);
+    const uint32_t hi_idx = blockIdx.x / tiles_per_hi, blk = blockIdx.x % tiles_per_hi;
+    const uint64_t base = ((uint64_t)hi_idx << (log_np + log_m)) + ((uint64_t)blk << log_t);
+
+    // load in LDS order (conflict-free), global digit = bitrev(lds digit)
+    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
+        const int c = pos & (T - 1), dl = pos >> log_t;
+        const uint32_t d = bitrev(dl, log_np);
+        L.store(pos, ldg(src + base + (uint64_t)d * m + c));
+    }
+    __syncthreads();
+    for (int s = 0; s < log_np; ++s) {
+        const int half = 1 << s;
+        for (int bf = threadIdx.x; bf < tile / 2; bf += blockDim.x) {
+            const int c = bf & (T - 1), b = bf >> log_t;
+            const int j = b & (half - 1);
+            const int lo_d = ((b >> s) << (s + 1)) | j;
+            const int i0 = (lo_d << log_t) | c, i1 = i0 + (half << log_t);
+            Fr u = L.load(i0), v = L.load(i1);
+            if (j) v = v * ldg(tw + ((uint32_t)j << (log_np - 1 - s)));
+            L.store(i0, u + v);
+            L.store(i1, u - v);
+        }
+        __syncthreads();
+    }
+    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
+        const int c = pos & (T - 1), d = pos >> log_t;
+        Fr v = L.load(pos);
+        const uint32_t jpp = (blk << log_t) + c;
+        const uint32_t e = (jpp * (uint32_t)d) << tw_shift;
+        v = v * two_level(lo, hi, h, e);
+        stg(dst + base + (uint64_t)d * m + c, v);
+    }
+}
+
+// ----------------------------------------------------------------------------------- last pass
+// Rows of n_P contiguous elements; tile = T rows i1 = blk*T + c (row stride = midN * n_P) at a
+// fixed middle digit `mid`.  DIF: natural load, bit-reversed inside LDS on the way out.
+// Output index = i1 + n1 * (mid + midN * i_P).   LDS layout [c][d].
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, int log_np, int log_t,
+           int log_n1, int log_mid, int use_scale, Fr scale) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+    const int tile = 1 << (log_np + log_t);
+    LdsPlanes L{smem, tile};
+    const int np = 1 << log_np;
+    const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
+
+    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
+        const int d = pos & (np - 1), c = pos >> log_np;
+        const uint64_t i1 = ((uint64_t)blk << log_t) + c;
+        L.store(pos, ldg(src + (((i1 << log_mid) + mid) << log_np) + d));
+    }
+    __syncthreads();
+    for (int s = log_np - 1; s >= 0; --s) {
+        const int half = 1 << s;
+        for (int bf = threadIdx.x; bf < tile / 2; bf += blockDim.x) {
+            const int b = bf & (np / 2 - 1), c = bf >> (log_np - 1);
+            const int j = b & (half - 1);
+            const int lo_d = ((b >> s) << (s + 1)) | j;
+            const int i0 = (c << log_np) | lo_d, i1 = i0 + half;
+            Fr u = L.load(i0), v = L.load(i1);
+            Fr t = u - v;
+            if (j) t = t * ldg(tw + ((uint32_t)j << (log_np - 1 - s)));
+            L.store(i0, u + v);
+            L.store(i1, t);
+        }
+        __syncthreads();
+    }
+    const int T = 1 << log_t;
+    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
+        const int c = pos & (T - 1), d = pos >> log_t;       // c fastest: T consecutive outputs
+        Fr v = L.load((c << log_np) | (int)bitrev(d, log_np));
+        if (use_scale) v = v * scale;
+        const uint64_t i1 = ((uint64_t)blk << log_t) + c;
+        const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)d << log_mid)) << log_n1);
+        stg(dst + o, v);
+    }
+}
+
+__global__ void k_scale(Fr* a, Fr s, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stg(a + i, ldg(a + i) * s);
+}
+int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n) {
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, s, n);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+// a[i] *= g^i   (EvaluationDomain::distribute_powers_zeta generalised), two-level table of g
+__global__ void k_distribute_powers(Fr* a, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    stg(a + i, ldg(a + i) * two_level(lo, hi, h, (uint32_t)i));
+}
+
+// ----------------------------------------------------------------------------------- host side
+static int build_powers(zk_ctx* ctx, const Fr& base, const Fr& mul, Fr* d_out, uint32_t count) {
+    hipLaunchKernelGGL(k_powers, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, mul, d_out, count);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+static uint64_t domain_key(uint32_t log_n, const Fr& omega, const Fr* scale) {
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](uint32_t v) { hsh = (hsh ^ v) * 1099511628211ull; };
+    mix(log_n);
+    for (int i = 0; i < 8; ++i) mix(omega.l[i]);
+    if (scale) for (int i = 0; i < 8; ++i) mix(scale->l[i] ^ 0x9e3779b9u);
+    return hsh;
+}
+
+static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* scale, std::shared_ptr<NttDomain>* out) {
+    const uint64_t key = domain_key(log_n, omega, scale);
+    auto it = ctx->domains.find(key);
+    if (it != ctx->domains.end()) { *out = it->second; return ZK_OK; }
+    auto d = std::make_shared<NttDomain>();
+    d->log_n = log_n;
+    d->omega = omega;
+    d->has_scale = scale != nullptr;
+    if (scale) d->scale = *scale;
+    const int P = log_n <= NTT_MAX_DIGIT ? 1 : (log_n <= 2 * NTT_MAX_DIGIT ? 2 : 3);
+    d->npass = P;
+    int rem = (int)log_n;
+    for (int p = 0; p < P; ++p) {
+        int b = (rem + (P - p) - 1) / (P - p);   // ceil split, big digits first
+        d->pass[p].log_np = b;
+        rem -= b;
+        d->pass[p].log_m = rem;
+    }
+    // two-level tables (only needed when P > 1)
+    if (P > 1) {
+        d->h = (int)(log_n + 1) / 2;
+        const uint32_t nlo = 1u << d->h, nhi = 1u << (log_n - d->h);
+        ZK_HIP(ctx, hipMalloc(&d->d_lo, sizeof(Fr) * nlo));
+        ZK_HIP(ctx, hipMalloc(&d->d_hi, sizeof(Fr) * nhi));
+        int rc = build_powers(ctx, omega, Fr::one(), d->d_lo, nlo);
+        if (rc) return rc;
+        Fr step = omega;
+        for (int i = 0; i < d->h; ++i) step = sqr(step);
+        rc = build_powers(ctx, step, Fr::one(), d->d_hi, nhi);
+        if (rc) return rc;
+        d->d_hi_scaled = d->d_hi;
+        if (scale) {
+            ZK_HIP(ctx, hipMalloc(&d->d_hi_scaled, sizeof(Fr) * nhi));
+            rc = build_powers(ctx, step, *scale, d->d_hi_scaled, nhi);
+            if (rc) return rc;
+        }
+    }
+    for (int p = 0; p < P; ++p) {
+        const int b = d->pass[p].log_np;
+        const uint32_t cnt = b ? (1u << (b - 1)) : 1u;
+        ZK_HIP(ctx, hipMalloc(&d->d_tw[p], sizeof(Fr) * cnt));
+        Fr w = omega;
+        for (uint32_t i = 0; i < log_n - (uint32_t)b; ++i) w = sqr(w);   // omega^(n/n_p)
+        int rc = build_powers(ctx, w, Fr::one(), d->d_tw[p], cnt);
+        if (rc) return rc;
+        d->pass[p].tw = d->d_tw[p];
+    }
+    if (ctx->domains.size() > 64) ctx->domains.clear();
+    ctx->domains[key] = d;
+    *out = d;
+    return ZK_OK;
+}
+
+static bool g_attr_set = false;
+static int set_lds_attr(zk_ctx* ctx) {
+    if (g_attr_set) return ZK_OK;
+    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 32));
+    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 32));
+    g_attr_set = true;
+    return ZK_OK;
+}
+
+static int pick_threads(int tile) { return tile >= 4096 ? 1024 : (tile >= 1024 ? 512 : (tile >= 256 ? 128 : 64)); }
+
+// Generic driver.  `scale` (nullable) multiplies every output; coset_pre (nullable): a[i] *= g^i
+// before the transform; coset_post (nullable): out[i] *= g^i after it.
+int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post) {
+    if (log_n == 0) {   // size-1 transform: identity (times the scale)
+        if (scale) {
+            hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, ctx->stream, d_data, *scale, (uint64_t)1);
+            ZK_CHECK_LAUNCH(ctx);
+        }
+        return ZK_OK;
+    }
+    int rc = set_lds_attr(ctx);
+    if (rc) return rc;
+    const uint64_t n = 1ull << log_n;
+
+    auto run_distribute = [&](const Fr& g) -> int {
+        const int h = (int)(log_n + 1) / 2;
+        const uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
+        Fr* tab = (Fr*)ctx->get_scratch(SC_TMP, sizeof(Fr) * (nlo + nhi));
+        if (!tab) return ZK_ERR_OOM;
+        int r = build_powers(ctx, g, Fr::one(), tab, nlo);
+        if (r) return r;
+        Fr step = g;
+        for (int i = 0; i < h; ++i) step = sqr(step);
+        r = build_powers(ctx, step, Fr::one(), tab + nlo, nhi);
+        if (r) return r;
+        hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_data, tab, tab + nlo, h, n);
+        ZK_CHECK_LAUNCH(ctx);
+        return ZK_OK;
+    };
+    if (coset_pre) { rc = run_distribute(*coset_pre); if (rc) return rc; }
+
+    std::shared_ptr<NttDomain> dom;
+    rc = get_domain(ctx, log_n, omega, scale, &dom);
+    if (rc) return rc;
+    const int P = dom->npass;
+    Fr* scratch = nullptr;
+    if (P > 1) {
+        scratch = (Fr*)ctx->get_scratch(SC_NTT, sizeof(Fr) * n);
+        if (!scratch) return ZK_ERR_OOM;
+    }
+    // buffers: P=1: data->data (whole transform inside one workgroup, safe in place)
+    //          P=2: data->scratch, scratch->data;   P=3: data->data, data->scratch, scratch->data
+    const Fr* cur = d_data;
+    for (int p = 0; p + 1 < P; ++p) {
+        const NttPass& ps = dom->pass[p];
+        int log_t = 12 - ps.log_np;
+        if (log_t > ps.log_m) log_t = ps.log_m;
+        const int tile = 1 << (ps.log_np + log_t);
+        Fr* out = (p == P - 2) ? scratch : d_data;
+        const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
+        const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, out, ps.tw,
+                           dom->d_lo, p == 0 ? dom->d_hi_scaled : dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift);
+        ZK_CHECK_LAUNCH(ctx);
+        cur = out;
+    }
+    {
+        const NttPass& ps = dom->pass[P - 1];
+        const int log_n1 = P == 1 ? 0 : dom->pass[0].log_np;
+        const int log_mid = P == 3 ? dom->pass[1].log_np : 0;
+        int log_t = 12 - ps.log_np;
+        if (log_t > log_n1) log_t = log_n1;
+        const int tile = 1 << (ps.log_np + log_t);
+        const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
+        const int use_scale = (P == 1 && scale) ? 1 : 0;
+        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, d_data, ps.tw,
+                           ps.log_np, log_t, log_n1, log_mid, use_scale, scale ? *scale : Fr::one());
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    if (coset_post) { rc = run_distribute(*coset_post); if (rc) return rc; }
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,324 @@
+// Element-wise and scan kernels over Fr / Fq columns (HBM-streaming side of the prover):
+//   field vector add/sub/mul            halo2curves Add/Sub/Mul           
+//   batch inversion                     ff::BatchInvert                    (K12, K7, K8)
+//   prefix product / prefix sum         permutation & lookup grand product (K7, K8)
+//   eval_polynomial, kate_division      halo2_proofs::arithmetic           (K9, K10, K11)
+// All kernels read/write 32-byte elements as two 16-byte transactions per lane, consecutive
+// lanes on consecutive elements (fully coalesced), grid-stride where a fixed grid is needed.
+#include "ctx.hpp"
+
+namespace zk {
+
+int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);   // ntt.hip
+__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count); // ntt.hip
+
+template <class F, int OP>
+__global__ void k_vec_op(const F* __restrict__ a, const F* __restrict__ b, F* __restrict__ o, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = ldg(a + i), y = ldg(b + i), r;
+    if (OP == ZK_OP_ADD) r = x + y;
+    else if (OP == ZK_OP_SUB) r = x - y;
+    else r = x * y;
+    stg(o + i, r);
+}
+
+template <class F>
+static int vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void* o, uint64_t n) {
+    dim3 g((unsigned)((n + 255) / 256)), t(256);
+    const F* A = (const F*)a; const F* B = (const F*)b; F* O = (F*)o;
+    switch (op) {
+        case ZK_OP_ADD: hipLaunchKernelGGL((k_vec_op<F, ZK_OP_ADD>), g, t, 0, ctx->stream, A, B, O, n); break;
+        case ZK_OP_SUB: hipLaunchKernelGGL((k_vec_op<F, ZK_OP_SUB>), g, t, 0, ctx->stream, A, B, O, n); break;
+        case ZK_OP_MUL: hipLaunchKernelGGL((k_vec_op<F, ZK_OP_MUL>), g, t, 0, ctx->stream, A, B, O, n); break;
+        default: return ctx->fail(ZK_ERR_INVALID_ARG, "unknown vector op %d", op);
+    }
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+// ---------------------------------------------------------------------------- batch inversion
+// Thread t owns the strided set {t, t+NT, t+2NT, ...} (coalesced): forward prefix products into
+// scratch, one Fermat inversion per thread, backward sweep.  Zeros are skipped (stay zero).
+constexpr int BI_PER_THREAD = 32;
+__global__ void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ pre, uint64_t n, uint64_t nt) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    Fr acc = Fr::one();
+    for (uint64_t i = t; i < n; i += nt) {
+        stg(pre + i, acc);
+        Fr v = ldg(a + i);
+        if (!v.is_zero()) acc = acc * v;
+    }
+    Fr iv = inv(acc);
+    uint64_t cnt = (n - t + nt - 1) / nt;
+    for (uint64_t k = cnt; k-- > 0;) {
+        uint64_t i = t + k * nt;
+        Fr v = ldg(a + i);
+        if (v.is_zero()) continue;
+        Fr p = ldg(pre + i);
+        stg(a + i, iv * p);
+        iv = iv * v;
+    }
+}
+
+// ------------------------------------------------------------------------------------- scans
+// Exclusive scan z[0] = id, z[i+1] = z[i] (op) a[i] in three kernels:
+//   A: each block scans a contiguous segment of SCAN_BLOCK*SCAN_PER elements (thread-local chunk
+//      + LDS Hillis-Steele over the 256 thread totals), writes locally-prefixed z, block total
+//   B: one block scans the block totals
+//   C: z[i] = off[block] (op) z[i]
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER = 8;
+struct OpMul { __device__ static Fr id() { return Fr::one(); } __device__ static Fr f(const Fr& a, const Fr& b) { return a * b; } };
+struct OpAdd { __device__ static Fr id() { return Fr::zero(); } __device__ static Fr f(const Fr& a, const Fr& b) { return a + b; } };
+
+template <class Op>
+__device__ __forceinline__ Fr block_exclusive_scan(Fr v, Fr* sh, Fr* total) {
+    // sh: SCAN_THREADS entries.  Returns exclusive prefix of v over the block; *total = block sum.
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        Fr x = sh[t];
+        if (t >= off) x = Op::f(sh[t - off], x);
+        __syncthreads();
+        sh[t] = x;
+        __syncthreads();
+    }
+    *total = sh[SCAN_THREADS - 1];
+    Fr ex = t ? sh[t - 1] : Op::id();
+    __syncthreads();
+    return ex;
+}
+
+template <class Op>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_a(const Fr* __restrict__ a, Fr* __restrict__ z, Fr* __restrict__ totals, uint64_t n) {
+    __shared__ Fr sh[SCAN_THREADS];
+    const uint64_t seg = (uint64_t)blockIdx.x * (SCAN_THREADS * SCAN_PER);
+    const uint64_t start = seg + (uint64_t)threadIdx.x * SCAN_PER;
+    Fr loc[SCAN_PER];
+    Fr acc = Op::id();
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        const uint64_t i = start + k;
+        loc[k] = acc;                       // exclusive within the thread
+        if (i < n) acc = Op::f(acc, ldg(a + i));
+    }
+    Fr total;
+    Fr ex = block_exclusive_scan<Op>(acc, sh, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        const uint64_t i = start + k;
+        if (i < n) stg(z + i, Op::f(ex, loc[k]));
+    }
+    if (threadIdx.x == 0) stg(totals + blockIdx.x, total);
+}
+// exclusive scan of `cnt` block totals in place, one block; handles cnt > SCAN_THREADS by a
+// serial carry over SCAN_THREADS-sized windows
+template <class Op>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_b(Fr* totals, uint32_t cnt) {
+    __shared__ Fr sh[SCAN_THREADS];
+    Fr carry = Op::id();
+    for (uint32_t base = 0; base < cnt; base += SCAN_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        Fr v = i < cnt ? ldg(totals + i) : Op::id();
+        Fr total;
+        Fr ex = block_exclusive_scan<Op>(v, sh, &total);
+        if (i < cnt) stg(totals + i, Op::f(carry, ex));
+        carry = Op::f(carry, total);
+    }
+}
+template <class Op>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_c(Fr* __restrict__ z, const Fr* __restrict__ offs, uint64_t n) {
+    if (blockIdx.x == 0) return;   // offset of block 0 is the identity
+    const Fr off = ldg(offs + blockIdx.x);
+    const uint64_t seg = (uint64_t)blockIdx.x * (SCAN_THREADS * SCAN_PER);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        const uint64_t i = seg + (uint64_t)k * SCAN_THREADS + threadIdx.x;   // coalesced
+        if (i < n) stg(z + i, Op::f(off, ldg(z + i)));
+    }
+}
+
+template <class Op>
+static int scan_run(zk_ctx* ctx, const Fr* d_a, Fr* d_z, uint64_t n) {
+    if (!n) return ZK_OK;
+    const uint32_t blocks = (uint32_t)((n + SCAN_THREADS * SCAN_PER - 1) / (SCAN_THREADS * SCAN_PER));
+    Fr* totals = (Fr*)ctx->get_scratch(SC_POLY2, sizeof(Fr) * blocks);
+    if (!totals) return ZK_ERR_OOM;
+    hipLaunchKernelGGL((k_scan_a<Op>), dim3(blocks), dim3(SCAN_THREADS), 0, ctx->stream, d_a, d_z, totals, n);
+    ZK_CHECK_LAUNCH(ctx);
+    if (blocks > 1) {
+        hipLaunchKernelGGL((k_scan_b<Op>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, totals, blocks);
+        ZK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL((k_scan_c<Op>), dim3(blocks), dim3(SCAN_THREADS), 0, ctx->stream, d_z, totals, n);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    return ZK_OK;
+}
+
+// --------------------------------------------------------------- eval_polynomial / kate_division
+// w[i] = c[i] * x^i through a two-level power table; block tree-sum; final sum on one block.
+__device__ __forceinline__ Fr two_level_pow(const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint64_t e) {
+    return ldg(lo + (e & ((1ull << h) - 1))) * ldg(hi + (e >> h));
+}
+__device__ __forceinline__ Fr block_sum(Fr v, Fr* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (t < off) sh[t] = sh[t] + sh[t + off];
+        __syncthreads();
+    }
+    Fr r = sh[0];
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, uint64_t n, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, Fr* __restrict__ partial) {
+    __shared__ Fr sh[256];
+    Fr acc = Fr::zero();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        acc = acc + ldg(c + i) * two_level_pow(lo, hi, h, i);
+    Fr s = block_sum(acc, sh);
+    if (threadIdx.x == 0) stg(partial + blockIdx.x, s);
+}
+__global__ void __launch_bounds__(256) k_sum_final(const Fr* __restrict__ partial, uint32_t cnt, Fr* out) {
+    __shared__ Fr sh[256];
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = acc + ldg(partial + i);
+    Fr s = block_sum(acc, sh);
+    if (threadIdx.x == 0) stg(out, s);
+}
+// w[i] = c[i+1] * x^i  (shifted weights for kate division), i in [0, n-1)
+__global__ void k_weight_shift(const Fr* __restrict__ c, uint64_t nm1, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, Fr* __restrict__ w) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nm1) stg(w + i, ldg(c + i + 1) * two_level_pow(lo, hi, h, i));
+}
+// q[i] = (total - excl[i]) * xinv^i  where excl = exclusive prefix sum of w and total = sum w
+__global__ void k_kate_finish(const Fr* __restrict__ excl, const Fr* __restrict__ total, uint64_t nm1, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, Fr* __restrict__ q) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nm1) stg(q + i, (ldg(total) - ldg(excl + i)) * two_level_pow(lo, hi, h, i));
+}
+__global__ void k_copy_shift(const Fr* __restrict__ c, uint64_t nm1, Fr* __restrict__ q) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nm1) stg(q + i, ldg(c + i + 1));
+}
+
+// two-level table of x^e for e < n into scratch slot; returns lo pointer, hi = lo + 2^h
+static int build_pow_table(zk_ctx* ctx, int slot, const Fr& x, uint64_t n, Fr** lo, Fr** hi, int* h_out) {
+    int bits = 1;
+    while ((1ull << bits) < n) ++bits;
+    const int h = (bits + 1) / 2;
+    const uint32_t nlo = 1u << h, nhi = 1u << (bits - h);
+    Fr* tab = (Fr*)ctx->get_scratch(slot, sizeof(Fr) * ((size_t)nlo + nhi));
+    if (!tab) return ZK_ERR_OOM;
+    hipLaunchKernelGGL(k_powers, dim3((nlo + 255) / 256), dim3(256), 0, ctx->stream, x, Fr::one(), tab, nlo);
+    Fr step = x;
+    for (int i = 0; i < h; ++i) step = sqr(step);
+    hipLaunchKernelGGL(k_powers, dim3((nhi + 255) / 256), dim3(256), 0, ctx->stream, step, Fr::one(), tab + nlo, nhi);
+    ZK_CHECK_LAUNCH(ctx);
+    *lo = tab; *hi = tab + nlo; *h_out = h;
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zk_field_vec_op(zk_ctx* ctx, int field, int op, const void* d_a, const void* d_b, void* d_out, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_a && d_b && d_out, "null device pointer");
+    if (n == 0) return ZK_OK;
+    if (field == ZK_FIELD_FR) return vec_op_launch<Fr>(ctx, op, d_a, d_b, d_out, n);
+    if (field == ZK_FIELD_FQ) return vec_op_launch<Fq>(ctx, op, d_a, d_b, d_out, n);
+    return ctx->fail(ZK_ERR_INVALID_ARG, "unknown field %d", field);
+}
+
+int zk_fr_scale(zk_ctx* ctx, void* d_a, const void* h_s, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_a && h_s, "null pointer");
+    return fr_scale_run(ctx, (Fr*)d_a, *(const Fr*)h_s, n);
+}
+
+int zk_fr_batch_invert(zk_ctx* ctx, void* d_a, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_a, "null pointer");
+    if (!n) return ZK_OK;
+    Fr* pre = (Fr*)ctx->get_scratch(SC_POLY, sizeof(Fr) * n);
+    if (!pre) return ZK_ERR_OOM;
+    uint64_t nt = (n + BI_PER_THREAD - 1) / BI_PER_THREAD;
+    nt = (nt + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_a, pre, (uint64_t)n, nt);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+int zk_fr_prefix_product(zk_ctx* ctx, const void* d_a, void* d_z, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_a && d_z && d_a != d_z, "null or aliased pointer");
+    return scan_run<OpMul>(ctx, (const Fr*)d_a, (Fr*)d_z, n);
+}
+int zk_fr_prefix_sum(zk_ctx* ctx, const void* d_a, void* d_z, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_a && d_z && d_a != d_z, "null or aliased pointer");
+    return scan_run<OpAdd>(ctx, (const Fr*)d_a, (Fr*)d_z, n);
+}
+
+int zk_poly_eval(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_x, void* h_out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_coeffs && h_x && h_out, "null pointer");
+    if (n == 0) { memset(h_out, 0, sizeof(Fr)); return ZK_OK; }
+    Fr *lo, *hi; int h;
+    int rc = build_pow_table(ctx, SC_TMP, *(const Fr*)h_x, n, &lo, &hi, &h);
+    if (rc) return rc;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    Fr* partial = (Fr*)ctx->get_scratch(SC_POLY2, sizeof(Fr) * (blocks + 1));
+    if (!partial) return ZK_ERR_OOM;
+    hipLaunchKernelGGL(k_eval_partial, dim3(blocks), dim3(256), 0, ctx->stream, (const Fr*)d_coeffs, (uint64_t)n, lo, hi, h, partial);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, partial + blocks);
+    ZK_CHECK_LAUNCH(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(h_out, partial + blocks, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_z, void* d_q) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_coeffs && h_z && d_q && d_q != d_coeffs, "null or aliased pointer");
+    if (n < 2) return ZK_OK;
+    const uint64_t nm1 = n - 1;
+    const Fr z = *(const Fr*)h_z;
+    const dim3 g((unsigned)((nm1 + 255) / 256)), t(256);
+    if (z.is_zero()) {   // q[i] = c[i+1]
+        hipLaunchKernelGGL(k_copy_shift, g, t, 0, ctx->stream, (const Fr*)d_coeffs, nm1, (Fr*)d_q);
+        ZK_CHECK_LAUNCH(ctx);
+        return ZK_OK;
+    }
+    // q[i] = z^-i * sum_{j >= i} c[j+1] z^j  = z^-i * (total - exclusive_prefix(w)[i]),  w[j] = c[j+1] z^j
+    Fr *lo, *hi; int h;
+    int rc = build_pow_table(ctx, SC_TMP, z, nm1, &lo, &hi, &h);
+    if (rc) return rc;
+    Fr* w = (Fr*)ctx->get_scratch(SC_POLY, sizeof(Fr) * (2 * nm1 + 2));
+    if (!w) return ZK_ERR_OOM;
+    Fr* excl = w + nm1;
+    Fr* total = excl + nm1;
+    hipLaunchKernelGGL(k_weight_shift, g, t, 0, ctx->stream, (const Fr*)d_coeffs, nm1, lo, hi, h, w);
+    ZK_CHECK_LAUNCH(ctx);
+    rc = scan_run<OpAdd>(ctx, w, excl, nm1);
+    if (rc) return rc;
+    // total = excl[nm1-1] + w[nm1-1]
+    hipLaunchKernelGGL((k_vec_op<Fr, ZK_OP_ADD>), dim3(1), dim3(64), 0, ctx->stream, (const Fr*)(excl + (nm1 - 1)), (const Fr*)(w + (nm1 - 1)), total, (uint64_t)1);
+    ZK_CHECK_LAUNCH(ctx);
+    Fr zinv = inv(z);
+    rc = build_pow_table(ctx, SC_TMP, zinv, nm1, &lo, &hi, &h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_kate_finish, g, t, 0, ctx->stream, (const Fr*)excl, (const Fr*)total, nm1, lo, hi, h, (Fr*)d_q);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+}  // extern "C"
