@@ -62,6 +62,16 @@ int zk_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int zk_timer_start(zk_ctx* ctx);
 int zk_timer_stop_ms(zk_ctx* ctx, float* ms);   /* synchronises on the stop event */
 
+/* Per-kernel HIP-event profiling on the context stream.  While enabled, every named kernel group
+ * ("msm_digits", "msm_sort", "msm_buckets", "msm_reduce", "msm_tail_host", "ntt_pass", "ntt_last",
+ * ...) is bracketed by an event pair; zk_prof_get drains the stream and returns the accumulated
+ * device milliseconds and launch count for one name.                                            */
+int zk_prof_enable(zk_ctx* ctx, int on);
+int zk_prof_reset(zk_ctx* ctx);
+int zk_prof_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* count);
+/* writes a ';'-separated list of the names seen so far into buf */
+int zk_prof_names(zk_ctx* ctx, char* buf, size_t len);
+
 /* ---- field vectors (halo2curves Fr/Fq Add/Sub/Mul, element-wise)  -- SURVEY 8a K4/K10 ---------- */
 int zk_field_vec_op(zk_ctx* ctx, int field, int op, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* out[i] = a[i] * s  (s: host pointer to one element) */

@@ -175,6 +175,23 @@ class Context:
         self._ck(lib().zk_timer_stop_ms(self.h, ctypes.byref(ms)))
         return ms.value
 
+    # ---- profiling
+    def prof_enable(self, on: bool = True):
+        self._ck(lib().zk_prof_enable(self.h, ctypes.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        self._ck(lib().zk_prof_reset(self.h))
+
+    def prof_get(self, name: str):
+        ms, cnt = ctypes.c_double(), ctypes.c_uint64()
+        self._ck(lib().zk_prof_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    def prof_names(self):
+        buf = ctypes.create_string_buffer(4096)
+        self._ck(lib().zk_prof_names(self.h, buf, ctypes.c_size_t(4096)))
+        return [x for x in buf.value.decode().split(";") if x]
+
     # ---- field vectors
     def field_vec_op(self, field: int, op: int, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):
         self._ck(lib().zk_field_vec_op(self.h, field, op, ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))

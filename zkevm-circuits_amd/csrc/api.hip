@@ -58,6 +58,8 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->domains.clear();
+    ctx->prof_resolve();
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -129,6 +131,38 @@ int zk_timer_stop_ms(zk_ctx* ctx, float* ms) {
     ZK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ZK_HIP(ctx, hipEventSynchronize(ctx->ev1));
     ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return ZK_OK;
+}
+int zk_prof_enable(zk_ctx* ctx, int on) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ctx->prof_on = on != 0;
+    return ZK_OK;
+}
+int zk_prof_reset(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_resolve();
+    ctx->prof.clear();
+    return ZK_OK;
+}
+int zk_prof_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* count) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, name && total_ms && count, "null pointer");
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_resolve();
+    auto it = ctx->prof.find(name);
+    *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    *count = it == ctx->prof.end() ? 0 : it->second.count;
+    return ZK_OK;
+}
+int zk_prof_names(zk_ctx* ctx, char* buf, size_t len) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, buf && len, "null pointer");
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_resolve();
+    std::string s;
+    for (auto& kv : ctx->prof) { if (!s.empty()) s += ";"; s += kv.first; }
+    snprintf(buf, len, "%s", s.c_str());
     return ZK_OK;
 }
 int zk_device_info(zk_ctx* ctx, char* name, size_t len, int* cu_count, size_t* hbm_bytes) {

@@ -36,6 +36,32 @@ struct zk_ctx {
     zk::Scratch scratch[8];
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
     std::vector<void*> pinned;   // small pinned host staging buffers
+    // per-kernel HIP-event profiling (zk_prof_*): off by default
+    bool prof_on = false;
+    struct ProfEntry { double ms = 0; uint64_t count = 0; };
+    std::map<std::string, ProfEntry> prof;
+    struct ProfPending { const char* name; hipEvent_t a, b; };
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void prof_resolve() {
+        for (auto& p : prof_pending) {
+            float ms = 0;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                auto& e = prof[p.name];
+                e.ms += ms;
+                e.count += 1;
+            }
+            prof_pool.push_back(p.a);
+            prof_pool.push_back(p.b);
+        }
+        prof_pending.clear();
+    }
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -57,6 +83,17 @@ struct zk_ctx {
         if (e != hipSuccess) { s.ptr = nullptr; fail(ZK_ERR_OOM, "scratch alloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
         s.cap = want;
         return s.ptr;
+    }
+};
+
+// RAII scope: records a HIP event pair around the enclosed launches on ctx->stream
+struct ZkProfScope {
+    zk_ctx* c; const char* name; hipEvent_t a = nullptr;
+    ZkProfScope(zk_ctx* ctx, const char* n) : c(ctx), name(n) {
+        if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ZkProfScope() {
+        if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({name, a, b}); }
     }
 };
 

@@ -185,20 +185,29 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     G1Xyzz* partial = buckets + nb;
     G1Xyzz* wsum = partial + (size_t)pl.W * red_blocks;
 
-    ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)nb * 4, ctx->stream));
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
-    hipLaunchKernelGGL(k_msm_count, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, counts);
-    ZK_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, cursor);
-    ZK_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_msm_scatter, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, cursor, idx);
-    ZK_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, nb, buckets);
-    ZK_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)buckets, pl.B, partial);
-    ZK_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)partial, red_blocks, wsum);
-    ZK_CHECK_LAUNCH(ctx);
+    {
+        ZkProfScope ps(ctx, "msm_sort");
+        ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)nb * 4, ctx->stream));
+        hipLaunchKernelGGL(k_msm_count, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, counts);
+        ZK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, cursor);
+        ZK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_msm_scatter, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, cursor, idx);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    {
+        ZkProfScope ps(ctx, "msm_buckets");
+        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, nb, buckets);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    {
+        ZkProfScope ps(ctx, "msm_reduce");
+        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)buckets, pl.B, partial);
+        ZK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)partial, red_blocks, wsum);
+        ZK_CHECK_LAUNCH(ctx);
+    }
 
     std::vector<G1Xyzz> hw(pl.W);
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, sizeof(G1Xyzz) * pl.W, hipMemcpyDeviceToHost, ctx->stream));

@@ -324,6 +324,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         Fr* out = (p == P - 2) ? scratch : d_data;
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
+        ZkProfScope pscope(ctx, "ntt_pass");
         hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, out, ps.tw,
                            dom->d_lo, p == 0 ? dom->d_hi_scaled : dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift);
         ZK_CHECK_LAUNCH(ctx);
@@ -338,6 +339,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const int tile = 1 << (ps.log_np + log_t);
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         const int use_scale = (P == 1 && scale) ? 1 : 0;
+        ZkProfScope pscope(ctx, "ntt_last");
         hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, d_data, ps.tw,
                            ps.log_np, log_t, log_n1, log_mid, use_scale, scale ? *scale : Fr::one());
         ZK_CHECK_LAUNCH(ctx);
