@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../zkevm-circuits_amd/csrc/ff.cuh"
+#include "../zkevm-circuits_amd/csrc/ff29.cuh"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -115,6 +116,36 @@ __global__ void k_field(uint64_t* out, const F* in) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 29-bit-limb Montgomery product chains
+template <class P, int OP>
+__global__ void k_field29(uint64_t* out, const zk::Fp<typename P::P32>* in) {
+    zk::F29<P> a[4], b = zk::unpack29<P>(zk::ldg(in + 4));
+    for (int i = 0; i < 4; ++i) { auto x = zk::ldg(in + i); x.l[0] ^= threadIdx.x; x.l[7] &= 0x0fffffffu; a[i] = zk::unpack29<P>(x); }
+    for (int it = 0; it < ITERS / 8; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (OP == 0) a[i] = zk::mul29(a[i], b);
+            if (OP == 1) { a[i] = zk::add29(a[i], b); zk::normalize29(a[i]); a[i].l[8] &= 0xffff; }
+            if (OP == 2) { a[i] = zk::sub29(a[i], b); zk::normalize29(a[i]); a[i].l[8] &= 0xffff; }
+            if (OP == 3) a[i] = zk::mul29(a[i], a[i]);
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 9; ++j) s += a[i].l[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// correctness dump: o32[i] = a*b (R=2^256 Montgomery), o29[i] = pack(mul29(unpack a, unpack b))
+__global__ void k_check29(const zk::Fq* a, const zk::Fq* b, zk::Fq* o32, zk::Fq* o29, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    zk::Fq x = zk::ldg(a + i), y = zk::ldg(b + i);
+    zk::stg(o32 + i, x * y);
+    zk::Fq29 r = zk::mul29(zk::unpack29<zk::Fq29P>(x), zk::unpack29<zk::Fq29P>(y));
+    zk::Fq29 d = zk::sub29(zk::add29(r, r), r);     // exercises add/sub: r + r - r + 4p
+    zk::normalize29(d);
+    zk::stg(o29 + i, zk::pack29(d));
+}
+
 template <class K>
 double time_kernel(K launch, int reps = 5) {
     hipEvent_t e0, e1;
@@ -163,5 +194,24 @@ int main() {
     report("Fr add", time_kernel([&] { hipLaunchKernelGGL((k_field<zk::Fr, 1>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
     report("Fr sub", time_kernel([&] { hipLaunchKernelGGL((k_field<zk::Fr, 2>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
     report("Fq mul", time_kernel([&] { hipLaunchKernelGGL((k_field<zk::Fq, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 mul", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sqr(as mul)", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 3>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 add+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 1>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sub+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 2>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fr29 mul", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
+    {   // correctness dump for offline verification (tools/check29.py)
+        const int n = 4096;
+        std::vector<zk::Fq> ha(n), hb(n), h32(n), h29(n);
+        uint64_t st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+        for (int i = 0; i < n; ++i) { for (int j = 0; j < 8; ++j) { ha[i].l[j] = rnd(); hb[i].l[j] = rnd(); } ha[i].l[7] &= 0x1fffffffu; hb[i].l[7] &= 0x1fffffffu; }
+        zk::Fq *da, *db, *d32, *d29;
+        CK(hipMalloc(&da, n * 32)); CK(hipMalloc(&db, n * 32)); CK(hipMalloc(&d32, n * 32)); CK(hipMalloc(&d29, n * 32));
+        CK(hipMemcpy(da, ha.data(), n * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), n * 32, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_check29, dim3(n / 256), dim3(256), 0, 0, da, db, d32, d29, n);
+        CK(hipMemcpy(h32.data(), d32, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(h29.data(), d29, n * 32, hipMemcpyDeviceToHost));
+        FILE* f = fopen("gpurun_out/check29.bin", "wb");
+        if (f) { fwrite(ha.data(), 32, n, f); fwrite(hb.data(), 32, n, f); fwrite(h32.data(), 32, n, f); fwrite(h29.data(), 32, n, f); fclose(f); }
+    }
     return 0;
 }

@@ -77,31 +77,105 @@ __global__ void k_msm_scatter(const Fr* __restrict__ scalars, uint64_t n, int c,
     });
 }
 
-// exclusive scan of u32 counts (single block, 1024 threads, contiguous chunk per thread);
-// writes offsets[0..cnt] (cnt+1 entries) and a copy into cursor[0..cnt)
-__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t sh[1024];
-    const uint32_t per = (cnt + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, cnt);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += counts[i];
-    sh[threadIdx.x] = sum;
+// ---- exclusive scan of the bucket counts, three small kernels (4096 counts per block) ----------
+constexpr int SCAN_T = 1024, SCAN_ITEMS = 4;
+__device__ __forceinline__ uint32_t block_scan_u32(uint32_t v, uint32_t* sh, uint32_t* total) {
+    sh[threadIdx.x] = v;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = sh[threadIdx.x];
-        if ((int)threadIdx.x >= off) v += sh[threadIdx.x - off];
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+        uint32_t x = sh[threadIdx.x];
+        if ((int)threadIdx.x >= off) x += sh[threadIdx.x - off];
         __syncthreads();
-        sh[threadIdx.x] = v;
+        sh[threadIdx.x] = x;
         __syncthreads();
     }
-    uint32_t run = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
-    for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; cursor[i] = run; run += counts[i]; }
-    if (threadIdx.x == 1023) offsets[cnt] = sh[1023];
+    *total = sh[SCAN_T - 1];
+    const uint32_t ex = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
+    __syncthreads();
+    return ex;
+}
+__global__ void __launch_bounds__(SCAN_T) k_scan_u32_a(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t sh[SCAN_T];
+    const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS) + threadIdx.x * SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { c[k] = base + k < cnt ? counts[base + k] : 0u; sum += c[k]; }
+    uint32_t total;
+    uint32_t run = block_scan_u32(sum, sh, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < cnt) offsets[base + k] = run; run += c[k]; }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint32_t nblocks, uint32_t* offsets, uint32_t cnt) {
+    __shared__ uint32_t sh[SCAN_T];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += SCAN_T) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_tot[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_u32(v, sh, &total);
+        if (i < nblocks) block_tot[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) offsets[cnt] = carry;
+}
+// adds the block offset, mirrors into `cursor`, and bins every bucket by size (descending order
+// of size -> a wave works on buckets of equal length; big ones start first)
+constexpr uint32_t SIZE_BINS = 256;
+__global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_tot,
+                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ size_hist) {
+    __shared__ uint32_t lh[SIZE_BINS];
+    if (threadIdx.x < SIZE_BINS) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t off = block_tot[blockIdx.x];
+    const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_T + threadIdx.x;
+        if (i < cnt) {
+            const uint32_t o = offsets[i] + off;
+            offsets[i] = o;
+            cursor[i] = o;
+            atomicAdd(&lh[min(counts[i], SIZE_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SIZE_BINS && lh[threadIdx.x]) atomicAdd(&size_hist[threadIdx.x], lh[threadIdx.x]);
+}
+// size_hist (256 bins) -> start offset of each bin in the descending-size order
+__global__ void k_size_bins_scan(uint32_t* size_hist) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t run = 0;
+    for (int b = SIZE_BINS - 1; b >= 0; --b) { const uint32_t c = size_hist[b]; size_hist[b] = run; run += c; }
+}
+// order[pos] = bucket id, grouped by size bin (block-aggregated reservation of output ranges)
+__global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order) {
+    __shared__ uint32_t lh[SIZE_BINS], lbase[SIZE_BINS];
+    if (threadIdx.x < SIZE_BINS) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
+    uint32_t bin[SCAN_ITEMS], rank[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_T + threadIdx.x;
+        bin[k] = i < cnt ? min(counts[i], SIZE_BINS - 1) : 0xffffffffu;
+        if (i < cnt) rank[k] = atomicAdd(&lh[bin[k]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SIZE_BINS && lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&size_cursor[threadIdx.x], lh[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_T + threadIdx.x;
+        if (i < cnt) order[lbase[bin[k]] + rank[k]] = i;
+    }
 }
 
-__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx, uint32_t nbuckets, G1Xyzz* __restrict__ buckets) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
+__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ order, uint32_t nbuckets, G1Xyzz* __restrict__ buckets) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbuckets) return;
+    const uint32_t b = order[t];
     const uint32_t lo = offsets[b], hi = offsets[b + 1];
     G1Xyzz acc = G1Xyzz::identity();
     for (uint32_t j = lo; j < hi; ++j) {
@@ -171,14 +245,18 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
 
-    // u32 workspace: counts[nb] | offsets[nb+1] | cursor[nb] | idx[n*W]
-    const size_t words = (size_t)nb * 3 + 1 + (size_t)n * pl.W;
+    // u32 workspace: counts[nb] | size_hist[256] | offsets[nb+1] | cursor[nb] | order[nb] | block_tot | idx[n*W]
+    const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+    const size_t words = (size_t)nb * 4 + 1 + SIZE_BINS + scan_blocks + (size_t)n * pl.W;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* counts = ws;
-    uint32_t* offsets = counts + nb;
+    uint32_t* size_hist = counts + nb;
+    uint32_t* offsets = size_hist + SIZE_BINS;
     uint32_t* cursor = offsets + nb + 1;
-    uint32_t* idx = cursor + nb;
+    uint32_t* order = cursor + nb;
+    uint32_t* block_tot = order + nb;
+    uint32_t* idx = block_tot + scan_blocks;
     const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
     G1Xyzz* buckets = (G1Xyzz*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz) * ((size_t)nb + (size_t)pl.W * red_blocks + pl.W));
     if (!buckets) return ZK_ERR_OOM;
@@ -188,17 +266,21 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)nb * 4, ctx->stream));
+        ZK_HIP(ctx, hipMemsetAsync(counts, 0, ((size_t)nb + SIZE_BINS) * 4, ctx->stream));
         hipLaunchKernelGGL(k_msm_count, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, counts);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, cursor);
+        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, block_tot);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
+        hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, (const uint32_t*)block_tot, cursor, size_hist);
+        hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist);
+        hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_msm_scatter, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, cursor, idx);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
         ZkProfScope ps(ctx, "msm_buckets");
-        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, nb, buckets);
+        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, (const uint32_t*)order, nb, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
     {

@@ -6,42 +6,42 @@
 // MI355X design: mixed-radix Cooley-Tukey in P <= 3 passes of <= 2^10 points each.  A pass stages
 // a [digit x T] tile in LDS (T consecutive elements of the fastest-varying remaining index, so
 // every global access is a T*32-byte contiguous run), runs all log2(n_p) radix-2 stages out of
-// LDS, applies the inter-pass twiddle omega^(j''*i_p) on the way out (two-level table, also carries
-// the 1/n scale of the inverse transform for free) and writes back.  Input index is read big-endian
-// in the digits, output little-endian; the last pass writes to the digit-reversed position, so
-// no separate transpose / bit-reversal kernel exists.  LDS is laid out as four u64 planes so a
-// wave's accesses are 8-byte strided (ds_read_b64 / ds_write_b64, bank-conflict-free on
-// contiguous runs).
+// LDS, applies the inter-pass twiddle omega^(j''*i_p) on the way out (two-level table) and writes
+// back.  Input index is read big-endian in the digits, output little-endian; the last pass writes
+// to the digit-reversed position, so no separate transpose / bit-reversal kernel exists.
+//
+// Arithmetic: inside a pass elements live in LDS as nine 29-bit limbs (ff29.cuh; one u32 plane
+// per limb, so a wave's accesses are 4-byte strided and bank-conflict-free on contiguous runs).
+// Butterflies use the carry-free 29-bit Montgomery product with twiddles held in R' = 2^261 form,
+// so data stays in halo2curves' R = 2^256 form with no conversion; sums are kept lazily reduced
+// and only the value written back to HBM is brought to the canonical representative.
 #include "ctx.hpp"
+#include "ff29.cuh"
 
 namespace zk {
 
 constexpr int NTT_MAX_DIGIT = 10;
-constexpr int NTT_TILE = 4096;         // elements staged per workgroup (128 KiB of LDS)
+constexpr int NTT_TILE = 4096;         // elements staged per workgroup (9 x 4 B x 4096 = 144 KiB LDS)
 constexpr int NTT_THREADS = 1024;
+constexpr int NTT_LDS_BYTES_PER_ELT = 36;
 
 struct NttPass {
     int log_np;     // digit size
-    int log_t;      // tile columns
-    int log_m;      // stride of the digit (non-last) / unused (last)
-    const Fr* tw;   // n_p/2 butterfly twiddles: (omega^(n/n_p))^x
+    int log_m;      // stride of the digit (non-last)
+    const Fr* tw;   // n_p/2 butterfly twiddles (omega^(n/n_p))^x, R' form
 };
 
 struct NttDomain {
     uint32_t log_n = 0;
-    Fr omega;
-    bool has_scale = false;
-    Fr scale;
     int npass = 0;
     NttPass pass[3];
     int h = 0;                // two-level split: omega^e = lo[e & (2^h-1)] * hi[e >> h]
-    Fr* d_lo = nullptr;       // 2^h entries
-    Fr* d_hi = nullptr;       // 2^(log_n-h) entries
-    Fr* d_hi_scaled = nullptr; // same, pre-multiplied by `scale` (used by pass 0 only); == d_hi if no scale
+    Fr* d_lo = nullptr;       // 2^h entries, R' form
+    Fr* d_hi = nullptr;       // 2^(log_n-h) entries, R' form
     Fr* d_tw[3] = {nullptr, nullptr, nullptr};
+    Fr final_mul;             // (scale or 1) in R' form: last-pass output multiplier
     ~NttDomain() {
         if (d_lo) (void)hipFree(d_lo);
-        if (d_hi_scaled && d_hi_scaled != d_hi) (void)hipFree(d_hi_scaled);
         if (d_hi) (void)hipFree(d_hi);
         for (auto p : d_tw) if (p) (void)hipFree(p);
     }
@@ -50,23 +50,31 @@ struct NttDomain {
 // ------------------------------------------------------------------------------------- helpers
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-struct LdsPlanes {
-    uint64_t* p;     // 4 planes of `stride` u64
-    int stride;
-    __device__ __forceinline__ Fr load(int idx) const {
-        Fr r;
+// R (2^256) Montgomery form -> R' (2^261) form: multiply by 32
+__host__ __device__ __forceinline__ Fr to_rprime(Fr x) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { uint64_t v = p[k * stride + idx]; r.l[2 * k] = (uint32_t)v; r.l[2 * k + 1] = (uint32_t)(v >> 32); }
+    for (int i = 0; i < 5; ++i) x = dbl(x);
+    return x;
+}
+
+struct Lds29 {
+    uint32_t* p;     // 9 planes of `stride` u32
+    int stride;
+    __device__ __forceinline__ Fr29 load(int idx) const {
+        Fr29 r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r.l[k] = p[k * stride + idx];
         return r;
     }
-    __device__ __forceinline__ void store(int idx, const Fr& v) const {
+    __device__ __forceinline__ void store(int idx, const Fr29& v) const {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k * stride + idx] = (uint64_t)v.l[2 * k] | ((uint64_t)v.l[2 * k + 1] << 32);
+        for (int k = 0; k < 9; ++k) p[k * stride + idx] = v.l[k];
     }
 };
 
-// out[j] = base^j * mul   (table builder; one thread per entry, square-and-multiply)
-__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count) {
+// out[j] = base^j * mul   (table builder; one thread per entry, square-and-multiply).
+// rprime != 0: store in R' = 2^261 Montgomery form.
+__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count, int rprime) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fr r = mul, b = base;
@@ -76,24 +84,29 @@ __global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count) {
         b = sqr(b);
         e >>= 1;
     }
-    stg(out + j, r);
+    stg(out + j, rprime ? to_rprime(r) : r);
 }
 
 __device__ __forceinline__ Fr two_level(const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint32_t e) {
     return ldg(lo + (e & ((1u << h) - 1))) * ldg(hi + (e >> h));
 }
+// both tables in R' form -> product in R' form, normalised, < 2p
+__device__ __forceinline__ Fr29 two_level29(const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint32_t e) {
+    return mul29(unpack29<Fr29P>(ldg(lo + (e & ((1u << h) - 1)))), unpack29<Fr29P>(ldg(hi + (e >> h))));
+}
 
 // ------------------------------------------------------------------------------ non-last pass
 // Tile = [n_p digits][T columns], element (d, c) lives at base + d*m + c with
 // base = hi_idx * (n_p*m) + blk*T.  DIT: loaded bit-reversed in d, leaves in natural d = i_p.
-// On the way out: multiply by omega^((j'' * i_p) << tw_shift) * [scale], j'' = blk*T + c.
+// On the way out: multiply by omega^((j'' * i_p) << tw_shift), j'' = blk*T + c.
+// LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
            const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
-    LdsPlanes L{smem, tile};
-    const int T = 1 << log_t, np = 1 << log_np;
+    Lds29 L{smem, tile};
+    const int T = 1 << log_t;
     const uint64_t m = 1ull << log_m;
     const uint32_t tiles_per_hi = (uint32_t)(m >> log_t);
     const uint32_t hi_idx = blockIdx.x / tiles_per_hi, blk = blockIdx.x % tiles_per_hi;
@@ -103,7 +116,7 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
     for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
         const int c = pos & (T - 1), dl = pos >> log_t;
         const uint32_t d = bitrev(dl, log_np);
-        L.store(pos, ldg(src + base + (uint64_t)d * m + c));
+        L.store(pos, unpack29<Fr29P>(ldg(src + base + (uint64_t)d * m + c)));
     }
     __syncthreads();
     for (int s = 0; s < log_np; ++s) {
@@ -113,65 +126,75 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
             const int j = b & (half - 1);
             const int lo_d = ((b >> s) << (s + 1)) | j;
             const int i0 = (lo_d << log_t) | c, i1 = i0 + (half << log_t);
-            Fr u = L.load(i0), v = L.load(i1);
-            if (j) v = v * ldg(tw + ((uint32_t)j << (log_np - 1 - s)));
-            L.store(i0, u + v);
-            L.store(i1, u - v);
+            Fr29 u = L.load(i0), x = L.load(i1);
+            // v = x * w  (normalised, < 2p); w = 1 still goes through the product so that v is
+            // reduced: x itself may be a lazy sum
+            Fr29 v = mul29(x, unpack29<Fr29P>(ldg(tw + ((uint32_t)j << (log_np - 1 - s)))));
+            Fr29 a0 = add29(u, v), a1 = sub29k<4>(u, v);
+            normalize29(a0);
+            normalize29(a1);
+            L.store(i0, a0);
+            L.store(i1, a1);
         }
         __syncthreads();
     }
     for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
         const int c = pos & (T - 1), d = pos >> log_t;
-        Fr v = L.load(pos);
         const uint32_t jpp = (blk << log_t) + c;
         const uint32_t e = (jpp * (uint32_t)d) << tw_shift;
-        v = v * two_level(lo, hi, h, e);
-        stg(dst + base + (uint64_t)d * m + c, v);
+        Fr29 v = mul29(L.load(pos), two_level29(lo, hi, h, e));
+        stg(dst + base + (uint64_t)d * m + c, pack29_lt2p(v));
     }
 }
 
 // ----------------------------------------------------------------------------------- last pass
 // Rows of n_P contiguous elements; tile = T rows i1 = blk*T + c (row stride = midN * n_P) at a
-// fixed middle digit `mid`.  DIF: natural load, bit-reversed inside LDS on the way out.
-// Output index = i1 + n1 * (mid + midN * i_P).   LDS layout [c][d].
+// fixed middle digit `mid`.  LDS layout [c][d].  DIT like the other passes: the tile is filled in
+// LDS order (bank-conflict-free) from the bit-reversed global digit -- 32-byte sectors of a
+// 32 KiB row, all consumed by the same workgroup in the same sweep -- and leaves in natural order.
+// Output index = i1 + n1 * (mid + midN * i_P).  Every output is multiplied by `fin` (1 or the
+// inverse-transform scale, R' form), which also brings the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, int log_np, int log_t,
-           int log_n1, int log_mid, int use_scale, Fr scale) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+           int log_n1, int log_mid, Fr fin) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
-    LdsPlanes L{smem, tile};
+    Lds29 L{smem, tile};
     const int np = 1 << log_np;
     const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
 
     for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
-        const int d = pos & (np - 1), c = pos >> log_np;
+        const int dl = pos & (np - 1), c = pos >> log_np;
+        const uint32_t d = bitrev(dl, log_np);
         const uint64_t i1 = ((uint64_t)blk << log_t) + c;
-        L.store(pos, ldg(src + (((i1 << log_mid) + mid) << log_np) + d));
+        L.store(pos, unpack29<Fr29P>(ldg(src + (((i1 << log_mid) + mid) << log_np) + d)));
     }
     __syncthreads();
-    for (int s = log_np - 1; s >= 0; --s) {
+    for (int s = 0; s < log_np; ++s) {
         const int half = 1 << s;
         for (int bf = threadIdx.x; bf < tile / 2; bf += blockDim.x) {
             const int b = bf & (np / 2 - 1), c = bf >> (log_np - 1);
             const int j = b & (half - 1);
             const int lo_d = ((b >> s) << (s + 1)) | j;
             const int i0 = (c << log_np) | lo_d, i1 = i0 + half;
-            Fr u = L.load(i0), v = L.load(i1);
-            Fr t = u - v;
-            if (j) t = t * ldg(tw + ((uint32_t)j << (log_np - 1 - s)));
-            L.store(i0, u + v);
-            L.store(i1, t);
+            Fr29 u = L.load(i0), x = L.load(i1);
+            Fr29 v = mul29(x, unpack29<Fr29P>(ldg(tw + ((uint32_t)j << (log_np - 1 - s)))));
+            Fr29 a0 = add29(u, v), a1 = sub29k<4>(u, v);
+            normalize29(a0);
+            normalize29(a1);
+            L.store(i0, a0);
+            L.store(i1, a1);
         }
         __syncthreads();
     }
     const int T = 1 << log_t;
+    const Fr29 fin29 = unpack29<Fr29P>(fin);
     for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
         const int c = pos & (T - 1), d = pos >> log_t;       // c fastest: T consecutive outputs
-        Fr v = L.load((c << log_np) | (int)bitrev(d, log_np));
-        if (use_scale) v = v * scale;
+        Fr29 v = mul29(L.load((c << log_np) | d), fin29);
         const uint64_t i1 = ((uint64_t)blk << log_t) + c;
         const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)d << log_mid)) << log_n1);
-        stg(dst + o, v);
+        stg(dst + o, pack29_lt2p(v));
     }
 }
 
@@ -194,8 +217,8 @@ __global__ void k_distribute_powers(Fr* a, const Fr* __restrict__ lo, const Fr* 
 }
 
 // ----------------------------------------------------------------------------------- host side
-static int build_powers(zk_ctx* ctx, const Fr& base, const Fr& mul, Fr* d_out, uint32_t count) {
-    hipLaunchKernelGGL(k_powers, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, mul, d_out, count);
+static int build_powers(zk_ctx* ctx, const Fr& base, const Fr& mul, Fr* d_out, uint32_t count, int rprime) {
+    hipLaunchKernelGGL(k_powers, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, mul, d_out, count, rprime);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
@@ -215,9 +238,7 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
     if (it != ctx->domains.end()) { *out = it->second; return ZK_OK; }
     auto d = std::make_shared<NttDomain>();
     d->log_n = log_n;
-    d->omega = omega;
-    d->has_scale = scale != nullptr;
-    if (scale) d->scale = *scale;
+    d->final_mul = to_rprime(scale ? *scale : Fr::one());
     const int P = log_n <= NTT_MAX_DIGIT ? 1 : (log_n <= 2 * NTT_MAX_DIGIT ? 2 : 3);
     d->npass = P;
     int rem = (int)log_n;
@@ -233,18 +254,12 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
         const uint32_t nlo = 1u << d->h, nhi = 1u << (log_n - d->h);
         ZK_HIP(ctx, hipMalloc(&d->d_lo, sizeof(Fr) * nlo));
         ZK_HIP(ctx, hipMalloc(&d->d_hi, sizeof(Fr) * nhi));
-        int rc = build_powers(ctx, omega, Fr::one(), d->d_lo, nlo);
+        int rc = build_powers(ctx, omega, Fr::one(), d->d_lo, nlo, 1);
         if (rc) return rc;
         Fr step = omega;
         for (int i = 0; i < d->h; ++i) step = sqr(step);
-        rc = build_powers(ctx, step, Fr::one(), d->d_hi, nhi);
+        rc = build_powers(ctx, step, Fr::one(), d->d_hi, nhi, 1);
         if (rc) return rc;
-        d->d_hi_scaled = d->d_hi;
-        if (scale) {
-            ZK_HIP(ctx, hipMalloc(&d->d_hi_scaled, sizeof(Fr) * nhi));
-            rc = build_powers(ctx, step, *scale, d->d_hi_scaled, nhi);
-            if (rc) return rc;
-        }
     }
     for (int p = 0; p < P; ++p) {
         const int b = d->pass[p].log_np;
@@ -252,7 +267,7 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
         ZK_HIP(ctx, hipMalloc(&d->d_tw[p], sizeof(Fr) * cnt));
         Fr w = omega;
         for (uint32_t i = 0; i < log_n - (uint32_t)b; ++i) w = sqr(w);   // omega^(n/n_p)
-        int rc = build_powers(ctx, w, Fr::one(), d->d_tw[p], cnt);
+        int rc = build_powers(ctx, w, Fr::one(), d->d_tw[p], cnt, 1);
         if (rc) return rc;
         d->pass[p].tw = d->d_tw[p];
     }
@@ -265,8 +280,8 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
 static bool g_attr_set = false;
 static int set_lds_attr(zk_ctx* ctx) {
     if (g_attr_set) return ZK_OK;
-    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 32));
-    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 32));
+    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT));
+    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT));
     g_attr_set = true;
     return ZK_OK;
 }
@@ -292,11 +307,11 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
         Fr* tab = (Fr*)ctx->get_scratch(SC_TMP, sizeof(Fr) * (nlo + nhi));
         if (!tab) return ZK_ERR_OOM;
-        int r = build_powers(ctx, g, Fr::one(), tab, nlo);
+        int r = build_powers(ctx, g, Fr::one(), tab, nlo, 0);
         if (r) return r;
         Fr step = g;
         for (int i = 0; i < h; ++i) step = sqr(step);
-        r = build_powers(ctx, step, Fr::one(), tab + nlo, nhi);
+        r = build_powers(ctx, step, Fr::one(), tab + nlo, nhi, 0);
         if (r) return r;
         hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_data, tab, tab + nlo, h, n);
         ZK_CHECK_LAUNCH(ctx);
@@ -325,8 +340,8 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
         ZkProfScope pscope(ctx, "ntt_pass");
-        hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, out, ps.tw,
-                           dom->d_lo, p == 0 ? dom->d_hi_scaled : dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, out, ps.tw,
+                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift);
         ZK_CHECK_LAUNCH(ctx);
         cur = out;
     }
@@ -338,10 +353,9 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         if (log_t > log_n1) log_t = log_n1;
         const int tile = 1 << (ps.log_np + log_t);
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
-        const int use_scale = (P == 1 && scale) ? 1 : 0;
         ZkProfScope pscope(ctx, "ntt_last");
-        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * 32, ctx->stream, cur, d_data, ps.tw,
-                           ps.log_np, log_t, log_n1, log_mid, use_scale, scale ? *scale : Fr::one());
+        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
+                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul);
         ZK_CHECK_LAUNCH(ctx);
     }
     if (coset_post) { rc = run_distribute(*coset_post); if (rc) return rc; }

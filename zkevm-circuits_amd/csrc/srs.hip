@@ -12,7 +12,7 @@
 
 namespace zk {
 
-__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count);   // ntt.hip
+__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count, int rprime);   // ntt.hip
 
 constexpr int FB_WINDOWS = 32;   // 256 bits / 8
 
@@ -143,14 +143,14 @@ int zk_srs_setup_with_s(zk_ctx* ctx, uint32_t k, const void* h_s, zk_srs** out) 
     Fr* w = sc + n;
     const dim3 g((unsigned)((n + 255) / 256)), t(256);
     // g[i] = s^i * G
-    hipLaunchKernelGGL(k_powers, g, t, 0, ctx->stream, s, Fr::one(), sc, (uint32_t)n);
+    hipLaunchKernelGGL(k_powers, g, t, 0, ctx->stream, s, Fr::one(), sc, (uint32_t)n, 0);
     hipLaunchKernelGGL(k_fb_mul, g, t, 0, ctx->stream, (const Fr*)sc, (const G1Affine*)table, r->g, n);
     // g_lagrange[i] = omega^i (s^n - 1) / (n (s - omega^i)) * G
     const Fr omega = fr_root_of_unity(k);
     Fr sn = s;
     for (uint32_t i = 0; i < k; ++i) sn = sqr(sn);
     const Fr c = (sn - Fr::one()) * fr_inv_host(fr_from_u64(n));
-    hipLaunchKernelGGL(k_powers, g, t, 0, ctx->stream, omega, Fr::one(), w, (uint32_t)n);
+    hipLaunchKernelGGL(k_powers, g, t, 0, ctx->stream, omega, Fr::one(), w, (uint32_t)n, 0);
     hipLaunchKernelGGL(k_lagrange_den, g, t, 0, ctx->stream, (const Fr*)w, s, sc, n);
     ZK_CHECK_LAUNCH(ctx);
     rc = zk_fr_batch_invert(ctx, sc, n);

@@ -10,7 +10,7 @@
 namespace zk {
 
 int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);   // ntt.hip
-__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count); // ntt.hip
+__global__ void k_powers(Fr base, Fr mul, Fr* out, uint32_t count, int rprime); // ntt.hip
 
 template <class F, int OP>
 __global__ void k_vec_op(const F* __restrict__ a, const F* __restrict__ b, F* __restrict__ o, uint64_t n) {
@@ -213,10 +213,10 @@ static int build_pow_table(zk_ctx* ctx, int slot, const Fr& x, uint64_t n, Fr** 
     const uint32_t nlo = 1u << h, nhi = 1u << (bits - h);
     Fr* tab = (Fr*)ctx->get_scratch(slot, sizeof(Fr) * ((size_t)nlo + nhi));
     if (!tab) return ZK_ERR_OOM;
-    hipLaunchKernelGGL(k_powers, dim3((nlo + 255) / 256), dim3(256), 0, ctx->stream, x, Fr::one(), tab, nlo);
+    hipLaunchKernelGGL(k_powers, dim3((nlo + 255) / 256), dim3(256), 0, ctx->stream, x, Fr::one(), tab, nlo, 0);
     Fr step = x;
     for (int i = 0; i < h; ++i) step = sqr(step);
-    hipLaunchKernelGGL(k_powers, dim3((nhi + 255) / 256), dim3(256), 0, ctx->stream, step, Fr::one(), tab + nlo, nhi);
+    hipLaunchKernelGGL(k_powers, dim3((nhi + 255) / 256), dim3(256), 0, ctx->stream, step, Fr::one(), tab + nlo, nhi, 0);
     ZK_CHECK_LAUNCH(ctx);
     *lo = tab; *hi = tab + nlo; *h_out = h;
     return ZK_OK;
