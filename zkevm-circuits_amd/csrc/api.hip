@@ -224,7 +224,10 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
-    return msm_run(ctx, (const Fr*)d_scalars, b, n, (G1Affine*)h_out_affine);
+    const G1Affine* brp = nullptr;
+    int rc = srs_bases_rp(ctx, srs, basis, &brp);
+    if (rc) return rc;
+    return msm_run_rp(ctx, (const Fr*)d_scalars, b, brp, n, (G1Affine*)h_out_affine);
 }
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;

@@ -101,6 +101,9 @@ struct zk_srs {
     uint32_t k = 0;
     zk::G1Affine* g = nullptr;
     zk::G1Affine* g_lagrange = nullptr;
+    // lazily built copies in R' = 2^261 Montgomery form (the MSM kernels' native base format)
+    zk::G1Affine* g_rp = nullptr;
+    zk::G1Affine* g_lagrange_rp = nullptr;
 };
 
 #define ZK_HIP(ctx, call)                                                                          \
@@ -134,4 +137,6 @@ Fr fr_zeta();
 int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale /*nullable*/, const Fr* coset_pre /*nullable: a[i] *= g^i before*/, const Fr* coset_post /*nullable: out[i] *= g^i after*/);
 int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);
 int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out);
+int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
+int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out);
 }  // namespace zk

@@ -19,6 +19,7 @@
 //                (Horner) -- 256 dependent doublings are latency-bound on a GPU lane and take
 //                ~100 us on one CPU core.
 #include "ctx.hpp"
+#include "ec29.cuh"
 #include "host_fq.hpp"
 
 namespace zk {
@@ -171,75 +172,86 @@ __global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __rest
     }
 }
 
-__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
-                                                     const uint32_t* __restrict__ order, uint32_t nbuckets, G1Xyzz* __restrict__ buckets) {
+// bases (canonical, R = 2^256 form) -> R' = 2^261 form (x32 mod p), identity preserved
+__global__ void k_bases_to_rprime(const G1Affine* __restrict__ in, G1Affine* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = ldg(in + i);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { p.x = dbl(p.x); p.y = dbl(p.y); }
+    stg(out + i, p);
+}
+
+__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ order, uint32_t nbuckets, G1Xyzz29* __restrict__ buckets) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets) return;
     const uint32_t b = order[t];
     const uint32_t lo = offsets[b], hi = offsets[b + 1];
-    G1Xyzz acc = G1Xyzz::identity();
+    G1Xyzz29 acc = identity29();
     for (uint32_t j = lo; j < hi; ++j) {
         const uint32_t v = idx[j];
-        G1Affine p = ldg(bases + (v & ~NEG_BIT));
-        if (v & NEG_BIT) p.y = neg(p.y);
-        acc = madd(acc, p);
+        G1Affine29 p = load_affine29(bases_rp + (v & ~NEG_BIT));
+        if ((v & NEG_BIT) && !is_identity29(p)) p.y = neg_canon29(p.y);
+        acc = madd29(acc, p);
     }
-    stg(buckets + b, acc);
+    stg29(buckets + b, acc);
 }
 
 // k * P for small k (< 2^16), MSB-first double-and-add
-__device__ __forceinline__ G1Xyzz mul_small(const G1Xyzz& p, uint32_t k) {
-    G1Xyzz acc = G1Xyzz::identity();
+__device__ __forceinline__ G1Xyzz29 mul_small(const G1Xyzz29& p, uint32_t k) {
+    G1Xyzz29 acc = identity29();
     for (int bit = 31 - __clz(k | 1); bit >= 0; --bit) {
-        acc = dbl(acc);
-        if ((k >> bit) & 1) acc = add(acc, p);
+        acc = dbl29pt(acc);
+        if ((k >> bit) & 1) acc = add29pt(acc, p);
     }
-    return k ? acc : G1Xyzz::identity();
+    return k ? acc : identity29();
 }
 
 constexpr int RED_G = 8;          // buckets folded per lane
 constexpr int RED_THREADS = 256;
 // grid: (groups_per_window / RED_THREADS, W); each block writes one partial per (window, block)
-__global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1Xyzz* __restrict__ buckets, uint32_t B, G1Xyzz* __restrict__ partial) {
-    __shared__ G1Xyzz sh[RED_THREADS];
+__global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1Xyzz29* __restrict__ buckets, uint32_t B, G1Xyzz29* __restrict__ partial) {
+    __shared__ G1Xyzz29 sh[RED_THREADS];
     const uint32_t w = blockIdx.y;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;     // group index in window
     const uint32_t groups = (B + RED_G - 1) / RED_G;
-    G1Xyzz acc = G1Xyzz::identity();
+    G1Xyzz29 acc = identity29();
     if (g < groups) {
         const uint32_t b0 = g * RED_G, b1 = min(b0 + RED_G, B);
-        G1Xyzz running = G1Xyzz::identity();
+        G1Xyzz29 running = identity29();
         for (uint32_t b = b1; b-- > b0;) {
-            running = add(running, ldg(buckets + (uint64_t)w * B + b));
-            acc = add(acc, running);
+            running = add29pt(running, ldg29(buckets + (uint64_t)w * B + b));
+            acc = add29pt(acc, running);
         }
         // acc = sum (b - b0 + 1) * B_b ; lift by b0: + b0 * running
-        if (b0) acc = add(acc, mul_small(running, b0));
+        if (b0) acc = add29pt(acc, mul_small(running, b0));
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[(uint64_t)w * gridDim.x + blockIdx.x] = sh[0];
 }
-// one block per window sums `cnt` partials
-__global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz* __restrict__ partial, uint32_t cnt, G1Xyzz* __restrict__ out) {
-    __shared__ G1Xyzz sh[RED_THREADS];
+// one block per window sums `cnt` partials; output in the canonical R-form XYZZ the host tail reads
+__global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* __restrict__ partial, uint32_t cnt, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz29 sh[RED_THREADS];
     const uint32_t w = blockIdx.x;
-    G1Xyzz acc = G1Xyzz::identity();
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add(acc, ldg(partial + (uint64_t)w * cnt + i));
+    G1Xyzz29 acc = identity29();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + (uint64_t)w * cnt + i));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[w] = sh[0];
+    if (threadIdx.x == 0) stg(out + w, to_std_xyzz(sh[0]));
 }
 
-int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out) {
+// bases_rp: device bases already in R' form (SRS cache) or nullptr -> converted into scratch
+int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine)); return ZK_OK; }
     if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
     const MsmPlan pl = make_plan(n);
@@ -258,12 +270,22 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     uint32_t* block_tot = order + nb;
     uint32_t* idx = block_tot + scan_blocks;
     const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
-    G1Xyzz* buckets = (G1Xyzz*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz) * ((size_t)nb + (size_t)pl.W * red_blocks + pl.W));
-    if (!buckets) return ZK_ERR_OOM;
-    G1Xyzz* partial = buckets + nb;
-    G1Xyzz* wsum = partial + (size_t)pl.W * red_blocks;
+    const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks;
+    char* bk = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29 + sizeof(G1Xyzz) * pl.W);
+    if (!bk) return ZK_ERR_OOM;
+    G1Xyzz29* buckets = (G1Xyzz29*)bk;
+    G1Xyzz29* partial = buckets + nb;
+    G1Xyzz* wsum = (G1Xyzz*)(bk + sizeof(G1Xyzz29) * npts29);
 
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
+    if (!d_bases_rp) {
+        G1Affine* conv = (G1Affine*)ctx->get_scratch(SC_MSM_MISC, sizeof(G1Affine) * n);
+        if (!conv) return ZK_ERR_OOM;
+        ZkProfScope ps(ctx, "msm_bases_convert");
+        hipLaunchKernelGGL(k_bases_to_rprime, gs, ts, 0, ctx->stream, d_bases, conv, (uint64_t)n);
+        ZK_CHECK_LAUNCH(ctx);
+        d_bases_rp = conv;
+    }
     {
         ZkProfScope ps(ctx, "msm_sort");
         ZK_HIP(ctx, hipMemsetAsync(counts, 0, ((size_t)nb + SIZE_BINS) * 4, ctx->stream));
@@ -280,14 +302,14 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     }
     {
         ZkProfScope ps(ctx, "msm_buckets");
-        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases, (const uint32_t*)offsets, (const uint32_t*)idx, (const uint32_t*)order, nb, buckets);
+        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx, (const uint32_t*)order, nb, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
         ZkProfScope ps(ctx, "msm_reduce");
-        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)buckets, pl.B, partial);
+        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz29*)buckets, pl.B, partial);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz*)partial, red_blocks, wsum);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz29*)partial, red_blocks, wsum);
         ZK_CHECK_LAUNCH(ctx);
     }
 
@@ -295,6 +317,25 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, sizeof(G1Xyzz) * pl.W, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     host::msm_tail(hw.data(), pl.W, pl.c, h_out);
+    return ZK_OK;
+}
+
+int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out) {
+    return msm_run_rp(ctx, d_scalars, d_bases, nullptr, n, h_out);
+}
+
+// R'-form copy of an SRS basis, built on first use and cached on the zk_srs
+int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out) {
+    zk_srs* s = const_cast<zk_srs*>(srs);
+    G1Affine** slot = basis ? &s->g_lagrange_rp : &s->g_rp;
+    const G1Affine* src = basis ? s->g_lagrange : s->g;
+    if (!*slot) {
+        const uint64_t n = 1ull << s->k;
+        ZK_HIP(ctx, hipMalloc(slot, sizeof(G1Affine) * n));
+        hipLaunchKernelGGL(k_bases_to_rprime, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src, *slot, n);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    *out = *slot;
     return ZK_OK;
 }
 

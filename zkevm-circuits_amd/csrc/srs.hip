@@ -168,6 +168,8 @@ void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs) {
     if (!srs) return;
     if (srs->g) (void)hipFree(srs->g);
     if (srs->g_lagrange) (void)hipFree(srs->g_lagrange);
+    if (srs->g_rp) (void)hipFree(srs->g_rp);
+    if (srs->g_lagrange_rp) (void)hipFree(srs->g_lagrange_rp);
     delete srs;
 }
 uint32_t zk_srs_k(const zk_srs* srs) { return srs ? srs->k : 0; }
