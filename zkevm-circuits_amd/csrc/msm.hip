@@ -61,21 +61,69 @@ __device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
     }
 }
 
-__global__ void k_msm_count(const Fr* __restrict__ scalars, uint64_t n, int c, int W, uint32_t B, uint32_t* __restrict__ counts) {
+// ---- sort phase --------------------------------------------------------------------------------
+// 1. k_msm_digits: every scalar leaves Montgomery form once and is recoded; digit codes go to a
+//    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 8):
+//      0xFFFF = zero digit, otherwise bit 15 = sign, bits 0..14 = bucket (|d| - 1).
+// 2. k_msm_lds_count / k_msm_lds_scatter: workgroup (r, w) owns bucket range r of window w
+//    (<= 2048 buckets).  It streams the whole digit row (2 MiB at 2^20, L2-resident, 16 B/lane)
+//    and keeps only digits in its range: counters / cursors live in LDS (ds_add_rtn_u32), so the
+//    sort needs no global atomics, and a workgroup's slice of `idx` is written by that workgroup
+//    alone -- partial lines merge in its XCD's L2 instead of costing one 64 B HBM write per index.
+//    Every workgroup does the same n digit tests whatever the scalar distribution: no skew.
+constexpr uint32_t DIG_ZERO = 0xFFFFu;
+constexpr int MSM_RANGE_MAX_BITS = 11;   // <= 2048 buckets per workgroup
+
+__global__ void k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, int c, int W, uint16_t* __restrict__ dig) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n_pad) return;
+    if (i >= n) { for (int w = 0; w < W; ++w) dig[(uint64_t)w * n_pad + i] = (uint16_t)DIG_ZERO; return; }
     const Fr s = from_mont(ldg(scalars + i));
-    recode(s, c, W, [&](int w, uint32_t b, bool) { atomicAdd(counts + (uint64_t)w * B + b, 1u); });
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * c, limb = bit >> 5, sh = bit & 31;
+        uint32_t d = limb < 8 ? (s.l[limb] >> sh) : 0u;
+        if (sh + c > 32 && limb + 1 < 8) d |= s.l[limb + 1] << (32 - sh);
+        d = (d & mask) + carry;
+        uint32_t code;
+        if (d > half) { carry = 1; const uint32_t mag = (1u << c) - d; code = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
+        else { carry = 0; code = d ? (d - 1) : DIG_ZERO; }
+        dig[(uint64_t)w * n_pad + i] = (uint16_t)code;
+    }
 }
 
-__global__ void k_msm_scatter(const Fr* __restrict__ scalars, uint64_t n, int c, int W, uint32_t B, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fr s = from_mont(ldg(scalars + i));
-    recode(s, c, W, [&](int w, uint32_t b, bool neg) {
-        const uint32_t pos = atomicAdd(cursor + (uint64_t)w * B + b, 1u);
-        idx[pos] = (uint32_t)i | (neg ? NEG_BIT : 0u);
-    });
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restrict__ dig, uint64_t n_pad, int range_bits, uint32_t B,
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx) {
+    __shared__ uint32_t lds[1 << MSM_RANGE_MAX_BITS];
+    const uint32_t r = blockIdx.x, w = blockIdx.y, range = 1u << range_bits, rmask = range - 1;
+    const uint64_t gbase = (uint64_t)w * B + ((uint64_t)r << range_bits);
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[gbase + t] : 0u;
+    __syncthreads();
+    const uint4* row = reinterpret_cast<const uint4*>(dig + (uint64_t)w * n_pad);
+    const uint64_t nvec = n_pad >> 3;
+    for (uint64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+        const uint4 q = row[v];
+        const uint32_t words[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t code = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const uint32_t b = code & 0x7FFFu;
+            if (code != DIG_ZERO && (b >> range_bits) == r) {
+                if (SCATTER) {
+                    const uint32_t pos = atomicAdd(&lds[b & rmask], 1u);
+                    idx[pos] = (uint32_t)(v * 8 + k) | ((code & 0x8000u) ? NEG_BIT : 0u);
+                } else {
+                    atomicAdd(&lds[b & rmask], 1u);
+                }
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[gbase + t] = lds[t];
+    }
 }
 
 // ---- exclusive scan of the bucket counts, three small kernels (4096 counts per block) ----------
@@ -259,7 +307,9 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
 
     // u32 workspace: counts[nb] | size_hist[256] | offsets[nb+1] | cursor[nb] | order[nb] | block_tot | idx[n*W]
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
-    const size_t words = (size_t)nb * 4 + 1 + SIZE_BINS + scan_blocks + (size_t)n * pl.W;
+    const uint64_t n_pad = ((uint64_t)n + 7) & ~7ull;
+    const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
+    const size_t words = (size_t)nb * 4 + 4 + SIZE_BINS + scan_blocks + (size_t)n * pl.W + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* counts = ws;
@@ -269,6 +319,10 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
     uint32_t* order = cursor + nb;
     uint32_t* block_tot = order + nb;
     uint32_t* idx = block_tot + scan_blocks;
+    uint16_t* dig = reinterpret_cast<uint16_t*>(ws + (((size_t)nb * 4 + 1 + SIZE_BINS + scan_blocks + (size_t)n * pl.W + 3) & ~(size_t)3));   // 16-B aligned
+    int range_bits = pl.c - 1;
+    if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
+    const dim3 sweep_grid(pl.B >> range_bits, pl.W);
     const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
     const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks;
     char* bk = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29 + sizeof(G1Xyzz) * pl.W);
@@ -288,8 +342,9 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
     }
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(counts, 0, ((size_t)nb + SIZE_BINS) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_msm_count, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, counts);
+        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)SIZE_BINS * 4, ctx->stream));
+        hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((n_pad + 255) / 256)), ts, 0, ctx->stream, d_scalars, (uint64_t)n, n_pad, pl.c, pl.W, dig);
+        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, block_tot);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
@@ -297,7 +352,7 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
         hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist);
         hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_msm_scatter, gs, ts, 0, ctx->stream, d_scalars, (uint64_t)n, pl.c, pl.W, pl.B, cursor, idx);
+        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
