@@ -123,6 +123,11 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
  * the affine result out).                                                                        */
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine);
 
+/* Host-only: out = sum of n affine points (no context, no device).  Used to finish a point-sharded
+ * MSM: each rank's 64-byte partial result is all-gathered as bytes (RCCL has no EC reduce op) and
+ * summed here.                                                                                   */
+int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine);
+
 /* ---- G1 element-wise (tests of the group law; halo2curves G1 Add / Double / Mul) --------------- */
 /* out[i] = a[i] + b[i], all affine (n x 64 B) */
 int zk_g1_affine_add_vec(zk_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);

@@ -1,5 +1,6 @@
 // C ABI glue (include/zkmi355.h): context, device memory, timers, and the NTT / MSM entry points.
 #include "ctx.hpp"
+#include "host_fq.hpp"
 
 namespace zk {
 
@@ -229,6 +230,28 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
     if (rc) return rc;
     return msm_run_rp(ctx, (const Fr*)d_scalars, b, brp, n, (G1Affine*)h_out_affine);
 }
+// Sum of n affine points on the HOST (no device, no context): combines the per-rank partial
+// results of a point-sharded MSM after they were all-gathered as raw bytes (RCCL has no
+// elliptic-curve reduction op, so the reduce step of the "all-reduce" runs here).
+int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine) {
+    if (!h_out_affine || (!h_points_affine && n)) return ZK_ERR_INVALID_ARG;
+    const G1Affine* p = (const G1Affine*)h_points_affine;
+    host::PXyzz acc;
+    memset(&acc, 0, sizeof acc);
+    const host::F4 one = host::fone<host::FqC>();
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i].is_identity()) continue;
+        host::PXyzz q;
+        memcpy(&q.x, &p[i].x, 32);
+        memcpy(&q.y, &p[i].y, 32);
+        q.zz = one;
+        q.zzz = one;
+        acc = host::padd(acc, q);
+    }
+    host::pto_affine(acc, (G1Affine*)h_out_affine);
+    return ZK_OK;
+}
+
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, h_out_affine && ((h_scalars && h_bases) || n == 0), "null pointer");

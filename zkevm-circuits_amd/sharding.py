@@ -1,0 +1,87 @@
+"""Multi-GPU layer of the prover hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X nodes; "gloo" in the CPU tests).
+
+The path shards by independent units:
+  * column sharding (production mode): a proof commits ~10^3 columns; rank r owns columns
+    {c : c % world == r}, runs MSM / NTT on them with no data-path collective, and the only
+    exchange is one all-gather of the 64-byte commitments per transcript round;
+  * point sharding of ONE MSM (few-column circuits, BASELINE config 5): rank r computes the MSM of
+    its contiguous slice of the points, the 64-byte partial results are all-gathered as raw bytes
+    (RCCL reduce ops are numeric: no elliptic-curve sum) and every rank adds them on the host.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import binding
+
+G1_BYTES = 64
+
+
+def columns_of_rank(num_columns: int, rank: int, world: int) -> List[int]:
+    """Round-robin column ownership."""
+    return list(range(rank, num_columns, world))
+
+
+def point_slice(n: int, rank: int, world: int) -> slice:
+    """Contiguous slice of an n-point MSM owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def g1_sum_host(points: np.ndarray) -> np.ndarray:
+    """Sum of affine points (n, 8) u64 on the host via the C ABI (zk_g1_sum_host)."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    out = np.empty(8, dtype=np.uint64)
+    rc = binding.lib().zk_g1_sum_host(pts.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(pts.shape[0]), out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise binding.ZkError(f"zk_g1_sum_host failed: {rc}")
+    return out
+
+
+def _device_for_backend(group=None) -> torch.device:
+    backend = dist.get_backend(group)
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+def all_gather_commitments(local: Dict[int, np.ndarray], num_columns: int, group=None) -> np.ndarray:
+    """Every rank contributes the commitments of the columns it owns; returns (num_columns, 8) u64
+    in column order on every rank.  One all_gather of world * ceil(C/world) * 64 bytes."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (num_columns + world - 1) // world
+    dev = _device_for_backend(group)
+    send = np.zeros((per, 8), dtype=np.uint64)
+    for slot, col in enumerate(columns_of_rank(num_columns, rank, world)):
+        send[slot] = local[col]
+    t = torch.from_numpy(send.view(np.uint8).reshape(-1)).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    res = np.zeros((num_columns, 8), dtype=np.uint64)
+    for r in range(world):
+        got = out[r].cpu().numpy().view(np.uint64).reshape(per, 8)
+        for slot, col in enumerate(columns_of_rank(num_columns, r, world)):
+            res[col] = got[slot]
+    return res
+
+
+def all_reduce_g1(partial: np.ndarray, group=None) -> np.ndarray:
+    """'All-reduce' of one G1 point: all_gather the raw 64 bytes, add on the host."""
+    world = dist.get_world_size(group)
+    dev = _device_for_backend(group)
+    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.uint8).reshape(-1)).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    pts = np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+    return g1_sum_host(pts)
+
+
+def msm_point_sharded(ctx: "binding.Context", d_scalars_ptr: int, d_bases_ptr: int, n_local: int, group=None) -> np.ndarray:
+    """One MSM split over the ranks: the pointers address THIS rank's slice (see point_slice)."""
+    partial = ctx.msm(d_scalars_ptr, d_bases_ptr, n_local)
+    return all_reduce_g1(partial, group)
