@@ -103,6 +103,18 @@ int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_
 int zk_fr_prefix_product(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
 int zk_fr_prefix_sum(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
 
+/* ---- quotient / expression evaluation: halo2_proofs::plonk::evaluation (evaluate_h, GraphEvaluator)
+ * + vanishing divide_by_vanishing_poly  -- SURVEY 8a K4, K5 ------------------------------------ */
+/* Runs one postfix program per row i of a 2^ext_k domain and writes out[i] (see quotient.hip for
+ * the instruction set: 3 x u32 per instruction {op, a, b}).  Columns are device pointers to
+ * 2^ext_k Fr values each (extended-coset evaluations, or Lagrange values when ext_k == k);
+ * PUSH_COL reads row (i + rot * 2^(ext_k-k)) mod 2^ext_k.  divide_by_vanishing != 0 multiplies the
+ * result by 1/(X^n - 1) evaluated on the zeta-coset.  d_out must not alias any input column.     */
+int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr, const void* const* h_col_ptrs, uint32_t num_cols,
+                     const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out);
+/* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
+int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
+
 /* ---- SRS: halo2_proofs::poly::kzg::commitment::ParamsKZG  -- SURVEY 8a A5 ---------------------- */
 /* Upload g (n = 2^k G1Affine) and optionally g_lagrange (may be NULL); host pointers.            */
 int zk_srs_create(zk_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagrange, zk_srs** out);

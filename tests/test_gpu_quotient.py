@@ -1,0 +1,98 @@
+"""GPU parity: the expression / quotient evaluator (halo2 evaluate_h restated as a postfix
+program) against a big-int evaluation of the same program in the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as b
+
+pytestmark = pytest.mark.gpu
+R = b.R_MOD
+
+
+def _run_oracle(prog, cols, consts, k, ext_k, divide):
+    ne, scale = 1 << ext_k, 1 << (ext_k - k)
+    out = []
+    tev = b.EvaluationDomain(2, k).t_evaluations if False else None
+    if divide:
+        zn, step = pow(b.FR_ZETA, 1 << k, R), pow(b.omega_for_k(ext_k), 1 << k, R)
+        tev = [b.fr_inv((zn * pow(step, j, R) - 1) % R) for j in range(scale)]
+    for i in range(ne):
+        st, acc = [], 0
+        for op, a, bb in prog:
+            if op == 1:
+                rot = bb if bb < (1 << 31) else bb - (1 << 32)
+                st.append(cols[a][(i + rot * scale) % ne])
+            elif op == 2: st.append(consts[a])
+            elif op == 3: y = st.pop(); st[-1] = (st[-1] + y) % R
+            elif op == 4: y = st.pop(); st[-1] = (st[-1] - y) % R
+            elif op == 5: y = st.pop(); st[-1] = st[-1] * y % R
+            elif op == 6: st[-1] = (-st[-1]) % R
+            elif op == 7: st[-1] = st[-1] * st[-1] % R
+            elif op == 8: st[-1] = 2 * st[-1] % R
+            elif op == 9: acc = (acc * consts[a] + st.pop()) % R
+            elif op == 10: st[-1] = st[-1] * consts[a] % R
+            elif op == 11: st[-1] = (st[-1] + consts[a]) % R
+        out.append(acc * tev[i % scale] % R if divide else acc)
+    return out
+
+
+@pytest.mark.parametrize("k,ext_k,divide", [(4, 4, False), (5, 7, True), (8, 10, True), (10, 10, False)])
+def test_program_matches_oracle(zk, ctx, cref, k, ext_k, divide):
+    rng = random.Random(100 * k + ext_k)
+    ne, ncols = 1 << ext_k, 5
+    cols = [[rng.randrange(R) for _ in range(ne)] for _ in range(ncols)]
+    consts = [rng.randrange(R) for _ in range(4)] + [0, 1, R - 1]
+    M32 = (1 << 32)
+    prog = [
+        # gate 1:  c0(rot 0) * c1(rot 1) - c2(rot -1)        -> fold with consts[0] (= "y")
+        (zk.Q_PUSH_COL, 0, 0), (zk.Q_PUSH_COL, 1, 1), (zk.Q_MUL, 0, 0), (zk.Q_PUSH_COL, 2, (-1) % M32), (zk.Q_SUB, 0, 0), (zk.Q_FOLD, 0, 0),
+        # gate 2:  (c3 + const1)^2 * 2 + const2 * c4(rot 3)
+        (zk.Q_PUSH_COL, 3, 0), (zk.Q_ADD_CONST, 1, 0), (zk.Q_SQUARE, 0, 0), (zk.Q_DOUBLE, 0, 0),
+        (zk.Q_PUSH_COL, 4, 3), (zk.Q_MUL_CONST, 2, 0), (zk.Q_ADD, 0, 0), (zk.Q_FOLD, 0, 0),
+        # gate 3:  -(c0 * c0 * c0) + const3  with a deeper stack
+        (zk.Q_PUSH_CONST, 3, 0), (zk.Q_PUSH_COL, 0, 0), (zk.Q_PUSH_COL, 0, 0), (zk.Q_PUSH_COL, 0, 0), (zk.Q_MUL, 0, 0), (zk.Q_MUL, 0, 0), (zk.Q_NEG, 0, 0), (zk.Q_ADD, 0, 0), (zk.Q_FOLD, 0, 0),
+        # edge constants 0, 1, r-1
+        (zk.Q_PUSH_CONST, 4, 0), (zk.Q_PUSH_CONST, 5, 0), (zk.Q_ADD, 0, 0), (zk.Q_PUSH_CONST, 6, 0), (zk.Q_MUL, 0, 0), (zk.Q_FOLD, 0, 0),
+    ]
+    dcols = [ctx.to_device(cref.to_mont(c)) for c in cols]
+    out = ctx.alloc(ne * 32)
+    ctx.quotient_eval(np.array(prog, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out, divide)
+    got = cref.from_mont(out.download((ne, 4)))
+    assert got == _run_oracle(prog, cols, consts, k, ext_k, divide)
+
+
+def test_vanishing_argument_end_to_end(zk, ctx, cref):
+    """A real quotient: a(X) * b(X) - c(X) vanishes on the domain, so h = (a*b - c)/(X^n - 1) is a
+    polynomial: evaluate on the extended coset on the GPU, come back to coefficients, check
+    a(x) b(x) - c(x) = h(x) (x^n - 1) at a random point -- the identity the verifier checks."""
+    k, ext_k = 8, 9
+    n, ne = 1 << k, 1 << ext_k
+    A, B = cref.rand_fr_stream(1, n), cref.rand_fr_stream(2, n)
+    C = cref.fe_binop("mul", 0, A, B)                       # Lagrange values satisfy the gate
+    bufs = []
+    for lag in (A, B, C):
+        d = ctx.to_device(lag)
+        ctx.ntt(d, k, inverse=True)                          # -> coefficients
+        e = ctx.alloc(ne * 32)
+        ctx.coeff_to_extended(d, k, ext_k, e)
+        bufs.append((d, e))
+    prog = [(zk.Q_PUSH_COL, 0, 0), (zk.Q_PUSH_COL, 1, 0), (zk.Q_MUL, 0, 0), (zk.Q_PUSH_COL, 2, 0), (zk.Q_SUB, 0, 0), (zk.Q_FOLD, 0, 0)]
+    h = ctx.alloc(ne * 32)
+    ctx.quotient_eval(np.array(prog, dtype=np.uint32), [e.ptr for _, e in bufs], cref.to_mont([1]), k, ext_k, h, True)
+    ctx.extended_to_coeff(h, ext_k)
+    hc = h.download((ne, 4))
+    assert not hc[n:].any()                                   # deg h < n  (deg(a*b) < 2n)
+    x = 0x1234567
+    ev = [cref.from_mont(ctx.poly_eval(d, n, cref.fr_const(x)).reshape(1, 4))[0] for d, _ in bufs]
+    hx = cref.eval_polynomial(np.ascontiguousarray(hc[:n]), x)
+    assert (ev[0] * ev[1] - ev[2]) % R == hx * (pow(x, n, R) - 1) % R
+
+
+def test_bad_programs_are_rejected(zk, ctx, cref):
+    out = ctx.alloc(32 * 16)
+    col = ctx.to_device(cref.rand_fr_stream(1, 16))
+    for prog in ([(zk.Q_ADD, 0, 0)], [(zk.Q_PUSH_COL, 3, 0)], [(zk.Q_PUSH_CONST, 9, 0)], [(99, 0, 0)], [(zk.Q_FOLD, 0, 0)]):
+        with pytest.raises(zk.ZkError):
+            ctx.quotient_eval(np.array(prog, dtype=np.uint32), [col.ptr], cref.to_mont([1]), 4, 4, out)

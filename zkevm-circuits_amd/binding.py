@@ -22,6 +22,8 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "zkmi355.h")
 
 FIELD_FR, FIELD_FQ = 0, 1
 OP_ADD, OP_SUB, OP_MUL = 0, 1, 2
+# quotient-program opcodes (csrc/quotient.hip)
+Q_END, Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_SQUARE, Q_DOUBLE, Q_FOLD, Q_MUL_CONST, Q_ADD_CONST = range(12)
 
 _lib = None
 
@@ -229,6 +231,18 @@ class Context:
 
     def kate_division(self, coeffs: DeviceBuffer, n: int, z_mont: np.ndarray, q: DeviceBuffer):
         self._ck(lib().zk_kate_division(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(z_mont)), ctypes.c_void_p(q.ptr)))
+
+    # ---- expression / quotient evaluation (halo2 evaluate_h)
+    def quotient_eval(self, program: np.ndarray, col_ptrs, consts: np.ndarray, k: int, ext_k: int, out: DeviceBuffer, divide_by_vanishing: bool = False):
+        prog = np.ascontiguousarray(program, dtype=np.uint32).reshape(-1, 3)
+        ptrs = (ctypes.c_void_p * max(len(col_ptrs), 1))(*[ctypes.c_void_p(p) for p in col_ptrs])
+        consts = np.ascontiguousarray(consts, dtype=np.uint64).reshape(-1, 4)
+        self._ck(lib().zk_quotient_eval(self.h, prog.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(prog.shape[0]), ptrs, ctypes.c_uint32(len(col_ptrs)),
+                                        _host_ptr(consts) if consts.size else None, ctypes.c_uint32(consts.shape[0]), ctypes.c_uint32(k), ctypes.c_uint32(ext_k),
+                                        ctypes.c_int(1 if divide_by_vanishing else 0), ctypes.c_void_p(out.ptr)))
+
+    def fr_powers(self, base_mont: np.ndarray, mul_mont: np.ndarray, out: DeviceBuffer, n: int):
+        self._ck(lib().zk_fr_powers(self.h, _host_ptr(np.ascontiguousarray(base_mont)), _host_ptr(np.ascontiguousarray(mul_mont)), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
 
     # ---- SRS / MSM (halo2 ParamsKZG / best_multiexp)
     def srs_create(self, k: int, g: np.ndarray, g_lagrange: Optional[np.ndarray] = None) -> Srs:
