@@ -140,6 +140,23 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size
  * summed here.                                                                                   */
 int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine);
 
+/* ---- full proof: halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC multi-open
+ * (poly::kzg::multiopen::ProverGWC)  -- SURVEY 8a A1, A4, K6-K11; see csrc/prover.hip ------------ */
+typedef struct zk_pk zk_pk;
+/* keygen_pk over a flat circuit description (the "pk blob" of zkevm-circuits_amd/plonk.py:
+ * header, permutation columns, constants, gate / lookup programs, fixed and sigma columns in
+ * Lagrange form).  Commits fixed and sigma columns, builds coefficient and extended-coset forms. */
+int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out);
+void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk);
+/* verifying-key side: (F + P) x 64-byte affine commitments (fixed, then sigma) and vk_repr (Fr)  */
+int zk_pk_vk(zk_ctx* ctx, const zk_pk* pk, void* h_commitments, void* h_vk_repr);
+/* create_proof: h_advice / h_instance are arrays of host pointers to n x 32-byte Lagrange columns;
+ * seed16 seeds the XorShift blinding RNG; the proof bytes (compressed points and canonical
+ * scalars, halo2 encoding) are written to h_proof.  Fails with ZK_ERR_INVALID_ARG if the witness
+ * does not satisfy the copy or lookup constraints.                                               */
+int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
+                    void* h_proof, size_t proof_cap, size_t* proof_len);
+
 /* ---- G1 element-wise (tests of the group law; halo2curves G1 Add / Double / Mul) --------------- */
 /* out[i] = a[i] + b[i], all affine (n x 64 B) */
 int zk_g1_affine_add_vec(zk_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);

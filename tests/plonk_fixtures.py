@@ -1,0 +1,106 @@
+"""Test circuits for the full-proof tests: PLONKish shapes that exercise every argument the
+reference's circuits use (custom gates with rotations, high-degree gates, multi-chunk permutation
+over advice/fixed/instance columns, multi-column logUp lookups) at sizes the Python verifier
+handles in seconds."""
+import random
+
+from zkevm_circuits_amd import plonk
+
+R = plonk.R_MOD
+
+
+def build_circuit(k: int, seed: int = 1, wide: bool = False):
+    """Returns (circuit, advice columns, instance columns) with a satisfying witness.
+
+    columns: fixed  0 q_mul | 1 q_add | 2 q_cube | 3 q_lookup | 4 table_a | 5 table_b | 6 constant
+             advice 0 a | 1 b | 2 c | (wide: 3 d | 4 e)
+             instance 0
+    gates:   q_mul * (a*b - c)                       degree 3
+             q_add * (a + b - c.next)                rotation +1
+             q_cube * (a*a*a*b + 7 - c.prev)         degree 5, rotation -1
+             (wide) q_mul * (d*e*a - d.next)         second pair of columns
+    lookup:  (q_lookup * a, q_lookup * b) in (table_a, table_b)
+    copies:  a[r] == c[r'] chains, b cells == instance cells, a cell == fixed constant
+    """
+    rng = random.Random(seed)
+    A = 5 if wide else 3
+    c = plonk.Circuit(k, num_fixed=7, num_advice=A, num_instance=1, blinding_factors=5)
+    n, u = c.n, c.u
+    q_mul, q_add, q_cube, q_lk, t_a, t_b, kon = (c.fixed_col(i) for i in range(7))
+    a, b_, cc = c.advice_col(0), c.advice_col(1), c.advice_col(2)
+    c.add_gate(q_mul * (a * b_ - cc))
+    c.add_gate(q_add * (a + b_ - cc.rot(1)))
+    c.add_gate(q_cube * (a * a * a * b_ + 7 - cc.rot(-1)))
+    if wide:
+        d_, e_ = c.advice_col(3), c.advice_col(4)
+        c.add_gate(q_mul * (d_ * e_ * a - d_.rot(1)))
+    c.add_lookup([q_lk * a, q_lk * b_], [t_a, t_b])
+
+    adv = [[0] * n for _ in range(A)]
+    inst = [[0] * n]
+    # table: (i, i^2 + 3) for i < 64, padded with (0, 0) -- row 0 holds (0, 0) so disabled rows match
+    tab = [(0, 0)] + [(i, (i * i + 3) % R) for i in range(1, 64)]
+    for row in range(u):
+        ta, tb = tab[row] if row < len(tab) else (0, 0)
+        c.fixed[4][row], c.fixed[5][row] = ta, tb
+    row = 1
+    regions = []
+    while row + 3 < u:
+        kind = rng.choice(["mul", "add", "cube", "lookup"])
+        if kind == "mul":
+            x, y = rng.randrange(R), rng.randrange(R)
+            adv[0][row], adv[1][row], adv[2][row] = x, y, x * y % R
+            c.fixed[0][row] = 1
+            if wide:
+                d0, e0 = rng.randrange(R), rng.randrange(R)
+                adv[3][row], adv[4][row] = d0, e0
+                adv[3][row + 1] = d0 * e0 % R * x % R
+            regions.append(("mul", row))
+            row += 3
+        elif kind == "add":
+            x, y = rng.randrange(R), rng.randrange(R)
+            adv[0][row], adv[1][row] = x, y
+            adv[2][row + 1] = (x + y) % R
+            c.fixed[1][row] = 1
+            regions.append(("add", row))
+            row += 3
+        elif kind == "cube":
+            x, y = rng.randrange(R), rng.randrange(R)
+            adv[0][row + 1], adv[1][row + 1] = x, y
+            adv[2][row] = (x * x * x % R * y + 7) % R
+            c.fixed[2][row + 1] = 1
+            regions.append(("cube", row + 1))
+            row += 3
+        else:
+            i = rng.randrange(1, min(64, u))
+            adv[0][row], adv[1][row] = tab[i]
+            c.fixed[3][row] = 1
+            regions.append(("lookup", row))
+            row += 3
+    # copy constraints: tie some cells together (values are made equal first)
+    muls = [r for kname, r in regions if kname == "mul"]
+    adds = [r for kname, r in regions if kname == "add"]
+    for r0, r1 in zip(muls[:-1:2], muls[1::2]):        # product of one mul feeds `a` of the next
+        x = adv[2][r0]
+        adv[0][r1] = x
+        adv[2][r1] = x * adv[1][r1] % R
+        if wide:
+            adv[3][r1 + 1] = adv[3][r1] * adv[4][r1] % R * x % R
+        c.copy((plonk.ADVICE, 2, r0), (plonk.ADVICE, 0, r1))
+    for j, r0 in enumerate(adds[:8]):                  # public inputs
+        inst[0][j] = adv[1][r0]
+        c.copy((plonk.ADVICE, 1, r0), (plonk.INSTANCE, 0, j))
+    if adds:                                           # a constant from a fixed column
+        r0 = adds[-1]
+        c.fixed[6][0] = 12345
+        adv[0][r0] = 12345
+        adv[2][r0 + 1] = (12345 + adv[1][r0]) % R
+        c.copy((plonk.ADVICE, 0, r0), (plonk.FIXED, 6, 0))
+    if wide:                                           # more permutation columns -> several chunks
+        c.enable_equality(plonk.ADVICE, 3)
+        c.enable_equality(plonk.ADVICE, 4)
+        if len(muls) >= 2:
+            adv[4][muls[1]] = adv[4][muls[0]]
+            adv[3][muls[1] + 1] = adv[3][muls[1]] * adv[4][muls[1]] % R * adv[0][muls[1]] % R
+            c.copy((plonk.ADVICE, 4, muls[0]), (plonk.ADVICE, 4, muls[1]))
+    return c, adv, inst

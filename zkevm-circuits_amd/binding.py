@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -54,6 +54,7 @@ def lib():
         _lib.zk_srs_k.restype = ctypes.c_uint32
         _lib.zk_ctx_destroy.restype = None
         _lib.zk_srs_destroy.restype = None
+        _lib.zk_pk_destroy.restype = None
     return _lib
 
 
@@ -127,6 +128,23 @@ class Srs:
     def destroy(self):
         if self.h:
             lib().zk_srs_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class ProvingKey:
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.h = ctx, handle
+
+    def vk(self, num_commitments: int):
+        """(commitments (num, 8) u64 affine Montgomery, vk_repr (4,) u64 Montgomery)."""
+        com = np.zeros((max(num_commitments, 1), 8), dtype=np.uint64)
+        rep = np.zeros(4, dtype=np.uint64)
+        self.ctx._ck(lib().zk_pk_vk(self.ctx.h, self.h, _host_ptr(com), _host_ptr(rep)))
+        return com[:num_commitments], rep
+
+    def destroy(self):
+        if self.h:
+            lib().zk_pk_destroy(self.ctx.h, self.h)
             self.h = None
 
 
@@ -282,6 +300,25 @@ class Context:
         out = buf.download(a.shape)
         buf.free()
         return out
+
+    # ---- full proofs (halo2 keygen_pk / create_proof, GWC)
+    def pk_create(self, srs: Srs, blob: bytes) -> "ProvingKey":
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        self._ck(lib().zk_pk_create(self.h, srs.h, buf, ctypes.c_size_t(len(blob)), ctypes.byref(h)))
+        return ProvingKey(self, h)
+
+    def create_proof(self, pk: "ProvingKey", advice: Sequence[np.ndarray], instance: Sequence[np.ndarray], seed: bytes = bytes(16)) -> bytes:
+        adv = [np.ascontiguousarray(a, dtype=np.uint64) for a in advice]
+        ins = [np.ascontiguousarray(a, dtype=np.uint64) for a in instance]
+        pa = (ctypes.c_void_p * max(len(adv), 1))(*[a.ctypes.data for a in adv])
+        pi = (ctypes.c_void_p * max(len(ins), 1))(*[a.ctypes.data for a in ins])
+        cap = 1 << 20
+        out = ctypes.create_string_buffer(cap)
+        n = ctypes.c_size_t()
+        assert len(seed) == 16
+        self._ck(lib().zk_create_proof(self.h, pk.h, pa, pi, ctypes.c_char_p(seed), out, ctypes.c_size_t(cap), ctypes.byref(n)))
+        return out.raw[:n.value]
 
     # ---- G1 element-wise
     def g1_affine_add(self, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):

@@ -1,0 +1,631 @@
+// Host orchestration of a full PLONKish/KZG proof on top of the device kernels: the surface of
+// halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC multi-open
+// (poly::kzg::multiopen::ProverGWC), which is what BASELINE.json's north_star names.
+// External crate; reference call sites
+// [REF circuit-benchmarks/src/super_circuit.rs:109-132], [REF prover/src/common/prover/utils.rs:31,55].
+//
+// What runs where:
+//   device : every commitment (MSM), every NTT / coset NTT, expression evaluation over the
+//            Lagrange and extended domains (quotient.hip), batch inversion, grand product /
+//            grand sum scans, polynomial evaluation, Kate division, linear combinations
+//   host   : transcript (Blake2b), RNG (XorShift), lookup multiplicity counting (hash join),
+//            program assembly, a handful of scalar field operations per challenge
+//
+// Protocol (one advice phase; mv-lookup/logUp lookups as in the Scroll halo2 fork, SURVEY note L):
+//   vk_repr, instances | advice commitments | theta | m commitments | beta, gamma |
+//   permutation Z commitments, lookup phi commitments | random poly | y | h pieces | x |
+//   evaluations | v | GWC witnesses.         The matching verifier is oracle/plonk_verifier.py.
+//
+// The circuit arrives as a flat "pk blob" (zkevm-circuits_amd/plonk.py serialises it; SURVEY 8f-1
+// export format): header, permutation columns, constants, gate programs, lookup programs, fixed
+// columns and sigma columns in Lagrange form.
+#include <algorithm>
+#include <array>
+#include <unordered_map>
+
+#include "ctx.hpp"
+#include "host_util.hpp"
+
+using namespace zk;
+using zk::host::F4;
+
+extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* const*, uint32_t, const void*, uint32_t, uint32_t, uint32_t, int, void*);
+extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
+
+namespace {
+
+enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECIAL = 3, CT_PERM_Z = 4, CT_SIGMA = 5, CT_LK_M = 6, CT_LK_PHI = 7, CT_RANDOM = 8, CT_H = 9 };
+enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
+enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11 };
+// abstract constant operands: user constants are [0, num_consts); challenges live above
+constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u;   // C_DELTA0 + j = beta * delta^j
+
+inline uint32_t colref(uint32_t type, uint32_t idx) { return (type << 24) | idx; }
+
+struct Instr { uint32_t op, a, b; };
+typedef std::vector<Instr> Prog;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+    bool alloc(size_t n) { release(); bytes = n; return hipMalloc(&p, n ? n : 1) == hipSuccess; }
+    Fr* fr() const { return (Fr*)p; }
+};
+
+struct Query { uint32_t type, idx; int32_t rot; };
+
+}  // namespace
+
+struct zk_pk {
+    uint32_t k = 0, bf = 0, d = 0, ext_k = 0, F = 0, A = 0, I = 0, P = 0, L = 0;
+    uint32_t chunk = 0, C = 0, u = 0;   // permutation chunk size, #chunks, last usable row index
+    std::vector<std::pair<uint32_t, uint32_t>> perm_cols;
+    std::vector<F4> consts;
+    std::vector<Prog> gates;
+    struct Lookup { std::vector<Prog> inputs, tables; };
+    std::vector<Lookup> lookups;
+    std::vector<Query> adv_q, fix_q;         // evaluation queries, in proof order
+    // device-resident key material
+    std::vector<DevBuf> fixed_lag, fixed_coeff, fixed_ext, sigma_lag, sigma_coeff, sigma_ext;
+    DevBuf l0_ext, llast_ext, lactive_ext, x_ext, omega_lag, l0_lag, llast_lag, lactive_lag;
+    std::vector<G1Affine> fixed_com, sigma_com;
+    F4 vk_repr;
+    const zk_srs* srs = nullptr;
+};
+
+namespace {
+
+#define PK_TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+struct Reader {
+    const uint8_t* p; size_t left; bool ok = true;
+    uint32_t u32() { if (left < 4) { ok = false; return 0; } uint32_t v; memcpy(&v, p, 4); p += 4; left -= 4; return v; }
+    const uint8_t* bytes(size_t n) { if (left < n) { ok = false; return nullptr; } const uint8_t* r = p; p += n; left -= n; return r; }
+    Prog prog() { Prog g; uint32_t len = u32(); for (uint32_t i = 0; i < len && ok; ++i) { Instr in; in.op = u32(); in.a = u32(); in.b = u32(); g.push_back(in); } return g; }
+};
+
+int commit_lagrange(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 1, d_vals, n, out); }
+int commit_coeff(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 0, d_vals, n, out); }
+
+// Lagrange values -> (coefficients, extended coset); any output may be skipped with nullptr
+int to_coeff_and_ext(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff, DevBuf* ext) {
+    const size_t n = (size_t)1 << pk->k, ne = (size_t)1 << pk->ext_k;
+    DevBuf tmp;
+    DevBuf* c = coeff ? coeff : &tmp;
+    if (!c->alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    PK_TRY(zk_d2d(ctx, c->p, lag.p, n * 32));
+    PK_TRY(zk_ntt(ctx, c->p, pk->k, 1));
+    if (ext) {
+        if (!ext->alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        PK_TRY(zk_coeff_to_extended(ctx, c->p, pk->k, pk->ext_k, ext->p));
+    }
+    PK_TRY(zk_ctx_sync(ctx));   // tmp may be freed on return
+    return ZK_OK;
+}
+
+void collect_queries(const Prog& g, std::vector<Query>* adv, std::vector<Query>* fix) {
+    for (const Instr& in : g) {
+        if (in.op != Q_PUSH_COL) continue;
+        const uint32_t type = in.a >> 24, idx = in.a & 0xFFFFFF;
+        std::vector<Query>* dst = type == CT_ADVICE ? adv : (type == CT_FIXED ? fix : nullptr);
+        if (!dst) continue;
+        bool seen = false;
+        for (const Query& q : *dst) if (q.idx == idx && q.rot == (int32_t)in.b) { seen = true; break; }
+        if (!seen) dst->push_back(Query{type, idx, (int32_t)in.b});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Program concretisation: abstract column references -> indices into a flat pointer table,
+// abstract constants -> indices into a flat constant table.
+struct Concrete {
+    std::vector<uint32_t> words;
+    std::vector<const void*> cols;
+    std::vector<F4> consts;
+    std::unordered_map<uint32_t, uint32_t> col_index, const_index;
+};
+
+struct Env {   // where an abstract column lives in the domain being evaluated
+    const zk_pk* pk;
+    bool extended;
+    const std::vector<DevBuf>* advice;      // Lagrange (extended == false) or extended cosets
+    const std::vector<DevBuf>* instance;
+    const std::vector<DevBuf>* perm_z;
+    const std::vector<DevBuf>* lk_m;
+    const std::vector<DevBuf>* lk_phi;
+    F4 theta, beta, gamma, y;
+    std::vector<F4> beta_delta;   // beta * delta^j
+};
+
+const void* resolve_col(const Env& e, uint32_t ref) {
+    const uint32_t type = ref >> 24, idx = ref & 0xFFFFFF;
+    const zk_pk* pk = e.pk;
+    switch (type) {
+        case CT_FIXED: return idx < pk->F ? (e.extended ? pk->fixed_ext[idx].p : pk->fixed_lag[idx].p) : nullptr;
+        case CT_ADVICE: return e.advice && idx < e.advice->size() ? (*e.advice)[idx].p : nullptr;
+        case CT_INSTANCE: return e.instance && idx < e.instance->size() ? (*e.instance)[idx].p : nullptr;
+        case CT_SPECIAL:
+            if (idx == SP_X) return e.extended ? pk->x_ext.p : pk->omega_lag.p;
+            if (idx == SP_L0) return e.extended ? pk->l0_ext.p : pk->l0_lag.p;
+            if (idx == SP_LLAST) return e.extended ? pk->llast_ext.p : pk->llast_lag.p;
+            if (idx == SP_LACTIVE) return e.extended ? pk->lactive_ext.p : pk->lactive_lag.p;
+            return nullptr;
+        case CT_PERM_Z: return e.perm_z && idx < e.perm_z->size() ? (*e.perm_z)[idx].p : nullptr;
+        case CT_SIGMA: return idx < pk->P ? (e.extended ? pk->sigma_ext[idx].p : pk->sigma_lag[idx].p) : nullptr;
+        case CT_LK_M: return e.lk_m && idx < e.lk_m->size() ? (*e.lk_m)[idx].p : nullptr;
+        case CT_LK_PHI: return e.lk_phi && idx < e.lk_phi->size() ? (*e.lk_phi)[idx].p : nullptr;
+        default: return nullptr;
+    }
+}
+bool resolve_const(const Env& e, uint32_t ref, F4* out) {
+    if (ref < e.pk->consts.size()) { *out = e.pk->consts[ref]; return true; }
+    switch (ref) {
+        case C_THETA: *out = e.theta; return true;
+        case C_BETA: *out = e.beta; return true;
+        case C_GAMMA: *out = e.gamma; return true;
+        case C_Y: *out = e.y; return true;
+        case C_ONE: *out = host::fr_one(); return true;
+        default: break;
+    }
+    if (ref >= C_DELTA0 && ref - C_DELTA0 < e.beta_delta.size()) { *out = e.beta_delta[ref - C_DELTA0]; return true; }
+    return false;
+}
+int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
+    for (const Instr& in : g) {
+        uint32_t a = in.a;
+        if (in.op == Q_PUSH_COL) {
+            auto it = c->col_index.find(in.a);
+            if (it == c->col_index.end()) {
+                const void* p = resolve_col(e, in.a);
+                if (!p) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", in.a);
+                a = (uint32_t)c->cols.size();
+                c->cols.push_back(p);
+                c->col_index[in.a] = a;
+            } else a = it->second;
+        } else if (in.op == Q_PUSH_CONST || in.op == Q_FOLD || in.op == Q_MUL_CONST || in.op == Q_ADD_CONST) {
+            auto it = c->const_index.find(in.a);
+            if (it == c->const_index.end()) {
+                F4 v;
+                if (!resolve_const(e, in.a, &v)) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved constant reference 0x%08x", in.a);
+                a = (uint32_t)c->consts.size();
+                c->consts.push_back(v);
+                c->const_index[in.a] = a;
+            } else a = it->second;
+        }
+        c->words.push_back(in.op); c->words.push_back(a); c->words.push_back(in.b);
+    }
+    return ZK_OK;
+}
+int run_program(zk_ctx* ctx, const Env& e, const Prog& g, bool divide, void* d_out) {
+    Concrete c;
+    PK_TRY(concretise(ctx, e, g, &c));
+    const uint32_t dom = e.extended ? e.pk->ext_k : e.pk->k;
+    return zk_quotient_eval(ctx, c.words.data(), (uint32_t)(c.words.size() / 3), c.cols.data(), (uint32_t)c.cols.size(),
+                            c.consts.empty() ? nullptr : c.consts.data(), (uint32_t)c.consts.size(), e.pk->k, dom, divide ? 1 : 0, d_out);
+}
+
+// ---- small program builder ----------------------------------------------------------------------
+struct PB {
+    Prog g;
+    PB& col(uint32_t type, uint32_t idx, int32_t rot = 0) { g.push_back({Q_PUSH_COL, colref(type, idx), (uint32_t)rot}); return *this; }
+    PB& cst(uint32_t ref) { g.push_back({Q_PUSH_CONST, ref, 0}); return *this; }
+    PB& op(uint32_t o) { g.push_back({o, 0, 0}); return *this; }
+    PB& mulc(uint32_t ref) { g.push_back({Q_MUL_CONST, ref, 0}); return *this; }
+    PB& addc(uint32_t ref) { g.push_back({Q_ADD_CONST, ref, 0}); return *this; }
+    PB& fold(uint32_t ref) { g.push_back({Q_FOLD, ref, 0}); return *this; }
+    PB& append(const Prog& o) { g.insert(g.end(), o.begin(), o.end()); return *this; }
+};
+// theta-compression of a list of expressions: ((e0 * theta + e1) * theta + e2) ...
+void push_compressed(PB& b, const std::vector<Prog>& exprs) {
+    for (size_t i = 0; i < exprs.size(); ++i) {
+        if (i) b.mulc(C_THETA);
+        b.append(exprs[i]);
+        if (i) b.op(Q_ADD);
+    }
+}
+void push_perm_col(PB& b, const std::pair<uint32_t, uint32_t>& c) { b.col(c.first, c.second, 0); }
+
+// usable-row masks in Lagrange form
+void lagrange_masks(const zk_pk* pk, std::vector<F4>* l0, std::vector<F4>* llast, std::vector<F4>* lactive) {
+    const size_t n = (size_t)1 << pk->k;
+    const F4 one = host::fr_one(), zero = host::fr_zero();
+    l0->assign(n, zero); llast->assign(n, zero); lactive->assign(n, zero);
+    (*l0)[0] = one;
+    (*llast)[pk->u] = one;
+    for (size_t i = 0; i < pk->u; ++i) (*lactive)[i] = one;
+}
+
+int upload(zk_ctx* ctx, DevBuf* b, const void* h, size_t bytes) {
+    if (!b->alloc(bytes)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", bytes);
+    return zk_h2d(ctx, b->p, h, bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk) {
+    if (ctx) (void)zk_ctx_sync(ctx);
+    delete pk;
+}
+
+// keygen_pk: parse the blob, make the key material device resident, commit fixed / sigma columns.
+int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, srs && h_blob && out, "null pointer");
+    Reader r{(const uint8_t*)h_blob, blob_len};
+    if (r.u32() != 0x4B505A4Bu || r.u32() != 1u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic/version");
+    std::unique_ptr<zk_pk> pk(new zk_pk());
+    pk->srs = srs;
+    pk->k = r.u32(); pk->bf = r.u32(); pk->d = r.u32(); pk->F = r.u32(); pk->A = r.u32(); pk->I = r.u32(); pk->P = r.u32(); pk->L = r.u32();
+    const uint32_t ngates = r.u32(), nconsts = r.u32();
+    if (!r.ok || pk->k < 2 || pk->d < 4 || pk->d > 17) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad header (k=%u, degree=%u)", pk->k, pk->d);
+    // commit_lagrange needs the Lagrange basis of exactly this domain (halo2: ParamsKZG::downsize)
+    if (pk->k != srs->k) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS is for k=%u but the circuit has k=%u: downsize the SRS first", srs->k, pk->k);
+    const size_t n = (size_t)1 << pk->k;
+    if (pk->bf + 2 >= n) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many blinding rows");
+    if (!srs->g_lagrange) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS has no Lagrange basis");
+    pk->u = (uint32_t)n - pk->bf - 1;
+    pk->chunk = pk->d - 2;
+    pk->C = pk->P ? (pk->P + pk->chunk - 1) / pk->chunk : 0;
+    pk->ext_k = pk->k;
+    while (((size_t)1 << pk->ext_k) < n * (pk->d - 1)) ++pk->ext_k;
+    for (uint32_t i = 0; i < pk->P; ++i) { uint32_t t = r.u32(), x = r.u32(); pk->perm_cols.push_back({t, x}); }
+    for (uint32_t i = 0; i < nconsts; ++i) { const uint8_t* b = r.bytes(32); F4 v; if (b) memcpy(v.l, b, 32); pk->consts.push_back(v); }
+    for (uint32_t i = 0; i < ngates; ++i) pk->gates.push_back(r.prog());
+    for (uint32_t i = 0; i < pk->L; ++i) {
+        zk_pk::Lookup lk;
+        const uint32_t m = r.u32();
+        for (uint32_t j = 0; j < m; ++j) lk.inputs.push_back(r.prog());
+        for (uint32_t j = 0; j < m; ++j) lk.tables.push_back(r.prog());
+        pk->lookups.push_back(std::move(lk));
+    }
+    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated");
+    // evaluation queries: gates, lookups, then permutation columns at rotation 0
+    for (const Prog& g : pk->gates) collect_queries(g, &pk->adv_q, &pk->fix_q);
+    for (const auto& lk : pk->lookups) { for (const Prog& g : lk.inputs) collect_queries(g, &pk->adv_q, &pk->fix_q); for (const Prog& g : lk.tables) collect_queries(g, &pk->adv_q, &pk->fix_q); }
+    for (const auto& pc : pk->perm_cols) {
+        Prog one{{Q_PUSH_COL, colref(pc.first, pc.second), 0}};
+        collect_queries(one, &pk->adv_q, &pk->fix_q);
+    }
+    // fixed + sigma columns
+    pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F); pk->fixed_ext.resize(pk->F);
+    pk->sigma_lag.resize(pk->P); pk->sigma_coeff.resize(pk->P); pk->sigma_ext.resize(pk->P);
+    pk->fixed_com.resize(pk->F); pk->sigma_com.resize(pk->P);
+    for (uint32_t i = 0; i < pk->F; ++i) {
+        const uint8_t* b = r.bytes(n * 32);
+        if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated fixed column");
+        PK_TRY(upload(ctx, &pk->fixed_lag[i], b, n * 32));
+        PK_TRY(commit_lagrange(ctx, srs, pk->fixed_lag[i].fr(), n, &pk->fixed_com[i]));
+        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->fixed_lag[i], &pk->fixed_coeff[i], &pk->fixed_ext[i]));
+    }
+    for (uint32_t i = 0; i < pk->P; ++i) {
+        const uint8_t* b = r.bytes(n * 32);
+        if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated sigma column");
+        PK_TRY(upload(ctx, &pk->sigma_lag[i], b, n * 32));
+        PK_TRY(commit_lagrange(ctx, srs, pk->sigma_lag[i].fr(), n, &pk->sigma_com[i]));
+        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->sigma_lag[i], &pk->sigma_coeff[i], &pk->sigma_ext[i]));
+    }
+    // l0, l_last, l_active and the X / omega^i columns
+    {
+        std::vector<F4> l0, ll, la;
+        lagrange_masks(pk.get(), &l0, &ll, &la);
+        PK_TRY(upload(ctx, &pk->l0_lag, l0.data(), n * 32));
+        PK_TRY(upload(ctx, &pk->llast_lag, ll.data(), n * 32));
+        PK_TRY(upload(ctx, &pk->lactive_lag, la.data(), n * 32));
+        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->l0_lag, nullptr, &pk->l0_ext));
+        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->llast_lag, nullptr, &pk->llast_ext));
+        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->lactive_lag, nullptr, &pk->lactive_ext));
+        const size_t ne = (size_t)1 << pk->ext_k;
+        if (!pk->x_ext.alloc(ne * 32) || !pk->omega_lag.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        const Fr w_ext = fr_root_of_unity(pk->ext_k), w = fr_root_of_unity(pk->k), zeta = fr_zeta(), one = Fr::one();
+        PK_TRY(zk_fr_powers(ctx, &w_ext, &zeta, pk->x_ext.p, ne));
+        PK_TRY(zk_fr_powers(ctx, &w, &one, pk->omega_lag.p, n));
+    }
+    // vk_repr: hash of the circuit shape and the fixed / sigma commitments
+    {
+        host::Blake2b hsh;
+        hsh.init("Halo2-Verify-Key");
+        const uint32_t hdr[10] = {pk->k, pk->bf, pk->d, pk->F, pk->A, pk->I, pk->P, pk->L, ngates, nconsts};
+        hsh.update(hdr, sizeof hdr);
+        for (const auto& c : pk->fixed_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
+        for (const auto& c : pk->sigma_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
+        uint8_t dg[64];
+        hsh.finalize(dg);
+        pk->vk_repr = host::fr_from_uniform(dg);
+    }
+    PK_TRY(zk_ctx_sync(ctx));
+    *out = pk.release();
+    return ZK_OK;
+}
+
+// vk side of the key: commitments (F fixed then P sigma, 64-byte affine each) and vk_repr
+int zk_pk_vk(zk_ctx* ctx, const zk_pk* pk, void* h_commitments, void* h_vk_repr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk, "null pointer");
+    if (h_commitments) {
+        G1Affine* o = (G1Affine*)h_commitments;
+        for (uint32_t i = 0; i < pk->F; ++i) o[i] = pk->fixed_com[i];
+        for (uint32_t i = 0; i < pk->P; ++i) o[pk->F + i] = pk->sigma_com[i];
+    }
+    if (h_vk_repr) memcpy(h_vk_repr, &pk->vk_repr, 32);
+    return ZK_OK;
+}
+
+// create_proof.  h_advice: A host pointers to n x 32 B Lagrange columns (rows >= n - bf are
+// overwritten with blinding values); h_instance: I host pointers to n x 32 B columns (zero padded).
+int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
+                    void* h_proof, size_t proof_cap, size_t* proof_len) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && seed16 && h_proof && proof_len && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
+    const zk_srs* srs = pk->srs;
+    const uint32_t k = pk->k, ext_k = pk->ext_k;
+    const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
+    host::XorShiftRng rng(seed16);
+    host::Transcript tr;
+    const F4 one = host::fr_one();
+
+    tr.common_scalar(pk->vk_repr);
+    // ---- instances (KZG: not committed; absorbed as scalars)
+    std::vector<DevBuf> inst_lag(pk->I), inst_coeff(pk->I), inst_ext(pk->I);
+    for (uint32_t i = 0; i < pk->I; ++i) {
+        const F4* v = (const F4*)h_instance[i];
+        for (size_t row = 0; row < pk->u; ++row) tr.common_scalar(v[row]);
+        PK_TRY(upload(ctx, &inst_lag[i], h_instance[i], n * 32));
+        PK_TRY(to_coeff_and_ext(ctx, pk, inst_lag[i], &inst_coeff[i], &inst_ext[i]));
+    }
+    // ---- advice: blind, commit
+    std::vector<DevBuf> adv_lag(pk->A), adv_coeff(pk->A), adv_ext(pk->A);
+    {
+        std::vector<F4> col(n);
+        for (uint32_t i = 0; i < pk->A; ++i) {
+            memcpy(col.data(), h_advice[i], n * 32);
+            for (size_t row = n - pk->bf; row < n; ++row) col[row] = rng.next_fr();
+            PK_TRY(upload(ctx, &adv_lag[i], col.data(), n * 32));
+            G1Affine com;
+            PK_TRY(commit_lagrange(ctx, srs, adv_lag[i].fr(), n, &com));
+            tr.write_point(com);
+        }
+    }
+    Env lag{pk, false, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}};
+    lag.theta = tr.squeeze();
+
+    // ---- lookups, round 1: multiplicities m
+    std::vector<DevBuf> lk_f(pk->L), lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        const auto& lk = pk->lookups[l];
+        PB pf, pt;
+        push_compressed(pf, lk.inputs); pf.fold(C_ONE);
+        push_compressed(pt, lk.tables); pt.fold(C_ONE);
+        if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        PK_TRY(run_program(ctx, lag, pf.g, false, lk_f[l].p));
+        PK_TRY(run_program(ctx, lag, pt.g, false, lk_t[l].p));
+        std::vector<F4> f(n), t(n), m(n, host::fr_zero());
+        PK_TRY(zk_d2h(ctx, f.data(), lk_f[l].p, n * 32));
+        PK_TRY(zk_d2h(ctx, t.data(), lk_t[l].p, n * 32));
+        struct KeyHash { size_t operator()(const std::array<uint64_t, 4>& a) const { return (size_t)(a[0] ^ (a[1] * 0x9E3779B97F4A7C15ULL) ^ (a[2] << 7) ^ (a[3] >> 3)); } };
+        std::unordered_map<std::array<uint64_t, 4>, uint32_t, KeyHash> where;
+        where.reserve(pk->u * 2);
+        for (size_t row = 0; row < pk->u; ++row) { std::array<uint64_t, 4> key; memcpy(key.data(), t[row].l, 32); where.emplace(key, (uint32_t)row); }
+        std::vector<uint64_t> cnt(n, 0);
+        for (size_t row = 0; row < pk->u; ++row) {
+            std::array<uint64_t, 4> key; memcpy(key.data(), f[row].l, 32);
+            auto it = where.find(key);
+            if (it == where.end()) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %zu is not in the table (witness does not satisfy the circuit)", l, row);
+            ++cnt[it->second];
+        }
+        for (size_t row = 0; row < pk->u; ++row) m[row] = host::fr_from_u64(cnt[row]);
+        for (size_t row = pk->u + 1; row < n; ++row) m[row] = rng.next_fr();
+        PK_TRY(upload(ctx, &lk_m[l], m.data(), n * 32));
+        G1Affine com;
+        PK_TRY(commit_lagrange(ctx, srs, lk_m[l].fr(), n, &com));
+        tr.write_point(com);
+    }
+    lag.lk_m = &lk_m;
+    lag.beta = tr.squeeze();
+    lag.gamma = tr.squeeze();
+    {   // beta * delta^j for the permutation numerators;  delta = 7^(2^28)
+        F4 delta = host::fr_pow(host::fr_from_u64(7), 1ull << 28), cur = lag.beta;
+        for (uint32_t j = 0; j < pk->P; ++j) { lag.beta_delta.push_back(cur); cur = host::fr_mul(cur, delta); }
+    }
+
+    // ---- permutation grand products
+    std::vector<DevBuf> pz_lag(pk->C);
+    {
+        DevBuf num, den, zbuf;
+        if (!num.alloc(n * 32) || !den.alloc(n * 32) || !zbuf.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        F4 start = one;
+        for (uint32_t c = 0; c < pk->C; ++c) {
+            PB pn, pd;
+            const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
+            for (uint32_t j = j0; j < j1; ++j) {
+                push_perm_col(pn, pk->perm_cols[j]); pn.col(CT_SPECIAL, SP_X).mulc(C_DELTA0 + j).op(Q_ADD).addc(C_GAMMA);
+                if (j > j0) pn.op(Q_MUL);
+                push_perm_col(pd, pk->perm_cols[j]); pd.col(CT_SIGMA, j).mulc(C_BETA).op(Q_ADD).addc(C_GAMMA);
+                if (j > j0) pd.op(Q_MUL);
+            }
+            pn.fold(C_ONE); pd.fold(C_ONE);
+            PK_TRY(run_program(ctx, lag, pn.g, false, num.p));
+            PK_TRY(run_program(ctx, lag, pd.g, false, den.p));
+            PK_TRY(zk_fr_batch_invert(ctx, den.p, n));
+            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, num.p, den.p, num.p, n));
+            PK_TRY(zk_fr_prefix_product(ctx, num.p, zbuf.p, n));           // z[0] = 1, z[i+1] = z[i] * ratio[i]
+            PK_TRY(zk_fr_scale(ctx, zbuf.p, &start, n));                    // chain the chunks: Z_c(1) = Z_{c-1}(omega^u)
+            if (!pz_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            PK_TRY(zk_d2d(ctx, pz_lag[c].p, zbuf.p, n * 32));
+            std::vector<F4> blind(pk->bf);
+            for (auto& b : blind) b = rng.next_fr();
+            PK_TRY(zk_h2d(ctx, (char*)pz_lag[c].p + (n - pk->bf) * 32, blind.data(), pk->bf * 32));
+            PK_TRY(zk_d2h(ctx, &start, (char*)pz_lag[c].p + (size_t)pk->u * 32, 32));
+            G1Affine com;
+            PK_TRY(commit_lagrange(ctx, srs, pz_lag[c].fr(), n, &com));
+            tr.write_point(com);
+        }
+        if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
+    }
+    // ---- lookups, round 2: grand sums phi
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        // g[i] = 1/(f+beta) - m/(t+beta)  via one batch inversion of (f+beta) and (t+beta)
+        DevBuf inv, g, phi;
+        if (!inv.alloc(2 * n * 32) || !g.alloc(n * 32) || !phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        std::vector<DevBuf> tmpcols(2);
+        Env e2 = lag;
+        // program over explicit buffers: use CT_LK_PHI slots 0/1 as scratch references for f and t
+        std::vector<DevBuf> ft(2);
+        ft[0] = std::move(lk_f[l]); ft[1] = std::move(lk_t[l]);
+        e2.lk_phi = &ft;
+        PB a, b;
+        a.col(CT_LK_PHI, 0).addc(C_BETA).fold(C_ONE);
+        b.col(CT_LK_PHI, 1).addc(C_BETA).fold(C_ONE);
+        PK_TRY(run_program(ctx, e2, a.g, false, inv.p));
+        PK_TRY(run_program(ctx, e2, b.g, false, (char*)inv.p + n * 32));
+        PK_TRY(zk_fr_batch_invert(ctx, inv.p, 2 * n));
+        std::vector<DevBuf> iv(2);
+        // g = inv_f - m * inv_t
+        PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, (char*)inv.p + n * 32, g.p, n));
+        PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, inv.p, g.p, g.p, n));
+        PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
+        F4 closing;
+        PK_TRY(zk_d2h(ctx, &closing, (char*)phi.p + (size_t)pk->u * 32, 32));
+        if (!host::fr_is_zero(closing)) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: grand sum does not close", l);
+        std::vector<F4> blind(pk->bf);
+        for (auto& x : blind) x = rng.next_fr();
+        PK_TRY(zk_h2d(ctx, (char*)phi.p + (n - pk->bf) * 32, blind.data(), pk->bf * 32));
+        lk_f[l] = std::move(ft[0]); lk_t[l] = std::move(ft[1]);
+        G1Affine com;
+        PK_TRY(commit_lagrange(ctx, srs, phi.fr(), n, &com));
+        tr.write_point(com);
+        lk_phi[l] = std::move(phi);
+        PK_TRY(zk_ctx_sync(ctx));
+    }
+    // ---- vanishing argument: random polynomial
+    DevBuf random_coeff;
+    {
+        std::vector<F4> rc(n);
+        for (auto& x : rc) x = rng.next_fr();
+        PK_TRY(upload(ctx, &random_coeff, rc.data(), n * 32));
+        G1Affine com;
+        PK_TRY(commit_coeff(ctx, srs, random_coeff.fr(), n, &com));
+        tr.write_point(com);
+    }
+    lag.y = tr.squeeze();
+
+    // ---- coefficient and extended forms of everything the quotient reads
+    std::vector<DevBuf> pz_coeff(pk->C), pz_ext(pk->C), m_coeff(pk->L), m_ext(pk->L), phi_coeff(pk->L), phi_ext(pk->L);
+    for (uint32_t i = 0; i < pk->A; ++i) PK_TRY(to_coeff_and_ext(ctx, pk, adv_lag[i], &adv_coeff[i], &adv_ext[i]));
+    for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(to_coeff_and_ext(ctx, pk, pz_lag[c], &pz_coeff[c], &pz_ext[c]));
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        PK_TRY(to_coeff_and_ext(ctx, pk, lk_m[l], &m_coeff[l], &m_ext[l]));
+        PK_TRY(to_coeff_and_ext(ctx, pk, lk_phi[l], &phi_coeff[l], &phi_ext[l]));
+    }
+    // ---- the quotient program: gates, permutation, lookups, each folded with y
+    PB q;
+    for (const Prog& g : pk->gates) { q.append(g); q.fold(C_Y); }
+    const int32_t rot_last = -(int32_t)(pk->bf + 1);
+    if (pk->C) {
+        q.col(CT_SPECIAL, SP_L0).cst(C_ONE).col(CT_PERM_Z, 0).op(Q_SUB).op(Q_MUL).fold(C_Y);                                   // l0 (1 - Z_0)
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_PERM_Z, pk->C - 1).op(Q_SQUARE).col(CT_PERM_Z, pk->C - 1).op(Q_SUB).op(Q_MUL).fold(C_Y);   // l_last (Z^2 - Z)
+        for (uint32_t c = 1; c < pk->C; ++c)
+            q.col(CT_SPECIAL, SP_L0).col(CT_PERM_Z, c).col(CT_PERM_Z, c - 1, rot_last).op(Q_SUB).op(Q_MUL).fold(C_Y);          // l0 (Z_c - Z_{c-1}(w^last X))
+        for (uint32_t c = 0; c < pk->C; ++c) {
+            const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
+            q.col(CT_SPECIAL, SP_LACTIVE);
+            q.col(CT_PERM_Z, c, 1);
+            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SIGMA, j).mulc(C_BETA).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
+            q.col(CT_PERM_Z, c, 0);
+            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SPECIAL, SP_X).mulc(C_DELTA0 + j).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
+            q.op(Q_SUB).op(Q_MUL).fold(C_Y);
+        }
+    }
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        const auto& lk = pk->lookups[l];
+        q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
+        // l_active * ( (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta)) )
+        q.col(CT_SPECIAL, SP_LACTIVE);
+        q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
+        push_compressed(q, lk.inputs); q.addc(C_BETA).op(Q_MUL);
+        push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
+        push_compressed(q, lk.tables); q.addc(C_BETA);
+        q.col(CT_LK_M, l); push_compressed(q, lk.inputs); q.addc(C_BETA).op(Q_MUL);
+        q.op(Q_SUB).op(Q_SUB).op(Q_MUL).fold(C_Y);
+    }
+    Env ext = lag;
+    ext.extended = true; ext.advice = &adv_ext; ext.instance = &inst_ext; ext.perm_z = &pz_ext; ext.lk_m = &m_ext; ext.lk_phi = &phi_ext;
+    DevBuf h;
+    if (!h.alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    PK_TRY(run_program(ctx, ext, q.g, true, h.p));
+    PK_TRY(zk_extended_to_coeff(ctx, h.p, ext_k));
+    const uint32_t pieces = pk->d - 1;
+    for (uint32_t i = 0; i < pieces; ++i) {
+        G1Affine com;
+        PK_TRY(commit_coeff(ctx, srs, h.fr() + (size_t)i * n, n, &com));
+        tr.write_point(com);
+    }
+    adv_ext.clear(); pz_ext.clear(); m_ext.clear(); phi_ext.clear(); inst_ext.clear();   // extended forms no longer needed
+
+    const F4 x = tr.squeeze();
+    // ---- evaluations
+    const F4 w = [&] { Fr t = fr_root_of_unity(k); F4 r; memcpy(r.l, &t, 32); return r; }();
+    const F4 w_inv = host::fr_inv(w);
+    auto rotate = [&](int32_t rot) { F4 p = x; const F4 b = rot >= 0 ? w : w_inv; for (int32_t i = 0; i < (rot >= 0 ? rot : -rot); ++i) p = host::fr_mul(p, b); return p; };
+    struct Open { const Fr* poly; int32_t rot; F4 eval; };
+    std::vector<Open> opens;
+    auto eval_at = [&](const Fr* coeffs, int32_t rot, F4* out) -> int { const F4 pt = rotate(rot); return zk_poly_eval(ctx, coeffs, n, &pt, out); };
+    for (const Query& qy : pk->adv_q) { F4 e; PK_TRY(eval_at(adv_coeff[qy.idx].fr(), qy.rot, &e)); tr.write_scalar(e); opens.push_back({adv_coeff[qy.idx].fr(), qy.rot, e}); }
+    for (const Query& qy : pk->fix_q) { F4 e; PK_TRY(eval_at(pk->fixed_coeff[qy.idx].fr(), qy.rot, &e)); tr.write_scalar(e); opens.push_back({pk->fixed_coeff[qy.idx].fr(), qy.rot, e}); }
+    { F4 e; PK_TRY(eval_at(random_coeff.fr(), 0, &e)); tr.write_scalar(e); opens.push_back({random_coeff.fr(), 0, e}); }
+    for (uint32_t j = 0; j < pk->P; ++j) { F4 e; PK_TRY(eval_at(pk->sigma_coeff[j].fr(), 0, &e)); tr.write_scalar(e); opens.push_back({pk->sigma_coeff[j].fr(), 0, e}); }
+    for (uint32_t c = 0; c < pk->C; ++c) {
+        for (int32_t rot : {0, 1}) { F4 e; PK_TRY(eval_at(pz_coeff[c].fr(), rot, &e)); tr.write_scalar(e); opens.push_back({pz_coeff[c].fr(), rot, e}); }
+        if (c + 1 < pk->C) { F4 e; PK_TRY(eval_at(pz_coeff[c].fr(), rot_last, &e)); tr.write_scalar(e); opens.push_back({pz_coeff[c].fr(), rot_last, e}); }
+    }
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        for (int32_t rot : {0, 1}) { F4 e; PK_TRY(eval_at(phi_coeff[l].fr(), rot, &e)); tr.write_scalar(e); opens.push_back({phi_coeff[l].fr(), rot, e}); }
+        F4 e; PK_TRY(eval_at(m_coeff[l].fr(), 0, &e)); tr.write_scalar(e); opens.push_back({m_coeff[l].fr(), 0, e});
+    }
+    // h(X) = sum_i x^(n i) h_i(X): opened at x, the verifier derives its expected value itself
+    DevBuf hcomb;
+    {
+        if (!hcomb.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        F4 xn = x;
+        for (uint32_t i = 0; i < k; ++i) xn = host::fr_mul(xn, xn);
+        std::vector<uint32_t> words;
+        std::vector<const void*> cols;
+        for (uint32_t i = pieces; i-- > 0;) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(h.fr() + (size_t)i * n); }
+        PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &xn, 1, k, k, 0, hcomb.p));
+        F4 e; PK_TRY(eval_at(hcomb.fr(), 0, &e));
+        opens.push_back({hcomb.fr(), 0, e});   // not written: the verifier recomputes it
+    }
+    // ---- GWC multi-open: one witness per distinct point, in order of first appearance
+    const F4 v = tr.squeeze();
+    std::vector<int32_t> rots;
+    for (const Open& o : opens) if (std::find(rots.begin(), rots.end(), o.rot) == rots.end()) rots.push_back(o.rot);
+    DevBuf batch, wit;
+    if (!batch.alloc(n * 32) || !wit.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    for (int32_t rot : rots) {
+        std::vector<uint32_t> words;
+        std::vector<const void*> cols;
+        for (const Open& o : opens) if (o.rot == rot) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(o.poly); }
+        PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &v, 1, k, k, 0, batch.p));
+        const F4 z = rotate(rot);
+        PK_TRY(zk_kate_division(ctx, batch.p, n, &z, wit.p));
+        G1Affine com;
+        PK_TRY(commit_coeff(ctx, srs, wit.fr(), n - 1, &com));
+        tr.write_point(com);
+    }
+    PK_TRY(zk_ctx_sync(ctx));
+    *proof_len = tr.proof.size();
+    if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
+    memcpy(h_proof, tr.proof.data(), tr.proof.size());
+    return ZK_OK;
+}
+
+}  // extern "C"

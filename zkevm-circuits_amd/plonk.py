@@ -1,0 +1,219 @@
+"""Host-side circuit description for the prover: a small mirror of halo2's ``ConstraintSystem`` /
+``Expression`` / permutation ``Assembly`` that serialises to the flat "pk blob" consumed by
+``zk_pk_create`` (witness / constraint-system export format).
+
+In production the Rust shim fills the same blob from ``halo2_proofs::plonk::ConstraintSystem``
+(gates -> postfix programs, ``permutation::keygen::Assembly`` -> sigma columns, fixed columns in
+Lagrange form); this module lets tests and benches build circuits without Rust.
+
+Expressions are tiny ASTs with operator overloading:  ``a * b - c``, ``q * (x.rot(1) - x - 1)``.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FR_GENERATOR = 7
+FR_S = 28
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (R_MOD - 1) >> FR_S, R_MOD)
+FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)
+
+FIXED, ADVICE, INSTANCE = 0, 1, 2
+Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG = 1, 2, 3, 4, 5, 6
+BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 1
+
+
+def fr_mont_bytes(v: int) -> bytes:
+    return (((v % R_MOD) << 256) % R_MOD).to_bytes(32, "little")
+
+
+def column_to_mont(values: Sequence[int]) -> np.ndarray:
+    """Plain integers -> (n, 4) u64 Montgomery limbs (the layout every ABI call uses)."""
+    buf = b"".join(fr_mont_bytes(v) for v in values)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+# ------------------------------------------------------------------------------------ expressions
+class Expr:
+    def __add__(self, o): return Bin(Q_ADD, self, wrap(o))
+    def __radd__(self, o): return Bin(Q_ADD, wrap(o), self)
+    def __sub__(self, o): return Bin(Q_SUB, self, wrap(o))
+    def __rsub__(self, o): return Bin(Q_SUB, wrap(o), self)
+    def __mul__(self, o): return Bin(Q_MUL, self, wrap(o))
+    def __rmul__(self, o): return Bin(Q_MUL, wrap(o), self)
+    def __neg__(self): return Neg(self)
+
+
+class Col(Expr):
+    def __init__(self, ctype: int, index: int, rotation: int = 0):
+        self.ctype, self.index, self.rotation = ctype, index, rotation
+
+    def rot(self, r: int) -> "Col":
+        return Col(self.ctype, self.index, self.rotation + r)
+
+    def degree(self): return 1
+
+
+class Const(Expr):
+    def __init__(self, value: int):
+        self.value = value % R_MOD
+
+    def degree(self): return 0
+
+
+class Bin(Expr):
+    def __init__(self, op, a, b):
+        self.op, self.a, self.b = op, a, b
+
+    def degree(self):
+        return self.a.degree() + self.b.degree() if self.op == Q_MUL else max(self.a.degree(), self.b.degree())
+
+
+class Neg(Expr):
+    def __init__(self, a):
+        self.a = a
+
+    def degree(self): return self.a.degree()
+
+
+def wrap(x) -> Expr:
+    return x if isinstance(x, Expr) else Const(int(x))
+
+
+def colref(ctype: int, index: int) -> int:
+    return (ctype << 24) | index
+
+
+class Circuit:
+    """Shape + fixed assignment + copy constraints of one PLONKish circuit."""
+
+    def __init__(self, k: int, num_fixed: int, num_advice: int, num_instance: int, blinding_factors: int = 5):
+        self.k, self.n = k, 1 << k
+        self.F, self.A, self.I = num_fixed, num_advice, num_instance
+        self.bf = blinding_factors
+        self.u = self.n - self.bf - 1          # rows [0, u) are usable
+        self.gates: List[Expr] = []
+        self.lookups: List[Tuple[List[Expr], List[Expr]]] = []
+        self.perm_cols: List[Tuple[int, int]] = []
+        self.copies: List[Tuple[Tuple[int, int, int], Tuple[int, int, int]]] = []
+        self.fixed = [[0] * self.n for _ in range(num_fixed)]
+        self.consts: List[int] = []
+        self._const_index: Dict[int, int] = {}
+
+    # -- columns
+    def fixed_col(self, i, rot=0): return Col(FIXED, i, rot)
+    def advice_col(self, i, rot=0): return Col(ADVICE, i, rot)
+    def instance_col(self, i, rot=0): return Col(INSTANCE, i, rot)
+
+    # -- constraints
+    def add_gate(self, e: Expr): self.gates.append(e)
+    def add_lookup(self, inputs: Sequence[Expr], tables: Sequence[Expr]):
+        assert len(inputs) == len(tables)
+        self.lookups.append((list(inputs), list(tables)))
+
+    def enable_equality(self, ctype: int, index: int):
+        if (ctype, index) not in self.perm_cols:
+            self.perm_cols.append((ctype, index))
+
+    def copy(self, a: Tuple[int, int, int], b: Tuple[int, int, int]):
+        """(ctype, index, row) == (ctype, index, row)"""
+        for c in (a, b):
+            self.enable_equality(c[0], c[1])
+            assert c[2] < self.u, "copy constraint on an unusable row"
+        self.copies.append((a, b))
+
+    # -- derived shape
+    def degree(self) -> int:
+        d = 4 if self.lookups else 3
+        for g in self.gates:
+            d = max(d, g.degree())
+        return max(d, 4)
+
+    def extended_k(self) -> int:
+        ek = self.k
+        while (1 << ek) < self.n * (self.degree() - 1):
+            ek += 1
+        return ek
+
+    def omega(self) -> int:
+        return pow(FR_ROOT_OF_UNITY, 1 << (FR_S - self.k), R_MOD)
+
+    # -- compilation
+    def _const(self, v: int) -> int:
+        if v not in self._const_index:
+            self._const_index[v] = len(self.consts)
+            self.consts.append(v)
+        return self._const_index[v]
+
+    def compile(self, e: Expr) -> List[Tuple[int, int, int]]:
+        out: List[Tuple[int, int, int]] = []
+
+        def go(x: Expr):
+            if isinstance(x, Col):
+                out.append((Q_PUSH_COL, colref(x.ctype, x.index), x.rotation & 0xFFFFFFFF))
+            elif isinstance(x, Const):
+                out.append((Q_PUSH_CONST, self._const(x.value), 0))
+            elif isinstance(x, Neg):
+                go(x.a)
+                out.append((Q_NEG, 0, 0))
+            else:
+                go(x.a)
+                go(x.b)
+                out.append((x.op, 0, 0))
+        go(e)
+        return out
+
+    def sigma_columns(self) -> List[List[int]]:
+        """halo2 ``permutation::keygen::Assembly``: cycles of equal cells -> sigma_j(omega^i) =
+        delta^j' * omega^i' of the next cell in the cycle."""
+        P, n = len(self.perm_cols), self.n
+        pos = {c: j for j, c in enumerate(self.perm_cols)}
+        mapping = [[(j, i) for i in range(n)] for j in range(P)]
+        aux = [[(j, i) for i in range(n)] for j in range(P)]
+        sizes = [[1] * n for _ in range(P)]
+        for a, b in self.copies:
+            lc, lr, rc, rr = pos[(a[0], a[1])], a[2], pos[(b[0], b[1])], b[2]
+            if aux[lc][lr] == aux[rc][rr]:
+                continue
+            lcyc, rcyc = aux[lc][lr], aux[rc][rr]
+            if sizes[lcyc[0]][lcyc[1]] < sizes[rcyc[0]][rcyc[1]]:
+                lc, lr, rc, rr = rc, rr, lc, lr
+                lcyc, rcyc = rcyc, lcyc
+            sizes[lcyc[0]][lcyc[1]] += sizes[rcyc[0]][rcyc[1]]
+            i = (rc, rr)
+            while True:
+                aux[i[0]][i[1]] = lcyc
+                i = mapping[i[0]][i[1]]
+                if i == (rc, rr):
+                    break
+            mapping[lc][lr], mapping[rc][rr] = mapping[rc][rr], mapping[lc][lr]
+        w = self.omega()
+        wp = [1] * n
+        for i in range(1, n):
+            wp[i] = wp[i - 1] * w % R_MOD
+        dp = [pow(FR_DELTA, j, R_MOD) for j in range(P)]
+        return [[dp[mapping[j][i][0]] * wp[mapping[j][i][1]] % R_MOD for i in range(n)] for j in range(P)]
+
+    def blob(self) -> bytes:
+        """Serialise for zk_pk_create (layout documented in csrc/prover.hip)."""
+        gates = [self.compile(g) for g in self.gates]
+        lookups = [([self.compile(e) for e in ins], [self.compile(e) for e in tabs]) for ins, tabs in self.lookups]
+        sig = self.sigma_columns()
+
+        def prog(p):
+            return struct.pack("<I", len(p)) + b"".join(struct.pack("<III", *ins) for ins in p)
+
+        out = [struct.pack("<12I", BLOB_MAGIC, BLOB_VERSION, self.k, self.bf, self.degree(), self.F, self.A, self.I,
+                           len(self.perm_cols), len(self.lookups), len(gates), len(self.consts))]
+        out += [struct.pack("<II", t, i) for t, i in self.perm_cols]
+        out += [fr_mont_bytes(c) for c in self.consts]
+        out += [prog(g) for g in gates]
+        for ins, tabs in lookups:
+            out.append(struct.pack("<I", len(ins)))
+            out += [prog(p) for p in ins] + [prog(p) for p in tabs]
+        out += [column_to_mont(col).tobytes() for col in self.fixed]
+        out += [column_to_mont(col).tobytes() for col in sig]
+        return b"".join(out)
