@@ -112,3 +112,27 @@ def test_msm_2_20_closed_form_over_srs(zk, ctx, cref):
     both = bn254.g1_add(cref.affine_from_mont(lo)[0], cref.affine_from_mont(hi)[0])
     assert both == cref.affine_from_mont(want)[0]
     srs.destroy()
+
+
+@pytest.mark.parametrize("kind", ["boolean", "all_equal", "small_values", "two_values"])
+def test_msm_skewed_scalars_2_16(ctx, cref, kind):
+    """Selector / boolean / small-value columns put a large share of the points into one bucket:
+    the task split must keep the result exact (and the run time flat)."""
+    import time
+    n = 1 << 16
+    rng = random.Random(17)
+    P = cref.srs_powers(99, n)
+    if kind == "boolean":
+        vals = [rng.randrange(2) for _ in range(n)]
+    elif kind == "all_equal":
+        vals = [0x1234567] * n
+    elif kind == "small_values":
+        vals = [rng.randrange(256) for _ in range(n)]
+    else:
+        vals = [rng.choice([R - 1, 5]) for _ in range(n)]
+    S = cref.to_mont(vals)
+    t0 = time.perf_counter()
+    got = ctx.best_multiexp(S, P)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(got, cref.best_multiexp(S, P)), kind
+    assert dt < 0.5, f"{kind}: MSM took {dt:.3f}s -- a single lane is walking a giant bucket"

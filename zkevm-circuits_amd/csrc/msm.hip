@@ -197,8 +197,18 @@ __global__ void k_size_bins_scan(uint32_t* size_hist) {
     uint32_t run = 0;
     for (int b = SIZE_BINS - 1; b >= 0; --b) { const uint32_t c = size_hist[b]; size_hist[b] = run; run += c; }
 }
-// order[pos] = bucket id, grouped by size bin (block-aggregated reservation of output ranges)
-__global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order) {
+// ---- skew-proof work split ------------------------------------------------------------------------
+// A bucket with c points becomes ceil(c / TASK_CAP) tasks of <= TASK_CAP consecutive points, so no
+// lane ever walks more than TASK_CAP points whatever the scalar distribution (selector / boolean /
+// small-value columns put n/2 points into one bucket).  Tasks are numbered along the size-ordered
+// bucket sequence (a wave still sees equal-length work); single-task buckets write their bucket
+// directly, multi-task buckets write partials that one workgroup per bucket tree-sums afterwards.
+constexpr uint32_t TASK_CAP = 64;
+
+// order[pos] = bucket id, grouped by size bin (block-aggregated reservation of output ranges);
+// ntasks[pos] = number of tasks of that bucket
+__global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ ntasks) {
     __shared__ uint32_t lh[SIZE_BINS], lbase[SIZE_BINS];
     if (threadIdx.x < SIZE_BINS) lh[threadIdx.x] = 0;
     __syncthreads();
@@ -216,7 +226,25 @@ __global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __rest
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const uint32_t i = base + k * SCAN_T + threadIdx.x;
-        if (i < cnt) order[lbase[bin[k]] + rank[k]] = i;
+        if (i < cnt) {
+            const uint32_t pos = lbase[bin[k]] + rank[k];
+            order[pos] = i;
+            ntasks[pos] = (counts[i] + TASK_CAP - 1) / TASK_CAP;
+        }
+    }
+}
+// adds the block offsets of the task scan and lists the positions that own more than one task
+__global__ void __launch_bounds__(SCAN_T) k_task_offsets(const uint32_t* __restrict__ ntasks, uint32_t cnt, uint32_t* __restrict__ toff, const uint32_t* __restrict__ block_tot,
+                                                         uint32_t* __restrict__ multi, uint32_t* __restrict__ nmulti) {
+    const uint32_t off = block_tot[blockIdx.x];
+    const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_T + threadIdx.x;
+        if (i < cnt) {
+            toff[i] += off;
+            if (ntasks[i] > 1) multi[atomicAdd(nmulti, 1u)] = i;
+        }
     }
 }
 
@@ -230,20 +258,54 @@ __global__ void k_bases_to_rprime(const G1Affine* __restrict__ in, G1Affine* __r
     stg(out + i, p);
 }
 
+// one lane per task; toff[0..nbuckets] = exclusive scan of ntasks along the ordered sequence
 __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
-                                                     const uint32_t* __restrict__ order, uint32_t nbuckets, G1Xyzz29* __restrict__ buckets) {
+                                                     const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff,
+                                                     uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nbuckets) return;
-    const uint32_t b = order[t];
-    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    if (t >= toff[nbuckets]) return;
+    // position p with toff[p] <= t < toff[p+1]  (empty buckets have equal neighbours: upper bound)
+    uint32_t lo_p = 0, hi_p = nbuckets;
+    while (hi_p - lo_p > 1) {
+        const uint32_t mid = (lo_p + hi_p) >> 1;
+        if (toff[mid] <= t) lo_p = mid; else hi_p = mid;
+    }
+    const uint32_t p = lo_p, b = order[p], chunk = t - toff[p];
+    const uint32_t lo = offsets[b] + chunk * TASK_CAP, hi = min(lo + TASK_CAP, offsets[b + 1]);
     G1Xyzz29 acc = identity29();
     for (uint32_t j = lo; j < hi; ++j) {
         const uint32_t v = idx[j];
-        G1Affine29 p = load_affine29(bases_rp + (v & ~NEG_BIT));
-        if ((v & NEG_BIT) && !is_identity29(p)) p.y = neg_canon29(p.y);
-        acc = madd29(acc, p);
+        G1Affine29 q = load_affine29(bases_rp + (v & ~NEG_BIT));
+        if ((v & NEG_BIT) && !is_identity29(q)) q.y = neg_canon29(q.y);
+        acc = madd29(acc, q);
     }
-    stg29(buckets + b, acc);
+    if (ntasks[p] == 1) stg29(buckets + b, acc);
+    else stg29(partial + t, acc);
+}
+// buckets that never received a point keep stale memory otherwise
+__global__ void k_msm_clear_empty(const uint32_t* __restrict__ counts, uint32_t nbuckets, G1Xyzz29* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbuckets && counts[b] == 0) stg29(buckets + b, identity29());
+}
+// one workgroup per multi-task bucket: strided sums + LDS tree over its partials
+__global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict__ multi, const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial,
+                                                     G1Xyzz29* __restrict__ buckets) {
+    __shared__ G1Xyzz29 sh[256];
+    const uint32_t total = *nmulti;
+    for (uint32_t m = blockIdx.x; m < total; m += gridDim.x) {
+        const uint32_t p = multi[m], cnt = ntasks[p], base = toff[p];
+        G1Xyzz29 acc = identity29();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + base + i));
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off && threadIdx.x + off < cnt) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) stg29(buckets + order[p], sh[0]);
+        __syncthreads();
+    }
 }
 
 // k * P for small k (< 2^16), MSB-first double-and-add
@@ -305,30 +367,39 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
 
-    // u32 workspace: counts[nb] | size_hist[256] | offsets[nb+1] | cursor[nb] | order[nb] | block_tot | idx[n*W]
+    // u32 workspace: counts[nb] | size_hist[256] nmulti[4] | offsets[nb+1] | cursor[nb] | order[nb] | ntasks[nb] | toff[nb+1] | multi[nb] |
+    //                block_tot[2*scan_blocks] | idx[n*W] | (16-B aligned) dig[W*n_pad u16]
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
     const uint64_t n_pad = ((uint64_t)n + 7) & ~7ull;
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
-    const size_t words = (size_t)nb * 4 + 4 + SIZE_BINS + scan_blocks + (size_t)n * pl.W + dig_words;
+    const size_t head_words = (size_t)nb * 7 + 2 + SIZE_BINS + 4 + 2 * (size_t)scan_blocks + (size_t)n * pl.W;
+    const size_t words = head_words + 4 + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* counts = ws;
     uint32_t* size_hist = counts + nb;
-    uint32_t* offsets = size_hist + SIZE_BINS;
+    uint32_t* nmulti = size_hist + SIZE_BINS;
+    uint32_t* offsets = nmulti + 4;
     uint32_t* cursor = offsets + nb + 1;
     uint32_t* order = cursor + nb;
-    uint32_t* block_tot = order + nb;
-    uint32_t* idx = block_tot + scan_blocks;
-    uint16_t* dig = reinterpret_cast<uint16_t*>(ws + (((size_t)nb * 4 + 1 + SIZE_BINS + scan_blocks + (size_t)n * pl.W + 3) & ~(size_t)3));   // 16-B aligned
+    uint32_t* ntasks = order + nb;
+    uint32_t* toff = ntasks + nb;
+    uint32_t* multi = toff + nb + 1;
+    uint32_t* block_tot = multi + nb;
+    uint32_t* block_tot2 = block_tot + scan_blocks;
+    uint32_t* idx = block_tot2 + scan_blocks;
+    uint16_t* dig = reinterpret_cast<uint16_t*>(ws + ((head_words + 3) & ~(size_t)3));   // 16-B aligned
     int range_bits = pl.c - 1;
     if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
     const dim3 sweep_grid(pl.B >> range_bits, pl.W);
     const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
-    const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks;
+    const size_t max_tasks = (size_t)nb + ((size_t)n * pl.W) / TASK_CAP + 1;
+    const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks + max_tasks;
     char* bk = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29 + sizeof(G1Xyzz) * pl.W);
     if (!bk) return ZK_ERR_OOM;
     G1Xyzz29* buckets = (G1Xyzz29*)bk;
     G1Xyzz29* partial = buckets + nb;
+    G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
     G1Xyzz* wsum = (G1Xyzz*)(bk + sizeof(G1Xyzz29) * npts29);
 
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
@@ -342,7 +413,7 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
     }
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)SIZE_BINS * 4, ctx->stream));
+        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 4) * 4, ctx->stream));   // size_hist + nmulti
         hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((n_pad + 255) / 256)), ts, 0, ctx->stream, d_scalars, (uint64_t)n, n_pad, pl.c, pl.W, dig);
         hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         ZK_CHECK_LAUNCH(ctx);
@@ -350,14 +421,21 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
         hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, (const uint32_t*)block_tot, cursor, size_hist);
         hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist);
-        hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order);
+        hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
+        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb);
+        hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, (const uint32_t*)block_tot2, multi, nmulti);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
         ZkProfScope ps(ctx, "msm_buckets");
-        hipLaunchKernelGGL(k_msm_buckets, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx, (const uint32_t*)order, nb, buckets);
+        hipLaunchKernelGGL(k_msm_clear_empty, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)counts, nb, buckets);
+        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
+                           (const uint32_t*)order, (const uint32_t*)ntasks, (const uint32_t*)toff, nb, buckets, task_partial);
+        hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)multi, (const uint32_t*)nmulti, (const uint32_t*)order,
+                           (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
