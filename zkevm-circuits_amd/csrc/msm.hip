@@ -195,7 +195,10 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restric
 __global__ void k_size_bins_scan(uint32_t* size_hist) {
     if (threadIdx.x || blockIdx.x) return;
     uint32_t run = 0;
-    for (int b = SIZE_BINS - 1; b >= 0; --b) { const uint32_t c = size_hist[b]; size_hist[b] = run; run += c; }
+    for (int b = SIZE_BINS - 1; b >= 0; --b) {
+        if (b == 64) size_hist[SIZE_BINS] = run;   // M: buckets with more than TASK_CAP (= 64) points come first
+        const uint32_t c = size_hist[b]; size_hist[b] = run; run += c;
+    }
 }
 // ---- skew-proof work split ------------------------------------------------------------------------
 // A bucket with c points becomes ceil(c / TASK_CAP) tasks of <= TASK_CAP consecutive points, so no
@@ -233,18 +236,14 @@ __global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __rest
         }
     }
 }
-// adds the block offsets of the task scan and lists the positions that own more than one task
-__global__ void __launch_bounds__(SCAN_T) k_task_offsets(const uint32_t* __restrict__ ntasks, uint32_t cnt, uint32_t* __restrict__ toff, const uint32_t* __restrict__ block_tot,
-                                                         uint32_t* __restrict__ multi, uint32_t* __restrict__ nmulti) {
+// adds the block offsets of the task scan
+__global__ void __launch_bounds__(SCAN_T) k_task_offsets(uint32_t cnt, uint32_t* __restrict__ toff, const uint32_t* __restrict__ block_tot) {
     const uint32_t off = block_tot[blockIdx.x];
     const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const uint32_t i = base + k * SCAN_T + threadIdx.x;
-        if (i < cnt) {
-            toff[i] += off;
-            if (ntasks[i] > 1) multi[atomicAdd(nmulti, 1u)] = i;
-        }
+        if (i < cnt) toff[i] += off;
     }
 }
 
@@ -258,20 +257,7 @@ __global__ void k_bases_to_rprime(const G1Affine* __restrict__ in, G1Affine* __r
     stg(out + i, p);
 }
 
-// one lane per task; toff[0..nbuckets] = exclusive scan of ntasks along the ordered sequence
-__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
-                                                     const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff,
-                                                     uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= toff[nbuckets]) return;
-    // position p with toff[p] <= t < toff[p+1]  (empty buckets have equal neighbours: upper bound)
-    uint32_t lo_p = 0, hi_p = nbuckets;
-    while (hi_p - lo_p > 1) {
-        const uint32_t mid = (lo_p + hi_p) >> 1;
-        if (toff[mid] <= t) lo_p = mid; else hi_p = mid;
-    }
-    const uint32_t p = lo_p, b = order[p], chunk = t - toff[p];
-    const uint32_t lo = offsets[b] + chunk * TASK_CAP, hi = min(lo + TASK_CAP, offsets[b + 1]);
+__device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ idx, uint32_t lo, uint32_t hi) {
     G1Xyzz29 acc = identity29();
     for (uint32_t j = lo; j < hi; ++j) {
         const uint32_t v = idx[j];
@@ -279,22 +265,57 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
         if ((v & NEG_BIT) && !is_identity29(q)) q.y = neg_canon29(q.y);
         acc = madd29(acc, q);
     }
-    if (ntasks[p] == 1) stg29(buckets + b, acc);
-    else stg29(partial + t, acc);
+    return acc;
 }
-// buckets that never received a point keep stale memory otherwise
-__global__ void k_msm_clear_empty(const uint32_t* __restrict__ counts, uint32_t nbuckets, G1Xyzz29* __restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbuckets && counts[b] == 0) stg29(buckets + b, identity29());
+// Buckets are ordered by decreasing size, so the M = *nmulti buckets with more than TASK_CAP
+// points are exactly positions [0, M).  Single-task (and empty) buckets: one lane per position,
+// no search, result straight into the bucket.
+// One launch, virtual index v: the Tm = toff[M] tasks of the multi-task buckets come first (they
+// are the long poles and overlap with everything behind them), then one lane per ordinary bucket
+// position M + (v - Tm).  toff = exclusive scan of ntasks over positions.
+__global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ order, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ nmulti,
+                                                     uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial) {
+    const uint32_t M = *nmulti;
+    const uint32_t Tm = M ? toff[M] : 0u;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < Tm) {
+        uint32_t lo_p = 0, hi_p = M;             // toff[lo_p] <= v < toff[hi_p]
+        while (hi_p - lo_p > 1) {
+            const uint32_t mid = (lo_p + hi_p) >> 1;
+            if (toff[mid] <= v) lo_p = mid; else hi_p = mid;
+        }
+        const uint32_t b = order[lo_p], chunk = v - toff[lo_p];
+        const uint32_t lo = offsets[b] + chunk * TASK_CAP, hi = min(lo + TASK_CAP, offsets[b + 1]);
+        stg29(partial + v, accumulate_run(bases_rp, idx, lo, hi));
+        return;
+    }
+    const uint32_t p = M + (v - Tm);
+    if (p >= nbuckets) return;
+    const uint32_t b = order[p];
+    stg29(buckets + b, accumulate_run(bases_rp, idx, offsets[b], offsets[b + 1]));
+}
+constexpr uint32_t COMBINE_SMALL = 32;
+// multi-task buckets with few partials: one lane each, sequential sum
+__global__ void __launch_bounds__(256) k_msm_combine_small(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks,
+                                                           const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial, G1Xyzz29* __restrict__ buckets) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= *nmulti) return;
+    const uint32_t cnt = ntasks[m], base = toff[m];
+    if (cnt > COMBINE_SMALL) return;
+    G1Xyzz29 acc = ldg29(partial + base);
+    for (uint32_t i = 1; i < cnt; ++i) acc = add29pt(acc, ldg29(partial + base + i));
+    stg29(buckets + order[m], acc);
 }
 // one workgroup per multi-task bucket: strided sums + LDS tree over its partials
-__global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict__ multi, const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order,
+__global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial,
                                                      G1Xyzz29* __restrict__ buckets) {
     __shared__ G1Xyzz29 sh[256];
     const uint32_t total = *nmulti;
     for (uint32_t m = blockIdx.x; m < total; m += gridDim.x) {
-        const uint32_t p = multi[m], cnt = ntasks[p], base = toff[p];
+        const uint32_t p = m, cnt = ntasks[p], base = toff[p];
+        if (cnt <= COMBINE_SMALL) continue;      // handled by k_msm_combine_small (uniform across the workgroup)
         G1Xyzz29 acc = identity29();
         for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + base + i));
         sh[threadIdx.x] = acc;
@@ -424,17 +445,19 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
         hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb);
-        hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, (const uint32_t*)block_tot2, multi, nmulti);
+        hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
         ZkProfScope ps(ctx, "msm_buckets");
-        hipLaunchKernelGGL(k_msm_clear_empty, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)counts, nb, buckets);
+        // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
         hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
-                           (const uint32_t*)order, (const uint32_t*)ntasks, (const uint32_t*)toff, nb, buckets, task_partial);
-        hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)multi, (const uint32_t*)nmulti, (const uint32_t*)order,
+                           (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial);
+        hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
+                           (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
+        hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
