@@ -131,6 +131,10 @@ const void* zk_srs_g_lagrange(const zk_srs* srs); /* device pointer or NULL     
 int zk_msm_g1(zk_ctx* ctx, const void* d_scalars, const void* d_bases, size_t n, void* h_out_affine);
 /* ParamsKZG::commit (basis = 0, over g) / commit_lagrange (basis = 1, over g_lagrange).          */
 int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, size_t n, void* h_out_affine);
+/* `count` commitments over the same basis (ParamsKZG::commit_lagrange over every advice column
+ * of a phase): d_scalar_ptrs[i] addresses n Fr on the device, h_out_affine receives count x 64 B.
+ * Consecutive MSMs are pipelined on two streams.                                                 */
+int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine);
 /* best_multiexp over HOST slices, exactly the reference signature (copies in, computes, copies
  * the affine result out).                                                                        */
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine);

@@ -136,3 +136,21 @@ def test_msm_skewed_scalars_2_16(ctx, cref, kind):
     dt = time.perf_counter() - t0
     assert np.array_equal(got, cref.best_multiexp(S, P)), kind
     assert dt < 0.5, f"{kind}: MSM took {dt:.3f}s -- a single lane is walking a giant bucket"
+
+
+def test_commit_batch_matches_single_commits(ctx, cref):
+    k, n = 12, 1 << 12
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(4242))
+    cols = [cref.rand_fr_stream(300 + i, n) for i in range(5)]
+    cols[2][:] = 0                                  # an all-zero column commits to the identity
+    cols[3] = cref.to_mont([1] * n)                 # a selector-like column
+    bufs = [ctx.to_device(c) for c in cols]
+    for lagrange in (False, True):
+        single = np.stack([ctx.commit(srs, b_, n, lagrange=lagrange) for b_ in bufs])
+        batch = ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=lagrange)
+        assert np.array_equal(single, batch)
+        assert not batch[2].any()
+    basis = srs.download_g()
+    assert np.array_equal(ctx.commit_batch(srs, [bufs[0].ptr], n)[0], cref.best_multiexp(cols[0], basis))
+    assert ctx.commit_batch(srs, [], n).shape == (0, 8)
+    srs.destroy()

@@ -64,6 +64,9 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_p2) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -252,6 +255,19 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine) {
     return ZK_OK;
 }
 
+// Batch of commitments over the same basis: consecutive MSMs are pipelined (the latency-bound
+// bucket reduction of column i runs on a side stream under the sort + accumulation of column i+1).
+int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, srs && h_out_affine && (d_scalar_ptrs || !count), "null pointer");
+    ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
+    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
+    ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
+    const G1Affine* brp = nullptr;
+    int rc = srs_bases_rp(ctx, srs, basis, &brp);
+    if (rc) return rc;
+    return msm_batch_rp(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, n, (G1Affine*)h_out_affine);
+}
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, h_out_affine && ((h_scalars && h_bases) || n == 0), "null pointer");

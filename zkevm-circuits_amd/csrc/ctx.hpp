@@ -33,7 +33,10 @@ struct zk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
     // scratch arenas, grown on demand (never shrunk): index = purpose
-    zk::Scratch scratch[8];
+    zk::Scratch scratch[12];
+    // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
     std::vector<void*> pinned;   // small pinned host staging buffers
     // per-kernel HIP-event profiling (zk_prof_*): off by default
@@ -88,12 +91,12 @@ struct zk_ctx {
 
 // RAII scope: records a HIP event pair around the enclosed launches on ctx->stream
 struct ZkProfScope {
-    zk_ctx* c; const char* name; hipEvent_t a = nullptr;
-    ZkProfScope(zk_ctx* ctx, const char* n) : c(ctx), name(n) {
-        if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, c->stream); }
+    zk_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t s;
+    ZkProfScope(zk_ctx* ctx, const char* n, hipStream_t on = nullptr) : c(ctx), name(n), s(on ? on : ctx->stream) {
+        if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, s); }
     }
     ~ZkProfScope() {
-        if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({name, a, b}); }
+        if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, s); c->prof_pending.push_back({name, a, b}); }
     }
 };
 
@@ -124,7 +127,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);
@@ -138,5 +141,6 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
 int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);
 int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out);
 int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
+int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
 int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out);
 }  // namespace zk

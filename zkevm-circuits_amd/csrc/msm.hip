@@ -382,8 +382,9 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* 
 }
 
 // bases_rp: device bases already in R' form (SRS cache) or nullptr -> converted into scratch
-int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
-    if (n == 0) { memset(h_out, 0, sizeof(G1Affine)); return ZK_OK; }
+int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
+    if (count == 0) return ZK_OK;
+    if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
     if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
@@ -416,12 +417,19 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
     const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
     const size_t max_tasks = (size_t)nb + ((size_t)n * pl.W) / TASK_CAP + 1;
     const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks + max_tasks;
-    char* bk = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29 + sizeof(G1Xyzz) * pl.W);
-    if (!bk) return ZK_ERR_OOM;
-    G1Xyzz29* buckets = (G1Xyzz29*)bk;
-    G1Xyzz29* partial = buckets + nb;
-    G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
-    G1Xyzz* wsum = (G1Xyzz*)(bk + sizeof(G1Xyzz29) * npts29);
+    // bucket state is double-buffered: the reduction of MSM i (side stream) overlaps phase 1 of MSM i+1
+    char* bkbuf[2];
+    bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
+    bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count);
+    if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
+    if (!ctx->stream2) {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
+            ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
+        }
+    }
 
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
     if (!d_bases_rp) {
@@ -432,6 +440,14 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
         ZK_CHECK_LAUNCH(ctx);
         d_bases_rp = conv;
     }
+  for (size_t it = 0; it < count; ++it) {
+    const int par = (int)(it & 1);
+    const Fr* d_scalars = d_scalar_ptrs[it];
+    G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
+    G1Xyzz29* partial = buckets + nb;
+    G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
+    G1Xyzz* wsum = wsum_all + it * pl.W;
+    if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
         ZkProfScope ps(ctx, "msm_sort");
         ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 4) * 4, ctx->stream));   // size_hist + nmulti
@@ -461,21 +477,30 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
-    {
-        ZkProfScope ps(ctx, "msm_reduce");
-        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz29*)buckets, pl.B, partial);
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_p1[par], 0));
+    {   // latency-bound tail on the side stream: it hides under the next MSM's phase 1
+        ZkProfScope ps(ctx, "msm_reduce", ctx->stream2);
+        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, pl.B, partial);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream, (const G1Xyzz29*)partial, red_blocks, wsum);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)partial, red_blocks, wsum);
         ZK_CHECK_LAUNCH(ctx);
     }
-
-    std::vector<G1Xyzz> hw(pl.W);
-    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum, sizeof(G1Xyzz) * pl.W, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], ctx->stream2));
+  }
+    // join: the main stream waits for the outstanding reductions, then one copy of all window sums
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
+    if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
+    std::vector<G1Xyzz> hw((size_t)pl.W * count);
+    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * pl.W * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    host::msm_tail(hw.data(), pl.W, pl.c, h_out);
+    for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it * pl.W, pl.W, pl.c, h_out + it);
     return ZK_OK;
 }
 
+int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
+    return msm_batch_rp(ctx, &d_scalars, 1, d_bases, d_bases_rp, n, h_out);
+}
 int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out) {
     return msm_run_rp(ctx, d_scalars, d_bases, nullptr, n, h_out);
 }
