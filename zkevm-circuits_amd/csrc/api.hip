@@ -231,7 +231,12 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
     const G1Affine* brp = nullptr;
     int rc = srs_bases_rp(ctx, srs, basis, &brp);
     if (rc) return rc;
-    return msm_run_rp(ctx, (const Fr*)d_scalars, b, brp, n, (G1Affine*)h_out_affine);
+    const G1Affine* tab = nullptr;
+    size_t stride = 0;
+    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
+    if (rc) return rc;
+    const Fr* sp = (const Fr*)d_scalars;
+    return msm_batch_tab(ctx, &sp, 1, b, brp, tab, stride, n, (G1Affine*)h_out_affine);
 }
 // Sum of n affine points on the HOST (no device, no context): combines the per-rank partial
 // results of a point-sharded MSM after they were all-gathered as raw bytes (RCCL has no
@@ -266,7 +271,11 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
     const G1Affine* brp = nullptr;
     int rc = srs_bases_rp(ctx, srs, basis, &brp);
     if (rc) return rc;
-    return msm_batch_rp(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, n, (G1Affine*)h_out_affine);
+    const G1Affine* tab = nullptr;
+    size_t stride = 0;
+    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
+    if (rc) return rc;
+    return msm_batch_tab(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, tab, stride, n, (G1Affine*)h_out_affine);
 }
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;

@@ -107,6 +107,9 @@ struct zk_srs {
     // lazily built copies in R' = 2^261 Montgomery form (the MSM kernels' native base format)
     zk::G1Affine* g_rp = nullptr;
     zk::G1Affine* g_lagrange_rp = nullptr;
+    // lazily built fixed-base window tables [W][2^k] (R' form) and the window size they were built for
+    zk::G1Affine* tab[2] = {nullptr, nullptr};
+    int tab_c[2] = {0, 0};
 };
 
 #define ZK_HIP(ctx, call)                                                                          \
@@ -143,4 +146,7 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
 int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
 int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
 int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out);
+int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const G1Affine** out, size_t* stride);
+int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
+                  size_t n, G1Affine* h_out);
 }  // namespace zk

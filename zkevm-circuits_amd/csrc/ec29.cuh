@@ -164,6 +164,26 @@ __device__ __forceinline__ void stg29(G1Xyzz29* p, const G1Xyzz29& v) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+// a^(p-2) in the R' Montgomery domain (a normalised, < 2^258); result normalised, < 2p
+__device__ inline Fq29 inv29(const Fq29& a) {
+    Fq29 r = one29(), b = a;
+#pragma unroll 1
+    for (int i = 0; i < 254; ++i) {
+        // exponent p - 2: bits of the modulus with the low limb reduced by 2 (p = ...fd47, so no borrow)
+        const uint32_t limb = Fq29P::P32::M(i >> 5) - (i < 32 ? 2u : 0u);
+        if ((limb >> (i & 31)) & 1) r = mul29(r, b);
+        b = mul29(b, b);
+    }
+    return r;
+}
+// XYZZ (R', lazy) -> canonical affine in R' form, 8 x 32 limbs (the MSM kernels' base format)
+__device__ inline G1Affine to_affine_rp(const G1Xyzz29& p) {
+    if (is_identity29(p)) return G1Affine{Fq::zero(), Fq::zero()};
+    const Fq29 t = inv29(mul29(p.zz, p.zzz));
+    const Fq29 izz = mul29(t, p.zzz), izzz = mul29(t, p.zz);
+    return G1Affine{pack29_lt2p(mul29(p.x, izz)), pack29_lt2p(mul29(p.y, izzz))};
+}
+
 // lazily reduced R' coordinates -> canonical R = 2^256 Montgomery XYZZ (what the host tail reads):
 // x_R = x' * 2^256 / 2^261  (one product by the plain integer 2^256 mod p)
 __device__ __forceinline__ G1Xyzz to_std_xyzz(const G1Xyzz29& p) {

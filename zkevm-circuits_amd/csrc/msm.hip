@@ -257,6 +257,38 @@ __global__ void k_bases_to_rprime(const G1Affine* __restrict__ in, G1Affine* __r
     stg(out + i, p);
 }
 
+// Fixed-base window tables (SRS bases only): table[w][i] = 2^(c*w) * P_i, affine, R' form.  With
+// them every window's bucket b carries the same weight (b+1): the W per-window bucket arrays are
+// first folded into one, the weighted reduction runs over 2^(c-1) buckets instead of W * 2^(c-1),
+// and the host Horner tail disappears.
+__global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __restrict__ bases_rp, uint64_t n, int c, int W, G1Affine* __restrict__ table) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p0 = ldg(bases_rp + i);
+    stg(table + i, p0);
+    G1Xyzz29 cur = p0.is_identity() ? identity29() : G1Xyzz29{unpack29<Fq29P>(p0.x), unpack29<Fq29P>(p0.y), one29(), one29()};
+#pragma unroll 1
+    for (int w = 1; w < W; ++w) {
+#pragma unroll 1
+        for (int j = 0; j < c; ++j) cur = dbl29pt(cur);
+        const G1Affine a = to_affine_rp(cur);
+        stg(table + (uint64_t)w * n + i, a);
+        if (!a.is_identity()) cur = G1Xyzz29{unpack29<Fq29P>(a.x), unpack29<Fq29P>(a.y), one29(), one29()};   // keep Z = 1: cheaper doublings stay exact
+    }
+}
+// folded[b] = sum_w buckets[w*B + b]: four lanes per bucket (each takes every 4th window), LDS combine
+__global__ void __launch_bounds__(256) k_msm_fold_windows(const G1Xyzz29* __restrict__ buckets, uint32_t B, int W, G1Xyzz29* __restrict__ folded) {
+    __shared__ G1Xyzz29 sh[256];
+    const uint32_t b = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    G1Xyzz29 acc = identity29();
+    if (b < B) for (int w = (int)q; w < W; w += 4) acc = add29pt(acc, ldg29(buckets + (uint64_t)w * B + b));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (q < 2) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + 2]);
+    __syncthreads();
+    if (q == 0 && b < B) stg29(folded + b, add29pt(sh[threadIdx.x], sh[threadIdx.x + 1]));
+}
+
 __device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ idx, uint32_t lo, uint32_t hi) {
     G1Xyzz29 acc = identity29();
     for (uint32_t j = lo; j < hi; ++j) {
@@ -275,7 +307,8 @@ __device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ 
 // position M + (v - Tm).  toff = exclusive scan of ntasks over positions.
 __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ nmulti,
-                                                     uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial) {
+                                                     uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial,
+                                                     int log_b, uint64_t tab_stride) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
     const uint32_t M = *nmulti;
     const uint32_t Tm = M ? toff[M] : 0u;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,13 +320,13 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
         }
         const uint32_t b = order[lo_p], chunk = v - toff[lo_p];
         const uint32_t lo = offsets[b] + chunk * TASK_CAP, hi = min(lo + TASK_CAP, offsets[b + 1]);
-        stg29(partial + v, accumulate_run(bases_rp, idx, lo, hi));
+        stg29(partial + v, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi));
         return;
     }
     const uint32_t p = M + (v - Tm);
     if (p >= nbuckets) return;
     const uint32_t b = order[p];
-    stg29(buckets + b, accumulate_run(bases_rp, idx, offsets[b], offsets[b + 1]));
+    stg29(buckets + b, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, offsets[b], offsets[b + 1]));
 }
 constexpr uint32_t COMBINE_SMALL = 32;
 // multi-task buckets with few partials: one lane each, sequential sum
@@ -339,9 +372,12 @@ __device__ __forceinline__ G1Xyzz29 mul_small(const G1Xyzz29& p, uint32_t k) {
     return k ? acc : identity29();
 }
 
-constexpr int RED_G = 8;          // buckets folded per lane
+constexpr int RED_G_WIDE = 8, RED_G_FOLDED = 2;
 constexpr int RED_THREADS = 256;
 // grid: (groups_per_window / RED_THREADS, W); each block writes one partial per (window, block)
+// G = buckets folded per lane: 8 keeps the work low when W windows are reduced; 2 keeps the
+// dependent chain short when the window tables have already folded everything into one window.
+template <int RED_G>
 __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1Xyzz29* __restrict__ buckets, uint32_t B, G1Xyzz29* __restrict__ partial) {
     __shared__ G1Xyzz29 sh[RED_THREADS];
     const uint32_t w = blockIdx.y;
@@ -382,7 +418,9 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* 
 }
 
 // bases_rp: device bases already in R' form (SRS cache) or nullptr -> converted into scratch
-int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
+// d_table (nullable): fixed-base window table for exactly this plan (W windows of tab_stride points)
+int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
+                  size_t n, G1Affine* h_out) {
     if (count == 0) return ZK_OK;
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
     if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
@@ -414,9 +452,15 @@ int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, cons
     int range_bits = pl.c - 1;
     if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
     const dim3 sweep_grid(pl.B >> range_bits, pl.W);
-    const uint32_t red_blocks = ((pl.B + RED_G - 1) / RED_G + RED_THREADS - 1) / RED_THREADS;
+    // a lone MSM is latency-bound (short chains: G = 2); in a batch the reduction hides under the
+    // next MSM and only its work counts (G = 8)
+    const bool short_chain = d_table && count == 1;
+    const int red_g = short_chain ? RED_G_FOLDED : RED_G_WIDE;
+    const uint32_t red_blocks = ((pl.B + red_g - 1) / red_g + RED_THREADS - 1) / RED_THREADS;
     const size_t max_tasks = (size_t)nb + ((size_t)n * pl.W) / TASK_CAP + 1;
-    const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks + max_tasks;
+    const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks + max_tasks + pl.B;
+    if (!d_table) tab_stride = 0; else d_bases_rp = d_table;
+    const int red_W = d_table ? 1 : pl.W;     // windows the weighted reduction has to handle
     // bucket state is double-buffered: the reduction of MSM i (side stream) overlaps phase 1 of MSM i+1
     char* bkbuf[2];
     bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
@@ -446,6 +490,7 @@ int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, cons
     G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
     G1Xyzz29* partial = buckets + nb;
     G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
+    G1Xyzz29* folded = task_partial + max_tasks;
     G1Xyzz* wsum = wsum_all + it * pl.W;
     if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
@@ -470,7 +515,7 @@ int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, cons
         ZkProfScope ps(ctx, "msm_buckets");
         // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
         hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
-                           (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial);
+                           (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, pl.c - 1, (uint64_t)tab_stride);
         hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
@@ -481,9 +526,15 @@ int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, cons
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_p1[par], 0));
     {   // latency-bound tail on the side stream: it hides under the next MSM's phase 1
         ZkProfScope ps(ctx, "msm_reduce", ctx->stream2);
-        hipLaunchKernelGGL(k_msm_reduce, dim3(red_blocks, pl.W), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, pl.B, partial);
+        const G1Xyzz29* red_in = buckets;
+        if (d_table) {
+            hipLaunchKernelGGL(k_msm_fold_windows, dim3((pl.B + 63) / 64), dim3(256), 0, ctx->stream2, (const G1Xyzz29*)buckets, pl.B, pl.W, folded);
+            red_in = folded;
+        }
+        if (short_chain) hipLaunchKernelGGL((k_msm_reduce<RED_G_FOLDED>), dim3(red_blocks, red_W), dim3(RED_THREADS), 0, ctx->stream2, red_in, pl.B, partial);
+        else hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks, red_W), dim3(RED_THREADS), 0, ctx->stream2, red_in, pl.B, partial);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_msm_window_sum, dim3(pl.W), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)partial, red_blocks, wsum);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(red_W), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)partial, red_blocks, wsum);
         ZK_CHECK_LAUNCH(ctx);
     }
     ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], ctx->stream2));
@@ -494,7 +545,34 @@ int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, cons
     std::vector<G1Xyzz> hw((size_t)pl.W * count);
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * pl.W * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it * pl.W, pl.W, pl.c, h_out + it);
+    for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it * pl.W, red_W, pl.c, h_out + it);
+    return ZK_OK;
+}
+int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
+    return msm_batch_tab(ctx, d_scalar_ptrs, count, d_bases, d_bases_rp, nullptr, 0, n, h_out);
+}
+// Window table of an SRS basis for MSMs of n points, built on first use and cached on the zk_srs;
+// *out stays nullptr when the table would be too large or the plan does not match the cached one.
+int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const G1Affine** out, size_t* stride) {
+    *out = nullptr;
+    *stride = 0;
+    zk_srs* s = const_cast<zk_srs*>(srs);
+    const MsmPlan pl = make_plan(n);
+    const uint64_t ns = 1ull << s->k;
+    const size_t bytes = sizeof(G1Affine) * ns * pl.W;
+    if (n < 1024 || bytes > ((size_t)24 << 30)) return ZK_OK;
+    if (!s->tab[basis]) {
+        const G1Affine* rp = nullptr;
+        int rc = srs_bases_rp(ctx, srs, basis, &rp);
+        if (rc) return rc;
+        if (hipMalloc(&s->tab[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tab[basis] = nullptr; return ZK_OK; }   // no memory: fall back silently
+        s->tab_c[basis] = pl.c;
+        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tab[basis]);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    if (s->tab_c[basis] != pl.c) return ZK_OK;
+    *out = s->tab[basis];
+    *stride = ns;
     return ZK_OK;
 }
 
