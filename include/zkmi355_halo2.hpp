@@ -1,0 +1,187 @@
+// C++ host-side mirror of the halo2_proofs items on the hot path, over the C ABI (zkmi355.h).
+//
+// The reference is a Rust workspace and Rust is not available in this build image, so this header
+// is the compiled-language counterpart of the shim crate described in INTEGRATION.md: same names,
+// argument meaning and error behaviour as the halo2 items it mirrors, so call sites translate
+// one-to-one.  Header-only; link with -lzkmi355.
+//
+//   halo2_proofs::arithmetic::best_fft            -> zk::halo2::best_fft
+//   halo2_proofs::arithmetic::best_multiexp       -> zk::halo2::best_multiexp
+//   halo2_proofs::arithmetic::eval_polynomial     -> zk::halo2::eval_polynomial
+//   halo2_proofs::arithmetic::kate_division       -> zk::halo2::kate_division
+//   halo2_proofs::poly::EvaluationDomain          -> zk::halo2::EvaluationDomain
+//   halo2_proofs::poly::kzg::commitment::ParamsKZG-> zk::halo2::ParamsKZG
+//   halo2_proofs::plonk::{keygen_pk, create_proof}-> zk::halo2::{ProvingKey, create_proof}
+//   (reference call sites: circuit-benchmarks/src/super_circuit.rs:104-132,
+//    prover/src/common/prover/utils.rs:31,55, prover/src/utils.rs:77)
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "zkmi355.h"
+
+namespace zk {
+namespace halo2 {
+
+using Fr = std::array<uint64_t, 4>;        // Montgomery limbs, as halo2curves holds them
+using G1Affine = std::array<uint64_t, 8>;  // {x, y}; identity = zeros
+
+// halo2's plonk::Error / io errors surface as one exception type carrying the library message
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& msg) : std::runtime_error(msg), status(st) {}
+};
+
+class Context {
+   public:
+    explicit Context(int device = 0) {
+        int rc = zk_ctx_create(device, &ctx_);
+        if (rc) throw Error(rc, rc == ZK_ERR_NO_DEVICE ? "no gfx950 device (there is no CPU fallback)" : "zk_ctx_create failed");
+    }
+    ~Context() { zk_ctx_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    zk_ctx* raw() const { return ctx_; }
+    void check(int rc) const { if (rc) throw Error(rc, zk_last_error(ctx_)); }
+
+    // RAII device column
+    class Buffer {
+       public:
+        Buffer(const Context& c, size_t bytes) : c_(c), bytes_(bytes) { c_.check(zk_buf_alloc(c_.raw(), bytes, &p_)); }
+        ~Buffer() { zk_buf_free(c_.raw(), p_); }
+        Buffer(const Buffer&) = delete;
+        Buffer& operator=(const Buffer&) = delete;
+        void* ptr() const { return p_; }
+        size_t bytes() const { return bytes_; }
+        void upload(const void* h, size_t n) { c_.check(zk_h2d(c_.raw(), p_, h, n)); }
+        void download(void* h, size_t n) const { c_.check(zk_d2h(c_.raw(), h, p_, n)); }
+       private:
+        const Context& c_;
+        void* p_ = nullptr;
+        size_t bytes_;
+    };
+
+   private:
+    zk_ctx* ctx_ = nullptr;
+};
+
+// arithmetic::best_fft(a, omega, log_n): in place, natural order in and out
+inline void best_fft(const Context& c, std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
+    if (a.size() != (size_t(1) << log_n)) throw Error(ZK_ERR_INVALID_ARG, "best_fft: a.len() != 1 << log_n");
+    Context::Buffer d(c, a.size() * sizeof(Fr));
+    d.upload(a.data(), a.size() * sizeof(Fr));
+    c.check(zk_ntt_omega(c.raw(), d.ptr(), log_n, omega.data()));
+    d.download(a.data(), a.size() * sizeof(Fr));
+}
+
+// arithmetic::best_multiexp(coeffs, bases)
+inline G1Affine best_multiexp(const Context& c, const std::vector<Fr>& coeffs, const std::vector<G1Affine>& bases) {
+    if (coeffs.size() != bases.size()) throw Error(ZK_ERR_INVALID_ARG, "best_multiexp: coeffs.len() != bases.len()");
+    G1Affine out{};
+    c.check(zk_msm_g1_host(c.raw(), coeffs.data(), bases.data(), coeffs.size(), out.data()));
+    return out;
+}
+
+// arithmetic::eval_polynomial(poly, point)
+inline Fr eval_polynomial(const Context& c, const std::vector<Fr>& poly, const Fr& point) {
+    Context::Buffer d(c, poly.size() * sizeof(Fr) + 32);
+    d.upload(poly.data(), poly.size() * sizeof(Fr));
+    Fr out{};
+    c.check(zk_poly_eval(c.raw(), d.ptr(), poly.size(), point.data(), out.data()));
+    return out;
+}
+
+// arithmetic::kate_division(a, b): quotient of (a(X) - a(b)) / (X - b)
+inline std::vector<Fr> kate_division(const Context& c, const std::vector<Fr>& a, const Fr& b) {
+    if (a.size() < 2) return {};
+    Context::Buffer d(c, a.size() * sizeof(Fr)), q(c, (a.size() - 1) * sizeof(Fr));
+    d.upload(a.data(), a.size() * sizeof(Fr));
+    c.check(zk_kate_division(c.raw(), d.ptr(), a.size(), b.data(), q.ptr()));
+    std::vector<Fr> out(a.size() - 1);
+    q.download(out.data(), out.size() * sizeof(Fr));
+    return out;
+}
+
+// poly::EvaluationDomain::new(j, k)
+class EvaluationDomain {
+   public:
+    EvaluationDomain(const Context& c, uint32_t j, uint32_t k) : c_(c), k_(k) {
+        extended_k_ = k;
+        while ((size_t(1) << extended_k_) < (size_t(1) << k) * (j - 1)) ++extended_k_;
+    }
+    uint32_t k() const { return k_; }
+    uint32_t extended_k() const { return extended_k_; }
+    void lagrange_to_coeff(Context::Buffer& a) const { c_.check(zk_ntt(c_.raw(), a.ptr(), k_, 1)); }
+    void coeff_to_lagrange(Context::Buffer& a) const { c_.check(zk_ntt(c_.raw(), a.ptr(), k_, 0)); }
+    void coeff_to_extended(const Context::Buffer& coeffs, Context::Buffer& out) const { c_.check(zk_coeff_to_extended(c_.raw(), coeffs.ptr(), k_, extended_k_, out.ptr())); }
+    void extended_to_coeff(Context::Buffer& a) const { c_.check(zk_extended_to_coeff(c_.raw(), a.ptr(), extended_k_)); }
+   private:
+    const Context& c_;
+    uint32_t k_, extended_k_;
+};
+
+// poly::kzg::commitment::ParamsKZG<Bn256>
+class ParamsKZG {
+   public:
+    // ParamsKZG::unsafe_setup_with_s(k, s)
+    static ParamsKZG unsafe_setup_with_s(const Context& c, uint32_t k, const Fr& s) {
+        zk_srs* p = nullptr;
+        c.check(zk_srs_setup_with_s(c.raw(), k, s.data(), &p));
+        return ParamsKZG(c, p);
+    }
+    // after ParamsKZG::read_custom on the host: g and g_lagrange in RawBytes layout
+    static ParamsKZG from_points(const Context& c, uint32_t k, const std::vector<G1Affine>& g, const std::vector<G1Affine>& g_lagrange) {
+        zk_srs* p = nullptr;
+        c.check(zk_srs_create(c.raw(), k, g.data(), g_lagrange.empty() ? nullptr : g_lagrange.data(), &p));
+        return ParamsKZG(c, p);
+    }
+    ParamsKZG(ParamsKZG&& o) noexcept : c_(o.c_), srs_(o.srs_) { o.srs_ = nullptr; }
+    ~ParamsKZG() { if (srs_) zk_srs_destroy(c_.raw(), srs_); }
+    uint32_t k() const { return zk_srs_k(srs_); }
+    uint64_t n() const { return uint64_t(1) << k(); }
+    // ParamsKZG::commit (coefficient basis) / commit_lagrange
+    G1Affine commit(const Context::Buffer& poly, size_t n) const { G1Affine o{}; c_.check(zk_commit(c_.raw(), srs_, 0, poly.ptr(), n, o.data())); return o; }
+    G1Affine commit_lagrange(const Context::Buffer& poly, size_t n) const { G1Affine o{}; c_.check(zk_commit(c_.raw(), srs_, 1, poly.ptr(), n, o.data())); return o; }
+    // every column of a phase in one pipelined batch
+    std::vector<G1Affine> commit_lagrange_batch(const std::vector<const void*>& cols, size_t n) const {
+        std::vector<G1Affine> o(cols.size());
+        c_.check(zk_commit_batch(c_.raw(), srs_, 1, cols.data(), cols.size(), n, o.data()));
+        return o;
+    }
+    const zk_srs* raw() const { return srs_; }
+   private:
+    ParamsKZG(const Context& c, zk_srs* p) : c_(c), srs_(p) {}
+    const Context& c_;
+    zk_srs* srs_;
+};
+
+// plonk::keygen_pk result
+class ProvingKey {
+   public:
+    ProvingKey(const Context& c, const ParamsKZG& params, const std::vector<uint8_t>& circuit_blob) : c_(c) {
+        c_.check(zk_pk_create(c_.raw(), params.raw(), circuit_blob.data(), circuit_blob.size(), &pk_));
+    }
+    ~ProvingKey() { zk_pk_destroy(c_.raw(), pk_); }
+    ProvingKey(const ProvingKey&) = delete;
+    ProvingKey& operator=(const ProvingKey&) = delete;
+    const zk_pk* raw() const { return pk_; }
+   private:
+    const Context& c_;
+    zk_pk* pk_ = nullptr;
+};
+
+// plonk::create_proof(params, pk, circuits, instances, rng, transcript): the transcript bytes come back
+inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk, const std::vector<const void*>& advice_columns,
+                                         const std::vector<const void*>& instance_columns, const std::array<uint8_t, 16>& rng_seed) {
+    std::vector<uint8_t> proof(size_t(1) << 20);
+    size_t len = 0;
+    c.check(zk_create_proof(c.raw(), pk.raw(), advice_columns.data(), instance_columns.data(), rng_seed.data(), proof.data(), proof.size(), &len));
+    proof.resize(len);
+    return proof;
+}
+
+}  // namespace halo2
+}  // namespace zk

@@ -57,3 +57,36 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_cpp_mirror_header_compiles_and_links(zk, tmp_path):
+    """include/zkmi355_halo2.hpp (the compiled-language mirror of the halo2 items) builds with a
+    plain g++ against libzkmi355.so; without a GPU the context constructor throws (no fallback)."""
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('''
+#include "zkmi355_halo2.hpp"
+#include <cstdio>
+int main() {
+    try {
+        zk::halo2::Context ctx(0);
+        zk::halo2::Fr s{1, 0, 0, 0};
+        auto params = zk::halo2::ParamsKZG::unsafe_setup_with_s(ctx, 4, s);
+        std::printf("ctx ok k=%u\\n", params.k());
+    } catch (const zk::halo2::Error& e) {
+        std::printf("error %d: %s\\n", e.status, e.what());
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(zk.binding.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lzkmi355", f"-Wl,-rpath,{libdir}",
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
+    if torch.cuda.is_available():
+        assert "ctx ok k=4" in out
+    else:
+        assert "error -4" in out and "no CPU fallback" in out

@@ -4,20 +4,21 @@
 //
 // Pippenger, MI355X layout:
 //   1. digits    scalars leave Montgomery form (one Montgomery product by 1) and are recoded into
-//                W = ceil(256/c) signed c-bit digits; every non-zero digit is a (bucket, point)
-//                pair, bucket = window * 2^(c-1) + |d| - 1, the sign travels with the point index.
-//   2. sort      counting sort of the pairs by bucket: histogram (device atomics) -> exclusive scan
-//                -> scatter.  The scalars are re-recoded in the scatter pass instead of storing
-//                n*W digit words (ALU is cheaper than 4*n*W bytes of HBM traffic twice).
-//   3. buckets   one lane per bucket walks its contiguous run of point indices, gathers the affine
-//                base (64 B, coalescing is per-point not per-lane: the gather is the HBM-side cost)
-//                and accumulates with mixed XYZZ additions (8M + 2S, no inversions).
-//   4. reduce    per window: sum_b (b+1) * B_b.  Each lane folds G consecutive buckets with the
-//                running-sum trick, lifts its partial by its group offset with a short
-//                double-and-add, and a block tree-sum in LDS produces one point per window.
-//   5. tail      W window sums (2 KiB) go to the host, which runs the c doublings per window
-//                (Horner) -- 256 dependent doublings are latency-bound on a GPU lane and take
-//                ~100 us on one CPU core.
+//                W = ceil(256/c) signed c-bit digits, stored as a window-major u16 matrix; every
+//                non-zero digit is a (bucket, point) pair, bucket = window * 2^(c-1) + |d| - 1.
+//   2. sort      counting sort by bucket with LDS-privatised counters: workgroup (range, window)
+//                streams the digit row twice (count, scatter); no global atomics.
+//   3. buckets   buckets are ordered by size and split into tasks of <= 64 points (skew-proof);
+//                one lane per task gathers R'-form affine bases (64 B each) and accumulates with
+//                mixed XYZZ additions on 29-bit limbs (8M + 2S, no inversions); multi-task
+//                buckets are tree-combined afterwards.
+//   4. reduce    per window: sum_b (b+1) * B_b by running sums + LDS tree.  For SRS bases the
+//                fixed-base window tables (2^(c*w) * P_i precomputed) make every window's bucket b
+//                carry the same weight, so the W bucket arrays are folded first and ONE window is
+//                reduced.  Runs on a side stream: in a batch it hides under the next MSM.
+//   5. tail      window sums go to the host: Horner over the windows (c doublings each; a
+//                dependent doubling chain is issue-bound on one GPU lane) and the affine
+//                normalisation; with window tables only the normalisation is left.
 #include "ctx.hpp"
 #include "ec29.cuh"
 #include "host_fq.hpp"
