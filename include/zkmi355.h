@@ -161,6 +161,21 @@ int zk_pk_vk(zk_ctx* ctx, const zk_pk* pk, void* h_commitments, void* h_vk_repr)
 int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
                     void* h_proof, size_t proof_cap, size_t* proof_len);
 
+/* Phase-by-phase proving session (what the Rust shim drives: Circuit::synthesize runs on the host
+ * once per phase and needs the challenges of the earlier phases -- the SuperCircuit has three
+ * phases, zkevm-circuits/src/util.rs:120-133).  begin -> zk_proof_advice_phase x num_phases ->
+ * finish.  zk_create_proof is begin + all phases + finish for witnesses known up front.          */
+typedef struct zk_proof zk_proof;
+int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
+/* commits the advice columns of the current phase (h_cols[j] = advice column col_index[j], exactly
+ * the columns of that phase) and writes the challenges that become usable after it to
+ * h_challenges (32 B each, Montgomery Fr, challenge-index order)                                 */
+int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols,
+                          void* h_challenges, uint32_t* num_challenges);
+/* consumes the session (freed on success and on failure)                                         */
+int zk_proof_finish(zk_ctx* ctx, zk_proof* proof, void* h_proof, size_t proof_cap, size_t* proof_len);
+void zk_proof_abort(zk_ctx* ctx, zk_proof* proof);
+
 /* ---- G1 element-wise (tests of the group law; halo2curves G1 Add / Double / Mul) --------------- */
 /* out[i] = a[i] + b[i], all affine (n x 64 B) */
 int zk_g1_affine_add_vec(zk_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);

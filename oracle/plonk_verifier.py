@@ -77,6 +77,22 @@ def decompress_g1(raw: bytes):
 
 
 # ------------------------------------------------------------------------------------ expressions
+C_CHAL0 = 0xFFFD0000
+
+
+class Consts:
+    """user constants + (once known) the user challenges behind the abstract references"""
+
+    def __init__(self, consts, challenges=None):
+        self.consts, self.challenges = consts, challenges
+
+    def __getitem__(self, a):
+        if a >= C_CHAL0:
+            assert self.challenges is not None, "challenge used where none is available"
+            return self.challenges[a - C_CHAL0]
+        return self.consts[a]
+
+
 def eval_program(prog, lookup_col, consts) -> int:
     st: List[int] = []
     for op, a, bb in prog:
@@ -102,16 +118,17 @@ def compress(vals: Sequence[int], theta: int) -> int:
     return acc
 
 
-def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]]) -> Optional[str]:
+def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]], challenges=None) -> Optional[str]:
     """MockProver-style check over the usable rows; returns None or a description of the failure."""
     n, u = circ.n, circ.u
+    consts = Consts(circ.consts, challenges)
     cols = {FIXED: circ.fixed, ADVICE: advice, INSTANCE: instance}
     gates = [circ.compile(g) for g in circ.gates]
     lookups = [([circ.compile(e) for e in i], [circ.compile(e) for e in t]) for i, t in circ.lookups]
     for row in range(u):
         look = lambda t, i, rot: cols[t][i][(row + rot) % n]
         for gi, g in enumerate(gates):
-            if eval_program(g, look, circ.consts) != 0:
+            if eval_program(g, look, consts) != 0:
                 return f"gate {gi} not satisfied at row {row}"
     for a, c in circ.copies:
         if cols[a[0]][a[1]][a[2]] != cols[c[0]][c[1]][c[2]]:
@@ -120,10 +137,10 @@ def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequ
         table = set()
         for row in range(u):
             look = lambda t, i, rot: cols[t][i][(row + rot) % n]
-            table.add(tuple(eval_program(p, look, circ.consts) for p in tabs))
+            table.add(tuple(eval_program(p, look, consts) for p in tabs))
         for row in range(u):
             look = lambda t, i, rot: cols[t][i][(row + rot) % n]
-            if tuple(eval_program(p, look, circ.consts) for p in ins) not in table:
+            if tuple(eval_program(p, look, consts) for p in ins) not in table:
                 return f"lookup {li}: input at row {row} not in table"
     return None
 
@@ -170,7 +187,19 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
     for col in instance:
         for row in range(u):
             tr.common_scalar(col[row])
-    adv_com = [tr.read_point() for _ in range(A)]
+    # advice commitments phase by phase, each followed by that phase's challenges
+    adv_com = [None] * A
+    adv_phase = getattr(circ, "advice_phase", [0] * A)
+    chal_phase = getattr(circ, "challenge_phase", [])
+    challenges = [0] * len(chal_phase)
+    for ph in range(max([0] + list(adv_phase) + list(chal_phase)) + 1):
+        for i in range(A):
+            if adv_phase[i] == ph:
+                adv_com[i] = tr.read_point()
+        for ci, cp in enumerate(chal_phase):
+            if cp == ph:
+                challenges[ci] = tr.squeeze()
+    consts = Consts(circ.consts, challenges)
     theta = tr.squeeze()
     m_com = [tr.read_point() for _ in range(L)]
     beta, gamma = tr.squeeze(), tr.squeeze()
@@ -230,7 +259,7 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
         nonlocal acc
         acc = (acc * y + term) % R
     for g in gates:
-        fold(eval_program(g, col_eval, circ.consts))
+        fold(eval_program(g, col_eval, consts))
     if C:
         fold(l0 * (1 - z_eval[0][0]) % R)
         zl = z_eval[C - 1][0]
@@ -247,8 +276,8 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
             fold(l_active * (left - right) % R)
     for l, (ins, tabs) in enumerate(lookups):
         p0, p1, me = lk_eval[l]
-        f = compress([eval_program(p, col_eval, circ.consts) for p in ins], theta)
-        t = compress([eval_program(p, col_eval, circ.consts) for p in tabs], theta)
+        f = compress([eval_program(p, col_eval, consts) for p in ins], theta)
+        t = compress([eval_program(p, col_eval, consts) for p in tabs], theta)
         fold(l0 * p0 % R)
         fold(l_last * p0 % R)
         fold(l_active * (((p1 - p0) * (f + beta) % R * (t + beta) - ((t + beta) - me * (f + beta))) % R) % R)

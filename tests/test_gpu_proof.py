@@ -112,3 +112,50 @@ def test_unsatisfied_witness_is_refused_or_unverifiable(zk, ctx, cref, srs8, s_g
     adv_bad[1][row] = (adv_bad[1][row] + 1) % b.R_MOD
     with pytest.raises(zk.ZkError):
         _prove(ctx, cref, circ, adv_bad, inst, srs8)
+
+
+def test_two_phase_proof_with_challenge(zk, ctx, cref, srs8, s_g2):
+    """Phases as in the SuperCircuit [REF zkevm-circuits/src/util.rs:120-133]: columns a, b are
+    first-phase; the RLC column c = a + r*b needs the challenge r squeezed after phase 0, so the
+    host synthesises it between two zk_proof_advice_phase calls (what the Rust shim does with
+    Circuit::synthesize per phase)."""
+    import random
+    k = 6
+    circ = plonk.Circuit(k, num_fixed=1, num_advice=4, num_instance=0, blinding_factors=5)
+    q, a, b_, c_, d_ = circ.fixed_col(0), circ.advice_col(0), circ.advice_col(1), circ.advice_col(2), circ.advice_col(3)
+    circ.advice_phase = [0, 0, 1, 1]
+    r = circ.challenge_usable_after(0)
+    r2 = circ.challenge_usable_after(0)
+    circ.add_gate(q * (a + r * b_ - c_))                 # RLC
+    circ.add_gate(q * (c_ * r2 + a * a * b_ - d_))       # a second challenge, degree 4 with the selector
+    circ.enable_equality(plonk.ADVICE, 2)
+    rng = random.Random(3)
+    n, u = circ.n, circ.u
+    av, bv = [0] * n, [0] * n
+    for row in range(u):
+        circ.fixed[0][row] = 1
+        av[row], bv[row] = rng.randrange(b.R_MOD), rng.randrange(b.R_MOD)
+    pk = ctx.pk_create(srs8[k], circ.blob())
+    com, rep = pk.vk(circ.F + len(circ.perm_cols))
+    sess = ctx.proof_session(pk, [], bytes(16))
+    ch = sess.advice_phase({0: plonk.column_to_mont(av), 1: plonk.column_to_mont(bv)})
+    assert ch.shape == (2, 4)
+    rv, r2v = cref.from_mont(ch)
+    cv = [(av[i] + rv * bv[i]) % b.R_MOD if i < u else 0 for i in range(n)]
+    dv = [(cv[i] * r2v + av[i] * av[i] * bv[i]) % b.R_MOD if i < u else 0 for i in range(n)]
+    assert pv.check_witness(circ, [av, bv, cv, dv], [], challenges=[rv, r2v]) is None
+    with pytest.raises(zk.ZkError):                      # wrong column set for phase 1
+        sess.advice_phase({2: plonk.column_to_mont(cv)})
+    assert sess.advice_phase({2: plonk.column_to_mont(cv), 3: plonk.column_to_mont(dv)}).shape == (0, 4)
+    proof = sess.finish()
+    pk.destroy()
+    assert pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [], proof, s_g2)
+    # a witness built with the WRONG challenge must not verify
+    pk = ctx.pk_create(srs8[k], circ.blob())
+    sess = ctx.proof_session(pk, [], bytes(16))
+    sess.advice_phase({0: plonk.column_to_mont(av), 1: plonk.column_to_mont(bv)})
+    cbad = [(av[i] + (rv + 1) * bv[i]) % b.R_MOD if i < u else 0 for i in range(n)]
+    sess.advice_phase({2: plonk.column_to_mont(cbad), 3: plonk.column_to_mont(dv)})
+    bad = sess.finish()
+    pk.destroy()
+    assert not pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [], bad, s_g2)

@@ -55,6 +55,7 @@ def lib():
         _lib.zk_ctx_destroy.restype = None
         _lib.zk_srs_destroy.restype = None
         _lib.zk_pk_destroy.restype = None
+        _lib.zk_proof_abort.restype = None
     return _lib
 
 
@@ -145,6 +146,43 @@ class ProvingKey:
     def destroy(self):
         if self.h:
             lib().zk_pk_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class ProofSession:
+    """begin -> advice_phase(...) per phase (returns that phase's challenges) -> finish()."""
+
+    def __init__(self, ctx: "Context", pk: ProvingKey, instance: Sequence[np.ndarray], seed: bytes):
+        self.ctx = ctx
+        ins = [np.ascontiguousarray(a, dtype=np.uint64) for a in instance]
+        pi = (ctypes.c_void_p * max(len(ins), 1))(*[a.ctypes.data for a in ins])
+        h = ctypes.c_void_p()
+        assert len(seed) == 16
+        ctx._ck(lib().zk_proof_begin(ctx.h, pk.h, pi, ctypes.c_char_p(seed), ctypes.byref(h)))
+        self.h = h
+
+    def advice_phase(self, columns: dict) -> np.ndarray:
+        """columns: {advice column index: (n, 4) u64 Montgomery array}; returns (num_challenges, 4) u64."""
+        idx = sorted(columns)
+        cols = [np.ascontiguousarray(columns[i], dtype=np.uint64) for i in idx]
+        ci = (ctypes.c_uint32 * max(len(idx), 1))(*idx)
+        pc = (ctypes.c_void_p * max(len(idx), 1))(*[c.ctypes.data for c in cols])
+        out = np.zeros((64, 4), dtype=np.uint64)
+        cnt = ctypes.c_uint32()
+        self.ctx._ck(lib().zk_proof_advice_phase(self.ctx.h, self.h, ci, pc, ctypes.c_uint32(len(idx)), _host_ptr(out), ctypes.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def finish(self) -> bytes:
+        cap = 1 << 20
+        out = ctypes.create_string_buffer(cap)
+        n = ctypes.c_size_t()
+        h, self.h = self.h, None
+        self.ctx._ck(lib().zk_proof_finish(self.ctx.h, h, out, ctypes.c_size_t(cap), ctypes.byref(n)))
+        return out.raw[:n.value]
+
+    def abort(self):
+        if self.h:
+            lib().zk_proof_abort(self.ctx.h, self.h)
             self.h = None
 
 
@@ -327,6 +365,9 @@ class Context:
         assert len(seed) == 16
         self._ck(lib().zk_create_proof(self.h, pk.h, pa, pi, ctypes.c_char_p(seed), out, ctypes.c_size_t(cap), ctypes.byref(n)))
         return out.raw[:n.value]
+
+    def proof_session(self, pk: "ProvingKey", instance: Sequence[np.ndarray], seed: bytes = bytes(16)) -> "ProofSession":
+        return ProofSession(self, pk, instance, seed)
 
     # ---- G1 element-wise
     def g1_affine_add(self, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):

@@ -38,7 +38,8 @@ enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECI
 enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
 enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11 };
 // abstract constant operands: user constants are [0, num_consts); challenges live above
-constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u;   // C_DELTA0 + j = beta * delta^j
+constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u,   // C_DELTA0 + j = beta * delta^j
+                   C_CHAL0 = 0xFFFD0000u;                                                                                      // C_CHAL0 + i = user challenge i
 
 inline uint32_t colref(uint32_t type, uint32_t idx) { return (type << 24) | idx; }
 
@@ -72,12 +73,25 @@ struct zk_pk {
     struct Lookup { std::vector<Prog> inputs, tables; };
     std::vector<Lookup> lookups;
     std::vector<Query> adv_q, fix_q;         // evaluation queries, in proof order
+    uint32_t num_phases = 1;
+    std::vector<uint32_t> adv_phase;         // phase of every advice column (halo2 FirstPhase/SecondPhase/...)
+    std::vector<uint32_t> chal_phase;        // challenge i becomes available after this phase
     // device-resident key material
     std::vector<DevBuf> fixed_lag, fixed_coeff, fixed_ext, sigma_lag, sigma_coeff, sigma_ext;
     DevBuf l0_ext, llast_ext, lactive_ext, x_ext, omega_lag, l0_lag, llast_lag, lactive_lag;
     std::vector<G1Affine> fixed_com, sigma_com;
     F4 vk_repr;
     const zk_srs* srs = nullptr;
+};
+
+struct zk_proof {
+    const zk_pk* pk;
+    host::XorShiftRng rng;
+    host::Transcript tr;
+    std::vector<DevBuf> inst_lag, inst_coeff, inst_ext, adv_lag;
+    uint32_t phase = 0;
+    std::vector<F4> challenges;
+    zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), inst_ext(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
 
 namespace {
@@ -142,6 +156,7 @@ struct Env {   // where an abstract column lives in the domain being evaluated
     const std::vector<DevBuf>* lk_phi;
     F4 theta, beta, gamma, y;
     std::vector<F4> beta_delta;   // beta * delta^j
+    std::vector<F4> challenges;   // user challenges (halo2 `Challenge`), by index
 };
 
 const void* resolve_col(const Env& e, uint32_t ref) {
@@ -175,6 +190,7 @@ bool resolve_const(const Env& e, uint32_t ref, F4* out) {
         default: break;
     }
     if (ref >= C_DELTA0 && ref - C_DELTA0 < e.beta_delta.size()) { *out = e.beta_delta[ref - C_DELTA0]; return true; }
+    if (ref >= C_CHAL0 && ref - C_CHAL0 < e.challenges.size()) { *out = e.challenges[ref - C_CHAL0]; return true; }
     return false;
 }
 int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
@@ -261,7 +277,9 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, srs && h_blob && out, "null pointer");
     Reader r{(const uint8_t*)h_blob, blob_len};
-    if (r.u32() != 0x4B505A4Bu || r.u32() != 1u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic/version");
+    if (r.u32() != 0x4B505A4Bu) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic");
+    const uint32_t version = r.u32();
+    if (version != 1u && version != 2u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: unsupported version %u", version);
     std::unique_ptr<zk_pk> pk(new zk_pk());
     pk->srs = srs;
     pk->k = r.u32(); pk->bf = r.u32(); pk->d = r.u32(); pk->F = r.u32(); pk->A = r.u32(); pk->I = r.u32(); pk->P = r.u32(); pk->L = r.u32();
@@ -277,6 +295,14 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
     pk->C = pk->P ? (pk->P + pk->chunk - 1) / pk->chunk : 0;
     pk->ext_k = pk->k;
     while (((size_t)1 << pk->ext_k) < n * (pk->d - 1)) ++pk->ext_k;
+    pk->adv_phase.assign(pk->A, 0);
+    if (version >= 2) {   // phases: [num_challenges][A x advice phase][num_challenges x challenge phase]
+        const uint32_t nch = r.u32();
+        if (nch > 4096) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many challenges");
+        for (uint32_t i = 0; i < pk->A; ++i) { pk->adv_phase[i] = r.u32(); if (pk->adv_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->adv_phase[i] + 1; }
+        for (uint32_t i = 0; i < nch; ++i) { pk->chal_phase.push_back(r.u32()); if (pk->chal_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->chal_phase[i] + 1; }
+        if (!r.ok || pk->num_phases > 16) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad phase table");
+    }
     for (uint32_t i = 0; i < pk->P; ++i) { uint32_t t = r.u32(), x = r.u32(); pk->perm_cols.push_back({t, x}); }
     for (uint32_t i = 0; i < nconsts; ++i) { const uint8_t* b = r.bytes(32); F4 v; if (b) memcpy(v.l, b, 32); pk->consts.push_back(v); }
     for (uint32_t i = 0; i < ngates; ++i) pk->gates.push_back(r.prog());
@@ -335,6 +361,8 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         hsh.init("Halo2-Verify-Key");
         const uint32_t hdr[10] = {pk->k, pk->bf, pk->d, pk->F, pk->A, pk->I, pk->P, pk->L, ngates, nconsts};
         hsh.update(hdr, sizeof hdr);
+        if (!pk->adv_phase.empty()) hsh.update(pk->adv_phase.data(), pk->adv_phase.size() * 4);
+        if (!pk->chal_phase.empty()) hsh.update(pk->chal_phase.data(), pk->chal_phase.size() * 4);
         for (const auto& c : pk->fixed_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
         for (const auto& c : pk->sigma_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
         uint8_t dg[64];
@@ -359,42 +387,94 @@ int zk_pk_vk(zk_ctx* ctx, const zk_pk* pk, void* h_commitments, void* h_vk_repr)
     return ZK_OK;
 }
 
-// create_proof.  h_advice: A host pointers to n x 32 B Lagrange columns (rows >= n - bf are
-// overwritten with blinding values); h_instance: I host pointers to n x 32 B columns (zero padded).
-int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
-                    void* h_proof, size_t proof_cap, size_t* proof_len) {
+// ---- proving session: begin -> one call per advice phase -> finish ---------------------------------
+// halo2's create_proof synthesises the circuit once per phase and squeezes that phase's challenges
+// after committing its advice columns (the SuperCircuit has three phases
+// [REF zkevm-circuits/src/util.rs:120-133]); witness synthesis stays on the host, so the phases
+// are separate calls and each returns the challenges the next synthesis pass needs.
+void zk_proof_abort(zk_ctx* ctx, zk_proof* pr) {
+    if (ctx) (void)zk_ctx_sync(ctx);
+    delete pr;
+}
+
+int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, pk && seed16 && h_proof && proof_len && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
+    ZK_REQUIRE(ctx, pk && seed16 && out && (h_instance || !pk->I), "null pointer");
+    const size_t n = (size_t)1 << pk->k;
+    std::unique_ptr<zk_proof> pr(new zk_proof(pk, seed16));
+    pr->tr.common_scalar(pk->vk_repr);
+    // instances (KZG: not committed; absorbed as scalars)
+    for (uint32_t i = 0; i < pk->I; ++i) {
+        const F4* v = (const F4*)h_instance[i];
+        for (size_t row = 0; row < pk->u; ++row) pr->tr.common_scalar(v[row]);
+        PK_TRY(upload(ctx, &pr->inst_lag[i], h_instance[i], n * 32));
+        PK_TRY(to_coeff_and_ext(ctx, pk, pr->inst_lag[i], &pr->inst_coeff[i], &pr->inst_ext[i]));
+    }
+    *out = pr.release();
+    return ZK_OK;
+}
+
+// Commits the advice columns of the current phase (h_cols[j] is advice column col_index[j]; exactly
+// the columns of this phase, each n x 32 B Lagrange values; rows >= n - bf are replaced by blinding
+// values) and squeezes the challenges that become available after it into h_challenges (Fr each,
+// in challenge-index order); *num_challenges receives how many were written.
+int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && (ncols == 0 || (col_index && h_cols)), "null pointer");
+    const zk_pk* pk = pr->pk;
+    if (pr->phase >= pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "all %u advice phases are already committed", pk->num_phases);
+    const size_t n = (size_t)1 << pk->k;
+    uint32_t expected = 0;
+    for (uint32_t i = 0; i < pk->A; ++i) expected += pk->adv_phase[i] == pr->phase;
+    if (ncols != expected) return ctx->fail(ZK_ERR_INVALID_ARG, "phase %u has %u advice columns, %u were passed", pr->phase, expected, ncols);
+    std::vector<const void*> by_col(pk->A, nullptr);
+    for (uint32_t j = 0; j < ncols; ++j) {
+        const uint32_t c = col_index[j];
+        if (c >= pk->A || pk->adv_phase[c] != pr->phase || by_col[c] || !h_cols[j]) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u does not belong to phase %u (or is repeated)", c, pr->phase);
+        by_col[c] = h_cols[j];
+    }
+    std::vector<F4> col(n);
+    std::vector<const void*> ptrs;
+    for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
+        if (!by_col[c]) continue;
+        memcpy(col.data(), by_col[c], n * 32);
+        for (size_t row = n - pk->bf; row < n; ++row) col[row] = pr->rng.next_fr();
+        PK_TRY(upload(ctx, &pr->adv_lag[c], col.data(), n * 32));
+        ptrs.push_back(pr->adv_lag[c].p);
+    }
+    std::vector<G1Affine> coms(ptrs.size());
+    PK_TRY(zk_commit_batch(ctx, pk->srs, 1, ptrs.data(), ptrs.size(), n, coms.data()));   // pipelined MSMs
+    for (const G1Affine& com : coms) pr->tr.write_point(com);
+    uint32_t written = 0;
+    for (uint32_t i = 0; i < pk->chal_phase.size(); ++i) {
+        if (pk->chal_phase[i] != pr->phase) continue;
+        pr->challenges[i] = pr->tr.squeeze();
+        if (h_challenges) memcpy((uint8_t*)h_challenges + 32 * written, &pr->challenges[i], 32);
+        ++written;
+    }
+    if (num_challenges) *num_challenges = written;
+    ++pr->phase;
+    return ZK_OK;
+}
+
+// Everything after the advice phases: lookups, permutation, quotient, evaluations, multi-open.
+// Consumes the session (it is freed whether or not the call succeeds).
+int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_cap, size_t* proof_len) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    std::unique_ptr<zk_proof> pr(pr_raw);
+    ZK_REQUIRE(ctx, pr && h_proof && proof_len, "null pointer");
+    const zk_pk* pk = pr->pk;
+    if (pr->phase != pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "only %u of %u advice phases were committed", pr->phase, pk->num_phases);
     const zk_srs* srs = pk->srs;
     const uint32_t k = pk->k, ext_k = pk->ext_k;
     const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
-    host::XorShiftRng rng(seed16);
-    host::Transcript tr;
+    host::XorShiftRng& rng = pr->rng;
+    host::Transcript& tr = pr->tr;
+    std::vector<DevBuf>&inst_lag = pr->inst_lag, &inst_coeff = pr->inst_coeff, &inst_ext = pr->inst_ext, &adv_lag = pr->adv_lag;
+    std::vector<DevBuf> adv_coeff(pk->A), adv_ext(pk->A);
     const F4 one = host::fr_one();
-
-    tr.common_scalar(pk->vk_repr);
-    // ---- instances (KZG: not committed; absorbed as scalars)
-    std::vector<DevBuf> inst_lag(pk->I), inst_coeff(pk->I), inst_ext(pk->I);
-    for (uint32_t i = 0; i < pk->I; ++i) {
-        const F4* v = (const F4*)h_instance[i];
-        for (size_t row = 0; row < pk->u; ++row) tr.common_scalar(v[row]);
-        PK_TRY(upload(ctx, &inst_lag[i], h_instance[i], n * 32));
-        PK_TRY(to_coeff_and_ext(ctx, pk, inst_lag[i], &inst_coeff[i], &inst_ext[i]));
-    }
-    // ---- advice: blind, commit
-    std::vector<DevBuf> adv_lag(pk->A), adv_coeff(pk->A), adv_ext(pk->A);
-    {
-        std::vector<F4> col(n);
-        for (uint32_t i = 0; i < pk->A; ++i) {
-            memcpy(col.data(), h_advice[i], n * 32);
-            for (size_t row = n - pk->bf; row < n; ++row) col[row] = rng.next_fr();
-            PK_TRY(upload(ctx, &adv_lag[i], col.data(), n * 32));
-            G1Affine com;
-            PK_TRY(commit_lagrange(ctx, srs, adv_lag[i].fr(), n, &com));
-            tr.write_point(com);
-        }
-    }
-    Env lag{pk, false, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}};
+    (void)inst_coeff;
+    Env lag{pk, false, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
 
     // ---- lookups, round 1: multiplicities m
@@ -626,6 +706,24 @@ int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, c
     if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
     memcpy(h_proof, tr.proof.data(), tr.proof.size());
     return ZK_OK;
+}
+
+// One-shot create_proof: every advice column is known up front (no column depends on a challenge,
+// or the caller derived them already); runs the phases back to back.
+int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
+                    void* h_proof, size_t proof_cap, size_t* proof_len) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && seed16 && h_proof && proof_len && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
+    zk_proof* pr = nullptr;
+    PK_TRY(zk_proof_begin(ctx, pk, h_instance, seed16, &pr));
+    for (uint32_t ph = 0; ph < pk->num_phases; ++ph) {
+        std::vector<uint32_t> idx;
+        std::vector<const void*> cols;
+        for (uint32_t c = 0; c < pk->A; ++c) if (pk->adv_phase[c] == ph) { idx.push_back(c); cols.push_back(h_advice[c]); }
+        const int rc = zk_proof_advice_phase(ctx, pr, idx.data(), cols.data(), (uint32_t)idx.size(), nullptr, nullptr);
+        if (rc) { zk_proof_abort(ctx, pr); return rc; }
+    }
+    return zk_proof_finish(ctx, pr, h_proof, proof_cap, proof_len);
 }
 
 }  // extern "C"

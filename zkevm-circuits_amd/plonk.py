@@ -23,7 +23,8 @@ FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)
 
 FIXED, ADVICE, INSTANCE = 0, 1, 2
 Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG = 1, 2, 3, 4, 5, 6
-BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 1
+BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 2
+C_CHAL0 = 0xFFFD0000   # abstract constant reference of user challenge i (csrc/prover.hip)
 
 
 def fr_mont_bytes(v: int) -> bytes:
@@ -60,6 +61,15 @@ class Col(Expr):
 class Const(Expr):
     def __init__(self, value: int):
         self.value = value % R_MOD
+
+    def degree(self): return 0
+
+
+class Challenge(Expr):
+    """halo2 ``Challenge``: a transcript challenge usable in gates of later phases."""
+
+    def __init__(self, index: int):
+        self.index = index
 
     def degree(self): return 0
 
@@ -102,6 +112,8 @@ class Circuit:
         self.fixed = [[0] * self.n for _ in range(num_fixed)]
         self.consts: List[int] = []
         self._const_index: Dict[int, int] = {}
+        self.advice_phase = [0] * num_advice      # halo2 FirstPhase = 0, SecondPhase = 1, ...
+        self.challenge_phase: List[int] = []      # challenge i is squeezed after this phase
 
     # -- columns
     def fixed_col(self, i, rot=0): return Col(FIXED, i, rot)
@@ -113,6 +125,13 @@ class Circuit:
     def add_lookup(self, inputs: Sequence[Expr], tables: Sequence[Expr]):
         assert len(inputs) == len(tables)
         self.lookups.append((list(inputs), list(tables)))
+
+    def challenge_usable_after(self, phase: int) -> "Challenge":
+        self.challenge_phase.append(phase)
+        return Challenge(len(self.challenge_phase) - 1)
+
+    def num_phases(self) -> int:
+        return max([0] + self.advice_phase + self.challenge_phase) + 1
 
     def enable_equality(self, ctype: int, index: int):
         if (ctype, index) not in self.perm_cols:
@@ -156,6 +175,8 @@ class Circuit:
                 out.append((Q_PUSH_COL, colref(x.ctype, x.index), x.rotation & 0xFFFFFFFF))
             elif isinstance(x, Const):
                 out.append((Q_PUSH_CONST, self._const(x.value), 0))
+            elif isinstance(x, Challenge):
+                out.append((Q_PUSH_CONST, C_CHAL0 + x.index, 0))
             elif isinstance(x, Neg):
                 go(x.a)
                 out.append((Q_NEG, 0, 0))
@@ -208,6 +229,9 @@ class Circuit:
 
         out = [struct.pack("<12I", BLOB_MAGIC, BLOB_VERSION, self.k, self.bf, self.degree(), self.F, self.A, self.I,
                            len(self.perm_cols), len(self.lookups), len(gates), len(self.consts))]
+        out.append(struct.pack("<I", len(self.challenge_phase)))
+        out += [struct.pack("<I", p) for p in self.advice_phase]
+        out += [struct.pack("<I", p) for p in self.challenge_phase]
         out += [struct.pack("<II", t, i) for t, i in self.perm_cols]
         out += [fr_mont_bytes(c) for c in self.consts]
         out += [prog(g) for g in gates]
