@@ -166,6 +166,10 @@ int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, c
  * phases, zkevm-circuits/src/util.rs:120-133).  begin -> zk_proof_advice_phase x num_phases ->
  * finish.  zk_create_proof is begin + all phases + finish for witnesses known up front.          */
 typedef struct zk_proof zk_proof;
+/* multi-open scheme of the session: GWC (ProverGWC, what north_star names; default) or SHPLONK
+ * (ProverSHPLONK / BDFG21, what the reference's call sites instantiate: two commitments in total) */
+enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };
+int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* proof, int kind);
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
 /* commits the advice columns of the current phase (h_cols[j] = advice column col_index[j], exactly
  * the columns of that phase) and writes the challenges that become usable after it to

@@ -170,7 +170,84 @@ def _queries(circ):
     return adv, fix
 
 
-def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequence[int]], proof: bytes, s_g2) -> bool:
+def _interpolate(xs, ys):
+    """coefficients (low first) of the polynomial through (xs[i], ys[i])"""
+    m = len(xs)
+    out = [0] * m
+    for a in range(m):
+        num, den = [1], 1
+        for c in range(m):
+            if c == a:
+                continue
+            nx = [0] * (len(num) + 1)
+            for t, v in enumerate(num):
+                nx[t + 1] = (nx[t + 1] + v) % R
+                nx[t] = (nx[t] - v * xs[c]) % R
+            num = nx
+            den = den * (xs[a] - xs[c]) % R
+        sc = ys[a] * b.fr_inv(den) % R
+        for t, v in enumerate(num):
+            out[t] = (out[t] + v * sc) % R
+    return out
+
+
+def _verify_shplonk(tr, proof, opens, rots, point, s_g2) -> bool:
+    """SHPLONK / BDFG21 verifier for the prover's variant: sets in order of first
+    appearance, Horner powers of y inside a set and of v across sets."""
+    y, v = tr.squeeze(), tr.squeeze()
+    polys = []          # (commitment, [rots], [evals])
+    for com, rot, e in opens:
+        for p in polys:
+            if p[0] is com:
+                p[1].append(rot); p[2].append(e)
+                break
+        else:
+            polys.append((com, [rot], [e]))
+    sets = []           # (sorted rots, [poly indices])
+    for pi, p in enumerate(polys):
+        key = sorted(p[1])
+        for s_ in sets:
+            if s_[0] == key:
+                s_[1].append(pi)
+                break
+        else:
+            sets.append((key, [pi]))
+    h_com = tr.read_point()
+    u = tr.squeeze()
+    pi_com = tr.read_point()
+    if tr.pos != len(proof):
+        return False
+    zT = 1
+    for r_ in rots:
+        zT = zT * (u - point(r_)) % R
+    L, cpow = None, 1
+    for key, members in reversed(sets):
+        zs = [point(r_) for r_ in key]
+        qcom, Ru = None, 0
+        for pi in members:
+            com, prots, pevals = polys[pi]
+            ys = [pevals[prots.index(r_)] for r_ in key]
+            rj = _interpolate(zs, ys)
+            rju = 0
+            for c in reversed(rj):
+                rju = (rju * u + c) % R
+            qcom = b.g1_add(b.g1_mul(qcom, y) if qcom is not None else None, com)
+            Ru = (Ru * y + rju) % R
+        zt = 1
+        for r_ in rots:
+            if r_ not in key:
+                zt = zt * (u - point(r_)) % R
+        coef = cpow * zt % R
+        term = b.g1_add(qcom, b.g1_neg(b.g1_mul(b.G1_GEN, Ru)))
+        L = b.g1_add(L, b.g1_mul(term, coef))
+        cpow = cpow * v % R
+    L = b.g1_add(L, b.g1_neg(b.g1_mul(h_com, zT)))
+    # L(X) = (X - u) pi(X):  e(L + u pi, G2) == e(pi, [s]G2)
+    lhs = b.g1_add(L, b.g1_mul(pi_com, u))
+    return pr.pairing_check([(lhs, pr.ec_neg(pr.G2_GEN)), (pi_com, s_g2)])
+
+
+def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequence[int]], proof: bytes, s_g2, multiopen: str = "gwc") -> bool:
     """vk_commitments: F fixed then P sigma affine points (int tuples); s_g2: [s]G2 of the SRS."""
     n, k, u, bf, d = circ.n, circ.k, circ.u, circ.bf, circ.degree()
     F, A, I, Pn, L = circ.F, circ.A, circ.I, len(circ.perm_cols), len(circ.lookups)
@@ -288,12 +365,14 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
         hc = b.g1_add(b.g1_mul(hc, xn) if hc is not None else None, com)
     opens.append((hc, 0, h_eval))
 
-    # ---- GWC: one witness per distinct point, in order of first appearance
-    v = tr.squeeze()
     rots = []
     for _, rot, _ in opens:
         if rot not in rots:
             rots.append(rot)
+    if multiopen == "shplonk":
+        return _verify_shplonk(tr, proof, opens, rots, point, s_g2)
+    # ---- GWC: one witness per distinct point, in order of first appearance
+    v = tr.squeeze()
     witnesses = [tr.read_point() for _ in rots]
     if tr.pos != len(proof):
         return False

@@ -114,6 +114,36 @@ def test_unsatisfied_witness_is_refused_or_unverifiable(zk, ctx, cref, srs8, s_g
         _prove(ctx, cref, circ, adv_bad, inst, srs8)
 
 
+@pytest.mark.parametrize("k,wide,seed", [(6, False, 11), (7, True, 12)])
+def test_shplonk_multiopen(zk, ctx, cref, srs8, s_g2, k, wide, seed):
+    """ProverSHPLONK (BDFG21) is what the reference's call sites instantiate
+    [REF circuit-benchmarks/src/super_circuit.rs:117-132]: two commitments close the proof."""
+    circ, adv, inst = build_circuit(k, seed, wide)
+    pk = ctx.pk_create(srs8[k], circ.blob())
+    com, rep = pk.vk(circ.F + len(circ.perm_cols))
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+
+    def prove(kind):
+        sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], bytes(16))
+        sess.set_multiopen(kind)
+        sess.advice_phase({i: plonk.column_to_mont(c) for i, c in enumerate(adv)})
+        return sess.finish()
+    gwc, shp = prove(0), prove(1)
+    pk.destroy()
+    def safe_verify(proof, scheme):
+        try:
+            return pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen=scheme)
+        except AssertionError:      # malformed encoding / truncated proof
+            return False
+    assert len(shp) < len(gwc)                       # 2 closing commitments instead of one per point
+    assert safe_verify(shp, "shplonk")
+    assert safe_verify(gwc, "gwc")
+    assert not safe_verify(shp, "gwc") and not safe_verify(gwc, "shplonk")
+    bad = bytearray(shp)
+    bad[-40] ^= 1            # inside the final commitment
+    assert not safe_verify(bytes(bad), "shplonk")
+
+
 def test_two_phase_proof_with_challenge(zk, ctx, cref, srs8, s_g2):
     """Phases as in the SuperCircuit [REF zkevm-circuits/src/util.rs:120-133]: columns a, b are
     first-phase; the RLC column c = a + r*b needs the challenge r squeezed after phase 0, so the

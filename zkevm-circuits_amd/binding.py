@@ -161,6 +161,10 @@ class ProofSession:
         ctx._ck(lib().zk_proof_begin(ctx.h, pk.h, pi, ctypes.c_char_p(seed), ctypes.byref(h)))
         self.h = h
 
+    def set_multiopen(self, kind: int):
+        """0 = GWC (default), 1 = SHPLONK."""
+        self.ctx._ck(lib().zk_proof_set_multiopen(self.ctx.h, self.h, ctypes.c_int(kind)))
+
     def advice_phase(self, columns: dict) -> np.ndarray:
         """columns: {advice column index: (n, 4) u64 Montgomery array}; returns (num_challenges, 4) u64."""
         idx = sorted(columns)

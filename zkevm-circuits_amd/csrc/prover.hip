@@ -90,6 +90,7 @@ struct zk_proof {
     host::Transcript tr;
     std::vector<DevBuf> inst_lag, inst_coeff, inst_ext, adv_lag;
     uint32_t phase = 0;
+    int multiopen = ZK_MULTIOPEN_GWC;
     std::vector<F4> challenges;
     zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), inst_ext(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
@@ -397,6 +398,13 @@ void zk_proof_abort(zk_ctx* ctx, zk_proof* pr) {
     delete pr;
 }
 
+int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* pr, int kind) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && (kind == ZK_MULTIOPEN_GWC || kind == ZK_MULTIOPEN_SHPLONK), "unknown multi-open scheme");
+    pr->multiopen = kind;
+    return ZK_OK;
+}
+
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, pk && seed16 && out && (h_instance || !pk->I), "null pointer");
@@ -684,12 +692,144 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         F4 e; PK_TRY(eval_at(hcomb.fr(), 0, &e));
         opens.push_back({hcomb.fr(), 0, e});   // not written: the verifier recomputes it
     }
-    // ---- GWC multi-open: one witness per distinct point, in order of first appearance
-    const F4 v = tr.squeeze();
     std::vector<int32_t> rots;
     for (const Open& o : opens) if (std::find(rots.begin(), rots.end(), o.rot) == rots.end()) rots.push_back(o.rot);
     DevBuf batch, wit;
     if (!batch.alloc(n * 32) || !wit.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    if (pr->multiopen == ZK_MULTIOPEN_SHPLONK) {
+        // ---- SHPLONK / BDFG21 (poly::kzg::multiopen::ProverSHPLONK): what the reference's
+        // call sites instantiate.  Two commitments whatever the number of polynomials and points.
+        const F4 y = tr.squeeze(), v = tr.squeeze();
+        // distinct polynomials with their (rotation, eval) lists, grouped into rotation sets
+        struct PolyQ { const Fr* poly; std::vector<int32_t> rots; std::vector<F4> evals; };
+        std::vector<PolyQ> polys;
+        for (const Open& o : opens) {
+            auto it = std::find_if(polys.begin(), polys.end(), [&](const PolyQ& p) { return p.poly == o.poly; });
+            if (it == polys.end()) { polys.push_back({o.poly, {}, {}}); it = polys.end() - 1; }
+            it->rots.push_back(o.rot); it->evals.push_back(o.eval);
+        }
+        struct Set { std::vector<int32_t> rots; std::vector<size_t> members; };
+        std::vector<Set> sets;
+        for (size_t pi = 0; pi < polys.size(); ++pi) {
+            std::vector<int32_t> key = polys[pi].rots;
+            std::sort(key.begin(), key.end());
+            auto it = std::find_if(sets.begin(), sets.end(), [&](const Set& s_) { return s_.rots == key; });
+            if (it == sets.end()) { sets.push_back({key, {}}); it = sets.end() - 1; }
+            it->members.push_back(pi);
+        }
+        // r_j(X): interpolation of poly j's evaluations over its set's points (degree < |S|), host side
+        auto interpolate = [&](const std::vector<F4>& xs, const std::vector<F4>& ys) {
+            const size_t m = xs.size();
+            std::vector<F4> out(m, host::fr_zero());
+            for (size_t a = 0; a < m; ++a) {
+                std::vector<F4> num{host::fr_one()};       // prod_{b != a} (X - x_b)
+                F4 den = host::fr_one();
+                for (size_t b2 = 0; b2 < m; ++b2) {
+                    if (b2 == a) continue;
+                    std::vector<F4> nx(num.size() + 1, host::fr_zero());
+                    for (size_t t = 0; t < num.size(); ++t) { nx[t + 1] = host::fr_add(nx[t + 1], num[t]); nx[t] = host::fr_sub(nx[t], host::fr_mul(num[t], xs[b2])); }
+                    num.swap(nx);
+                    den = host::fr_mul(den, host::fr_sub(xs[a], xs[b2]));
+                }
+                const F4 sc = host::fr_mul(ys[a], host::fr_inv(den));
+                for (size_t t = 0; t < num.size(); ++t) out[t] = host::fr_add(out[t], host::fr_mul(num[t], sc));
+            }
+            return out;
+        };
+        auto eval_small = [&](const std::vector<F4>& c, const F4& at) { F4 acc = host::fr_zero(); for (size_t t = c.size(); t-- > 0;) acc = host::fr_add(host::fr_mul(acc, at), c[t]); return acc; };
+        std::vector<DevBuf> qfull(sets.size()), hset(sets.size());
+        std::vector<std::vector<F4>> Rset(sets.size());
+        DevBuf tmp;
+        if (!tmp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        for (size_t si = 0; si < sets.size(); ++si) {
+            const Set& st = sets[si];
+            std::vector<F4> zs;
+            for (int32_t r_ : st.rots) zs.push_back(rotate(r_));
+            // Qfull_i = Horner over the set's polynomials with y;  R_i = same combination of the r_j
+            std::vector<uint32_t> words;
+            std::vector<const void*> cols;
+            std::vector<F4> R(st.rots.size(), host::fr_zero());
+            for (size_t pi : st.members) {
+                words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u});
+                cols.push_back(polys[pi].poly);
+                std::vector<F4> ys(st.rots.size());
+                for (size_t a = 0; a < st.rots.size(); ++a) {
+                    const size_t where = std::find(polys[pi].rots.begin(), polys[pi].rots.end(), st.rots[a]) - polys[pi].rots.begin();
+                    ys[a] = polys[pi].evals[where];
+                }
+                const std::vector<F4> rj = interpolate(zs, ys);
+                for (size_t t = 0; t < R.size(); ++t) R[t] = host::fr_add(host::fr_mul(R[t], y), rj[t]);
+            }
+            Rset[si] = R;
+            if (!qfull[si].alloc(n * 32) || !hset[si].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &y, 1, k, k, 0, qfull[si].p));
+            // h_i = (Qfull_i - R_i) / prod (X - z): subtract R_i from the low coefficients, divide point by point
+            PK_TRY(zk_d2d(ctx, hset[si].p, qfull[si].p, n * 32));
+            std::vector<F4> low(R.size());
+            PK_TRY(zk_d2h(ctx, low.data(), hset[si].p, R.size() * 32));
+            for (size_t t = 0; t < R.size(); ++t) low[t] = host::fr_sub(low[t], R[t]);
+            PK_TRY(zk_h2d(ctx, hset[si].p, low.data(), R.size() * 32));
+            size_t len = n;
+            for (const F4& z : zs) {
+                PK_TRY(zk_kate_division(ctx, hset[si].p, len, &z, tmp.p));
+                --len;
+                PK_TRY(zk_d2d(ctx, hset[si].p, tmp.p, len * 32));
+                ZK_HIP(ctx, hipMemsetAsync((char*)hset[si].p + len * 32, 0, (n - len) * 32, ctx->stream));
+            }
+        }
+        // h = Horner over the sets with v; commit
+        {
+            std::vector<uint32_t> words;
+            std::vector<const void*> cols;
+            for (size_t si = 0; si < sets.size(); ++si) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(hset[si].p); }
+            PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &v, 1, k, k, 0, batch.p));
+            G1Affine com;
+            PK_TRY(commit_coeff(ctx, srs, batch.fr(), n, &com));
+            tr.write_point(com);
+        }
+        const F4 u = tr.squeeze();
+        // L(X) = sum_i c_i Z_{T\\S_i}(u) (Qfull_i(X) - R_i(u)) - Z_T(u) h(X),  c_i = v^(s-1-i);   pi = L / (X - u)
+        std::vector<F4> coef(sets.size() + 1);
+        F4 zT = host::fr_one(), constant = host::fr_zero(), cpow = host::fr_one();
+        for (int32_t r_ : rots) zT = host::fr_mul(zT, host::fr_sub(u, rotate(r_)));
+        for (size_t si = sets.size(); si-- > 0;) {
+            F4 zt = host::fr_one();
+            for (int32_t r_ : rots) if (std::find(sets[si].rots.begin(), sets[si].rots.end(), r_) == sets[si].rots.end()) zt = host::fr_mul(zt, host::fr_sub(u, rotate(r_)));
+            coef[si] = host::fr_mul(cpow, zt);
+            constant = host::fr_add(constant, host::fr_mul(coef[si], eval_small(Rset[si], u)));
+            cpow = host::fr_mul(cpow, v);
+        }
+        coef[sets.size()] = zT;
+        {
+            std::vector<uint32_t> words;
+            std::vector<const void*> cols;
+            for (size_t si = 0; si < sets.size(); ++si) {
+                words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_MUL_CONST, (uint32_t)si, 0u});
+                if (si) words.insert(words.end(), {Q_ADD, 0u, 0u});
+                cols.push_back(qfull[si].p);
+            }
+            words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_MUL_CONST, (uint32_t)sets.size(), 0u, Q_SUB, 0u, 0u});
+            cols.push_back(batch.p);
+            coef.push_back(host::fr_one());
+            words.insert(words.end(), {Q_FOLD, (uint32_t)sets.size() + 1, 0u});
+            PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), coef.data(), (uint32_t)coef.size(), k, k, 0, tmp.p));
+            F4 c0;
+            PK_TRY(zk_d2h(ctx, &c0, tmp.p, 32));
+            c0 = host::fr_sub(c0, constant);
+            PK_TRY(zk_h2d(ctx, tmp.p, &c0, 32));
+            PK_TRY(zk_kate_division(ctx, tmp.p, n, &u, wit.p));
+            G1Affine com;
+            PK_TRY(commit_coeff(ctx, srs, wit.fr(), n - 1, &com));
+            tr.write_point(com);
+        }
+        PK_TRY(zk_ctx_sync(ctx));
+        *proof_len = tr.proof.size();
+        if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
+        memcpy(h_proof, tr.proof.data(), tr.proof.size());
+        return ZK_OK;
+    }
+    // ---- GWC multi-open: one witness per distinct point, in order of first appearance
+    const F4 v = tr.squeeze();
     for (int32_t rot : rots) {
         std::vector<uint32_t> words;
         std::vector<const void*> cols;
