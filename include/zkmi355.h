@@ -96,6 +96,9 @@ int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k);
 /* ---- polynomial helpers: halo2_proofs::arithmetic  -- SURVEY 8a K9, K10 ------------------------ */
 /* eval_polynomial(coeffs, x) -> one Fr on the host */
 int zk_poly_eval(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_x, void* h_out);
+/* eval_polynomial of `count` polynomials (device pointers, n coefficients each) at one point:
+ * one power table and one synchronisation for all of them; h_out receives count Fr               */
+int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t count, size_t n, const void* h_x, void* h_out);
 /* kate_division(coeffs, z): d_q receives n-1 coefficients of (f(X) - f(z)) / (X - z)             */
 int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_z, void* d_q);
 /* z[0] = 1 (product) / 0 (sum); z[i+1] = z[i] (*|+) a[i]: the permutation / lookup grand product

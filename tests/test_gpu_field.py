@@ -71,3 +71,15 @@ def test_eval_polynomial_and_kate_division(ctx, cref, n):
             dQ = ctx.alloc((n - 1) * 32)
             ctx.kate_division(dC, n, xm, dQ)
             assert np.array_equal(dQ.download((n - 1, 4)), cref.kate_division(C, x))
+
+
+@pytest.mark.parametrize("n,count", [(1, 1), (100, 3), (4096, 7), (1 << 16, 20)])
+def test_eval_polynomial_batch(ctx, cref, n, count):
+    """zk_poly_eval_batch == eval_polynomial applied to each column (one launch, one sync)."""
+    polys = [cref.rand_fr_stream(7000 + 13 * i + n, n) for i in range(count)]
+    bufs = [ctx.to_device(p) for p in polys]
+    for x in (0xDEADBEEF12345 + n, 0, bn254.R_MOD - 1):
+        got = ctx.poly_eval_batch(bufs, n, cref.fr_const(x))
+        vals = cref.from_mont(got)
+        for i in range(count):
+            assert vals[i] == cref.eval_polynomial(polys[i], x), (n, i, x)

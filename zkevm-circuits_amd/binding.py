@@ -289,6 +289,14 @@ class Context:
         self._ck(lib().zk_poly_eval(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(x_mont)), _host_ptr(out)))
         return out
 
+    def poly_eval_batch(self, polys, n: int, x_mont: np.ndarray) -> np.ndarray:
+        """eval_polynomial of several device polynomials (n coefficients each) at one point -> (count, 4) u64."""
+        count = len(polys)
+        out = np.empty((count, 4), dtype=np.uint64)
+        ptrs = (ctypes.c_void_p * max(count, 1))(*[ctypes.c_void_p(p.ptr) for p in polys])
+        self._ck(lib().zk_poly_eval_batch(self.h, ptrs, ctypes.c_size_t(count), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(x_mont)), _host_ptr(out)))
+        return out
+
     def kate_division(self, coeffs: DeviceBuffer, n: int, z_mont: np.ndarray, q: DeviceBuffer):
         self._ck(lib().zk_kate_division(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(z_mont)), ctypes.c_void_p(q.ptr)))
 

@@ -59,6 +59,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->domains.clear();
+    for (auto& kv : ctx->pow_tables) (void)hipFree(kv.second);
     ctx->prof_resolve();
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);

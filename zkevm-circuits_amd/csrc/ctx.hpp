@@ -38,6 +38,7 @@ struct zk_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
+    std::map<uint64_t, void*> pow_tables;                         // cached two-level power tables of the coset generators
     std::vector<void*> pinned;   // small pinned host staging buffers
     // per-kernel HIP-event profiling (zk_prof_*): off by default
     bool prof_on = false;

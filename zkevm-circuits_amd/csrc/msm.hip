@@ -75,7 +75,9 @@ __device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
 constexpr uint32_t DIG_ZERO = 0xFFFFu;
 constexpr int MSM_RANGE_MAX_BITS = 11;   // <= 2048 buckets per workgroup
 
-__global__ void k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, int c, int W, uint16_t* __restrict__ dig) {
+// wflag[w] is raised when window w holds at least one non-zero digit: the sweeps skip the others
+// (selector / boolean / small-value columns leave most windows empty).
+__global__ void k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, int c, int W, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     if (i >= n) { for (int w = 0; w < W; ++w) dig[(uint64_t)w * n_pad + i] = (uint16_t)DIG_ZERO; return; }
@@ -91,15 +93,21 @@ __global__ void k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_
         if (d > half) { carry = 1; const uint32_t mag = (1u << c) - d; code = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
         else { carry = 0; code = d ? (d - 1) : DIG_ZERO; }
         dig[(uint64_t)w * n_pad + i] = (uint16_t)code;
+        const uint64_t any = __ballot(code != DIG_ZERO);
+        if (any && (uint32_t)__builtin_ctzll(any) == (threadIdx.x & 63u)) wflag[w] = 1u;
     }
 }
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restrict__ dig, uint64_t n_pad, int range_bits, uint32_t B,
-                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx) {
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx, const uint32_t* __restrict__ wflag) {
     __shared__ uint32_t lds[1 << MSM_RANGE_MAX_BITS];
     const uint32_t r = blockIdx.x, w = blockIdx.y, range = 1u << range_bits, rmask = range - 1;
     const uint64_t gbase = (uint64_t)w * B + ((uint64_t)r << range_bits);
+    if (wflag[w] == 0u) {      // empty window: nothing to count or place
+        if (!SCATTER) for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[gbase + t] = 0u;
+        return;
+    }
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[gbase + t] : 0u;
     __syncthreads();
     const uint4* row = reinterpret_cast<const uint4*>(dig + (uint64_t)w * n_pad);
@@ -428,19 +436,20 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
 
-    // u32 workspace: counts[nb] | size_hist[256] nmulti[4] | offsets[nb+1] | cursor[nb] | order[nb] | ntasks[nb] | toff[nb+1] | multi[nb] |
+    // u32 workspace: counts[nb] | size_hist[256] nmulti[4] wflag[64] | offsets[nb+1] | cursor[nb] | order[nb] | ntasks[nb] | toff[nb+1] | multi[nb] |
     //                block_tot[2*scan_blocks] | idx[n*W] | (16-B aligned) dig[W*n_pad u16]
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
     const uint64_t n_pad = ((uint64_t)n + 7) & ~7ull;
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
-    const size_t head_words = (size_t)nb * 7 + 2 + SIZE_BINS + 4 + 2 * (size_t)scan_blocks + (size_t)n * pl.W;
+    const size_t head_words = (size_t)nb * 7 + 2 + SIZE_BINS + 68 + 2 * (size_t)scan_blocks + (size_t)n * pl.W;
     const size_t words = head_words + 4 + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* counts = ws;
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
-    uint32_t* offsets = nmulti + 4;
+    uint32_t* wflag = nmulti + 4;          // 64 words: W <= 64 windows (c >= 4)
+    uint32_t* offsets = wflag + 64;
     uint32_t* cursor = offsets + nb + 1;
     uint32_t* order = cursor + nb;
     uint32_t* ntasks = order + nb;
@@ -496,9 +505,9 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 4) * 4, ctx->stream));   // size_hist + nmulti
-        hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((n_pad + 255) / 256)), ts, 0, ctx->stream, d_scalars, (uint64_t)n, n_pad, pl.c, pl.W, dig);
-        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));   // size_hist + nmulti + wflag
+        hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((n_pad + 255) / 256)), ts, 0, ctx->stream, d_scalars, (uint64_t)n, n_pad, pl.c, pl.W, dig, wflag);
+        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, block_tot);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
@@ -509,7 +518,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb);
         hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx);
+        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx, (const uint32_t*)wflag);
         ZK_CHECK_LAUNCH(ctx);
     }
     {

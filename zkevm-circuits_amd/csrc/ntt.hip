@@ -305,14 +305,22 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
     auto run_distribute = [&](const Fr& g) -> int {
         const int h = (int)(log_n + 1) / 2;
         const uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
-        Fr* tab = (Fr*)ctx->get_scratch(SC_TMP, sizeof(Fr) * (nlo + nhi));
-        if (!tab) return ZK_ERR_OOM;
-        int r = build_powers(ctx, g, Fr::one(), tab, nlo, 0);
-        if (r) return r;
-        Fr step = g;
-        for (int i = 0; i < h; ++i) step = sqr(step);
-        r = build_powers(ctx, step, Fr::one(), tab + nlo, nhi, 0);
-        if (r) return r;
+        // the coset generators are a handful of constants (zeta, zeta^-1): keep their tables
+        const uint64_t key = domain_key(log_n, g, nullptr) ^ 0xC05E7ull;
+        Fr* tab = nullptr;
+        auto it = ctx->pow_tables.find(key);
+        if (it != ctx->pow_tables.end()) {
+            tab = (Fr*)it->second;
+        } else {
+            if (hipMalloc(&tab, sizeof(Fr) * ((size_t)nlo + nhi)) != hipSuccess) return ctx->fail(ZK_ERR_OOM, "coset table allocation failed");
+            int r = build_powers(ctx, g, Fr::one(), tab, nlo, 0);
+            if (r) return r;
+            Fr step = g;
+            for (int i = 0; i < h; ++i) step = sqr(step);
+            r = build_powers(ctx, step, Fr::one(), tab + nlo, nhi, 0);
+            if (r) return r;
+            ctx->pow_tables[key] = tab;
+        }
         hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_data, tab, tab + nlo, h, n);
         ZK_CHECK_LAUNCH(ctx);
         return ZK_OK;

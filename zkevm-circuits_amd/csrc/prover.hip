@@ -31,6 +31,7 @@ using zk::host::F4;
 
 extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* const*, uint32_t, const void*, uint32_t, uint32_t, uint32_t, int, void*);
 extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
+extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
 
 namespace {
 
@@ -667,17 +668,32 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     struct Open { const Fr* poly; int32_t rot; F4 eval; };
     std::vector<Open> opens;
     auto eval_at = [&](const Fr* coeffs, int32_t rot, F4* out) -> int { const F4 pt = rotate(rot); return zk_poly_eval(ctx, coeffs, n, &pt, out); };
-    for (const Query& qy : pk->adv_q) { F4 e; PK_TRY(eval_at(adv_coeff[qy.idx].fr(), qy.rot, &e)); tr.write_scalar(e); opens.push_back({adv_coeff[qy.idx].fr(), qy.rot, e}); }
-    for (const Query& qy : pk->fix_q) { F4 e; PK_TRY(eval_at(pk->fixed_coeff[qy.idx].fr(), qy.rot, &e)); tr.write_scalar(e); opens.push_back({pk->fixed_coeff[qy.idx].fr(), qy.rot, e}); }
-    { F4 e; PK_TRY(eval_at(random_coeff.fr(), 0, &e)); tr.write_scalar(e); opens.push_back({random_coeff.fr(), 0, e}); }
-    for (uint32_t j = 0; j < pk->P; ++j) { F4 e; PK_TRY(eval_at(pk->sigma_coeff[j].fr(), 0, &e)); tr.write_scalar(e); opens.push_back({pk->sigma_coeff[j].fr(), 0, e}); }
+    // every (polynomial, rotation) the proof opens, in transcript order; evaluated in one batch per point
+    for (const Query& qy : pk->adv_q) opens.push_back({adv_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
+    for (const Query& qy : pk->fix_q) opens.push_back({pk->fixed_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
+    opens.push_back({random_coeff.fr(), 0, host::fr_zero()});
+    for (uint32_t j = 0; j < pk->P; ++j) opens.push_back({pk->sigma_coeff[j].fr(), 0, host::fr_zero()});
     for (uint32_t c = 0; c < pk->C; ++c) {
-        for (int32_t rot : {0, 1}) { F4 e; PK_TRY(eval_at(pz_coeff[c].fr(), rot, &e)); tr.write_scalar(e); opens.push_back({pz_coeff[c].fr(), rot, e}); }
-        if (c + 1 < pk->C) { F4 e; PK_TRY(eval_at(pz_coeff[c].fr(), rot_last, &e)); tr.write_scalar(e); opens.push_back({pz_coeff[c].fr(), rot_last, e}); }
+        for (int32_t rot : {0, 1}) opens.push_back({pz_coeff[c].fr(), rot, host::fr_zero()});
+        if (c + 1 < pk->C) opens.push_back({pz_coeff[c].fr(), rot_last, host::fr_zero()});
     }
     for (uint32_t l = 0; l < pk->L; ++l) {
-        for (int32_t rot : {0, 1}) { F4 e; PK_TRY(eval_at(phi_coeff[l].fr(), rot, &e)); tr.write_scalar(e); opens.push_back({phi_coeff[l].fr(), rot, e}); }
-        F4 e; PK_TRY(eval_at(m_coeff[l].fr(), 0, &e)); tr.write_scalar(e); opens.push_back({m_coeff[l].fr(), 0, e});
+        for (int32_t rot : {0, 1}) opens.push_back({phi_coeff[l].fr(), rot, host::fr_zero()});
+        opens.push_back({m_coeff[l].fr(), 0, host::fr_zero()});
+    }
+    {
+        std::vector<int32_t> distinct;
+        for (const Open& o : opens) if (std::find(distinct.begin(), distinct.end(), o.rot) == distinct.end()) distinct.push_back(o.rot);
+        for (int32_t rot : distinct) {
+            std::vector<const void*> ptrs;
+            std::vector<size_t> where;
+            for (size_t i = 0; i < opens.size(); ++i) if (opens[i].rot == rot) { ptrs.push_back(opens[i].poly); where.push_back(i); }
+            std::vector<F4> vals(ptrs.size());
+            const F4 pt = rotate(rot);
+            PK_TRY(zk_poly_eval_batch(ctx, ptrs.data(), ptrs.size(), n, &pt, vals.data()));
+            for (size_t j = 0; j < where.size(); ++j) opens[where[j]].eval = vals[j];
+        }
+        for (const Open& o : opens) tr.write_scalar(o.eval);
     }
     // h(X) = sum_i x^(n i) h_i(X): opened at x, the verifier derives its expected value itself
     DevBuf hcomb;

@@ -183,6 +183,23 @@ __global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, 
     Fr s = block_sum(acc, sh);
     if (threadIdx.x == 0) stg(partial + blockIdx.x, s);
 }
+// batched forms: blockIdx.y selects the polynomial
+__global__ void __launch_bounds__(256) k_eval_partial_multi(const Fr* const* __restrict__ polys, uint64_t n, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, Fr* __restrict__ partial) {
+    __shared__ Fr sh[256];
+    const Fr* c = polys[blockIdx.y];
+    Fr acc = Fr::zero();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        acc = acc + ldg(c + i) * two_level_pow(lo, hi, h, i);
+    Fr s = block_sum(acc, sh);
+    if (threadIdx.x == 0) stg(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, s);
+}
+__global__ void __launch_bounds__(256) k_sum_final_multi(const Fr* __restrict__ partial, uint32_t cnt, Fr* __restrict__ out) {
+    __shared__ Fr sh[256];
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = acc + ldg(partial + (size_t)blockIdx.x * cnt + i);
+    Fr s = block_sum(acc, sh);
+    if (threadIdx.x == 0) stg(out + blockIdx.x, s);
+}
 __global__ void __launch_bounds__(256) k_sum_final(const Fr* __restrict__ partial, uint32_t cnt, Fr* out) {
     __shared__ Fr sh[256];
     Fr acc = Fr::zero();
@@ -282,6 +299,32 @@ int zk_poly_eval(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_x, v
     hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, partial + blocks);
     ZK_CHECK_LAUNCH(ctx);
     ZK_HIP(ctx, hipMemcpyAsync(h_out, partial + blocks, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// eval_polynomial of `count` polynomials at ONE point: one power table, one launch pair, one sync
+// (the prover opens hundreds of columns at the same few points x * omega^rot)
+int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t count, size_t n, const void* h_x, void* h_out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_coeff_ptrs || !count) && h_x && h_out, "null pointer");
+    if (count == 0) return ZK_OK;
+    if (n == 0) { memset(h_out, 0, sizeof(Fr) * count); return ZK_OK; }
+    Fr *lo, *hi; int h;
+    int rc = build_pow_table(ctx, SC_TMP, *(const Fr*)h_x, n, &lo, &hi, &h);
+    if (rc) return rc;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    char* sc = (char*)ctx->get_scratch(SC_POLY2, sizeof(Fr) * ((size_t)blocks + 1) * count + 8 * count + 64);
+    if (!sc) return ZK_ERR_OOM;
+    Fr* partial = (Fr*)sc;
+    Fr* results = partial + (size_t)blocks * count;
+    const Fr** d_ptrs = (const Fr**)(results + count);
+    ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_coeff_ptrs, 8 * count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks, (unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)d_ptrs, (uint64_t)n, lo, hi, h, partial);
+    hipLaunchKernelGGL(k_sum_final_multi, dim3((unsigned)count), dim3(256), 0, ctx->stream, (const Fr*)partial, blocks, results);
+    ZK_CHECK_LAUNCH(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(h_out, results, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
