@@ -117,6 +117,11 @@ int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr,
                      const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out);
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
+/* n uniformly random Fr (Montgomery form) on the device: element i = Fr::from_uniform_bytes of
+ * ChaCha20 block (first_block + i) under key32 / stream_id (64-bit counter in state words 12..13,
+ * stream id in 14..15).  What the prover draws its blinding polynomial from (halo2 takes an RngCore
+ * from the caller; plonk/vanishing/prover.rs fills the random poly from it element by element).    */
+int zk_fr_random(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, uint64_t first_block, void* d_out, size_t n);
 
 /* ---- SRS: halo2_proofs::poly::kzg::commitment::ParamsKZG  -- SURVEY 8a A5 ---------------------- */
 /* Upload g (n = 2^k G1Affine) and optionally g_lagrange (may be NULL); host pointers.            */
@@ -138,6 +143,10 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
  * of a phase): d_scalar_ptrs[i] addresses n Fr on the device, h_out_affine receives count x 64 B.
  * Consecutive MSMs are pipelined on two streams.                                                 */
 int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine);
+/* zk_commit_batch for columns still in host memory: column i+1 is uploaded (copy stream) while the
+ * MSM of column i runs; d_cols[i] (n x 32 B device buffers) receive the columns.  This is the shape
+ * of halo2's advice commitment loop (plonk/prover.rs: one commit_lagrange per witness column).     */
+int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* h_cols, void* const* d_cols, size_t count, size_t n, void* h_out_affine);
 /* best_multiexp over HOST slices, exactly the reference signature (copies in, computes, copies
  * the affine result out).                                                                        */
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine);

@@ -513,3 +513,33 @@ def mock_prover_challenge(i: int) -> int:
     for _ in range(i):
         h = hashlib.blake2b(h, digest_size=64).digest()
     return fr_from_uniform_bytes(h)
+
+
+# ---- ChaCha20 counter-mode field sampling (zk_fr_random) ------------------------------------------
+# Restates RFC 7539 section 2.3 (block function) with the original 64-bit counter / 64-bit stream
+# layout (state words 12..13 = block counter, 14..15 = stream id), followed by halo2curves'
+# Fr::from_uniform_bytes (lo + hi * 2^256 mod r over 64 little-endian bytes).
+def chacha20_block(key32: bytes, counter: int, stream: int) -> bytes:
+    import struct
+    k = struct.unpack("<8I", key32)
+    init = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574, *k,
+            counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, stream & 0xFFFFFFFF, (stream >> 32) & 0xFFFFFFFF]
+    x = list(init)
+
+    def rotl(v, c):
+        return ((v << c) & 0xFFFFFFFF) | (v >> (32 - c))
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return struct.pack("<16I", *[(a + b) & 0xFFFFFFFF for a, b in zip(x, init)])
+
+
+def fr_random_chacha(key32: bytes, stream: int, first_block: int, n: int):
+    return [fr_from_uniform_bytes(chacha20_block(key32, first_block + i, stream)) for i in range(n)]

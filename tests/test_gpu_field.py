@@ -83,3 +83,18 @@ def test_eval_polynomial_batch(ctx, cref, n, count):
         vals = cref.from_mont(got)
         for i in range(count):
             assert vals[i] == cref.eval_polynomial(polys[i], x), (n, i, x)
+
+
+@pytest.mark.parametrize("n,first", [(1, 0), (1000, 0), (4099, (1 << 32) - 7)])
+def test_fr_random_chacha(ctx, cref, n, first):
+    """zk_fr_random == ChaCha20 block (RFC 7539 KAT-pinned oracle) -> from_uniform_bytes."""
+    key = bytes((7 * i + 3) & 0xFF for i in range(32))
+    stream = 0x1122334455667788
+    out = ctx.alloc(n * 32)
+    ctx.fr_random(key, stream, first, out, n)
+    got = cref.from_mont(out.download((n, 4)))
+    idx = sorted({0, n - 1, n // 2, min(n - 1, 9)})
+    for i in idx:
+        assert got[i] == bn254.fr_from_uniform_bytes(bn254.chacha20_block(key, first + i, stream)), i
+    if n <= 1000:
+        assert [int(v) for v in got] == bn254.fr_random_chacha(key, stream, first, n)

@@ -154,3 +154,21 @@ def test_commit_batch_matches_single_commits(ctx, cref):
     assert np.array_equal(ctx.commit_batch(srs, [bufs[0].ptr], n)[0], cref.best_multiexp(cols[0], basis))
     assert ctx.commit_batch(srs, [], n).shape == (0, 8)
     srs.destroy()
+
+
+def test_commit_batch_h2d_uploads_and_commits(ctx, cref):
+    """zk_commit_batch_h2d: host columns are uploaded on the copy stream under the previous MSM."""
+    k, n = 13, 1 << 13
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(99))
+    cols = [cref.rand_fr_stream(500 + i, n) for i in range(6)]
+    cols[1] = cref.to_mont([0, 1] * (n // 2))
+    dev = [ctx.alloc(n * 32) for _ in cols]
+    for basis in (0, 1):
+        got = ctx.commit_batch_h2d(srs, basis, cols, dev, n)
+        want = np.stack([ctx.commit(srs, ctx.to_device(c), n, lagrange=bool(basis)) for c in cols])
+        assert np.array_equal(got, want)
+        for c, d in zip(cols, dev):
+            assert np.array_equal(d.download(c.shape), c)
+    basis_pts = srs.download_g()
+    assert np.array_equal(ctx.commit_batch_h2d(srs, 0, cols[:1], dev[:1], n)[0], cref.best_multiexp(cols[0], basis_pts))
+    srs.destroy()

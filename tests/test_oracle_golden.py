@@ -128,3 +128,13 @@ def test_kzg_identity_with_pairing():
     s_g2 = pr.ec_mul(pr.G2_GEN, s)
     rhs_q = pr.ec_add(s_g2, pr.ec_neg(pr.ec_mul(pr.G2_GEN, z)))
     assert pr.pairing_check([(lhs, pr.ec_neg(pr.G2_GEN)), (W, rhs_q)])
+
+
+def test_chacha20_block_rfc7539_vector():
+    """RFC 7539 section 2.3.2 known-answer test for the block function behind zk_fr_random."""
+    key = bytes(range(32))
+    blk = b.chacha20_block(key, 1 | (0x09000000 << 32), 0x4A000000)
+    assert blk.hex() == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    vals = b.fr_random_chacha(key, 7, 0, 4)
+    assert len(set(vals)) == 4 and all(0 <= v < b.R_MOD for v in vals)

@@ -297,6 +297,21 @@ class Context:
         self._ck(lib().zk_poly_eval_batch(self.h, ptrs, ctypes.c_size_t(count), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(x_mont)), _host_ptr(out)))
         return out
 
+    def fr_random(self, key32: bytes, stream_id: int, first_block: int, out: DeviceBuffer, n: int):
+        """n uniform Fr from ChaCha20 blocks (counter mode) + from_uniform_bytes."""
+        assert len(key32) == 32
+        self._ck(lib().zk_fr_random(self.h, ctypes.c_char_p(key32), ctypes.c_uint64(stream_id), ctypes.c_uint64(first_block), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
+
+    def commit_batch_h2d(self, srs: "Srs", basis: int, host_cols, dev_cols, n: int) -> np.ndarray:
+        """commit `host_cols` (numpy (n,4) u64 each) while uploading them into dev_cols (overlapped)."""
+        count = len(host_cols)
+        hc = [np.ascontiguousarray(c, dtype=np.uint64) for c in host_cols]
+        hp = (ctypes.c_void_p * max(count, 1))(*[ctypes.c_void_p(c.ctypes.data) for c in hc])
+        dp = (ctypes.c_void_p * max(count, 1))(*[ctypes.c_void_p(d.ptr) for d in dev_cols])
+        out = np.empty((count, 8), dtype=np.uint64)
+        self._ck(lib().zk_commit_batch_h2d(self.h, srs.h, ctypes.c_int(basis), hp, dp, ctypes.c_size_t(count), ctypes.c_size_t(n), _host_ptr(out)))
+        return out
+
     def kate_division(self, coeffs: DeviceBuffer, n: int, z_mont: np.ndarray, q: DeviceBuffer):
         self._ck(lib().zk_kate_division(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(z_mont)), ctypes.c_void_p(q.ptr)))
 

@@ -60,12 +60,14 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->domains.clear();
     for (auto& kv : ctx->pow_tables) (void)hipFree(kv.second);
+    ctx->pool_trim();
     ctx->prof_resolve();
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); (void)hipEventDestroy(ctx->ev_copy); }
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_p2) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -265,18 +267,23 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine) {
 // bucket reduction of column i runs on a side stream under the sort + accumulation of column i+1).
 int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, srs && h_out_affine && (d_scalar_ptrs || !count), "null pointer");
-    ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
-    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
-    ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
-    const G1Affine* brp = nullptr;
-    int rc = srs_bases_rp(ctx, srs, basis, &brp);
+    return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr);
+}
+// Same, for columns that still live in host memory: column i + 1 is uploaded on the copy stream
+// while the MSM of column i runs.  d_cols[i] (n x 32 B each) receive the uploaded columns.
+int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* h_cols, void* const* d_cols, size_t count, size_t n, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (h_cols && d_cols) || !count, "null pointer");
+    for (size_t i = 0; i < count; ++i) ZK_REQUIRE(ctx, h_cols[i] && d_cols[i], "null column pointer");
+    struct Stage { zk_ctx* ctx; const void* const* h; void* const* d; size_t bytes; } st{ctx, h_cols, d_cols, n * sizeof(Fr)};
+    int rc = zk::copy_stream_open(ctx);
     if (rc) return rc;
-    const G1Affine* tab = nullptr;
-    size_t stride = 0;
-    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
-    if (rc) return rc;
-    return msm_batch_tab(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, tab, stride, n, (G1Affine*)h_out_affine);
+    auto fn = [](void* user, size_t it) -> int {
+        Stage* s = (Stage*)user;
+        ZK_HIP(s->ctx, hipMemcpyAsync(s->d[it], s->h[it], s->bytes, hipMemcpyHostToDevice, s->ctx->stream_copy));
+        return zk::copy_stream_fence(s->ctx);
+    };
+    return zk::commit_batch_staged(ctx, srs, basis, (const void* const*)d_cols, count, n, h_out_affine, fn, &st);
 }
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
@@ -292,3 +299,34 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size
 }
 
 }  // extern "C"
+
+namespace zk {
+int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user) {
+    ZK_REQUIRE(ctx, srs && h_out_affine && (d_scalar_ptrs || !count), "null pointer");
+    ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
+    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
+    ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
+    const G1Affine* brp = nullptr;
+    int rc = srs_bases_rp(ctx, srs, basis, &brp);
+    if (rc) return rc;
+    const G1Affine* tab = nullptr;
+    size_t stride = 0;
+    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
+    if (rc) return rc;
+    return msm_batch_tab(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, tab, stride, n, (G1Affine*)h_out_affine, stage, stage_user);
+}
+int copy_stream_open(zk_ctx* ctx) {
+    if (!ctx->stream_copy) {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
+    }
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_copy, 0));
+    return ZK_OK;
+}
+int copy_stream_fence(zk_ctx* ctx) {
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream_copy));
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0));
+    return ZK_OK;
+}
+}  // namespace zk

@@ -37,9 +37,44 @@ struct zk_ctx {
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
+    // copy stream: host -> device staging of the next column under the current MSM (api.hip)
+    hipStream_t stream_copy = nullptr;
+    hipEvent_t ev_copy = nullptr;
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
     std::map<uint64_t, void*> pow_tables;                         // cached two-level power tables of the coset generators
     std::vector<void*> pinned;   // small pinned host staging buffers
+    // Device block pool for the prover's column buffers: a proof allocates and frees hundreds of
+    // n x 32 B / 2^ext_k x 32 B blocks, and hipFree is a device-wide synchronisation.  Blocks are
+    // recycled by exact size; every user is ordered on `stream`, so reuse needs no extra fence.
+    std::map<size_t, std::vector<void*>> pool;
+    size_t pool_bytes = 0, pool_cap = (size_t)96 << 30;
+    void* pool_get(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!bytes) bytes = 256;
+        auto it = pool.find(bytes);
+        if (it != pool.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); pool_bytes -= bytes; return p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) == hipSuccess) return p;
+        (void)hipGetLastError();
+        pool_trim();                                   // give cached blocks back and retry once
+        if (hipMalloc(&p, bytes) == hipSuccess) return p;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    void pool_put(void* p, size_t bytes) {
+        if (!p) return;
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!bytes) bytes = 256;
+        if (pool_bytes + bytes > pool_cap) { (void)hipStreamSynchronize(stream); (void)hipFree(p); return; }
+        pool[bytes].push_back(p);
+        pool_bytes += bytes;
+    }
+    void pool_trim() {
+        (void)hipStreamSynchronize(stream);
+        for (auto& kv : pool) for (void* p : kv.second) (void)hipFree(p);
+        pool.clear();
+        pool_bytes = 0;
+    }
     // per-kernel HIP-event profiling (zk_prof_*): off by default
     bool prof_on = false;
     struct ProfEntry { double ms = 0; uint64_t count = 0; };
@@ -148,6 +183,13 @@ int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const 
 int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);
 int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out);
 int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const G1Affine** out, size_t* stride);
+// stage(user, it) makes the scalars of MSM `it` available (ordered before the main stream's next
+// launches); it is called with 0 before the first MSM and with it + 1 once MSM `it` is enqueued,
+// so an upload on the copy stream runs under the previous MSM.
+typedef int (*MsmStageFn)(void* user, size_t it);
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
-                  size_t n, G1Affine* h_out);
+                  size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
+int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user);
+int copy_stream_open(zk_ctx* ctx);      // copy stream starts after everything enqueued on the main stream so far
+int copy_stream_fence(zk_ctx* ctx);     // main stream continues after everything enqueued on the copy stream so far
 }  // namespace zk

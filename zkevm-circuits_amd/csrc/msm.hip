@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* 
 // bases_rp: device bases already in R' form (SRS cache) or nullptr -> converted into scratch
 // d_table (nullable): fixed-base window table for exactly this plan (W windows of tab_stride points)
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
-                  size_t n, G1Affine* h_out) {
+                  size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user) {
     if (count == 0) return ZK_OK;
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
     if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
@@ -494,6 +494,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         ZK_CHECK_LAUNCH(ctx);
         d_bases_rp = conv;
     }
+    if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
   for (size_t it = 0; it < count; ++it) {
     const int par = (int)(it & 1);
     const Fr* d_scalars = d_scalar_ptrs[it];
@@ -548,6 +549,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         ZK_CHECK_LAUNCH(ctx);
     }
     ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], ctx->stream2));
+    if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
   }
     // join: the main stream waits for the outstanding reductions, then one copy of all window sums
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));

@@ -23,6 +23,8 @@
 #include <array>
 #include <unordered_map>
 
+#include <chrono>
+#include <cstdlib>
 #include "ctx.hpp"
 #include "host_util.hpp"
 
@@ -31,6 +33,7 @@ using zk::host::F4;
 
 extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* const*, uint32_t, const void*, uint32_t, uint32_t, uint32_t, int, void*);
 extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
+extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, size_t);
 extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
 
 namespace {
@@ -47,21 +50,55 @@ inline uint32_t colref(uint32_t type, uint32_t idx) { return (type << 24) | idx;
 struct Instr { uint32_t op, a, b; };
 typedef std::vector<Instr> Prog;
 
+// Inside a PoolScope (the proof-session entry points) DevBuf blocks come from and return to the
+// context's block pool; outside (key generation: buffers that live as long as the key) they are
+// plain hipMalloc / hipFree.  A session must not outlive its context.
+static thread_local zk_ctx* tl_pool_ctx = nullptr;
+struct PoolScope {
+    zk_ctx* prev;
+    explicit PoolScope(zk_ctx* c) : prev(tl_pool_ctx) { tl_pool_ctx = c; }
+    ~PoolScope() { tl_pool_ctx = prev; }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    zk_ctx* owner = nullptr;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; } return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owner(o.owner) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; owner = o.owner; o.p = nullptr; } return *this; }
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
-    bool alloc(size_t n) { release(); bytes = n; return hipMalloc(&p, n ? n : 1) == hipSuccess; }
+    void release() {
+        if (!p) return;
+        if (owner) owner->pool_put(p, bytes); else (void)hipFree(p);
+        p = nullptr;
+    }
+    bool alloc(size_t n) {
+        release();
+        bytes = n;
+        owner = tl_pool_ctx;
+        if (owner) { p = owner->pool_get(n); return p != nullptr; }
+        return hipMalloc(&p, n ? n : 1) == hipSuccess;
+    }
     Fr* fr() const { return (Fr*)p; }
 };
 
 struct Query { uint32_t type, idx; int32_t rot; };
+
+// ZK_PROVER_TRACE=1: wall-clock per prover stage on stderr (device drained at every mark)
+struct StageTrace {
+    zk_ctx* ctx; bool on; std::chrono::steady_clock::time_point t0;
+    explicit StageTrace(zk_ctx* c) : ctx(c), on(getenv("ZK_PROVER_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zk prover] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 }  // namespace
 
@@ -122,7 +159,7 @@ int to_coeff_and_ext(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* co
         if (!ext->alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         PK_TRY(zk_coeff_to_extended(ctx, c->p, pk->k, pk->ext_k, ext->p));
     }
-    PK_TRY(zk_ctx_sync(ctx));   // tmp may be freed on return
+    if (!tl_pool_ctx) PK_TRY(zk_ctx_sync(ctx));   // tmp is hipFree'd on return (pooled blocks are stream-ordered)
     return ZK_OK;
 }
 
@@ -408,6 +445,7 @@ int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* pr, int kind) {
 
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
+    PoolScope pool_scope(ctx);
     ZK_REQUIRE(ctx, pk && seed16 && out && (h_instance || !pk->I), "null pointer");
     const size_t n = (size_t)1 << pk->k;
     std::unique_ptr<zk_proof> pr(new zk_proof(pk, seed16));
@@ -429,6 +467,7 @@ int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, 
 // in challenge-index order); *num_challenges receives how many were written.
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
+    PoolScope pool_scope(ctx);
     ZK_REQUIRE(ctx, pr && (ncols == 0 || (col_index && h_cols)), "null pointer");
     const zk_pk* pk = pr->pk;
     if (pr->phase >= pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "all %u advice phases are already committed", pk->num_phases);
@@ -442,17 +481,30 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         if (c >= pk->A || pk->adv_phase[c] != pr->phase || by_col[c] || !h_cols[j]) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u does not belong to phase %u (or is repeated)", c, pr->phase);
         by_col[c] = h_cols[j];
     }
-    std::vector<F4> col(n);
-    std::vector<const void*> ptrs;
+    StageTrace trace(ctx);
+    // Column c+1 is uploaded on the copy stream while the MSM of column c runs; the last bf rows of
+    // every column are blinding values (drawn up front, in column-index = transcript order).
+    struct Stage {
+        zk_ctx* ctx; size_t body, tail;
+        std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind;
+    } sg{ctx, (n - pk->bf) * 32, (size_t)pk->bf * 32, {}, {}, {}};
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
-        memcpy(col.data(), by_col[c], n * 32);
-        for (size_t row = n - pk->bf; row < n; ++row) col[row] = pr->rng.next_fr();
-        PK_TRY(upload(ctx, &pr->adv_lag[c], col.data(), n * 32));
-        ptrs.push_back(pr->adv_lag[c].p);
+        if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
+        sg.src.push_back(by_col[c]);
+        sg.dst.push_back(pr->adv_lag[c].p);
+        for (uint32_t r = 0; r < pk->bf; ++r) sg.blind.push_back(pr->rng.next_fr());
     }
-    std::vector<G1Affine> coms(ptrs.size());
-    PK_TRY(zk_commit_batch(ctx, pk->srs, 1, ptrs.data(), ptrs.size(), n, coms.data()));   // pipelined MSMs
+    PK_TRY(copy_stream_open(ctx));
+    auto stage = [](void* user, size_t it) -> int {
+        Stage* s_ = (Stage*)user;
+        ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[it], s_->src[it], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+        ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[it] + s_->body, s_->blind.data() + it * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+        return copy_stream_fence(s_->ctx);
+    };
+    std::vector<G1Affine> coms(sg.dst.size());
+    PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg));
+    trace.mark("advice upload + commits");
     for (const G1Affine& com : coms) pr->tr.write_point(com);
     uint32_t written = 0;
     for (uint32_t i = 0; i < pk->chal_phase.size(); ++i) {
@@ -470,6 +522,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
 // Consumes the session (it is freed whether or not the call succeeds).
 int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_cap, size_t* proof_len) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
+    PoolScope pool_scope(ctx);
     std::unique_ptr<zk_proof> pr(pr_raw);
     ZK_REQUIRE(ctx, pr && h_proof && proof_len, "null pointer");
     const zk_pk* pk = pr->pk;
@@ -483,6 +536,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     std::vector<DevBuf> adv_coeff(pk->A), adv_ext(pk->A);
     const F4 one = host::fr_one();
     (void)inst_coeff;
+    StageTrace trace(ctx);
     Env lag{pk, false, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
 
@@ -517,6 +571,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         PK_TRY(commit_lagrange(ctx, srs, lk_m[l].fr(), n, &com));
         tr.write_point(com);
     }
+    trace.mark("lookup m");
     lag.lk_m = &lk_m;
     lag.beta = tr.squeeze();
     lag.gamma = tr.squeeze();
@@ -559,6 +614,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
     }
+    trace.mark("permutation Z");
     // ---- lookups, round 2: grand sums phi
     for (uint32_t l = 0; l < pk->L; ++l) {
         // g[i] = 1/(f+beta) - m/(t+beta)  via one batch inversion of (f+beta) and (t+beta)
@@ -594,16 +650,20 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         lk_phi[l] = std::move(phi);
         PK_TRY(zk_ctx_sync(ctx));
     }
+    trace.mark("lookup phi");
     // ---- vanishing argument: random polynomial
     DevBuf random_coeff;
     {
-        std::vector<F4> rc(n);
-        for (auto& x : rc) x = rng.next_fr();
-        PK_TRY(upload(ctx, &random_coeff, rc.data(), n * 32));
+        // n uniform coefficients: ChaCha20 in counter mode on the device, keyed from the session RNG
+        uint32_t key[8];
+        for (uint32_t& w_ : key) w_ = rng.next_u32();
+        if (!random_coeff.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        PK_TRY(zk_fr_random(ctx, (const uint8_t*)key, 0, 0, random_coeff.p, n));
         G1Affine com;
         PK_TRY(commit_coeff(ctx, srs, random_coeff.fr(), n, &com));
         tr.write_point(com);
     }
+    trace.mark("random poly");
     lag.y = tr.squeeze();
 
     // ---- coefficient and extended forms of everything the quotient reads
@@ -614,6 +674,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         PK_TRY(to_coeff_and_ext(ctx, pk, lk_m[l], &m_coeff[l], &m_ext[l]));
         PK_TRY(to_coeff_and_ext(ctx, pk, lk_phi[l], &phi_coeff[l], &phi_ext[l]));
     }
+    trace.mark("coeff + extended forms");
     // ---- the quotient program: gates, permutation, lookups, each folded with y
     PB q;
     for (const Prog& g : pk->gates) { q.append(g); q.fold(C_Y); }
@@ -652,6 +713,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     if (!h.alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
     PK_TRY(run_program(ctx, ext, q.g, true, h.p));
     PK_TRY(zk_extended_to_coeff(ctx, h.p, ext_k));
+    trace.mark("quotient eval + ifft");
     const uint32_t pieces = pk->d - 1;
     for (uint32_t i = 0; i < pieces; ++i) {
         G1Affine com;
@@ -660,6 +722,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     }
     adv_ext.clear(); pz_ext.clear(); m_ext.clear(); phi_ext.clear(); inst_ext.clear();   // extended forms no longer needed
 
+    trace.mark("h commits");
     const F4 x = tr.squeeze();
     // ---- evaluations
     const F4 w = [&] { Fr t = fr_root_of_unity(k); F4 r; memcpy(r.l, &t, 32); return r; }();
@@ -695,6 +758,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         for (const Open& o : opens) tr.write_scalar(o.eval);
     }
+    trace.mark("evaluations");
     // h(X) = sum_i x^(n i) h_i(X): opened at x, the verifier derives its expected value itself
     DevBuf hcomb;
     {
@@ -708,6 +772,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         F4 e; PK_TRY(eval_at(hcomb.fr(), 0, &e));
         opens.push_back({hcomb.fr(), 0, e});   // not written: the verifier recomputes it
     }
+    trace.mark("h recombination");
     std::vector<int32_t> rots;
     for (const Open& o : opens) if (std::find(rots.begin(), rots.end(), o.rot) == rots.end()) rots.push_back(o.rot);
     DevBuf batch, wit;
@@ -839,6 +904,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             tr.write_point(com);
         }
         PK_TRY(zk_ctx_sync(ctx));
+        trace.mark("multiopen (shplonk)");
         *proof_len = tr.proof.size();
         if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
         memcpy(h_proof, tr.proof.data(), tr.proof.size());
@@ -858,6 +924,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         tr.write_point(com);
     }
     PK_TRY(zk_ctx_sync(ctx));
+    trace.mark("multiopen");
     *proof_len = tr.proof.size();
     if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
     memcpy(h_proof, tr.proof.data(), tr.proof.size());

@@ -239,6 +239,34 @@ static int build_pow_table(zk_ctx* ctx, int slot, const Fr& x, uint64_t n, Fr** 
     return ZK_OK;
 }
 
+
+// ---- uniformly random field elements: ChaCha20 block -> from_uniform_bytes ----------------------
+// Element i is halo2curves' Fr::from_uniform_bytes (lo + hi * 2^256 mod r over the 64 little-endian
+// bytes) of ChaCha20 block i: key = the caller's 32 bytes, 64-bit block counter = i in state words
+// 12..13, 64-bit stream id in words 14..15 (the djb layout, which rand_chacha's ChaCha20Rng uses
+// too).  Counter mode, so the blinding polynomial of a proof is one launch instead of n sequential
+// draws from a host generator.
+struct ChaChaKey { uint32_t w[8]; };
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+#define ZK_CHACHA_QR(a, b, c, d) a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+__global__ void __launch_bounds__(256) k_fr_random(ChaChaKey key, uint32_t s_lo, uint32_t s_hi, uint64_t first, Fr* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ctr = first + i;
+    const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.w[0], key.w[1], key.w[2], key.w[3],
+                             key.w[4], key.w[5], key.w[6], key.w[7], (uint32_t)ctr, (uint32_t)(ctr >> 32), s_lo, s_hi};
+    uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7];
+    uint32_t x8 = in[8], x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+    for (int r = 0; r < 10; ++r) {
+        ZK_CHACHA_QR(x0, x4, x8, x12) ZK_CHACHA_QR(x1, x5, x9, x13) ZK_CHACHA_QR(x2, x6, x10, x14) ZK_CHACHA_QR(x3, x7, x11, x15)
+        ZK_CHACHA_QR(x0, x5, x10, x15) ZK_CHACHA_QR(x1, x6, x11, x12) ZK_CHACHA_QR(x2, x7, x8, x13) ZK_CHACHA_QR(x3, x4, x9, x14)
+    }
+    Fr lo{{x0 + in[0], x1 + in[1], x2 + in[2], x3 + in[3], x4 + in[4], x5 + in[5], x6 + in[6], x7 + in[7]}};
+    Fr hi{{x8 + in[8], x9 + in[9], x10 + in[10], x11 + in[11], x12 + in[12], x13 + in[13], x14 + in[14], x15 + in[15]}};
+    // lo, hi may exceed r: they go in as the row operand of the CIOS product (any 256-bit value is fine there)
+    stg(out + i, Fr::r2() * lo + (Fr::r2() * hi) * Fr::r2());
+}
+#undef ZK_CHACHA_QR
 }  // namespace zk
 
 using namespace zk;
@@ -360,6 +388,17 @@ int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_
     rc = build_pow_table(ctx, SC_TMP, zinv, nm1, &lo, &hi, &h);
     if (rc) return rc;
     hipLaunchKernelGGL(k_kate_finish, g, t, 0, ctx->stream, (const Fr*)excl, (const Fr*)total, nm1, lo, hi, h, (Fr*)d_q);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+int zk_fr_random(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, uint64_t first_block, void* d_out, size_t n) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, key32 && (d_out || !n), "null pointer");
+    if (!n) return ZK_OK;
+    ChaChaKey key;
+    memcpy(key.w, key32, 32);   // little-endian words
+    hipLaunchKernelGGL(k_fr_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), first_block, (Fr*)d_out, (uint64_t)n);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
