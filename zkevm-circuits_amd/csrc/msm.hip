@@ -64,7 +64,7 @@ __device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
 
 // ---- sort phase --------------------------------------------------------------------------------
 // 1. k_msm_digits: every scalar leaves Montgomery form once and is recoded; digit codes go to a
-//    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 8):
+//    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 16):
 //      0xFFFF = zero digit, otherwise bit 15 = sign, bits 0..14 = bucket (|d| - 1).
 // 2. k_msm_lds_count / k_msm_lds_scatter: workgroup (r, w) owns bucket range r of window w
 //    (<= 2048 buckets).  It streams the whole digit row (2 MiB at 2^20, L2-resident, 16 B/lane)
@@ -77,32 +77,52 @@ constexpr int MSM_RANGE_MAX_BITS = 11;   // <= 2048 buckets per workgroup
 
 // wflag[w] is raised when window w holds at least one non-zero digit: the sweeps skip the others
 // (selector / boolean / small-value columns leave most windows empty).
-__global__ void k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, int c, int W, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
+template <int C>
+__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
+    constexpr int W = (256 + C - 1) / C;      // window bits are a template parameter: every limb index below is static
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    if (i >= n) { for (int w = 0; w < W; ++w) dig[(uint64_t)w * n_pad + i] = (uint16_t)DIG_ZERO; return; }
+    if (i >= n) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) dig[(uint64_t)w * n_pad + i] = (uint16_t)DIG_ZERO;
+        return;
+    }
     const Fr s = from_mont(ldg(scalars + i));
     uint32_t carry = 0;
-    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    constexpr uint32_t mask = (1u << C) - 1, half = 1u << (C - 1);
+#pragma unroll
     for (int w = 0; w < W; ++w) {
-        const int bit = w * c, limb = bit >> 5, sh = bit & 31;
-        uint32_t d = limb < 8 ? (s.l[limb] >> sh) : 0u;
-        if (sh + c > 32 && limb + 1 < 8) d |= s.l[limb + 1] << (32 - sh);
+        const int bit = w * C, limb = bit >> 5, sh = bit & 31;
+        uint32_t d = limb < 8 ? (s.l[limb < 8 ? limb : 7] >> sh) : 0u;
+        if (sh + C > 32 && limb + 1 < 8) d |= s.l[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
         d = (d & mask) + carry;
         uint32_t code;
-        if (d > half) { carry = 1; const uint32_t mag = (1u << c) - d; code = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
+        if (d > half) { carry = 1; const uint32_t mag = (1u << C) - d; code = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
         else { carry = 0; code = d ? (d - 1) : DIG_ZERO; }
         dig[(uint64_t)w * n_pad + i] = (uint16_t)code;
         const uint64_t any = __ballot(code != DIG_ZERO);
         if (any && (uint32_t)__builtin_ctzll(any) == (threadIdx.x & 63u)) wflag[w] = 1u;
     }
 }
+static void launch_digits(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, uint64_t n_pad, uint16_t* dig, uint32_t* wflag) {
+#define ZK_DIG_CASE(C) case C: hipLaunchKernelGGL(k_msm_digits<C>, grid, dim3(256), 0, st, scalars, n, n_pad, dig, wflag); break;
+    switch (c) {
+        ZK_DIG_CASE(4) ZK_DIG_CASE(5) ZK_DIG_CASE(6) ZK_DIG_CASE(7) ZK_DIG_CASE(8) ZK_DIG_CASE(9) ZK_DIG_CASE(10)
+        ZK_DIG_CASE(11) ZK_DIG_CASE(12) ZK_DIG_CASE(13) ZK_DIG_CASE(14) ZK_DIG_CASE(15) ZK_DIG_CASE(16)
+    }
+#undef ZK_DIG_CASE
+}
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restrict__ dig, uint64_t n_pad, int range_bits, uint32_t B,
-                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx, const uint32_t* __restrict__ wflag) {
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx, const uint32_t* __restrict__ wflag, uint32_t nwin) {
     __shared__ uint32_t lds[1 << MSM_RANGE_MAX_BITS];
-    const uint32_t r = blockIdx.x, w = blockIdx.y, range = 1u << range_bits, rmask = range - 1;
+    // XCD-aware placement: workgroups go to the 8 XCDs round-robin by linear id, so id = xcd + 8 * j
+    // with window = xcd + 8 * (j / ranges): all range-workgroups of a window share one XCD and its
+    // L2 serves the window's digit row to all of them (read from HBM / MALL once, not once per XCD).
+    const uint32_t nranges = B >> range_bits, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t r = slot % nranges, w = xcd + 8u * (slot / nranges), range = 1u << range_bits, rmask = range - 1;
+    if (w >= nwin) return;
     const uint64_t gbase = (uint64_t)w * B + ((uint64_t)r << range_bits);
     if (wflag[w] == 0u) {      // empty window: nothing to count or place
         if (!SCATTER) for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[gbase + t] = 0u;
@@ -110,24 +130,61 @@ __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restri
     }
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[gbase + t] : 0u;
     __syncthreads();
+    // 16 digits per lane and trip, two digits per 32-bit word.  A digit belongs to this workgroup
+    // when the range field of its code (bits range_bits..14) equals r: xor with the wanted field,
+    // mask, and a carry trick turn "half-word == 0" into one flag bit per digit (~3 VALU per digit
+    // instead of a shift / mask / compare chain per digit).  The hits of a lane are then walked
+    // with a loop that runs max-over-lanes(hits) times, so the LDS atomics go out with several
+    // active lanes each.  The next trip's loads are issued before the current one is processed.
+    const uint32_t field = (0x7FFFu & ~rmask) * 0x00010001u, want = (r << range_bits) * 0x00010001u;
+    const bool zero_aliases = (0x7FFFu >> range_bits) == r;       // DIG_ZERO = 0xFFFF carries this range's field
     const uint4* row = reinterpret_cast<const uint4*>(dig + (uint64_t)w * n_pad);
-    const uint64_t nvec = n_pad >> 3;
-    for (uint64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-        const uint4 q = row[v];
-        const uint32_t words[4] = {q.x, q.y, q.z, q.w};
+    const uint64_t nvec = n_pad >> 4;
+    uint64_t v = threadIdx.x;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (v < nvec) { q0 = row[2 * v]; q1 = row[2 * v + 1]; }
+    while (v < nvec) {
+        const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint64_t vn = v + blockDim.x;
+        if (vn < nvec) { q0 = row[2 * vn]; q1 = row[2 * vn + 1]; }
+        uint32_t m = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t code = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-            const uint32_t b = code & 0x7FFFu;
-            if (code != DIG_ZERO && (b >> range_bits) == r) {
-                if (SCATTER) {
-                    const uint32_t pos = atomicAdd(&lds[b & rmask], 1u);
-                    idx[pos] = (uint32_t)(v * 8 + k) | ((code & 0x8000u) ? NEG_BIT : 0u);
-                } else {
-                    atomicAdd(&lds[b & rmask], 1u);
-                }
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t z = (wd[j] ^ want) & field;                    // half == 0  <=>  digit in range
+            uint32_t nz = (z + 0x7FFF7FFFu) & 0x80008000u;                 // bit 15 / 31  <=>  half != 0
+            if (zero_aliases) {
+                if ((wd[j] & 0xFFFFu) == DIG_ZERO) nz |= 0x8000u;
+                if ((wd[j] >> 16) == DIG_ZERO) nz |= 0x80000000u;
             }
+            m = (m >> 2) | nz;                                            // word j ends at bits 1 + 2j / 17 + 2j
         }
+        uint32_t hits = ~m & 0xAAAAAAAAu;
+        while (hits) {
+            const uint32_t p = (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1;
+            const uint32_t j = (p & 15u) >> 1, hi = p >> 4;
+            uint32_t word = wd[0];
+#pragma unroll
+            for (uint32_t t = 1; t < 8; ++t) word = j == t ? wd[t] : word;
+            const uint32_t code = (word >> (hi * 16)) & 0xFFFFu;
+            // Runs of equal scalars (grand products that stay constant over unused rows, selector
+            // columns) put the same bucket in every lane, and 64 atomics on one LDS word serialise.
+            // Peel the first active lane's bucket: its lanes share one atomic; the rest go alone.
+            const uint32_t slot = code & rmask;
+            const uint32_t lead = __builtin_amdgcn_readfirstlane(slot);
+            const uint64_t same = __ballot(slot == lead);
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t pos = 0;
+            if (slot == lead) {
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                if (rank == 0) pos = atomicAdd(&lds[slot], (uint32_t)__popcll(same));
+                if (SCATTER) pos = __shfl(pos, (int)__builtin_ctzll(same)) + rank;
+            } else {
+                pos = atomicAdd(&lds[slot], 1u);
+            }
+            if (SCATTER) idx[pos] = (uint32_t)(v * 16 + 2 * j + hi) | ((code & 0x8000u) ? NEG_BIT : 0u);
+        }
+        v = vn;
     }
     if (!SCATTER) {
         __syncthreads();
@@ -337,29 +394,79 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     const uint32_t b = order[p];
     stg29(buckets + b, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, offsets[b], offsets[b + 1]));
 }
+// ---- combining the task partials of multi-task buckets ---------------------------------------------
+// 1. k_msm_combine_wave: one lane per task partial; lanes of a wave that belong to the same bucket
+//    are summed with a segmented shuffle reduction (<= 6 dependent additions), the first lane of
+//    every segment writes the sum back.  What is left per bucket are its "leader" slots: its first
+//    task and every task index that is a multiple of 64 -- 64x fewer partials for a giant bucket
+//    (n/2 points of a selector column: 8192 partials -> 128 leaders).
+// 2. k_msm_combine_small / k_msm_combine: sum the leaders of a bucket (one lane / one workgroup).
+__device__ __forceinline__ uint32_t bucket_of_task(const uint32_t* __restrict__ toff, uint32_t M, uint32_t v) {
+    uint32_t lo_p = 0, hi_p = M;                 // toff[lo_p] <= v < toff[hi_p]
+    while (hi_p - lo_p > 1) {
+        const uint32_t mid = (lo_p + hi_p) >> 1;
+        if (toff[mid] <= v) lo_p = mid; else hi_p = mid;
+    }
+    return lo_p;
+}
+__device__ __forceinline__ G1Xyzz29 shfl_down_pt(const G1Xyzz29& p, int off) {
+    G1Xyzz29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = __shfl_down(p.x.l[i], off);
+        r.y.l[i] = __shfl_down(p.y.l[i], off);
+        r.zz.l[i] = __shfl_down(p.zz.l[i], off);
+        r.zzz.l[i] = __shfl_down(p.zzz.l[i], off);
+    }
+    return r;
+}
+__global__ void __launch_bounds__(256) k_msm_combine_wave(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ toff, G1Xyzz29* __restrict__ partial) {
+    const uint32_t M = *nmulti;
+    const uint32_t Tm = M ? toff[M] : 0u;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    if ((v & ~63u) >= Tm) return;                // whole wave past the last task
+    const bool live = v < Tm;
+    uint32_t key = 0xFFFFFF00u + lane;           // dead lanes: unique keys, never merged
+    G1Xyzz29 acc = identity29();
+    if (live) { key = bucket_of_task(toff, M, v); acc = ldg29(partial + v); }
+    const uint32_t prev = __shfl_up(key, 1);
+    bool merged = false;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t okey = __shfl_down(key, off);
+        const bool take = lane + off < 64u && okey == key;
+        if (!__ballot(take)) break;              // segments are contiguous: no pair at this distance, none further
+        const G1Xyzz29 other = shfl_down_pt(acc, off);
+        if (take) { acc = add29pt(acc, other); merged = true; }
+    }
+    if (live && merged && (lane == 0 || prev != key)) stg29(partial + v, acc);
+}
+// leader slots of a bucket whose tasks are [base, base + cnt): base, then the multiples of 64 inside
+__device__ __forceinline__ uint32_t leader_count(uint32_t base, uint32_t cnt) { return ((base + cnt - 1) >> 6) - (base >> 6) + 1; }
+__device__ __forceinline__ uint32_t leader_slot(uint32_t base, uint32_t i) { return i ? (((base >> 6) + i) << 6) : base; }
+
 constexpr uint32_t COMBINE_SMALL = 32;
-// multi-task buckets with few partials: one lane each, sequential sum
+// multi-task buckets with few leaders: one lane each, sequential sum
 __global__ void __launch_bounds__(256) k_msm_combine_small(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks,
                                                            const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial, G1Xyzz29* __restrict__ buckets) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= *nmulti) return;
-    const uint32_t cnt = ntasks[m], base = toff[m];
+    const uint32_t base = toff[m], cnt = leader_count(base, ntasks[m]);
     if (cnt > COMBINE_SMALL) return;
     G1Xyzz29 acc = ldg29(partial + base);
-    for (uint32_t i = 1; i < cnt; ++i) acc = add29pt(acc, ldg29(partial + base + i));
+    for (uint32_t i = 1; i < cnt; ++i) acc = add29pt(acc, ldg29(partial + leader_slot(base, i)));
     stg29(buckets + order[m], acc);
 }
-// one workgroup per multi-task bucket: strided sums + LDS tree over its partials
+// one workgroup per multi-task bucket with many leaders: strided sums + LDS tree
 __global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial,
                                                      G1Xyzz29* __restrict__ buckets) {
     __shared__ G1Xyzz29 sh[256];
     const uint32_t total = *nmulti;
     for (uint32_t m = blockIdx.x; m < total; m += gridDim.x) {
-        const uint32_t p = m, cnt = ntasks[p], base = toff[p];
+        const uint32_t p = m, base = toff[p], cnt = leader_count(base, ntasks[p]);
         if (cnt <= COMBINE_SMALL) continue;      // handled by k_msm_combine_small (uniform across the workgroup)
         G1Xyzz29 acc = identity29();
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + base + i));
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + leader_slot(base, i)));
         sh[threadIdx.x] = acc;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
@@ -439,7 +546,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     // u32 workspace: counts[nb] | size_hist[256] nmulti[4] wflag[64] | offsets[nb+1] | cursor[nb] | order[nb] | ntasks[nb] | toff[nb+1] | multi[nb] |
     //                block_tot[2*scan_blocks] | idx[n*W] | (16-B aligned) dig[W*n_pad u16]
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
-    const uint64_t n_pad = ((uint64_t)n + 7) & ~7ull;
+    const uint64_t n_pad = ((uint64_t)n + 15) & ~15ull;
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
     const size_t head_words = (size_t)nb * 7 + 2 + SIZE_BINS + 68 + 2 * (size_t)scan_blocks + (size_t)n * pl.W;
     const size_t words = head_words + 4 + dig_words;
@@ -461,7 +568,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     uint16_t* dig = reinterpret_cast<uint16_t*>(ws + ((head_words + 3) & ~(size_t)3));   // 16-B aligned
     int range_bits = pl.c - 1;
     if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
-    const dim3 sweep_grid(pl.B >> range_bits, pl.W);
+    const dim3 sweep_grid(8u * ((pl.W + 7) / 8) * (pl.B >> range_bits));
     // a lone MSM is latency-bound (short chains: G = 2); in a batch the reduction hides under the
     // next MSM and only its work counts (G = 8)
     const bool short_chain = d_table && count == 1;
@@ -507,8 +614,8 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     {
         ZkProfScope ps(ctx, "msm_sort");
         ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));   // size_hist + nmulti + wflag
-        hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((n_pad + 255) / 256)), ts, 0, ctx->stream, d_scalars, (uint64_t)n, n_pad, pl.c, pl.W, dig, wflag);
-        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag);
+        launch_digits(pl.c, dim3((unsigned)((n_pad + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
+        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, block_tot);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
@@ -519,7 +626,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb);
         hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx, (const uint32_t*)wflag);
+        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
     }
     {
@@ -527,6 +634,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
         hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
                            (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, pl.c - 1, (uint64_t)tab_stride);
+        hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
         hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,

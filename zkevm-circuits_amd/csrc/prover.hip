@@ -583,9 +583,10 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // ---- permutation grand products
     std::vector<DevBuf> pz_lag(pk->C);
     {
-        DevBuf num, den, zbuf;
-        if (!num.alloc(n * 32) || !den.alloc(n * 32) || !zbuf.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        F4 start = one;
+        // All chunks are enqueued back to back (ratios -> unscaled running products); the chunks are
+        // chained afterwards with one small download: Z_c = Z_c^raw * prod_{c' < c} Z_c'^raw(omega^u).
+        DevBuf num, den, tails_d;
+        if (!num.alloc(n * 32) || !den.alloc(n * 32) || !tails_d.alloc((size_t)pk->C * 32 + 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         for (uint32_t c = 0; c < pk->C; ++c) {
             PB pn, pd;
             const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
@@ -600,18 +601,28 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             PK_TRY(run_program(ctx, lag, pd.g, false, den.p));
             PK_TRY(zk_fr_batch_invert(ctx, den.p, n));
             PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, num.p, den.p, num.p, n));
-            PK_TRY(zk_fr_prefix_product(ctx, num.p, zbuf.p, n));           // z[0] = 1, z[i+1] = z[i] * ratio[i]
-            PK_TRY(zk_fr_scale(ctx, zbuf.p, &start, n));                    // chain the chunks: Z_c(1) = Z_{c-1}(omega^u)
             if (!pz_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            PK_TRY(zk_d2d(ctx, pz_lag[c].p, zbuf.p, n * 32));
-            std::vector<F4> blind(pk->bf);
-            for (auto& b : blind) b = rng.next_fr();
-            PK_TRY(zk_h2d(ctx, (char*)pz_lag[c].p + (n - pk->bf) * 32, blind.data(), pk->bf * 32));
-            PK_TRY(zk_d2h(ctx, &start, (char*)pz_lag[c].p + (size_t)pk->u * 32, 32));
-            G1Affine com;
-            PK_TRY(commit_lagrange(ctx, srs, pz_lag[c].fr(), n, &com));
-            tr.write_point(com);
+            PK_TRY(zk_fr_prefix_product(ctx, num.p, pz_lag[c].p, n));      // z[0] = 1, z[i+1] = z[i] * ratio[i]
+            ZK_HIP(ctx, hipMemcpyAsync((char*)tails_d.p + (size_t)c * 32, (char*)pz_lag[c].p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
         }
+        std::vector<F4> tails(pk->C);
+        if (pk->C) PK_TRY(zk_d2h(ctx, tails.data(), tails_d.p, (size_t)pk->C * 32));
+        trace.mark("  perm: running products");
+        std::vector<F4> blind((size_t)pk->C * pk->bf);
+        std::vector<const void*> zptrs(pk->C);
+        F4 start = one;
+        for (uint32_t c = 0; c < pk->C; ++c) {
+            if (c) PK_TRY(zk_fr_scale(ctx, pz_lag[c].p, &start, n));       // Z_c(1) = Z_{c-1}(omega^u)
+            start = host::fr_mul(start, tails[c]);
+            for (uint32_t r_ = 0; r_ < pk->bf; ++r_) blind[(size_t)c * pk->bf + r_] = rng.next_fr();
+            ZK_HIP(ctx, hipMemcpyAsync((char*)pz_lag[c].p + (n - pk->bf) * 32, blind.data() + (size_t)c * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
+            zptrs[c] = pz_lag[c].p;
+        }
+        trace.mark("  perm: chain + blind");
+        std::vector<G1Affine> coms(pk->C);
+        PK_TRY(zk_commit_batch(ctx, srs, 1, zptrs.data(), pk->C, n, coms.data()));
+        trace.mark("  perm: commits");
+        for (const G1Affine& com : coms) tr.write_point(com);
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
     }
     trace.mark("permutation Z");
