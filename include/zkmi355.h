@@ -117,6 +117,11 @@ int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr,
                      const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out);
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
+/* logUp multiplicities (halo2 Scroll fork, plonk/mv_lookup/prover.rs: m(X)): d_m[i] = number of rows
+ * r < usable_rows with d_inputs[r] == d_table[i] for i < usable_rows (a value that occurs in several
+ * table rows is credited to the lowest one), 0 for usable_rows <= i < n.  *bad_row = lowest input
+ * row whose value is not in the table, UINT64_MAX when every input is found.                        */
+int zk_lookup_multiplicities(zk_ctx* ctx, const void* d_inputs, const void* d_table, size_t usable_rows, void* d_m, size_t n, uint64_t* bad_row);
 /* n uniformly random Fr (Montgomery form) on the device: element i = Fr::from_uniform_bytes of
  * ChaCha20 block (first_block + i) under key32 / stream_id (64-bit counter in state words 12..13,
  * stream id in 14..15).  What the prover draws its blinding polynomial from (halo2 takes an RngCore

@@ -98,3 +98,28 @@ def test_fr_random_chacha(ctx, cref, n, first):
         assert got[i] == bn254.fr_from_uniform_bytes(bn254.chacha20_block(key, first + i, stream)), i
     if n <= 1000:
         assert [int(v) for v in got] == bn254.fr_random_chacha(key, stream, first, n)
+
+
+@pytest.mark.parametrize("n,usable,distinct", [(64, 58, 10), (4096, 4090, 300), (1 << 16, (1 << 16) - 6, 50000)])
+def test_lookup_multiplicities(ctx, cref, n, usable, distinct):
+    """zk_lookup_multiplicities == dict-based count; duplicates credit the lowest table row; misses are reported."""
+    rng = random.Random(n)
+    pool = [rng.randrange(bn254.R_MOD) for _ in range(distinct)]
+    table = [pool[rng.randrange(distinct)] if i >= distinct else pool[i] for i in range(n)]      # every pool value present, with repeats
+    inputs = [pool[rng.randrange(distinct)] for _ in range(n)]
+    first = {}
+    for i in range(usable):
+        first.setdefault(table[i], i)
+    want = [0] * n
+    for r_ in range(usable):
+        want[first[inputs[r_]]] += 1
+    dT, dI, dM = ctx.to_device(cref.to_mont(table)), ctx.to_device(cref.to_mont(inputs)), ctx.alloc(n * 32)
+    assert ctx.lookup_multiplicities(dI, dT, usable, dM, n) is None
+    assert [int(v) for v in cref.from_mont(dM.download((n, 4)))] == want
+    # an input that is not in the table: the lowest offending row is reported
+    bad_rows = sorted(rng.sample(range(usable), 2))
+    for r_ in bad_rows:
+        inputs[r_] = (max(pool) + 1 + r_) % bn254.R_MOD
+        assert inputs[r_] not in first
+    dI = ctx.to_device(cref.to_mont(inputs))
+    assert ctx.lookup_multiplicities(dI, dT, usable, dM, n) == bad_rows[0]

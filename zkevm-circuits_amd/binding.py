@@ -302,6 +302,13 @@ class Context:
         assert len(key32) == 32
         self._ck(lib().zk_fr_random(self.h, ctypes.c_char_p(key32), ctypes.c_uint64(stream_id), ctypes.c_uint64(first_block), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
 
+    def lookup_multiplicities(self, inputs: DeviceBuffer, table: DeviceBuffer, usable_rows: int, m: DeviceBuffer, n: int) -> Optional[int]:
+        """logUp m(X) on the device; returns the lowest input row missing from the table, or None."""
+        bad = ctypes.c_uint64()
+        self._ck(lib().zk_lookup_multiplicities(self.h, ctypes.c_void_p(inputs.ptr), ctypes.c_void_p(table.ptr), ctypes.c_size_t(usable_rows),
+                                                ctypes.c_void_p(m.ptr), ctypes.c_size_t(n), ctypes.byref(bad)))
+        return None if bad.value == 0xFFFFFFFFFFFFFFFF else bad.value
+
     def commit_batch_h2d(self, srs: "Srs", basis: int, host_cols, dev_cols, n: int) -> np.ndarray:
         """commit `host_cols` (numpy (n,4) u64 each) while uploading them into dev_cols (overlapped)."""
         count = len(host_cols)

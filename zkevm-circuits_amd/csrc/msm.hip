@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint
 // adds the block offset, mirrors into `cursor`, and bins every bucket by size (descending order
 // of size -> a wave works on buckets of equal length; big ones start first)
 constexpr uint32_t SIZE_BINS = 256;
+constexpr uint32_t TASK_CAP = 48;       // points per task, see "skew-proof work split" below
 __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_tot,
                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ size_hist) {
     __shared__ uint32_t lh[SIZE_BINS];
@@ -262,7 +263,7 @@ __global__ void k_size_bins_scan(uint32_t* size_hist) {
     if (threadIdx.x || blockIdx.x) return;
     uint32_t run = 0;
     for (int b = SIZE_BINS - 1; b >= 0; --b) {
-        if (b == 64) size_hist[SIZE_BINS] = run;   // M: buckets with more than TASK_CAP (= 64) points come first
+        if (b == (int)TASK_CAP) size_hist[SIZE_BINS] = run;   // M: buckets with more than TASK_CAP points come first
         const uint32_t c = size_hist[b]; size_hist[b] = run; run += c;
     }
 }
@@ -272,7 +273,6 @@ __global__ void k_size_bins_scan(uint32_t* size_hist) {
 // small-value columns put n/2 points into one bucket).  Tasks are numbered along the size-ordered
 // bucket sequence (a wave still sees equal-length work); single-task buckets write their bucket
 // directly, multi-task buckets write partials that one workgroup per bucket tree-sums afterwards.
-constexpr uint32_t TASK_CAP = 64;
 
 // order[pos] = bucket id, grouped by size bin (block-aggregated reservation of output ranges);
 // ntasks[pos] = number of tasks of that bucket

@@ -34,6 +34,7 @@ using zk::host::F4;
 extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* const*, uint32_t, const void*, uint32_t, uint32_t, uint32_t, int, void*);
 extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
 extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, size_t);
+extern "C" int zk_lookup_multiplicities(zk_ctx*, const void*, const void*, size_t, void*, size_t, uint64_t*);
 extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
 
 namespace {
@@ -550,23 +551,16 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         PK_TRY(run_program(ctx, lag, pf.g, false, lk_f[l].p));
         PK_TRY(run_program(ctx, lag, pt.g, false, lk_t[l].p));
-        std::vector<F4> f(n), t(n), m(n, host::fr_zero());
-        PK_TRY(zk_d2h(ctx, f.data(), lk_f[l].p, n * 32));
-        PK_TRY(zk_d2h(ctx, t.data(), lk_t[l].p, n * 32));
-        struct KeyHash { size_t operator()(const std::array<uint64_t, 4>& a) const { return (size_t)(a[0] ^ (a[1] * 0x9E3779B97F4A7C15ULL) ^ (a[2] << 7) ^ (a[3] >> 3)); } };
-        std::unordered_map<std::array<uint64_t, 4>, uint32_t, KeyHash> where;
-        where.reserve(pk->u * 2);
-        for (size_t row = 0; row < pk->u; ++row) { std::array<uint64_t, 4> key; memcpy(key.data(), t[row].l, 32); where.emplace(key, (uint32_t)row); }
-        std::vector<uint64_t> cnt(n, 0);
-        for (size_t row = 0; row < pk->u; ++row) {
-            std::array<uint64_t, 4> key; memcpy(key.data(), f[row].l, 32);
-            auto it = where.find(key);
-            if (it == where.end()) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %zu is not in the table (witness does not satisfy the circuit)", l, row);
-            ++cnt[it->second];
-        }
-        for (size_t row = 0; row < pk->u; ++row) m[row] = host::fr_from_u64(cnt[row]);
-        for (size_t row = pk->u + 1; row < n; ++row) m[row] = rng.next_fr();
-        PK_TRY(upload(ctx, &lk_m[l], m.data(), n * 32));
+        trace.mark("  lookup: compress f, t");
+        // multiplicities on the device (hash table over the usable table rows), blinding rows from the session RNG
+        if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        uint64_t bad_row = UINT64_MAX;
+        PK_TRY(zk_lookup_multiplicities(ctx, lk_f[l].p, lk_t[l].p, pk->u, lk_m[l].p, n, &bad_row));
+        if (bad_row != UINT64_MAX) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %llu is not in the table (witness does not satisfy the circuit)", l, (unsigned long long)bad_row);
+        std::vector<F4> blind(n - pk->u - 1);
+        for (auto& x : blind) x = rng.next_fr();
+        PK_TRY(zk_h2d(ctx, (char*)lk_m[l].p + ((size_t)pk->u + 1) * 32, blind.data(), blind.size() * 32));
+        trace.mark("  lookup: multiplicities");
         G1Affine com;
         PK_TRY(commit_lagrange(ctx, srs, lk_m[l].fr(), n, &com));
         tr.write_point(com);
