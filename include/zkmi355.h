@@ -89,6 +89,13 @@ int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega)
 /* EvaluationDomain::coeff_to_extended: d_coeffs (2^k) -> d_out (2^ext_k): scale by zeta^i,
  * zero-pad, NTT over the extended domain.                                                       */
 int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out);
+/* One coset of the extended domain (EvaluationDomain::coeff_to_extended_part): d_out[i] =
+ * f(g * omega^i) for i < 2^k, f given by 2^k coefficients; h_g is one Fr.  The extended domain of
+ * halo2 is the union of the cosets g_r = zeta * omega_ext^r, r < 2^(ext_k-k): extended index
+ * i * 2^(ext_k-k) + r  <->  element i of coset r.  d_out may alias d_coeffs.                       */
+int zk_coeff_to_coset(zk_ctx* ctx, const void* d_coeffs, uint32_t k, const void* h_g, void* d_out);
+/* d_dst[i * stride + offset] = d_src[i] * scale, i < n: interleaves coset values into extended order */
+int zk_fr_scatter_scaled(zk_ctx* ctx, const void* d_src, size_t n, const void* h_scale, void* d_dst, size_t stride, size_t offset);
 /* EvaluationDomain::extended_to_coeff: inverse NTT over the extended domain, unscale by zeta^-i;
  * in place on d_ext (2^ext_k); the caller truncates to n*(deg-1).                               */
 int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k);

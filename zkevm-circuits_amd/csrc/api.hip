@@ -209,6 +209,15 @@ int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t
     int rc = ntt_run(ctx, (Fr*)d_out, ext_k, fr_root_of_unity(ext_k), nullptr, &zeta, nullptr);
     return rc;
 }
+// One coset of the extended domain: out[i] = f(g * omega^i), i < 2^k  (EvaluationDomain::
+// coeff_to_extended_part in newer halo2: the extended domain is the union of the 2^(ext_k-k)
+// cosets g_r = zeta * omega_ext^r of H, and a rotation is an index shift inside each of them).
+int zk_coeff_to_coset(zk_ctx* ctx, const void* d_coeffs, uint32_t k, const void* h_g, void* d_out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_coeffs && d_out && h_g, "null pointer");
+    ZK_REQUIRE(ctx, k <= 28, "k exceeds the two-adicity of Fr (28)");
+    return ntt_run(ctx, (Fr*)d_out, k, fr_root_of_unity(k), nullptr, (const Fr*)h_g, nullptr, d_coeffs == d_out ? nullptr : (const Fr*)d_coeffs);
+}
 int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, d_ext, "null pointer");

@@ -210,10 +210,10 @@ int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n) {
 }
 
 // a[i] *= g^i   (EvaluationDomain::distribute_powers_zeta generalised), two-level table of g
-__global__ void k_distribute_powers(Fr* a, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint64_t n) {
+__global__ void k_distribute_powers(const Fr* src, Fr* dst, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    stg(a + i, ldg(a + i) * two_level(lo, hi, h, (uint32_t)i));
+    stg(dst + i, ldg(src + i) * two_level(lo, hi, h, (uint32_t)i));
 }
 
 // ----------------------------------------------------------------------------------- host side
@@ -289,9 +289,11 @@ static int set_lds_attr(zk_ctx* ctx) {
 static int pick_threads(int tile) { return tile >= 4096 ? 1024 : (tile >= 1024 ? 512 : (tile >= 256 ? 128 : 64)); }
 
 // Generic driver.  `scale` (nullable) multiplies every output; coset_pre (nullable): a[i] *= g^i
-// before the transform; coset_post (nullable): out[i] *= g^i after it.
-int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post) {
+// before the transform; coset_post (nullable): out[i] *= g^i after it.  d_src (nullable): the input
+// is read from d_src and d_data only receives the result (out of place, no extra copy).
+int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, const Fr* d_src) {
     if (log_n == 0) {   // size-1 transform: identity (times the scale)
+        if (d_src && d_src != d_data) ZK_HIP(ctx, hipMemcpyAsync(d_data, d_src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
         if (scale) {
             hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, ctx->stream, d_data, *scale, (uint64_t)1);
             ZK_CHECK_LAUNCH(ctx);
@@ -302,7 +304,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
     if (rc) return rc;
     const uint64_t n = 1ull << log_n;
 
-    auto run_distribute = [&](const Fr& g) -> int {
+    auto run_distribute = [&](const Fr& g, const Fr* from) -> int {
         const int h = (int)(log_n + 1) / 2;
         const uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
         // the coset generators are a handful of constants (zeta, zeta^-1): keep their tables
@@ -321,11 +323,12 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
             if (r) return r;
             ctx->pow_tables[key] = tab;
         }
-        hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_data, tab, tab + nlo, h, n);
+        hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, from, d_data, tab, tab + nlo, h, n);
         ZK_CHECK_LAUNCH(ctx);
         return ZK_OK;
     };
-    if (coset_pre) { rc = run_distribute(*coset_pre); if (rc) return rc; }
+    const Fr* cur = d_src ? d_src : d_data;
+    if (coset_pre) { rc = run_distribute(*coset_pre, cur); if (rc) return rc; cur = d_data; }
 
     std::shared_ptr<NttDomain> dom;
     rc = get_domain(ctx, log_n, omega, scale, &dom);
@@ -338,7 +341,6 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
     }
     // buffers: P=1: data->data (whole transform inside one workgroup, safe in place)
     //          P=2: data->scratch, scratch->data;   P=3: data->data, data->scratch, scratch->data
-    const Fr* cur = d_data;
     for (int p = 0; p + 1 < P; ++p) {
         const NttPass& ps = dom->pass[p];
         int log_t = 12 - ps.log_np;
@@ -366,7 +368,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
                            ps.log_np, log_t, log_n1, log_mid, dom->final_mul);
         ZK_CHECK_LAUNCH(ctx);
     }
-    if (coset_post) { rc = run_distribute(*coset_post); if (rc) return rc; }
+    if (coset_post) { rc = run_distribute(*coset_post, d_data); if (rc) return rc; }
     return ZK_OK;
 }
 

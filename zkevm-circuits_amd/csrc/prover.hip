@@ -35,6 +35,8 @@ extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* 
 extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
 extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, size_t);
 extern "C" int zk_lookup_multiplicities(zk_ctx*, const void*, const void*, size_t, void*, size_t, uint64_t*);
+extern "C" int zk_coeff_to_coset(zk_ctx*, const void*, uint32_t, const void*, void*);
+extern "C" int zk_fr_scatter_scaled(zk_ctx*, const void*, size_t, const void*, void*, size_t, size_t);
 extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
 
 namespace {
@@ -116,8 +118,13 @@ struct zk_pk {
     std::vector<uint32_t> adv_phase;         // phase of every advice column (halo2 FirstPhase/SecondPhase/...)
     std::vector<uint32_t> chal_phase;        // challenge i becomes available after this phase
     // device-resident key material
-    std::vector<DevBuf> fixed_lag, fixed_coeff, fixed_ext, sigma_lag, sigma_coeff, sigma_ext;
-    DevBuf l0_ext, llast_ext, lactive_ext, x_ext, omega_lag, l0_lag, llast_lag, lactive_lag;
+    std::vector<DevBuf> fixed_lag, fixed_coeff, sigma_lag, sigma_coeff;
+    DevBuf omega_lag, l0_lag, llast_lag, lactive_lag, l0_coeff, llast_coeff, lactive_coeff;
+    // cosets of the key's own columns (fixed, sigma, l0 / l_last / l_active, X), filled by the first
+    // proof and reused by later ones when they fit the budget (ZK_PK_COSET_CACHE_GB, default 48):
+    // part_cache[r][column reference]
+    mutable std::vector<std::unordered_map<uint32_t, DevBuf>> part_cache;
+    mutable int part_cache_state = -1;       // -1 undecided, 0 off, 1 on
     std::vector<G1Affine> fixed_com, sigma_com;
     F4 vk_repr;
     const zk_srs* srs = nullptr;
@@ -127,11 +134,11 @@ struct zk_proof {
     const zk_pk* pk;
     host::XorShiftRng rng;
     host::Transcript tr;
-    std::vector<DevBuf> inst_lag, inst_coeff, inst_ext, adv_lag;
+    std::vector<DevBuf> inst_lag, inst_coeff, adv_lag;
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
     std::vector<F4> challenges;
-    zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), inst_ext(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
+    zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
 
 namespace {
@@ -148,20 +155,12 @@ struct Reader {
 int commit_lagrange(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 1, d_vals, n, out); }
 int commit_coeff(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 0, d_vals, n, out); }
 
-// Lagrange values -> (coefficients, extended coset); any output may be skipped with nullptr
-int to_coeff_and_ext(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff, DevBuf* ext) {
-    const size_t n = (size_t)1 << pk->k, ne = (size_t)1 << pk->ext_k;
-    DevBuf tmp;
-    DevBuf* c = coeff ? coeff : &tmp;
-    if (!c->alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-    PK_TRY(zk_d2d(ctx, c->p, lag.p, n * 32));
-    PK_TRY(zk_ntt(ctx, c->p, pk->k, 1));
-    if (ext) {
-        if (!ext->alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        PK_TRY(zk_coeff_to_extended(ctx, c->p, pk->k, pk->ext_k, ext->p));
-    }
-    if (!tl_pool_ctx) PK_TRY(zk_ctx_sync(ctx));   // tmp is hipFree'd on return (pooled blocks are stream-ordered)
-    return ZK_OK;
+// Lagrange values -> coefficients (EvaluationDomain::lagrange_to_coeff)
+int to_coeff(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff) {
+    const size_t n = (size_t)1 << pk->k;
+    if (!coeff->alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
+    return ntt_run(ctx, coeff->fr(), pk->k, omega_inv, &ninv, nullptr, nullptr, lag.fr());
 }
 
 void collect_queries(const Prog& g, std::vector<Query>* adv, std::vector<Query>* fix) {
@@ -186,10 +185,10 @@ struct Concrete {
     std::unordered_map<uint32_t, uint32_t> col_index, const_index;
 };
 
-struct Env {   // where an abstract column lives in the domain being evaluated
+struct Env {   // where an abstract column lives in the form being read (Lagrange values or coefficients)
     const zk_pk* pk;
-    bool extended;
-    const std::vector<DevBuf>* advice;      // Lagrange (extended == false) or extended cosets
+    const std::unordered_map<uint32_t, const void*>* part;   // non-null: one coset of the extended domain, by column reference
+    const std::vector<DevBuf>* advice;
     const std::vector<DevBuf>* instance;
     const std::vector<DevBuf>* perm_z;
     const std::vector<DevBuf>* lk_m;
@@ -202,18 +201,19 @@ struct Env {   // where an abstract column lives in the domain being evaluated
 const void* resolve_col(const Env& e, uint32_t ref) {
     const uint32_t type = ref >> 24, idx = ref & 0xFFFFFF;
     const zk_pk* pk = e.pk;
+    if (e.part) { auto it = e.part->find(ref); return it == e.part->end() ? nullptr : it->second; }
     switch (type) {
-        case CT_FIXED: return idx < pk->F ? (e.extended ? pk->fixed_ext[idx].p : pk->fixed_lag[idx].p) : nullptr;
+        case CT_FIXED: return idx < pk->F ? pk->fixed_lag[idx].p : nullptr;
         case CT_ADVICE: return e.advice && idx < e.advice->size() ? (*e.advice)[idx].p : nullptr;
         case CT_INSTANCE: return e.instance && idx < e.instance->size() ? (*e.instance)[idx].p : nullptr;
         case CT_SPECIAL:
-            if (idx == SP_X) return e.extended ? pk->x_ext.p : pk->omega_lag.p;
-            if (idx == SP_L0) return e.extended ? pk->l0_ext.p : pk->l0_lag.p;
-            if (idx == SP_LLAST) return e.extended ? pk->llast_ext.p : pk->llast_lag.p;
-            if (idx == SP_LACTIVE) return e.extended ? pk->lactive_ext.p : pk->lactive_lag.p;
+            if (idx == SP_X) return pk->omega_lag.p;
+            if (idx == SP_L0) return pk->l0_lag.p;
+            if (idx == SP_LLAST) return pk->llast_lag.p;
+            if (idx == SP_LACTIVE) return pk->lactive_lag.p;
             return nullptr;
         case CT_PERM_Z: return e.perm_z && idx < e.perm_z->size() ? (*e.perm_z)[idx].p : nullptr;
-        case CT_SIGMA: return idx < pk->P ? (e.extended ? pk->sigma_ext[idx].p : pk->sigma_lag[idx].p) : nullptr;
+        case CT_SIGMA: return idx < pk->P ? pk->sigma_lag[idx].p : nullptr;
         case CT_LK_M: return e.lk_m && idx < e.lk_m->size() ? (*e.lk_m)[idx].p : nullptr;
         case CT_LK_PHI: return e.lk_phi && idx < e.lk_phi->size() ? (*e.lk_phi)[idx].p : nullptr;
         default: return nullptr;
@@ -259,12 +259,30 @@ int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
     }
     return ZK_OK;
 }
-int run_program(zk_ctx* ctx, const Env& e, const Prog& g, bool divide, void* d_out) {
+// Every form the prover evaluates over has n = 2^k rows (Lagrange values, or one coset of the
+// extended domain), so a rotation is a plain index shift modulo n.
+int run_program(zk_ctx* ctx, const Env& e, const Prog& g, void* d_out) {
     Concrete c;
     PK_TRY(concretise(ctx, e, g, &c));
-    const uint32_t dom = e.extended ? e.pk->ext_k : e.pk->k;
     return zk_quotient_eval(ctx, c.words.data(), (uint32_t)(c.words.size() / 3), c.cols.data(), (uint32_t)c.cols.size(),
-                            c.consts.empty() ? nullptr : c.consts.data(), (uint32_t)c.consts.size(), e.pk->k, dom, divide ? 1 : 0, d_out);
+                            c.consts.empty() ? nullptr : c.consts.data(), (uint32_t)c.consts.size(), e.pk->k, e.pk->k, 0, d_out);
+}
+// coefficient form of an abstract column (nullptr for X, which has no stored polynomial)
+const Fr* coeff_of(const zk_pk* pk, uint32_t ref, const std::vector<DevBuf>& adv, const std::vector<DevBuf>& inst, const std::vector<DevBuf>& pz,
+                   const std::vector<DevBuf>& lkm, const std::vector<DevBuf>& lkphi) {
+    const uint32_t type = ref >> 24, idx = ref & 0xFFFFFF;
+    auto at = [&](const std::vector<DevBuf>& v) -> const Fr* { return idx < v.size() ? v[idx].fr() : nullptr; };
+    switch (type) {
+        case CT_FIXED: return at(pk->fixed_coeff);
+        case CT_ADVICE: return at(adv);
+        case CT_INSTANCE: return at(inst);
+        case CT_SPECIAL: return idx == SP_L0 ? pk->l0_coeff.fr() : idx == SP_LLAST ? pk->llast_coeff.fr() : idx == SP_LACTIVE ? pk->lactive_coeff.fr() : nullptr;
+        case CT_PERM_Z: return at(pz);
+        case CT_SIGMA: return at(pk->sigma_coeff);
+        case CT_LK_M: return at(lkm);
+        case CT_LK_PHI: return at(lkphi);
+        default: return nullptr;
+    }
 }
 
 // ---- small program builder ----------------------------------------------------------------------
@@ -362,22 +380,22 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         collect_queries(one, &pk->adv_q, &pk->fix_q);
     }
     // fixed + sigma columns
-    pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F); pk->fixed_ext.resize(pk->F);
-    pk->sigma_lag.resize(pk->P); pk->sigma_coeff.resize(pk->P); pk->sigma_ext.resize(pk->P);
+    pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F);
+    pk->sigma_lag.resize(pk->P); pk->sigma_coeff.resize(pk->P);
     pk->fixed_com.resize(pk->F); pk->sigma_com.resize(pk->P);
     for (uint32_t i = 0; i < pk->F; ++i) {
         const uint8_t* b = r.bytes(n * 32);
         if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated fixed column");
         PK_TRY(upload(ctx, &pk->fixed_lag[i], b, n * 32));
         PK_TRY(commit_lagrange(ctx, srs, pk->fixed_lag[i].fr(), n, &pk->fixed_com[i]));
-        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->fixed_lag[i], &pk->fixed_coeff[i], &pk->fixed_ext[i]));
+        PK_TRY(to_coeff(ctx, pk.get(), pk->fixed_lag[i], &pk->fixed_coeff[i]));
     }
     for (uint32_t i = 0; i < pk->P; ++i) {
         const uint8_t* b = r.bytes(n * 32);
         if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated sigma column");
         PK_TRY(upload(ctx, &pk->sigma_lag[i], b, n * 32));
         PK_TRY(commit_lagrange(ctx, srs, pk->sigma_lag[i].fr(), n, &pk->sigma_com[i]));
-        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->sigma_lag[i], &pk->sigma_coeff[i], &pk->sigma_ext[i]));
+        PK_TRY(to_coeff(ctx, pk.get(), pk->sigma_lag[i], &pk->sigma_coeff[i]));
     }
     // l0, l_last, l_active and the X / omega^i columns
     {
@@ -386,14 +404,13 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         PK_TRY(upload(ctx, &pk->l0_lag, l0.data(), n * 32));
         PK_TRY(upload(ctx, &pk->llast_lag, ll.data(), n * 32));
         PK_TRY(upload(ctx, &pk->lactive_lag, la.data(), n * 32));
-        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->l0_lag, nullptr, &pk->l0_ext));
-        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->llast_lag, nullptr, &pk->llast_ext));
-        PK_TRY(to_coeff_and_ext(ctx, pk.get(), pk->lactive_lag, nullptr, &pk->lactive_ext));
-        const size_t ne = (size_t)1 << pk->ext_k;
-        if (!pk->x_ext.alloc(ne * 32) || !pk->omega_lag.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        const Fr w_ext = fr_root_of_unity(pk->ext_k), w = fr_root_of_unity(pk->k), zeta = fr_zeta(), one = Fr::one();
-        PK_TRY(zk_fr_powers(ctx, &w_ext, &zeta, pk->x_ext.p, ne));
+        PK_TRY(to_coeff(ctx, pk.get(), pk->l0_lag, &pk->l0_coeff));
+        PK_TRY(to_coeff(ctx, pk.get(), pk->llast_lag, &pk->llast_coeff));
+        PK_TRY(to_coeff(ctx, pk.get(), pk->lactive_lag, &pk->lactive_coeff));
+        if (!pk->omega_lag.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        const Fr w = fr_root_of_unity(pk->k), one = Fr::one();
         PK_TRY(zk_fr_powers(ctx, &w, &one, pk->omega_lag.p, n));
+        PK_TRY(zk_ctx_sync(ctx));
     }
     // vk_repr: hash of the circuit shape and the fixed / sigma commitments
     {
@@ -456,7 +473,7 @@ int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, 
         const F4* v = (const F4*)h_instance[i];
         for (size_t row = 0; row < pk->u; ++row) pr->tr.common_scalar(v[row]);
         PK_TRY(upload(ctx, &pr->inst_lag[i], h_instance[i], n * 32));
-        PK_TRY(to_coeff_and_ext(ctx, pk, pr->inst_lag[i], &pr->inst_coeff[i], &pr->inst_ext[i]));
+        PK_TRY(to_coeff(ctx, pk, pr->inst_lag[i], &pr->inst_coeff[i]));
     }
     *out = pr.release();
     return ZK_OK;
@@ -533,12 +550,11 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
     host::XorShiftRng& rng = pr->rng;
     host::Transcript& tr = pr->tr;
-    std::vector<DevBuf>&inst_lag = pr->inst_lag, &inst_coeff = pr->inst_coeff, &inst_ext = pr->inst_ext, &adv_lag = pr->adv_lag;
-    std::vector<DevBuf> adv_coeff(pk->A), adv_ext(pk->A);
+    std::vector<DevBuf>&inst_lag = pr->inst_lag, &inst_coeff = pr->inst_coeff, &adv_lag = pr->adv_lag;
+    std::vector<DevBuf> adv_coeff(pk->A);
     const F4 one = host::fr_one();
-    (void)inst_coeff;
     StageTrace trace(ctx);
-    Env lag{pk, false, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
+    Env lag{pk, nullptr, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
 
     // ---- lookups, round 1: multiplicities m
@@ -549,8 +565,8 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         push_compressed(pf, lk.inputs); pf.fold(C_ONE);
         push_compressed(pt, lk.tables); pt.fold(C_ONE);
         if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        PK_TRY(run_program(ctx, lag, pf.g, false, lk_f[l].p));
-        PK_TRY(run_program(ctx, lag, pt.g, false, lk_t[l].p));
+        PK_TRY(run_program(ctx, lag, pf.g, lk_f[l].p));
+        PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
         trace.mark("  lookup: compress f, t");
         // multiplicities on the device (hash table over the usable table rows), blinding rows from the session RNG
         if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
@@ -591,8 +607,8 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 if (j > j0) pd.op(Q_MUL);
             }
             pn.fold(C_ONE); pd.fold(C_ONE);
-            PK_TRY(run_program(ctx, lag, pn.g, false, num.p));
-            PK_TRY(run_program(ctx, lag, pd.g, false, den.p));
+            PK_TRY(run_program(ctx, lag, pn.g, num.p));
+            PK_TRY(run_program(ctx, lag, pd.g, den.p));
             PK_TRY(zk_fr_batch_invert(ctx, den.p, n));
             PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, num.p, den.p, num.p, n));
             if (!pz_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
@@ -634,8 +650,8 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         PB a, b;
         a.col(CT_LK_PHI, 0).addc(C_BETA).fold(C_ONE);
         b.col(CT_LK_PHI, 1).addc(C_BETA).fold(C_ONE);
-        PK_TRY(run_program(ctx, e2, a.g, false, inv.p));
-        PK_TRY(run_program(ctx, e2, b.g, false, (char*)inv.p + n * 32));
+        PK_TRY(run_program(ctx, e2, a.g, inv.p));
+        PK_TRY(run_program(ctx, e2, b.g, (char*)inv.p + n * 32));
         PK_TRY(zk_fr_batch_invert(ctx, inv.p, 2 * n));
         std::vector<DevBuf> iv(2);
         // g = inv_f - m * inv_t
@@ -671,15 +687,15 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     trace.mark("random poly");
     lag.y = tr.squeeze();
 
-    // ---- coefficient and extended forms of everything the quotient reads
-    std::vector<DevBuf> pz_coeff(pk->C), pz_ext(pk->C), m_coeff(pk->L), m_ext(pk->L), phi_coeff(pk->L), phi_ext(pk->L);
-    for (uint32_t i = 0; i < pk->A; ++i) PK_TRY(to_coeff_and_ext(ctx, pk, adv_lag[i], &adv_coeff[i], &adv_ext[i]));
-    for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(to_coeff_and_ext(ctx, pk, pz_lag[c], &pz_coeff[c], &pz_ext[c]));
+    // ---- coefficient forms of everything the quotient reads and the proof opens
+    std::vector<DevBuf> pz_coeff(pk->C), m_coeff(pk->L), phi_coeff(pk->L);
+    for (uint32_t i = 0; i < pk->A; ++i) PK_TRY(to_coeff(ctx, pk, adv_lag[i], &adv_coeff[i]));
+    for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(to_coeff(ctx, pk, pz_lag[c], &pz_coeff[c]));
     for (uint32_t l = 0; l < pk->L; ++l) {
-        PK_TRY(to_coeff_and_ext(ctx, pk, lk_m[l], &m_coeff[l], &m_ext[l]));
-        PK_TRY(to_coeff_and_ext(ctx, pk, lk_phi[l], &phi_coeff[l], &phi_ext[l]));
+        PK_TRY(to_coeff(ctx, pk, lk_m[l], &m_coeff[l]));
+        PK_TRY(to_coeff(ctx, pk, lk_phi[l], &phi_coeff[l]));
     }
-    trace.mark("coeff + extended forms");
+    trace.mark("coefficient forms");
     // ---- the quotient program: gates, permutation, lookups, each folded with y
     PB q;
     for (const Prog& g : pk->gates) { q.append(g); q.fold(C_Y); }
@@ -712,11 +728,62 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         q.col(CT_LK_M, l); push_compressed(q, lk.inputs); q.addc(C_BETA).op(Q_MUL);
         q.op(Q_SUB).op(Q_SUB).op(Q_MUL).fold(C_Y);
     }
-    Env ext = lag;
-    ext.extended = true; ext.advice = &adv_ext; ext.instance = &inst_ext; ext.perm_z = &pz_ext; ext.lk_m = &m_ext; ext.lk_phi = &phi_ext;
+    // The extended domain is evaluated one coset at a time (g_r = zeta * omega_ext^r, r < 2^(ext_k-k)):
+    // every column the program reads is taken to that coset with a size-n transform of its
+    // coefficients, the program runs over n rows (rotations are index shifts inside a coset), and
+    // the result, divided by the vanishing polynomial -- a constant g_r^n - 1 on a coset of H --
+    // lands at stride 2^(ext_k-k) in the extended buffer.  Live memory is one n-row block per
+    // column instead of 2^(ext_k-k) of them: what lets 10^3-column circuits fit.
     DevBuf h;
     if (!h.alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-    PK_TRY(run_program(ctx, ext, q.g, true, h.p));
+    {
+        std::vector<uint32_t> refs;
+        for (const Instr& in : q.g) if (in.op == Q_PUSH_COL && std::find(refs.begin(), refs.end(), in.a) == refs.end()) refs.push_back(in.a);
+        const uint32_t nparts = 1u << (ext_k - k);
+        auto of_key = [](uint32_t ref) { const uint32_t t = ref >> 24; return t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL; };
+        if (pk->part_cache_state < 0) {       // decide once: do the key's own cosets fit the budget?
+            size_t key_cols = 0;
+            for (uint32_t ref : refs) key_cols += of_key(ref);
+            const char* env = getenv("ZK_PK_COSET_CACHE_GB");
+            const double budget = (env ? atof(env) : 48.0) * (double)(1ull << 30);
+            pk->part_cache_state = (double)key_cols * nparts * n * 32.0 <= budget ? 1 : 0;
+            if (pk->part_cache_state) pk->part_cache.resize(nparts);
+        }
+        const bool cache_on = pk->part_cache_state == 1;
+        std::vector<DevBuf> part_buf(refs.size());
+        for (size_t i = 0; i < refs.size(); ++i)
+            if (!(cache_on && of_key(refs[i])) && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        DevBuf hpart;
+        if (!hpart.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        std::unordered_map<uint32_t, const void*> part_of;
+        Env part = lag;
+        part.part = &part_of;
+        const Fr w_n = fr_root_of_unity(k), w_ext = fr_root_of_unity(ext_k);
+        Fr g = fr_zeta();
+        for (uint32_t r_ = 0; r_ < nparts; ++r_) {
+            for (size_t i = 0; i < refs.size(); ++i) {
+                void* dst = part_buf[i].p;
+                if (cache_on && of_key(refs[i])) {
+                    DevBuf& slot = pk->part_cache[r_][refs[i]];
+                    part_of[refs[i]] = slot.p;
+                    if (slot.p) continue;                 // computed by an earlier proof
+                    if (!slot.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                    dst = slot.p;
+                }
+                part_of[refs[i]] = dst;
+                if (refs[i] == colref(CT_SPECIAL, SP_X)) { PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n)); continue; }   // X on the coset: g * omega^i
+                const Fr* cf = coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
+                if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
+                PK_TRY(zk_coeff_to_coset(ctx, cf, k, &g, dst));
+            }
+            PK_TRY(run_program(ctx, part, q.g, hpart.p));
+            Fr gn = g;
+            for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
+            const Fr vinv = fr_inv_host(gn - Fr::one());
+            PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, &vinv, h.p, nparts, r_));
+            g = g * w_ext;
+        }
+    }
     PK_TRY(zk_extended_to_coeff(ctx, h.p, ext_k));
     trace.mark("quotient eval + ifft");
     const uint32_t pieces = pk->d - 1;
@@ -725,7 +792,6 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         PK_TRY(commit_coeff(ctx, srs, h.fr() + (size_t)i * n, n, &com));
         tr.write_point(com);
     }
-    adv_ext.clear(); pz_ext.clear(); m_ext.clear(); phi_ext.clear(); inst_ext.clear();   // extended forms no longer needed
 
     trace.mark("h commits");
     const F4 x = tr.squeeze();

@@ -240,6 +240,13 @@ static int build_pow_table(zk_ctx* ctx, int slot, const Fr& x, uint64_t n, Fr** 
 }
 
 
+// dst[i * stride + offset] = src[i] * s: interleaves one coset's values into the extended domain
+__global__ void __launch_bounds__(256) k_scatter_scaled(const Fr* __restrict__ src, uint64_t n, Fr s, Fr* __restrict__ dst, uint64_t stride, uint64_t offset) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    stg(dst + i * stride + offset, ldg(src + i) * s);
+}
+
 // ---- uniformly random field elements: ChaCha20 block -> from_uniform_bytes ----------------------
 // Element i is halo2curves' Fr::from_uniform_bytes (lo + hi * 2^256 mod r over the 64 little-endian
 // bytes) of ChaCha20 block i: key = the caller's 32 bytes, 64-bit block counter = i in state words
@@ -399,6 +406,16 @@ int zk_fr_random(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, uint64_t
     ChaChaKey key;
     memcpy(key.w, key32, 32);   // little-endian words
     hipLaunchKernelGGL(k_fr_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), first_block, (Fr*)d_out, (uint64_t)n);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
+int zk_fr_scatter_scaled(zk_ctx* ctx, const void* d_src, size_t n, const void* h_scale, void* d_dst, size_t stride, size_t offset) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_src && d_dst && h_scale) || !n, "null pointer");
+    ZK_REQUIRE(ctx, stride >= 1 && offset < stride, "need offset < stride");
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_scatter_scaled, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_src, (uint64_t)n, *(const Fr*)h_scale, (Fr*)d_dst, (uint64_t)stride, (uint64_t)offset);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
