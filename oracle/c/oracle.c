@@ -348,6 +348,13 @@ API void orc_best_multiexp(const fe *scalars, const aff *bases, size_t n, int th
     jac_to_aff(out, &total);
     free(k);
 }
+API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

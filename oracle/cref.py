@@ -28,10 +28,39 @@ def build(force: bool = False) -> str:
     return so
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        # libgomp reads these when it is loaded.  On a box whose cgroup quota is far below the
+        # visible core count, one spinning thread per visible core turns every parallel region
+        # into seconds of barrier time: size the team to what can run, and sleep at barriers.
+        user = os.environ.get("OMP_NUM_THREADS")
+        team = int(user) if user and user.isdigit() else usable_cpus()
+        os.environ.setdefault("OMP_NUM_THREADS", str(team))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = ctypes.CDLL(build())
+        _LIB.orc_set_num_threads(team)   # the OpenMP runtime may already be loaded (torch) with its own team size
     return _LIB
 
 

@@ -95,10 +95,37 @@ __device__ __forceinline__ Fr29 two_level29(const Fr* __restrict__ lo, const Fr*
     return mul29(unpack29<Fr29P>(ldg(lo + (e & ((1u << h) - 1)))), unpack29<Fr29P>(ldg(hi + (e >> h))));
 }
 
+// ------------------------------------------------------------------------------- butterflies
+// (u, x) -> (u + x w, u - x w); x w is reduced below 2p by the product, the sums stay lazy
+__device__ __forceinline__ void bfly29(Fr29& u, Fr29& x, const Fr29& w) {
+    const Fr29 v = mul29(x, w);
+    Fr29 a0 = add29(u, v), a1 = sub29k<4>(u, v);
+    normalize29(a0);
+    normalize29(a1);
+    u = a0;
+    x = a1;
+}
+__device__ __forceinline__ Fr29 tw29(const Fr* __restrict__ tw, uint32_t idx) { return unpack29<Fr29P>(ldg(tw + idx)); }
+// DIT stages s (and s+1 when R == 2) on the 2^R elements at digit offsets {0, h, 2h, 3h}, h = 2^s,
+// j = digit mod h.  Radix-4 keeps both stages in registers: half the LDS round trips and barriers
+// of two radix-2 stages, same four products.
+template <int R>
+__device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Fr* __restrict__ tw, int log_np, int s, int j) {
+    const Fr29 w0 = tw29(tw, (uint32_t)j << (log_np - 1 - s));
+    bfly29(e[0], e[1], w0);
+    if (R == 2) {
+        bfly29(e[2], e[3], w0);
+        bfly29(e[0], e[2], tw29(tw, (uint32_t)j << (log_np - 2 - s)));
+        bfly29(e[1], e[3], tw29(tw, (uint32_t)(j + (1 << s)) << (log_np - 2 - s)));
+    }
+}
+
 // ------------------------------------------------------------------------------ non-last pass
 // Tile = [n_p digits][T columns], element (d, c) lives at base + d*m + c with
-// base = hi_idx * (n_p*m) + blk*T.  DIT: loaded bit-reversed in d, leaves in natural d = i_p.
-// On the way out: multiply by omega^((j'' * i_p) << tw_shift), j'' = blk*T + c.
+// base = hi_idx * (n_p*m) + blk*T.  DIT: the first step reads its operands straight from global
+// memory (digit bit-reversed), the steps in between go through LDS, the last step multiplies by
+// the inter-pass twiddle omega^((j'' * i_p) << tw_shift), j'' = blk*T + c, and writes to global
+// memory: no staging copy on either side.  Steps are radix-4 (radix-2 first when log_np is odd).
 // LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
@@ -112,89 +139,91 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
     const uint32_t hi_idx = blockIdx.x / tiles_per_hi, blk = blockIdx.x % tiles_per_hi;
     const uint64_t base = ((uint64_t)hi_idx << (log_np + log_m)) + ((uint64_t)blk << log_t);
 
-    // load in LDS order (conflict-free), global digit = bitrev(lds digit)
-    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
-        const int c = pos & (T - 1), dl = pos >> log_t;
-        const uint32_t d = bitrev(dl, log_np);
-        L.store(pos, unpack29<Fr29P>(ldg(src + base + (uint64_t)d * m + c)));
-    }
-    __syncthreads();
-    for (int s = 0; s < log_np; ++s) {
-        const int half = 1 << s;
-        for (int bf = threadIdx.x; bf < tile / 2; bf += blockDim.x) {
-            const int c = bf & (T - 1), b = bf >> log_t;
-            const int j = b & (half - 1);
-            const int lo_d = ((b >> s) << (s + 1)) | j;
-            const int i0 = (lo_d << log_t) | c, i1 = i0 + (half << log_t);
-            Fr29 u = L.load(i0), x = L.load(i1);
-            // v = x * w  (normalised, < 2p); w = 1 still goes through the product so that v is
-            // reduced: x itself may be a lazy sum
-            Fr29 v = mul29(x, unpack29<Fr29P>(ldg(tw + ((uint32_t)j << (log_np - 1 - s)))));
-            Fr29 a0 = add29(u, v), a1 = sub29k<4>(u, v);
-            normalize29(a0);
-            normalize29(a1);
-            L.store(i0, a0);
-            L.store(i1, a1);
+    for (int s = 0; s < log_np;) {
+        const int r = ((log_np - s) & 1) ? 1 : 2;
+        const bool first = s == 0, last = s + r == log_np;
+        const int hgt = 1 << s, items = tile >> r;
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            const int c = it & (T - 1), b = it >> log_t;      // c fastest: T-element contiguous runs in global memory
+            const int j = b & (hgt - 1);
+            const int lo_d = ((b >> s) << (s + r)) | j;
+            Fr29 e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= (1 << r)) break;
+                const int dl = lo_d + k * hgt;
+                e[k] = first ? unpack29<Fr29P>(ldg(src + base + (uint64_t)bitrev(dl, log_np) * m + c)) : L.load((dl << log_t) | c);
+            }
+            if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= (1 << r)) break;
+                const int dl = lo_d + k * hgt;
+                if (last) {
+                    const uint32_t jpp = (blk << log_t) + c;
+                    const Fr29 v = mul29(e[k], two_level29(lo, hi, h, (jpp * (uint32_t)dl) << tw_shift));
+                    stg(dst + base + (uint64_t)dl * m + c, pack29_lt2p(v));
+                } else {
+                    L.store((dl << log_t) | c, e[k]);
+                }
+            }
         }
-        __syncthreads();
-    }
-    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
-        const int c = pos & (T - 1), d = pos >> log_t;
-        const uint32_t jpp = (blk << log_t) + c;
-        const uint32_t e = (jpp * (uint32_t)d) << tw_shift;
-        Fr29 v = mul29(L.load(pos), two_level29(lo, hi, h, e));
-        stg(dst + base + (uint64_t)d * m + c, pack29_lt2p(v));
+        s += r;
+        if (s < log_np) __syncthreads();
     }
 }
 
 // ----------------------------------------------------------------------------------- last pass
 // Rows of n_P contiguous elements; tile = T rows i1 = blk*T + c (row stride = midN * n_P) at a
-// fixed middle digit `mid`.  LDS layout [c][d].  DIT like the other passes: the tile is filled in
-// LDS order (bank-conflict-free) from the bit-reversed global digit -- 32-byte sectors of a
-// 32 KiB row, all consumed by the same workgroup in the same sweep -- and leaves in natural order.
-// Output index = i1 + n1 * (mid + midN * i_P).  Every output is multiplied by `fin` (1 or the
-// inverse-transform scale, R' form), which also brings the lazy sums back below 2p.
+// fixed middle digit `mid`.  LDS layout [c][d].  Same step structure as the other passes: the
+// first step reads the bit-reversed digits of its rows from global memory (32-byte sectors of a
+// 32 KiB row, all consumed by this workgroup in the same sweep), the last step writes
+// output index = i1 + n1 * (mid + midN * i_P) with c fastest (T consecutive outputs).  Every
+// output is multiplied by `fin` (1 or the inverse-transform scale, R' form), which also brings
+// the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, int log_np, int log_t,
            int log_n1, int log_mid, Fr fin) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
-    const int np = 1 << log_np;
-    const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
-
-    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
-        const int dl = pos & (np - 1), c = pos >> log_np;
-        const uint32_t d = bitrev(dl, log_np);
-        const uint64_t i1 = ((uint64_t)blk << log_t) + c;
-        L.store(pos, unpack29<Fr29P>(ldg(src + (((i1 << log_mid) + mid) << log_np) + d)));
-    }
-    __syncthreads();
-    for (int s = 0; s < log_np; ++s) {
-        const int half = 1 << s;
-        for (int bf = threadIdx.x; bf < tile / 2; bf += blockDim.x) {
-            const int b = bf & (np / 2 - 1), c = bf >> (log_np - 1);
-            const int j = b & (half - 1);
-            const int lo_d = ((b >> s) << (s + 1)) | j;
-            const int i0 = (c << log_np) | lo_d, i1 = i0 + half;
-            Fr29 u = L.load(i0), x = L.load(i1);
-            Fr29 v = mul29(x, unpack29<Fr29P>(ldg(tw + ((uint32_t)j << (log_np - 1 - s)))));
-            Fr29 a0 = add29(u, v), a1 = sub29k<4>(u, v);
-            normalize29(a0);
-            normalize29(a1);
-            L.store(i0, a0);
-            L.store(i1, a1);
-        }
-        __syncthreads();
-    }
     const int T = 1 << log_t;
+    const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
     const Fr29 fin29 = unpack29<Fr29P>(fin);
-    for (int pos = threadIdx.x; pos < tile; pos += blockDim.x) {
-        const int c = pos & (T - 1), d = pos >> log_t;       // c fastest: T consecutive outputs
-        Fr29 v = mul29(L.load((c << log_np) | d), fin29);
-        const uint64_t i1 = ((uint64_t)blk << log_t) + c;
-        const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)d << log_mid)) << log_n1);
-        stg(dst + o, pack29_lt2p(v));
+
+    for (int s = 0; s < log_np;) {
+        const int r = ((log_np - s) & 1) ? 1 : 2;
+        const bool first = s == 0, last = s + r == log_np;
+        const int hgt = 1 << s, items = tile >> r;
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            int c, b;
+            if (last) { c = it & (T - 1); b = it >> log_t; }                              // c fastest: coalesced output
+            else { b = it & ((1 << (log_np - r)) - 1); c = it >> (log_np - r); }          // d fastest: conflict-free LDS
+            const int j = b & (hgt - 1);
+            const int lo_d = ((b >> s) << (s + r)) | j;
+            const uint64_t i1 = ((uint64_t)blk << log_t) + c;
+            Fr29 e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= (1 << r)) break;
+                const int dl = lo_d + k * hgt;
+                e[k] = first ? unpack29<Fr29P>(ldg(src + (((i1 << log_mid) + mid) << log_np) + bitrev(dl, log_np))) : L.load((c << log_np) | dl);
+            }
+            if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= (1 << r)) break;
+                const int dl = lo_d + k * hgt;
+                if (last) {
+                    const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)dl << log_mid)) << log_n1);
+                    stg(dst + o, pack29_lt2p(mul29(e[k], fin29)));
+                } else {
+                    L.store((c << log_np) | dl, e[k]);
+                }
+            }
+        }
+        s += r;
+        if (s < log_np) __syncthreads();
     }
 }
 
