@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-STREAMING = ("k_ntt_pass", "k_ntt_last", "k_vec_op", "k_scale", "k_distribute_powers", "k_msm_count", "k_msm_scatter")
+STREAMING = ("k_ntt_pass", "k_ntt_last", "k_vec_op", "k_scale", "k_distribute_powers", "k_msm_lds_sweep", "k_msm_digits")
 
 
 def short(name):
