@@ -208,6 +208,132 @@ def build_large(ctx, k: int, groups: int, seed: int = 1):
     return c, b"".join(parts), adv_m, inst_m, inst_int
 
 
+def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: int = 8, seed: int = 1):
+    """SURVEY 8d config 4 stand-in: a circuit with the SuperCircuit's *shape* (A advice, F fixed,
+    P permutation columns, L lookups, max degree d).  Same ingredients as `build_large`; to keep
+    the host side small only `distinct` advice triples hold distinct data (the other triples
+    alias them -- same gates, same witness, separate columns / commitments on the device) and the
+    selector classes share their content.  Returns (circuit shell, blob as a uint8 array,
+    advice arrays, instance arrays, instance ints)."""
+    import struct
+    rng = np.random.default_rng(seed)
+    groups = A // 3
+    S = max(1, (F - 4) // 2)                       # selector classes: q_mul[j], q_add[j]
+    assert F >= 2 * S + 4 and groups >= 1 and d >= 5 and P >= 2
+    c = plonk.Circuit(k, num_fixed=F, num_advice=A, num_instance=1, blinding_factors=5)
+    c.fixed = None                                  # fixed columns live in the blob only (numpy), not as Python ints
+    n, u = c.n, c.u
+    q_hi, q_lk, t_a, t_b = (c.fixed_col(2 * S + i) for i in range(4))
+    for g in range(groups):
+        a, b_, cc = (c.advice_col(3 * g + i) for i in range(3))
+        c.add_gate(c.fixed_col(2 * (g % S)) * (a * b_ - cc))
+        c.add_gate(c.fixed_col(2 * (g % S) + 1) * (a + b_ - cc.rot(1)))
+    a0, b0, c0 = c.advice_col(0), c.advice_col(1), c.advice_col(2)
+    hi = q_hi * (a0 * a0 + b0 - c0.rot(-1))          # degree 3, then one linear factor per extra degree
+    for i in range(d - 3):
+        hi = hi * ((a0 if i % 2 == 0 else b0) + (i + 1))
+    c.add_gate(hi)
+    for j in range(L):
+        g = j % groups
+        c.add_lookup([q_lk * c.advice_col(3 * g), q_lk * c.advice_col(3 * g + 1)], [t_a, t_b])
+    for col in range(min(P - 1, A)):
+        c.enable_equality(plonk.ADVICE, col)
+    c.enable_equality(plonk.INSTANCE, 0)
+    assert c.degree() == d, (c.degree(), d)
+    nreg = (u - 4) // 3
+    kinds = rng.integers(0, 4, size=nreg)
+    rows = 1 + 3 * np.arange(nreg)
+    r_mul, r_add, r_hi, r_lk = rows[kinds == 0], rows[kinds == 1], rows[kinds == 2] + 1, rows[kinds == 3]
+    tab_n = min(4096, u)
+    ti = np.arange(tab_n, dtype=np.uint64)
+    D = min(distinct, groups)
+    data = np.zeros((D, 3, n), dtype=np.uint64)
+    npairs = min(256, r_mul.size // 2)
+    src, dst = r_mul[0:2 * npairs:2], r_mul[1:2 * npairs:2]
+    for t in range(D):
+        x = rng.integers(0, 1 << 30, size=r_mul.size, dtype=np.uint64)
+        y = rng.integers(0, 1 << 30, size=r_mul.size, dtype=np.uint64)
+        data[t, 0, r_mul], data[t, 1, r_mul], data[t, 2, r_mul] = x, y, x * y
+        x = rng.integers(0, 1 << 30, size=r_add.size, dtype=np.uint64)
+        y = rng.integers(0, 1 << 30, size=r_add.size, dtype=np.uint64)
+        data[t, 0, r_add], data[t, 1, r_add], data[t, 2, r_add + 1] = x, y, x + y
+        i = rng.integers(1, tab_n, size=r_lk.size, dtype=np.uint64)       # every triple may be a lookup input
+        data[t, 0, r_lk], data[t, 1, r_lk] = i, i * i + 3
+        # copy pairs (product of a mul row feeds `a` of the next one), same pattern in every triple
+        data[t, 0, dst] = data[t, 2, src] % np.uint64(1 << 30)
+        data[t, 2, src] = data[t, 0, dst]
+        data[t, 0, src], data[t, 1, src] = data[t, 2, src], 1
+        data[t, 2, dst] = data[t, 0, dst] * data[t, 1, dst]
+    # the degree-d gate lives on triple 0: rows r_hi hold (x, y) with c[row-1] = x^2 + y
+    x = rng.integers(0, 1 << 20, size=r_hi.size, dtype=np.uint64)
+    y = rng.integers(0, 1 << 20, size=r_hi.size, dtype=np.uint64)
+    data[0, 0, r_hi], data[0, 1, r_hi], data[0, 2, r_hi - 1] = x, y, x * x + y
+    copies = []
+    for g in range(groups):
+        if 3 * g + 2 < min(P - 1, A):
+            copies += [((plonk.ADVICE, 3 * g + 2, int(s_)), (plonk.ADVICE, 3 * g, int(d_))) for s_, d_ in zip(src, dst)]
+    inst = np.zeros((1, n), dtype=np.uint64)
+    pub = r_add[:4]
+    inst[0, :pub.size] = data[0, 1, pub]
+    copies += [((plonk.ADVICE, 1, int(r0)), (plonk.INSTANCE, 0, j)) for j, r0 in enumerate(pub)]
+    c.copies = copies
+    data_m = [[to_mont_gpu(ctx, small_to_limbs(data[t, i])) for i in range(3)] for t in range(D)]
+    zero_col = np.zeros((n, 4), dtype=np.uint64)
+    adv_m = [data_m[(col // 3) % D][col % 3] if col < 3 * groups else zero_col for col in range(A)]
+    inst_m = [to_mont_gpu(ctx, small_to_limbs(inst[0]))]
+
+    def sel(rows_):
+        v = np.zeros(n, dtype=np.uint64)
+        v[rows_] = 1
+        return to_mont_gpu(ctx, small_to_limbs(v))
+    f_mul, f_add, f_hi, f_lk = sel(r_mul), sel(r_add), sel(r_hi), sel(r_lk)
+    ta = np.zeros(n, dtype=np.uint64); ta[1:tab_n] = ti[1:]
+    tb = np.zeros(n, dtype=np.uint64); tb[1:tab_n] = ti[1:] * ti[1:] + 3
+    f_ta, f_tb = to_mont_gpu(ctx, small_to_limbs(ta)), to_mont_gpu(ctx, small_to_limbs(tb))
+    fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb][i - 2 * S] if i < 2 * S + 4 else zero_col)
+    # ---- blob: header + programs, then F fixed and P sigma columns written in place (no Python-side copies)
+    Pn = len(c.perm_cols)
+    gates = [c.compile(g) for g in c.gates]
+    lookups = [([c.compile(e) for e in ins], [c.compile(e) for e in tabs]) for ins, tabs in c.lookups]
+
+    def prog(p):
+        return struct.pack("<I", len(p)) + b"".join(struct.pack("<III", *ins) for ins in p)
+    parts = [struct.pack("<12I", plonk.BLOB_MAGIC, plonk.BLOB_VERSION, k, c.bf, c.degree(), F, A, 1, Pn, len(c.lookups), len(gates), len(c.consts))]
+    parts.append(struct.pack("<I", 0))
+    parts += [struct.pack("<I", 0) for _ in range(A)]
+    parts += [struct.pack("<II", t, i_) for t, i_ in c.perm_cols]
+    parts += [plonk.fr_mont_bytes(v) for v in c.consts]
+    parts += [prog(g) for g in gates]
+    for ins, tabs in lookups:
+        parts.append(struct.pack("<I", len(ins)))
+        parts += [prog(p) for p in ins] + [prog(p) for p in tabs]
+    head = b"".join(parts)
+    col_bytes = n * 32
+    total = len(head) + (F + Pn) * col_bytes
+    raw = np.empty(total + 8, dtype=np.uint8)
+    shift = (-(raw.ctypes.data + len(head))) % 8       # columns 8-byte aligned in memory (u64 views below)
+    blob = raw[shift:shift + total]
+    blob[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+    off = len(head)
+    for i in range(F):
+        blob[off:off + col_bytes] = fixed_of(i).view(np.uint8).reshape(-1)
+        off += col_bytes
+    pos = {pc: j for j, pc in enumerate(c.perm_cols)}
+    omega_m = np.frombuffer(plonk.fr_mont_bytes(c.omega()), dtype=np.uint64).copy()
+    sig_view = [blob[off + j * col_bytes: off + (j + 1) * col_bytes].view(np.uint64).reshape(n, 4) for j in range(Pn)]
+    tmp = ctx.alloc(col_bytes)
+    for j in range(Pn):
+        ctx.fr_powers(omega_m, np.frombuffer(plonk.fr_mont_bytes(pow(plonk.FR_DELTA, j, R)), dtype=np.uint64).copy(), tmp, n)
+        sig_view[j][:] = tmp.download((n, 4))
+    tmp.free()
+    for (ta_, ia, ra), (tb_, ib, rb) in copies:
+        ja, jb = pos[(ta_, ia)], pos[(tb_, ib)]
+        va, vb = sig_view[ja][ra].copy(), sig_view[jb][rb].copy()
+        sig_view[ja][ra], sig_view[jb][rb] = vb, va
+    inst_int = [[int(v) for v in inst[0]]]
+    return c, blob, adv_m, inst_m, inst_int
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, default=16)
@@ -216,11 +342,16 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--large", action="store_true", help="vectorised builder (k >= 18, many columns)")
     ap.add_argument("--shplonk", action="store_true", help="SHPLONK multi-open instead of GWC")
+    ap.add_argument("--shape", default="", help="A,F,P,L,d: circuit with this many advice / fixed / permutation columns, lookups and "
+                    "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
     args = ap.parse_args()
 
     ctx = z.Context(0)
     t0 = time.perf_counter()
-    if args.large:
+    if args.shape:
+        sa, sf, sp, sl, sd = (int(v) for v in args.shape.split(","))
+        circ, blob, adv_m, inst_m, inst = build_shape(ctx, args.k, sa, sf, sp, sl, sd)
+    elif args.large:
         circ, blob, adv_m, inst_m, inst = build_large(ctx, args.k, args.groups)
     else:
         circ, adv, inst = build(args.k, args.groups)

@@ -384,6 +384,10 @@ class Context:
     # ---- full proofs (halo2 keygen_pk / create_proof, GWC)
     def pk_create(self, srs: Srs, blob: bytes) -> "ProvingKey":
         h = ctypes.c_void_p()
+        if isinstance(blob, np.ndarray):      # large keys: a uint8 array is passed by pointer, no copy
+            assert blob.dtype == np.uint8 and blob.flags["C_CONTIGUOUS"]
+            self._ck(lib().zk_pk_create(self.h, srs.h, _host_ptr(blob), ctypes.c_size_t(blob.nbytes), ctypes.byref(h)))
+            return ProvingKey(self, h)
         buf = ctypes.create_string_buffer(blob, len(blob))
         self._ck(lib().zk_pk_create(self.h, srs.h, buf, ctypes.c_size_t(len(blob)), ctypes.byref(h)))
         return ProvingKey(self, h)
