@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--large", action="store_true", help="vectorised builder (k >= 18, many columns)")
     ap.add_argument("--shplonk", action="store_true", help="SHPLONK multi-open instead of GWC")
+    ap.add_argument("--pinned", action="store_true", help="advice columns in page-locked host memory (zk_host_alloc)")
     ap.add_argument("--shape", default="", help="A,F,P,L,d: circuit with this many advice / fixed / permutation columns, lookups and "
                     "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
     args = ap.parse_args()
@@ -358,6 +359,13 @@ def main():
         blob = circ.blob()
         adv_m = [plonk.column_to_mont(c) for c in adv]
         inst_m = [plonk.column_to_mont(c) for c in inst]
+    if args.pinned:          # what a host integration would do: witness columns in page-locked memory
+        pinned = {}
+        for a in adv_m:
+            if id(a) not in pinned:
+                pinned[id(a)] = ctx.host_alloc(a.shape)
+                pinned[id(a)][:] = a
+        adv_m = [pinned[id(a)] for a in adv_m]
     t_build = time.perf_counter() - t0
 
     S = 0x5EC2E7
@@ -395,6 +403,7 @@ def main():
         "srs_setup_s": round(t_srs, 4), "host_circuit_build_s": round(t_build, 2), "verified_by_oracle": ok,
         "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + d - 3) // (d - 2) + 1 + (d - 1),
         "multiopen": "shplonk" if args.shplonk else "gwc", "data": "synthetic-shape",
+        "advice_host_memory": "pinned" if args.pinned else "pageable",
     }
     print(json.dumps(out), flush=True)
 

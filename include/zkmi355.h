@@ -55,6 +55,10 @@ int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
 int zk_ctx_sync(zk_ctx* ctx);
 int zk_buf_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr);
 int zk_buf_free(zk_ctx* ctx, void* d_ptr);
+/* Page-locked host memory for witness columns: uploads from it run at PCIe speed and overlap with
+ * compute (zk_commit_batch_h2d, zk_proof_advice_phase); pageable memory works too, at about half. */
+int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** h_ptr);
+int zk_host_free(zk_ctx* ctx, void* h_ptr);
 int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int zk_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int zk_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);

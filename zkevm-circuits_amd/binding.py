@@ -302,6 +302,22 @@ class Context:
         assert len(key32) == 32
         self._ck(lib().zk_fr_random(self.h, ctypes.c_char_p(key32), ctypes.c_uint64(stream_id), ctypes.c_uint64(first_block), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
 
+    def host_alloc(self, shape, dtype=np.uint64) -> np.ndarray:
+        """numpy array over page-locked host memory (zk_host_alloc); freed with host_free(array)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self._ck(lib().zk_host_alloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(p)))
+        buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._ck(lib().zk_host_free(self.h, ctypes.c_void_p(p)))
+
     def lookup_multiplicities(self, inputs: DeviceBuffer, table: DeviceBuffer, usable_rows: int, m: DeviceBuffer, n: int) -> Optional[int]:
         """logUp m(X) on the device; returns the lowest input row missing from the table, or None."""
         bad = ctypes.c_uint64()

@@ -107,6 +107,21 @@ int zk_buf_free(zk_ctx* ctx, void* d_ptr) {
     ZK_HIP(ctx, hipFree(d_ptr));
     return ZK_OK;
 }
+// Page-locked host memory: witness columns allocated here upload at PCIe speed and asynchronously
+// (pageable memory is staged through bounce buffers at roughly half the rate).
+int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** h_ptr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, h_ptr, "null pointer");
+    *h_ptr = nullptr;
+    hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx->fail(ZK_ERR_OOM, "hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); }
+    return ZK_OK;
+}
+int zk_host_free(zk_ctx* ctx, void* h_ptr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    if (h_ptr) ZK_HIP(ctx, hipHostFree(h_ptr));
+    return ZK_OK;
+}
 int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, (d_dst && h_src) || !bytes, "null pointer");

@@ -30,13 +30,28 @@ __device__ __forceinline__ bool fr_same(const Fr& a, const Fr& b) {
 }
 
 __global__ void __launch_bounds__(256) k_lk_insert(const Fr* __restrict__ table, uint32_t rows, uint32_t* slots, uint32_t mask) {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const Fr key = ldg(table + row);
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool active = row < rows;
+    const Fr key = active ? ldg(table + row) : Fr::zero();
+    // Fixed tables are padded with long runs of one default row.  Equal values inside a wave are
+    // represented by their first lane (the lowest row) only, so a run of a million equal rows
+    // sends 1/64 of the probes to that value's slot instead of hammering one L2 line.
+    bool rep = false;
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        uint32_t diff = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) diff |= key.l[i] ^ __shfl(key.l[i], src);
+        const uint64_t same = __ballot(diff == 0) & todo;
+        if ((int)lane == src) rep = true;
+        todo &= ~same;
+    }
+    if (!rep) return;
     uint32_t h = fr_hash(key) & mask;
     for (;;) {
-        // fixed tables are padded with long runs of one default row: look before touching the slot
-        // atomically, so a value that is already owned by a lower row costs one load and no atomic
+        // look before touching the slot atomically: a value that is already owned by a lower row
+        // costs one load and no atomic
         uint32_t old = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == LK_EMPTY) old = atomicCAS(&slots[h], LK_EMPTY, row);
         if (old == LK_EMPTY) return;
@@ -44,8 +59,11 @@ __global__ void __launch_bounds__(256) k_lk_insert(const Fr* __restrict__ table,
         h = (h + 1) & mask;
     }
 }
+constexpr int LK_COUNT_THREADS = 1024;
+constexpr int LK_BLOCK_SLOT_BITS = 11;
+constexpr uint32_t LK_BLOCK_SLOTS = 1u << LK_BLOCK_SLOT_BITS;     // 2 x LK_COUNT_THREADS
 // status[0] = lowest input row whose value is not in the table (LK_EMPTY if none)
-__global__ void __launch_bounds__(256) k_lk_count(const Fr* __restrict__ inputs, const Fr* __restrict__ table, uint32_t rows, const uint32_t* __restrict__ slots, uint32_t mask,
+__global__ void __launch_bounds__(LK_COUNT_THREADS) k_lk_count(const Fr* __restrict__ inputs, const Fr* __restrict__ table, uint32_t rows, const uint32_t* __restrict__ slots, uint32_t mask,
                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ status) {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t owner = LK_EMPTY;
@@ -59,16 +77,31 @@ __global__ void __launch_bounds__(256) k_lk_count(const Fr* __restrict__ inputs,
             h = (h + 1) & mask;
         }
     }
-    // one atomic per distinct owner in the wave: disabled rows all look up the same default value,
-    // and a million atomics on one counter would serialise
+    // Disabled rows all look up the same default value, and a million atomics on one counter would
+    // serialise.  Two levels of combining: lanes of a wave with the same owner share one update,
+    // and the waves of the workgroup merge their updates in a small LDS hash table (owner ->
+    // count) that is flushed with one global atomic per distinct owner of the workgroup.
+    __shared__ uint32_t t_key[LK_BLOCK_SLOTS], t_cnt[LK_BLOCK_SLOTS];
+    for (uint32_t i = threadIdx.x; i < LK_BLOCK_SLOTS; i += blockDim.x) { t_key[i] = LK_EMPTY; t_cnt[i] = 0u; }
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t todo = __ballot(owner != LK_EMPTY);
     while (todo) {
         const uint32_t lead = __shfl(owner, (int)__builtin_ctzll(todo));
         const uint64_t same = __ballot(owner == lead) & todo;
-        if (lane == (uint32_t)__builtin_ctzll(todo)) atomicAdd(&counts[lead], (uint32_t)__popcll(same));
+        if (lane == (uint32_t)__builtin_ctzll(todo)) {
+            uint32_t h = (lead * 0x9E3779B1u) >> (32 - LK_BLOCK_SLOT_BITS);
+            for (;;) {       // at most blockDim.x distinct owners for 2 * blockDim.x slots: always terminates
+                const uint32_t old = atomicCAS(&t_key[h], LK_EMPTY, lead);
+                if (old == LK_EMPTY || old == lead) { atomicAdd(&t_cnt[h], (uint32_t)__popcll(same)); break; }
+                h = (h + 1) & (LK_BLOCK_SLOTS - 1);
+            }
+        }
         todo &= ~same;
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LK_BLOCK_SLOTS; i += blockDim.x)
+        if (t_key[i] != LK_EMPTY) atomicAdd(&counts[t_key[i]], t_cnt[i]);
 }
 // m[i] = counts[i] as a Montgomery residue for i < rows, 0 for rows <= i < n (the caller overwrites the blinding rows)
 __global__ void __launch_bounds__(256) k_lk_to_fr(const uint32_t* __restrict__ counts, uint32_t rows, Fr* __restrict__ m, uint64_t n) {
@@ -77,6 +110,31 @@ __global__ void __launch_bounds__(256) k_lk_to_fr(const uint32_t* __restrict__ c
     Fr v = Fr::zero();
     if (i < rows) { v.l[0] = counts[i]; v = to_mont(v); }
     stg(m + i, v);
+}
+
+
+// Enqueues the whole computation on the context's stream; d_status (one u32 on the device, set to
+// 0xFFFFFFFF by the caller) receives the lowest offending input row.  No synchronisation: the
+// prover runs every lookup of a proof back to back and reads all status words at once.
+int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status) {
+    uint32_t cap = 16;
+    while (cap < 2 * usable_rows) cap <<= 1;
+    // scratch: slots[cap] | counts[usable_rows]   (reused by the next enqueue: same stream, so ordered)
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_TMP, ((size_t)cap + usable_rows + 4) * 4);
+    if (!ws) return ZK_ERR_OOM;
+    uint32_t *slots = ws, *counts = ws + cap;
+    ZK_HIP(ctx, hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)usable_rows * 4, ctx->stream));
+    const uint32_t rows = (uint32_t)usable_rows;
+    if (rows) {
+        hipLaunchKernelGGL(k_lk_insert, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_table, rows, slots, cap - 1);
+        hipLaunchKernelGGL(k_lk_count, dim3((rows + LK_COUNT_THREADS - 1) / LK_COUNT_THREADS), dim3(LK_COUNT_THREADS), 0, ctx->stream, d_inputs, d_table, rows,
+                           (const uint32_t*)slots, cap - 1, counts, d_status);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    hipLaunchKernelGGL(k_lk_to_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)counts, rows, d_m, (uint64_t)n);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
 }
 
 }  // namespace zk
@@ -88,24 +146,11 @@ extern "C" int zk_lookup_multiplicities(zk_ctx* ctx, const void* d_inputs, const
     ZK_REQUIRE(ctx, d_inputs && d_table && d_m && bad_row, "null pointer");
     ZK_REQUIRE(ctx, usable_rows <= n && n < (1ull << 31), "row counts out of range");
     *bad_row = UINT64_MAX;
-    uint32_t cap = 16;
-    while (cap < 2 * usable_rows) cap <<= 1;
-    // scratch: slots[cap] | counts[usable_rows] | status[1]
-    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_TMP, ((size_t)cap + usable_rows + 4) * 4);
-    if (!ws) return ZK_ERR_OOM;
-    uint32_t *slots = ws, *counts = ws + cap, *status = counts + usable_rows;
-    ZK_HIP(ctx, hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, ctx->stream));
-    ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)usable_rows * 4, ctx->stream));
+    uint32_t* status = (uint32_t*)ctx->get_scratch(SC_TMP2, 64);
+    if (!status) return ZK_ERR_OOM;
     ZK_HIP(ctx, hipMemsetAsync(status, 0xFF, 4, ctx->stream));
-    const uint32_t rows = (uint32_t)usable_rows;
-    if (rows) {
-        const dim3 g((rows + 255) / 256), t(256);
-        hipLaunchKernelGGL(k_lk_insert, g, t, 0, ctx->stream, (const Fr*)d_table, rows, slots, cap - 1);
-        hipLaunchKernelGGL(k_lk_count, g, t, 0, ctx->stream, (const Fr*)d_inputs, (const Fr*)d_table, rows, (const uint32_t*)slots, cap - 1, counts, status);
-        ZK_CHECK_LAUNCH(ctx);
-    }
-    hipLaunchKernelGGL(k_lk_to_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)counts, rows, (Fr*)d_m, (uint64_t)n);
-    ZK_CHECK_LAUNCH(ctx);
+    int rc = lookup_multiplicities_enqueue(ctx, (const Fr*)d_inputs, (const Fr*)d_table, usable_rows, (Fr*)d_m, n, status);
+    if (rc) return rc;
     uint32_t st = LK_EMPTY;
     ZK_HIP(ctx, hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

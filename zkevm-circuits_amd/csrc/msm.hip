@@ -64,7 +64,7 @@ __device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
 
 // ---- sort phase --------------------------------------------------------------------------------
 // 1. k_msm_digits: every scalar leaves Montgomery form once and is recoded; digit codes go to a
-//    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 16):
+//    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 64):
 //      0xFFFF = zero digit, otherwise bit 15 = sign, bits 0..14 = bucket (|d| - 1).
 // 2. k_msm_lds_count / k_msm_lds_scatter: workgroup (r, w) owns bucket range r of window w
 //    (<= 2048 buckets).  It streams the whole digit row (2 MiB at 2^20, L2-resident, 16 B/lane)
@@ -113,6 +113,11 @@ static void launch_digits(int c, dim3 grid, hipStream_t st, const Fr* scalars, u
 #undef ZK_DIG_CASE
 }
 
+// A row is also cut into MSM_SLICES slices (workgroup = range x slice): witness columns leave most
+// windows empty, and with one workgroup per (range, window) the few non-empty windows would keep
+// only a quarter of the CUs busy while each still streams a whole row.  Counters are laid out
+// [bucket][slice], so one exclusive scan over the flat array yields every (bucket, slice) cursor.
+constexpr int MSM_SLICES = 4;        // == SCAN_ITEMS: a scan thread sees the slices of one bucket
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restrict__ dig, uint64_t n_pad, int range_bits, uint32_t B,
                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx, const uint32_t* __restrict__ wflag, uint32_t nwin) {
@@ -121,14 +126,15 @@ __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restri
     // with window = xcd + 8 * (j / ranges): all range-workgroups of a window share one XCD and its
     // L2 serves the window's digit row to all of them (read from HBM / MALL once, not once per XCD).
     const uint32_t nranges = B >> range_bits, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t r = slot % nranges, w = xcd + 8u * (slot / nranges), range = 1u << range_bits, rmask = range - 1;
+    const uint32_t sl = slot % MSM_SLICES, r = (slot / MSM_SLICES) % nranges, w = xcd + 8u * (slot / (MSM_SLICES * nranges));
+    const uint32_t range = 1u << range_bits, rmask = range - 1;
     if (w >= nwin) return;
     const uint64_t gbase = (uint64_t)w * B + ((uint64_t)r << range_bits);
     if (wflag[w] == 0u) {      // empty window: nothing to count or place
-        if (!SCATTER) for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[gbase + t] = 0u;
+        if (!SCATTER) for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[(gbase + t) * MSM_SLICES + sl] = 0u;
         return;
     }
-    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[gbase + t] : 0u;
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[(gbase + t) * MSM_SLICES + sl] : 0u;
     __syncthreads();
     // 16 digits per lane and trip, two digits per 32-bit word.  A digit belongs to this workgroup
     // when the range field of its code (bits range_bits..14) equals r: xor with the wanted field,
@@ -139,8 +145,9 @@ __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restri
     const uint32_t field = (0x7FFFu & ~rmask) * 0x00010001u, want = (r << range_bits) * 0x00010001u;
     const bool zero_aliases = (0x7FFFu >> range_bits) == r;       // DIG_ZERO = 0xFFFF carries this range's field
     const uint4* row = reinterpret_cast<const uint4*>(dig + (uint64_t)w * n_pad);
-    const uint64_t nvec = n_pad >> 4;
-    uint64_t v = threadIdx.x;
+    const uint64_t nvec_slice = n_pad >> 4 >> 2, nvec = (uint64_t)(sl + 1) * nvec_slice;   // n_pad is a multiple of 16 * MSM_SLICES
+    static_assert(MSM_SLICES == 4, "slice arithmetic above assumes 4 slices");
+    uint64_t v = (uint64_t)sl * nvec_slice + threadIdx.x;
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     if (v < nvec) { q0 = row[2 * v]; q1 = row[2 * v + 1]; }
     while (v < nvec) {
@@ -188,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restri
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[gbase + t] = lds[t];
+        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[(gbase + t) * MSM_SLICES + sl] = lds[t];
     }
 }
 
@@ -221,7 +228,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_a(const uint32_t* __restric
     for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < cnt) offsets[base + k] = run; run += c[k]; }
     if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint32_t nblocks, uint32_t* offsets, uint32_t cnt) {
+__global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint32_t nblocks, uint32_t* offsets, uint32_t cnt, uint32_t* total_out) {
     __shared__ uint32_t sh[SCAN_T];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nblocks; base += SCAN_T) {
@@ -232,32 +239,35 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint
         if (i < nblocks) block_tot[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) offsets[cnt] = carry;
+    if (threadIdx.x == 0) { offsets[cnt] = carry; if (total_out) *total_out = carry; }
 }
-// adds the block offset, mirrors into `cursor`, and bins every bucket by size (descending order
-// of size -> a wave works on buckets of equal length; big ones start first)
+// Finishes the scan over the [bucket][slice] counters (adds the block offsets: slice_off = cursor
+// start of every (bucket, slice)), derives the per-bucket view (offsets[b] = slice_off[b][0],
+// counts[b] = sum of its slices) and bins every bucket by size (descending order of size -> a wave
+// works on buckets of equal length; big ones start first).
 constexpr uint32_t SIZE_BINS = 256;
 constexpr uint32_t TASK_CAP = 48;       // points per task, see "skew-proof work split" below
-__global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ counts, uint32_t cnt, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_tot,
-                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ size_hist) {
+__global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ slice_counts, uint32_t nbuckets, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
+                                                       uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_hist) {
     __shared__ uint32_t lh[SIZE_BINS];
     if (threadIdx.x < SIZE_BINS) lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t off = block_tot[blockIdx.x];
-    const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const uint32_t i = base + k * SCAN_T + threadIdx.x;
-        if (i < cnt) {
-            const uint32_t o = offsets[i] + off;
-            offsets[i] = o;
-            cursor[i] = o;
-            atomicAdd(&lh[min(counts[i], SIZE_BINS - 1)], 1u);
-        }
+    const uint32_t b = blockIdx.x * SCAN_T + threadIdx.x;        // SCAN_ITEMS == MSM_SLICES entries per bucket, one bucket per thread
+    if (b < nbuckets) {
+        const uint4 c = reinterpret_cast<const uint4*>(slice_counts)[b];
+        uint4 o = reinterpret_cast<const uint4*>(slice_off)[b];
+        o.x += off; o.y += off; o.z += off; o.w += off;
+        reinterpret_cast<uint4*>(slice_off)[b] = o;
+        const uint32_t total = c.x + c.y + c.z + c.w;
+        offsets[b] = o.x;
+        counts[b] = total;
+        atomicAdd(&lh[min(total, SIZE_BINS - 1)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < SIZE_BINS && lh[threadIdx.x]) atomicAdd(&size_hist[threadIdx.x], lh[threadIdx.x]);
 }
+static_assert(SCAN_ITEMS == MSM_SLICES, "k_scan_u32_a scans MSM_SLICES entries per thread: one bucket");
 // size_hist (256 bins) -> start offset of each bin in the descending-size order
 __global__ void k_size_bins_scan(uint32_t* size_hist) {
     if (threadIdx.x || blockIdx.x) return;
@@ -543,32 +553,34 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
 
-    // u32 workspace: counts[nb] | size_hist[256] nmulti[4] wflag[64] | offsets[nb+1] | cursor[nb] | order[nb] | ntasks[nb] | toff[nb+1] | multi[nb] |
-    //                block_tot[2*scan_blocks] | idx[n*W] | (16-B aligned) dig[W*n_pad u16]
+    // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] (both 16-B aligned) | counts[nb] | size_hist[256] nmulti[4] wflag[64] |
+    //                offsets[nb+1] | order[nb] | ntasks[nb] | toff[nb+1] | block_tot[scan_blocks_s + scan_blocks] | idx[n*W] |
+    //                (16-B aligned) dig[W*n_pad u16]
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
-    const uint64_t n_pad = ((uint64_t)n + 15) & ~15ull;
+    const uint32_t scan_blocks_s = (nb + SCAN_T - 1) / SCAN_T;                    // scan over the [bucket][slice] counters: one bucket per thread
+    const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
-    const size_t head_words = (size_t)nb * 7 + 2 + SIZE_BINS + 68 + 2 * (size_t)scan_blocks + (size_t)n * pl.W;
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + (size_t)n * pl.W;
     const size_t words = head_words + 4 + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
-    uint32_t* counts = ws;
+    uint32_t* slice_counts = ws;
+    uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
+    uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
     uint32_t* wflag = nmulti + 4;          // 64 words: W <= 64 windows (c >= 4)
     uint32_t* offsets = wflag + 64;
-    uint32_t* cursor = offsets + nb + 1;
-    uint32_t* order = cursor + nb;
+    uint32_t* order = offsets + nb + 1;
     uint32_t* ntasks = order + nb;
     uint32_t* toff = ntasks + nb;
-    uint32_t* multi = toff + nb + 1;
-    uint32_t* block_tot = multi + nb;
-    uint32_t* block_tot2 = block_tot + scan_blocks;
+    uint32_t* block_tot = toff + nb + 1;
+    uint32_t* block_tot2 = block_tot + scan_blocks_s;
     uint32_t* idx = block_tot2 + scan_blocks;
     uint16_t* dig = reinterpret_cast<uint16_t*>(ws + ((head_words + 3) & ~(size_t)3));   // 16-B aligned
     int range_bits = pl.c - 1;
     if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
-    const dim3 sweep_grid(8u * ((pl.W + 7) / 8) * (pl.B >> range_bits));
+    const dim3 sweep_grid(8u * ((pl.W + 7) / 8) * (pl.B >> range_bits) * MSM_SLICES);
     // a lone MSM is latency-bound (short chains: G = 2); in a batch the reduction hides under the
     // next MSM and only its work counts (G = 8)
     const bool short_chain = d_table && count == 1;
@@ -615,18 +627,18 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         ZkProfScope ps(ctx, "msm_sort");
         ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));   // size_hist + nmulti + wflag
         launch_digits(pl.c, dim3((unsigned)((n_pad + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
-        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
+        hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, block_tot);
-        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks, offsets, nb);
-        hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, offsets, (const uint32_t*)block_tot, cursor, size_hist);
+        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
+        hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
         hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist);
         hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
-        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
         ZK_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)offsets, idx, (const uint32_t*)wflag, (uint32_t)pl.W);
+        hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
     }
     {

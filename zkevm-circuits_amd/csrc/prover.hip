@@ -121,7 +121,7 @@ struct zk_pk {
     std::vector<DevBuf> fixed_lag, fixed_coeff, sigma_lag, sigma_coeff;
     DevBuf omega_lag, l0_lag, llast_lag, lactive_lag, l0_coeff, llast_coeff, lactive_coeff;
     // cosets of the key's own columns (fixed, sigma, l0 / l_last / l_active, X), filled by the first
-    // proof and reused by later ones when they fit the budget (ZK_PK_COSET_CACHE_GB, default 48):
+    // proof and reused by later ones when they fit the budget (ZK_PK_COSET_CACHE_GB, default 96):
     // part_cache[r][column reference]
     mutable std::vector<std::unordered_map<uint32_t, DevBuf>> part_cache;
     mutable int part_cache_state = -1;       // -1 undecided, 0 off, 1 on
@@ -557,29 +557,37 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     Env lag{pk, nullptr, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
 
-    // ---- lookups, round 1: multiplicities m
+    // ---- lookups, round 1: multiplicities m.  Every lookup is enqueued back to back (theta-compression,
+    // device hash join, blinding rows); one download of the status words, one pipelined batch of commits.
     std::vector<DevBuf> lk_f(pk->L), lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
-    for (uint32_t l = 0; l < pk->L; ++l) {
-        const auto& lk = pk->lookups[l];
-        PB pf, pt;
-        push_compressed(pf, lk.inputs); pf.fold(C_ONE);
-        push_compressed(pt, lk.tables); pt.fold(C_ONE);
-        if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        PK_TRY(run_program(ctx, lag, pf.g, lk_f[l].p));
-        PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
-        trace.mark("  lookup: compress f, t");
-        // multiplicities on the device (hash table over the usable table rows), blinding rows from the session RNG
-        if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        uint64_t bad_row = UINT64_MAX;
-        PK_TRY(zk_lookup_multiplicities(ctx, lk_f[l].p, lk_t[l].p, pk->u, lk_m[l].p, n, &bad_row));
-        if (bad_row != UINT64_MAX) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %llu is not in the table (witness does not satisfy the circuit)", l, (unsigned long long)bad_row);
-        std::vector<F4> blind(n - pk->u - 1);
-        for (auto& x : blind) x = rng.next_fr();
-        PK_TRY(zk_h2d(ctx, (char*)lk_m[l].p + ((size_t)pk->u + 1) * 32, blind.data(), blind.size() * 32));
-        trace.mark("  lookup: multiplicities");
-        G1Affine com;
-        PK_TRY(commit_lagrange(ctx, srs, lk_m[l].fr(), n, &com));
-        tr.write_point(com);
+    if (pk->L) {
+        DevBuf status;
+        if (!status.alloc((size_t)pk->L * 4)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        ZK_HIP(ctx, hipMemsetAsync(status.p, 0xFF, (size_t)pk->L * 4, ctx->stream));
+        const size_t nblind = n - pk->u - 1;
+        std::vector<F4> blind((size_t)pk->L * nblind);
+        std::vector<const void*> mptrs(pk->L);
+        for (uint32_t l = 0; l < pk->L; ++l) {
+            const auto& lk = pk->lookups[l];
+            PB pf, pt;
+            push_compressed(pf, lk.inputs); pf.fold(C_ONE);
+            push_compressed(pt, lk.tables); pt.fold(C_ONE);
+            if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32) || !lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            PK_TRY(run_program(ctx, lag, pf.g, lk_f[l].p));
+            PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
+            PK_TRY(lookup_multiplicities_enqueue(ctx, lk_f[l].fr(), lk_t[l].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l));
+            for (size_t i = 0; i < nblind; ++i) blind[l * nblind + i] = rng.next_fr();
+            ZK_HIP(ctx, hipMemcpyAsync((char*)lk_m[l].p + ((size_t)pk->u + 1) * 32, blind.data() + l * nblind, nblind * 32, hipMemcpyHostToDevice, ctx->stream));
+            mptrs[l] = lk_m[l].p;
+        }
+        std::vector<uint32_t> st(pk->L);
+        PK_TRY(zk_d2h(ctx, st.data(), status.p, (size_t)pk->L * 4));
+        for (uint32_t l = 0; l < pk->L; ++l)
+            if (st[l] != 0xFFFFFFFFu) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %u is not in the table (witness does not satisfy the circuit)", l, st[l]);
+        trace.mark("  lookup: m (all lookups)");
+        std::vector<G1Affine> coms(pk->L);
+        PK_TRY(zk_commit_batch(ctx, srs, 1, mptrs.data(), pk->L, n, coms.data()));
+        for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup m");
     lag.lk_m = &lk_m;
@@ -636,40 +644,46 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
     }
     trace.mark("permutation Z");
-    // ---- lookups, round 2: grand sums phi
-    for (uint32_t l = 0; l < pk->L; ++l) {
+    // ---- lookups, round 2: grand sums phi, again enqueued back to back with one closing check and one commit batch
+    if (pk->L) {
         // g[i] = 1/(f+beta) - m/(t+beta)  via one batch inversion of (f+beta) and (t+beta)
-        DevBuf inv, g, phi;
-        if (!inv.alloc(2 * n * 32) || !g.alloc(n * 32) || !phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        std::vector<DevBuf> tmpcols(2);
-        Env e2 = lag;
-        // program over explicit buffers: use CT_LK_PHI slots 0/1 as scratch references for f and t
-        std::vector<DevBuf> ft(2);
-        ft[0] = std::move(lk_f[l]); ft[1] = std::move(lk_t[l]);
-        e2.lk_phi = &ft;
-        PB a, b;
-        a.col(CT_LK_PHI, 0).addc(C_BETA).fold(C_ONE);
-        b.col(CT_LK_PHI, 1).addc(C_BETA).fold(C_ONE);
-        PK_TRY(run_program(ctx, e2, a.g, inv.p));
-        PK_TRY(run_program(ctx, e2, b.g, (char*)inv.p + n * 32));
-        PK_TRY(zk_fr_batch_invert(ctx, inv.p, 2 * n));
-        std::vector<DevBuf> iv(2);
-        // g = inv_f - m * inv_t
-        PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, (char*)inv.p + n * 32, g.p, n));
-        PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, inv.p, g.p, g.p, n));
-        PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
-        F4 closing;
-        PK_TRY(zk_d2h(ctx, &closing, (char*)phi.p + (size_t)pk->u * 32, 32));
-        if (!host::fr_is_zero(closing)) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: grand sum does not close", l);
-        std::vector<F4> blind(pk->bf);
-        for (auto& x : blind) x = rng.next_fr();
-        PK_TRY(zk_h2d(ctx, (char*)phi.p + (n - pk->bf) * 32, blind.data(), pk->bf * 32));
-        lk_f[l] = std::move(ft[0]); lk_t[l] = std::move(ft[1]);
-        G1Affine com;
-        PK_TRY(commit_lagrange(ctx, srs, phi.fr(), n, &com));
-        tr.write_point(com);
-        lk_phi[l] = std::move(phi);
-        PK_TRY(zk_ctx_sync(ctx));
+        DevBuf inv, g, closing_d;
+        if (!inv.alloc(2 * n * 32) || !g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        std::vector<F4> blind((size_t)pk->L * pk->bf);
+        std::vector<const void*> pptrs(pk->L);
+        for (uint32_t l = 0; l < pk->L; ++l) {
+            DevBuf phi;
+            if (!phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            Env e2 = lag;
+            // program over explicit buffers: use CT_LK_PHI slots 0/1 as scratch references for f and t
+            std::vector<DevBuf> ft(2);
+            ft[0] = std::move(lk_f[l]); ft[1] = std::move(lk_t[l]);
+            e2.lk_phi = &ft;
+            PB a, b;
+            a.col(CT_LK_PHI, 0).addc(C_BETA).fold(C_ONE);
+            b.col(CT_LK_PHI, 1).addc(C_BETA).fold(C_ONE);
+            PK_TRY(run_program(ctx, e2, a.g, inv.p));
+            PK_TRY(run_program(ctx, e2, b.g, (char*)inv.p + n * 32));
+            PK_TRY(zk_fr_batch_invert(ctx, inv.p, 2 * n));
+            // g = inv_f - m * inv_t
+            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, (char*)inv.p + n * 32, g.p, n));
+            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, inv.p, g.p, g.p, n));
+            PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
+            ZK_HIP(ctx, hipMemcpyAsync((char*)closing_d.p + (size_t)l * 32, (char*)phi.p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
+            for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
+            ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
+            lk_f[l].release(); lk_t[l].release(); ft.clear();                   // f, t are not needed again (the quotient recomputes them on its cosets)
+            pptrs[l] = phi.p;
+            lk_phi[l] = std::move(phi);
+        }
+        std::vector<F4> closing(pk->L);
+        PK_TRY(zk_d2h(ctx, closing.data(), closing_d.p, (size_t)pk->L * 32));
+        for (uint32_t l = 0; l < pk->L; ++l)
+            if (!host::fr_is_zero(closing[l])) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: grand sum does not close", l);
+        trace.mark("  lookup: phi (all lookups)");
+        std::vector<G1Affine> coms(pk->L);
+        PK_TRY(zk_commit_batch(ctx, srs, 1, pptrs.data(), pk->L, n, coms.data()));
+        for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup phi");
     // ---- vanishing argument: random polynomial
@@ -745,7 +759,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             size_t key_cols = 0;
             for (uint32_t ref : refs) key_cols += of_key(ref);
             const char* env = getenv("ZK_PK_COSET_CACHE_GB");
-            const double budget = (env ? atof(env) : 48.0) * (double)(1ull << 30);
+            const double budget = (env ? atof(env) : 96.0) * (double)(1ull << 30);
             pk->part_cache_state = (double)key_cols * nparts * n * 32.0 <= budget ? 1 : 0;
             if (pk->part_cache_state) pk->part_cache.resize(nparts);
         }
