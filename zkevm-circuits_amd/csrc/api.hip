@@ -231,7 +231,7 @@ int zk_coeff_to_coset(zk_ctx* ctx, const void* d_coeffs, uint32_t k, const void*
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, d_coeffs && d_out && h_g, "null pointer");
     ZK_REQUIRE(ctx, k <= 28, "k exceeds the two-adicity of Fr (28)");
-    return ntt_run(ctx, (Fr*)d_out, k, fr_root_of_unity(k), nullptr, (const Fr*)h_g, nullptr, d_coeffs == d_out ? nullptr : (const Fr*)d_coeffs);
+    return ntt_run(ctx, (Fr*)d_out, k, fr_root_of_unity(k), nullptr, (const Fr*)h_g, nullptr, d_coeffs == d_out ? nullptr : (const Fr*)d_coeffs, /*fuse_pre=*/true);
 }
 int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k) {
     if (!ctx) return ZK_ERR_INVALID_ARG;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Fr* __restrict__ tw
 // LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
-           const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift) {
+           const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
@@ -152,7 +152,13 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
             for (int k = 0; k < 4; ++k) {
                 if (k >= (1 << r)) break;
                 const int dl = lo_d + k * hgt;
-                e[k] = first ? unpack29<Fr29P>(ldg(src + base + (uint64_t)bitrev(dl, log_np) * m + c)) : L.load((dl << log_t) | c);
+                if (first) {
+                    const uint64_t gi = base + (uint64_t)bitrev(dl, log_np) * m + c;
+                    e[k] = unpack29<Fr29P>(ldg(src + gi));
+                    if (pre) e[k] = mul29(e[k], unpack29<Fr29P>(ldg(pre + gi)));     // coset shift a[i] * g^i fused into the load (table in R' form)
+                } else {
+                    e[k] = L.load((dl << log_t) | c);
+                }
             }
             if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
 #pragma unroll
@@ -183,7 +189,7 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
 // the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, int log_np, int log_t,
-           int log_n1, int log_mid, Fr fin) {
+           int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
@@ -207,7 +213,13 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
             for (int k = 0; k < 4; ++k) {
                 if (k >= (1 << r)) break;
                 const int dl = lo_d + k * hgt;
-                e[k] = first ? unpack29<Fr29P>(ldg(src + (((i1 << log_mid) + mid) << log_np) + bitrev(dl, log_np))) : L.load((c << log_np) | dl);
+                if (first) {
+                    const uint64_t gi = (((i1 << log_mid) + mid) << log_np) + bitrev(dl, log_np);
+                    e[k] = unpack29<Fr29P>(ldg(src + gi));
+                    if (pre) e[k] = mul29(e[k], unpack29<Fr29P>(ldg(pre + gi)));     // only when this is the only pass
+                } else {
+                    e[k] = L.load((c << log_np) | dl);
+                }
             }
             if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
 #pragma unroll
@@ -320,7 +332,7 @@ static int pick_threads(int tile) { return tile >= 4096 ? 1024 : (tile >= 1024 ?
 // Generic driver.  `scale` (nullable) multiplies every output; coset_pre (nullable): a[i] *= g^i
 // before the transform; coset_post (nullable): out[i] *= g^i after it.  d_src (nullable): the input
 // is read from d_src and d_data only receives the result (out of place, no extra copy).
-int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, const Fr* d_src) {
+int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, const Fr* d_src, bool fuse_pre) {
     if (log_n == 0) {   // size-1 transform: identity (times the scale)
         if (d_src && d_src != d_data) ZK_HIP(ctx, hipMemcpyAsync(d_data, d_src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
         if (scale) {
@@ -357,7 +369,24 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         return ZK_OK;
     };
     const Fr* cur = d_src ? d_src : d_data;
-    if (coset_pre) { rc = run_distribute(*coset_pre, cur); if (rc) return rc; cur = d_data; }
+    const Fr* pre_table = nullptr;       // full table g^i (R' form), multiplied in by the first pass as it loads
+    if (coset_pre && fuse_pre) {
+        const uint64_t key = domain_key(log_n, *coset_pre, nullptr) ^ 0xF0117ABull;
+        auto it = ctx->pow_tables.find(key);
+        if (it != ctx->pow_tables.end()) {
+            pre_table = (const Fr*)it->second;
+        } else {
+            Fr* tab = nullptr;
+            if (hipMalloc(&tab, sizeof(Fr) * n) != hipSuccess) { (void)hipGetLastError(); tab = nullptr; }    // no memory: separate pass below
+            if (tab) {
+                int r = build_powers(ctx, *coset_pre, Fr::one(), tab, (uint32_t)n, 1);
+                if (r) return r;
+                ctx->pow_tables[key] = tab;
+                pre_table = tab;
+            }
+        }
+    }
+    if (coset_pre && !pre_table) { rc = run_distribute(*coset_pre, cur); if (rc) return rc; cur = d_data; }
 
     std::shared_ptr<NttDomain> dom;
     rc = get_domain(ctx, log_n, omega, scale, &dom);
@@ -380,7 +409,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
         ZkProfScope pscope(ctx, "ntt_pass");
         hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, out, ps.tw,
-                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift);
+                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr);
         ZK_CHECK_LAUNCH(ctx);
         cur = out;
     }
@@ -394,7 +423,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         ZkProfScope pscope(ctx, "ntt_last");
         hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
-                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul);
+                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr);
         ZK_CHECK_LAUNCH(ctx);
     }
     if (coset_post) { rc = run_distribute(*coset_post, d_data); if (rc) return rc; }

@@ -790,7 +790,9 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
                 PK_TRY(zk_coeff_to_coset(ctx, cf, k, &g, dst));
             }
+            trace.mark("  quotient: cosets of the columns");
             PK_TRY(run_program(ctx, part, q.g, hpart.p));
+            trace.mark("  quotient: program");
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
             const Fr vinv = fr_inv_host(gn - Fr::one());
