@@ -13,8 +13,8 @@
 //      END
 //
 // One lane per extended-domain row; control flow is uniform across the grid (every lane runs the
-// same instruction), so there is no divergence.  The operand stack lives in LDS laid out
-// [slot][limb][lane] (4-byte strided: bank-conflict-free), column reads are fully coalesced for
+// same instruction), so there is no divergence.  The two topmost operands live in registers, deeper
+// ones in LDS laid out [slot][limb][lane] (4-byte strided: bank-conflict-free), column reads are fully coalesced for
 // rot = 0 and shifted-coalesced for rot != 0.  The result is multiplied by the precomputed
 // 1/(X^n - 1) on the coset (period 2^(ext_k-k)) before it is written.
 // HBM side: 32 B per (column, rotation) read + 32 B written per row -- the streaming-bound member
@@ -52,7 +52,22 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     const bool live = i < ne;
     const uint32_t rot_scale = 1u << (ext_k - k);
     Fr acc = Fr::zero();
+    // The two topmost stack elements live in registers (t0 = top, t1 = second); element j < sp - 2
+    // lives in LDS slot j.  Runs like `a b MUL c SUB` never touch LDS, and the LDS footprint per
+    // lane (what bounds occupancy here) is max_depth - 2 slots.
+    Fr t0 = Fr::zero(), t1 = Fr::zero();
     int sp = 0;
+    auto push = [&](const Fr& v) {
+        if (sp >= 2) st.put(sp - 2, t1);
+        t1 = t0;
+        t0 = v;
+        ++sp;
+    };
+    auto drop_to = [&](const Fr& top) {      // two operands consumed, `top` is the new top of stack
+        --sp;
+        t0 = top;
+        if (sp >= 2) t1 = st.get(sp - 2);
+    };
     for (uint32_t pc = 0; pc < prog_len; ++pc) {
         const uint32_t op = prog[3 * pc], a = prog[3 * pc + 1], b = prog[3 * pc + 2];
         if (op == Q_END) break;
@@ -60,19 +75,19 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
             case Q_PUSH_COL: {
                 const int64_t rot = (int32_t)b;
                 const uint64_t row = (i + (uint64_t)(rot * (int64_t)rot_scale)) & (ne - 1);
-                st.put(sp++, live ? ldg(cols[a] + row) : Fr::zero());
+                push(live ? ldg(cols[a] + row) : Fr::zero());
                 break;
             }
-            case Q_PUSH_CONST: st.put(sp++, ldg(consts + a)); break;
-            case Q_ADD: { Fr y = st.get(--sp), x = st.get(sp - 1); st.put(sp - 1, x + y); break; }
-            case Q_SUB: { Fr y = st.get(--sp), x = st.get(sp - 1); st.put(sp - 1, x - y); break; }
-            case Q_MUL: { Fr y = st.get(--sp), x = st.get(sp - 1); st.put(sp - 1, x * y); break; }
-            case Q_NEG: st.put(sp - 1, neg(st.get(sp - 1))); break;
-            case Q_SQUARE: st.put(sp - 1, sqr(st.get(sp - 1))); break;
-            case Q_DOUBLE: st.put(sp - 1, dbl(st.get(sp - 1))); break;
-            case Q_FOLD: acc = acc * ldg(consts + a) + st.get(--sp); break;
-            case Q_MUL_CONST: st.put(sp - 1, st.get(sp - 1) * ldg(consts + a)); break;
-            case Q_ADD_CONST: st.put(sp - 1, st.get(sp - 1) + ldg(consts + a)); break;
+            case Q_PUSH_CONST: push(ldg(consts + a)); break;
+            case Q_ADD: drop_to(t1 + t0); break;
+            case Q_SUB: drop_to(t1 - t0); break;
+            case Q_MUL: drop_to(t1 * t0); break;
+            case Q_NEG: t0 = neg(t0); break;
+            case Q_SQUARE: t0 = sqr(t0); break;
+            case Q_DOUBLE: t0 = dbl(t0); break;
+            case Q_FOLD: acc = acc * ldg(consts + a) + t0; drop_to(t1); break;
+            case Q_MUL_CONST: t0 = t0 * ldg(consts + a); break;
+            case Q_ADD_CONST: t0 = t0 + ldg(consts + a); break;
             default: break;
         }
     }
@@ -151,7 +166,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     if (!tev.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_tev, tev.data(), tev_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
-    const size_t lds = (size_t)depth * 8 * Q_THREADS * 4;
+    const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 8 * Q_THREADS * 4;    // the two topmost elements are in registers
     static bool attr_set = false;
     if (!attr_set) {
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 8 * Q_THREADS * 4));
