@@ -347,7 +347,19 @@ def main():
                     "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
     args = ap.parse_args()
 
-    ctx = z.Context(0)
+    # multi-GPU: launched with `python -m torch.distributed.run --nproc-per-node N bench_proof.py ...`
+    # -> one rank per GPU, sharded proving session (zk_proof_set_sharding), rank 0 reports.
+    world, rank, shard = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), None
+    device = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from zkevm_circuits_amd import sharding as shard
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
+        # fewer GPUs than ranks (single-GPU test box): ranks share a device and exchange over gloo
+        dist.init_process_group(backend="nccl" if torch.cuda.device_count() >= world else "gloo")
+    ctx = z.Context(device)
     t0 = time.perf_counter()
     if args.shape:
         sa, sf, sp, sl, sd = (int(v) for v in args.shape.split(","))
@@ -382,11 +394,21 @@ def main():
     proof = b""
     for _ in range(args.repeat):
         t0 = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+            t0 = time.perf_counter()
         sess = ctx.proof_session(pk, inst_m, bytes(16))
         sess.set_multiopen(1 if args.shplonk else 0)
+        keep = shard.shard_session(sess) if world > 1 else None
         sess.advice_phase({i: c for i, c in enumerate(adv_m)})
         proof = sess.finish()
+        del keep
+        if world > 1:
+            dist.barrier()
         times.append(time.perf_counter() - t0)
+    if world > 1 and rank != 0:
+        dist.destroy_process_group()
+        return
     ok = None
     if not args.no_verify:
         from oracle import cref, pairing as pr, plonk_verifier as pv
@@ -403,8 +425,11 @@ def main():
         "srs_setup_s": round(t_srs, 4), "host_circuit_build_s": round(t_build, 2), "verified_by_oracle": ok,
         "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + d - 3) // (d - 2) + 1 + (d - 1),
         "multiopen": "shplonk" if args.shplonk else "gwc", "data": "synthetic-shape",
-        "advice_host_memory": "pinned" if args.pinned else "pageable",
+        "advice_host_memory": "pinned" if args.pinned else "pageable", "n_gpus": world,
     }
+    if world > 1:
+        out["metric"] = f"synthetic-shape full proof wall-clock (s), {world} ranks (sharded session)"
+        dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 
 

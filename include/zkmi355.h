@@ -199,6 +199,16 @@ typedef struct zk_proof zk_proof;
 enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };
 int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* proof, int kind);
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
+/* Multi-GPU proving: one process per GPU, every rank runs the SAME session calls on
+ * the same key, witness and seed.  Rank r then commits only columns r, r + world, ... and evaluates
+ * only cosets r, r + world, ... of the quotient; commitments (64 B each) and finished cosets
+ * (2^k x 32 B each) are exchanged through `gather`, so all ranks produce the same transcript and
+ * the same proof bytes as an unsharded session.  gather(user, send, bytes, recv) must all-gather
+ * `bytes` bytes from every rank into recv (world x bytes, rank-major) and return 0 -- e.g.
+ * torch.distributed.all_gather_into_tensor over RCCL, see zkevm-circuits_amd/sharding.py.
+ * Call between zk_proof_begin and the first advice phase.                                          */
+typedef int (*zk_allgather_fn)(void* user, const void* h_send, size_t bytes, void* h_recv);
+int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* proof, uint32_t rank, uint32_t world, zk_allgather_fn gather, void* user);
 /* commits the advice columns of the current phase (h_cols[j] = advice column col_index[j], exactly
  * the columns of that phase) and writes the challenges that become usable after it to
  * h_challenges (32 B each, Montgomery Fr, challenge-index order)                                 */

@@ -1,0 +1,26 @@
+"""GPU: a proving session sharded over ranks (commitments and quotient cosets split
+over the ranks, 64-byte points and finished cosets all-gathered) yields, on every rank, exactly the
+bytes of the unsharded session.  The box has one GPU, so the ranks share cuda:0 and exchange over
+gloo; the code path is the one an 8-GPU node runs with backend nccl (RCCL)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world,k,multiopen", [(2, 7, 0), (3, 8, 1)])
+def test_sharded_session_matches_single(tmp_path, world, k, multiopen):
+    port = 29500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "_sharded_proof_worker.py"), str(tmp_path), str(k), str(multiopen)]
+    env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    single = open(tmp_path / "proof_single.bin", "rb").read()
+    assert len(single) > 500
+    for r in range(world):
+        assert open(tmp_path / f"proof_{r}.bin", "rb").read() == single, f"rank {r} produced a different proof"

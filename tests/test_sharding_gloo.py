@@ -48,6 +48,15 @@ def _worker(rank, world, port, q):
         # slices tile [0, n)
         sizes = [sharding.point_slice(n, r, world) for r in range(world)]
         assert sizes[0].start == 0 and sizes[-1].stop == n and all(a.stop == b_.start for a, b_ in zip(sizes, sizes[1:]))
+        # --- the all-gather callback a sharded proving session calls from C (zk_proof_set_sharding)
+        import ctypes
+        cb = sharding.make_allgather()
+        nbytes = 96
+        send = (ctypes.c_uint8 * nbytes)(*[(7 * rank + i) & 0xFF for i in range(nbytes)])
+        recv = (ctypes.c_uint8 * (nbytes * world))()
+        assert cb(None, ctypes.addressof(send), nbytes, ctypes.addressof(recv)) == 0
+        for r in range(world):
+            assert list(recv[r * nbytes:(r + 1) * nbytes]) == [(7 * r + i) & 0xFF for i in range(nbytes)]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

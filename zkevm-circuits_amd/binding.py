@@ -165,6 +165,11 @@ class ProofSession:
         """0 = GWC (default), 1 = SHPLONK."""
         self.ctx._ck(lib().zk_proof_set_multiopen(self.ctx.h, self.h, ctypes.c_int(kind)))
 
+    def set_sharding(self, rank: int, world: int, allgather_cb):
+        """This rank's share of a multi-GPU proof; allgather_cb is a sharding.ALLGATHER_FN instance."""
+        self._gather_cb = allgather_cb          # keep the ctypes thunk alive
+        self.ctx._ck(lib().zk_proof_set_sharding(self.ctx.h, self.h, ctypes.c_uint32(rank), ctypes.c_uint32(world), allgather_cb, None))
+
     def advice_phase(self, columns: dict) -> np.ndarray:
         """columns: {advice column index: (n, 4) u64 Montgomery array}; returns (num_challenges, 4) u64."""
         idx = sorted(columns)

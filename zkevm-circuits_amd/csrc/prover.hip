@@ -137,6 +137,11 @@ struct zk_proof {
     std::vector<DevBuf> inst_lag, inst_coeff, adv_lag;
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
+    // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
+    // commitments and quotient cosets are split over the ranks, results exchanged through `gather`
+    uint32_t rank = 0, world = 1;
+    zk_allgather_fn gather = nullptr;
+    void* gather_user = nullptr;
     std::vector<F4> challenges;
     zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
@@ -316,6 +321,22 @@ void lagrange_masks(const zk_pk* pk, std::vector<F4>* l0, std::vector<F4>* llast
     for (size_t i = 0; i < pk->u; ++i) (*lactive)[i] = one;
 }
 
+// `count` commitments over one basis, split over the ranks of a sharded session: rank r commits
+// columns i = r, r + world, ... (pipelined batch) and the 64-byte points are all-gathered, so every
+// rank ends up with all of them in order and the transcripts stay identical.
+int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out) {
+    if (pr->world <= 1 || !pr->gather) return zk_commit_batch(ctx, srs, basis, ptrs, count, n, out);
+    const size_t per = (count + pr->world - 1) / pr->world;
+    std::vector<const void*> mine;
+    for (size_t i = pr->rank; i < count; i += pr->world) mine.push_back(ptrs[i]);
+    std::vector<G1Affine> local(per), all(per * pr->world);
+    memset((void*)local.data(), 0, sizeof(G1Affine) * per);
+    PK_TRY(zk_commit_batch(ctx, srs, basis, mine.data(), mine.size(), n, local.data()));
+    if (per && pr->gather(pr->gather_user, local.data(), per * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+    for (size_t i = 0; i < count; ++i) out[i] = all[(i % pr->world) * per + i / pr->world];
+    return ZK_OK;
+}
+
 int upload(zk_ctx* ctx, DevBuf* b, const void* h, size_t bytes) {
     if (!b->alloc(bytes)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", bytes);
     return zk_h2d(ctx, b->p, h, bytes);
@@ -461,6 +482,14 @@ int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* pr, int kind) {
     return ZK_OK;
 }
 
+int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* pr, uint32_t rank, uint32_t world, zk_allgather_fn gather, void* user) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && world >= 1 && rank < world && (world == 1 || gather), "need rank < world and an all-gather callback");
+    ZK_REQUIRE(ctx, pr->phase == 0, "sharding must be set before the first advice phase");
+    pr->rank = rank; pr->world = world; pr->gather = gather; pr->gather_user = user;
+    return ZK_OK;
+}
+
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
@@ -505,6 +534,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     struct Stage {
         zk_ctx* ctx; size_t body, tail;
         std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind;
+        uint32_t world = 1;
     } sg{ctx, (n - pk->bf) * 32, (size_t)pk->bf * 32, {}, {}, {}};
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
@@ -514,14 +544,33 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         for (uint32_t r = 0; r < pk->bf; ++r) sg.blind.push_back(pr->rng.next_fr());
     }
     PK_TRY(copy_stream_open(ctx));
+    // Sharded session: every rank uploads every column (each GPU has its own PCIe link; all of them
+    // are needed for the quotient) but commits only columns rank, rank + world, ...: the upload of
+    // `world` columns hides one MSM.
+    sg.world = pr->world > 1 && pr->gather ? pr->world : 1;
     auto stage = [](void* user, size_t it) -> int {
         Stage* s_ = (Stage*)user;
-        ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[it], s_->src[it], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
-        ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[it] + s_->body, s_->blind.data() + it * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+        for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
+            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind.data() + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+        }
         return copy_stream_fence(s_->ctx);
     };
     std::vector<G1Affine> coms(sg.dst.size());
-    PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg));
+    if (sg.world == 1) {
+        PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg));
+    } else {
+        const size_t total = sg.dst.size(), per = (total + sg.world - 1) / sg.world;
+        std::vector<const void*> mine;
+        for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) mine.push_back(sg.dst[c_]);
+        std::vector<G1Affine> local(per), all(per * sg.world);
+        memset((void*)local.data(), 0, sizeof(G1Affine) * per);
+        PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));   // MSM j reads group j of `world` columns
+        for (size_t grp = mine.size(); grp * sg.world < total; ++grp) PK_TRY(stage(&sg, grp));                   // a last group without a column of this rank
+        PK_TRY(zk_ctx_sync(ctx));
+        if (per && pr->gather(pr->gather_user, local.data(), per * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+        for (size_t c_ = 0; c_ < total; ++c_) coms[c_] = all[(c_ % sg.world) * per + c_ / sg.world];
+    }
     trace.mark("advice upload + commits");
     for (const G1Affine& com : coms) pr->tr.write_point(com);
     uint32_t written = 0;
@@ -586,7 +635,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (st[l] != 0xFFFFFFFFu) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %u is not in the table (witness does not satisfy the circuit)", l, st[l]);
         trace.mark("  lookup: m (all lookups)");
         std::vector<G1Affine> coms(pk->L);
-        PK_TRY(zk_commit_batch(ctx, srs, 1, mptrs.data(), pk->L, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data()));
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup m");
@@ -638,7 +687,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         trace.mark("  perm: chain + blind");
         std::vector<G1Affine> coms(pk->C);
-        PK_TRY(zk_commit_batch(ctx, srs, 1, zptrs.data(), pk->C, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, zptrs.data(), pk->C, n, coms.data()));
         trace.mark("  perm: commits");
         for (const G1Affine& com : coms) tr.write_point(com);
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
@@ -682,7 +731,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (!host::fr_is_zero(closing[l])) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: grand sum does not close", l);
         trace.mark("  lookup: phi (all lookups)");
         std::vector<G1Affine> coms(pk->L);
-        PK_TRY(zk_commit_batch(ctx, srs, 1, pptrs.data(), pk->L, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, pptrs.data(), pk->L, n, coms.data()));
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup phi");
@@ -774,7 +823,19 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         part.part = &part_of;
         const Fr w_n = fr_root_of_unity(k), w_ext = fr_root_of_unity(ext_k);
         Fr g = fr_zeta();
+        // sharded session: rank q evaluates cosets q, q + world, ...; after every round of `world`
+        // cosets the (already divided) results are all-gathered and interleaved into h on every rank
+        const bool sharded = pr->world > 1 && pr->gather;
+        const Fr one_fr = Fr::one();
+        std::vector<uint8_t> send, recv;
+        DevBuf rtmp;
+        if (sharded) {
+            send.assign(n * 32, 0);
+            recv.resize((size_t)pr->world * n * 32);
+            if (!rtmp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        }
         for (uint32_t r_ = 0; r_ < nparts; ++r_) {
+          if (!sharded || r_ % pr->world == pr->rank) {
             for (size_t i = 0; i < refs.size(); ++i) {
                 void* dst = part_buf[i].p;
                 if (cache_on && of_key(refs[i])) {
@@ -796,17 +857,31 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
             const Fr vinv = fr_inv_host(gn - Fr::one());
-            PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, &vinv, h.p, nparts, r_));
+            if (sharded) PK_TRY(zk_fr_scale(ctx, hpart.p, &vinv, n));            // peers receive the finished values
+            PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &vinv, h.p, nparts, r_));
+          }
             g = g * w_ext;
+            if (sharded && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
+                const uint32_t round0 = r_ - r_ % pr->world;                        // first coset of this round
+                if (round0 + pr->rank < nparts) PK_TRY(zk_d2h(ctx, send.data(), hpart.p, n * 32));
+                if (pr->gather(pr->gather_user, send.data(), n * 32, recv.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+                for (uint32_t q_ = 0; q_ < pr->world; ++q_) {
+                    if (q_ == pr->rank || round0 + q_ >= nparts) continue;
+                    PK_TRY(zk_h2d(ctx, rtmp.p, recv.data() + (size_t)q_ * n * 32, n * 32));
+                    PK_TRY(zk_fr_scatter_scaled(ctx, rtmp.p, n, &one_fr, h.p, nparts, round0 + q_));
+                }
+            }
         }
     }
     PK_TRY(zk_extended_to_coeff(ctx, h.p, ext_k));
     trace.mark("quotient eval + ifft");
     const uint32_t pieces = pk->d - 1;
-    for (uint32_t i = 0; i < pieces; ++i) {
-        G1Affine com;
-        PK_TRY(commit_coeff(ctx, srs, h.fr() + (size_t)i * n, n, &com));
-        tr.write_point(com);
+    {
+        std::vector<const void*> hptrs(pieces);
+        for (uint32_t i = 0; i < pieces; ++i) hptrs[i] = h.fr() + (size_t)i * n;
+        std::vector<G1Affine> coms(pieces);
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 0, hptrs.data(), pieces, n, coms.data()));
+        for (const G1Affine& com : coms) tr.write_point(com);
     }
 
     trace.mark("h commits");

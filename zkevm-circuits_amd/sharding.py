@@ -85,3 +85,37 @@ def msm_point_sharded(ctx: "binding.Context", d_scalars_ptr: int, d_bases_ptr: i
     """One MSM split over the ranks: the pointers address THIS rank's slice (see point_slice)."""
     partial = ctx.msm(d_scalars_ptr, d_bases_ptr, n_local)
     return all_reduce_g1(partial, group)
+
+
+# ---------------------------------------------------------------- sharded proof sessions
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+def make_allgather(group=None):
+    """ctypes callback for zk_proof_set_sharding: all-gathers `bytes` host bytes from every rank
+    (rank-major) with torch.distributed -- over RCCL (tensors staged through the rank's GPU) when
+    the backend is nccl, over gloo on the CPU otherwise.  Keep the returned object alive for the
+    lifetime of the session."""
+    dev = _device_for_backend(group)
+    world = dist.get_world_size(group)
+
+    def gather(_user, send_ptr, nbytes, recv_ptr):
+        try:
+            src = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send_ptr))
+            dst = np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * world)).from_address(recv_ptr))
+            t_in = torch.from_numpy(src).to(dev)
+            t_out = torch.empty(nbytes * world, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(t_out, t_in, group=group)
+            dst[:] = t_out.cpu().numpy()
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            print(f"[zkmi355 sharding] all-gather failed: {e!r}", flush=True)
+            return 1
+    return ALLGATHER_FN(gather)
+
+
+def shard_session(session: "binding.ProofSession", group=None):
+    """Turns `session` into this rank's share of a multi-GPU proof (same calls on every rank)."""
+    cb = make_allgather(group)
+    session.set_sharding(dist.get_rank(group), dist.get_world_size(group), cb)
+    return cb
