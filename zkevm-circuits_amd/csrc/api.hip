@@ -47,6 +47,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
     zk_ctx* c = new zk_ctx();
     c->device = device;
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) { delete c; return ZK_ERR_HIP; }
+    c->pool_cap = (size_t)((double)c->prop.totalGlobalMem * 0.8);    // blocks of finished proofs stay pooled up to 80 % of the device
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }
     c->own_stream = true;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return ZK_ERR_HIP; }

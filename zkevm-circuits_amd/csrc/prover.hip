@@ -134,7 +134,7 @@ struct zk_proof {
     const zk_pk* pk;
     host::XorShiftRng rng;
     host::Transcript tr;
-    std::vector<DevBuf> inst_lag, inst_coeff, adv_lag;
+    std::vector<DevBuf> inst_lag, inst_coeff, adv_lag, adv_coeff;
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
@@ -143,7 +143,7 @@ struct zk_proof {
     zk_allgather_fn gather = nullptr;
     void* gather_user = nullptr;
     std::vector<F4> challenges;
-    zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), adv_lag(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
+    zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), adv_lag(k->A), adv_coeff(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
 
 namespace {
@@ -535,12 +535,16 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         zk_ctx* ctx; size_t body, tail;
         std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind;
         uint32_t world = 1;
+        const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
     } sg{ctx, (n - pk->bf) * 32, (size_t)pk->bf * 32, {}, {}, {}};
+    sg.pk = pk;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
         if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
         sg.src.push_back(by_col[c]);
         sg.dst.push_back(pr->adv_lag[c].p);
+        sg.lag.push_back(&pr->adv_lag[c]);
+        sg.coeff.push_back(&pr->adv_coeff[c]);
         for (uint32_t r = 0; r < pk->bf; ++r) sg.blind.push_back(pr->rng.next_fr());
     }
     PK_TRY(copy_stream_open(ctx));
@@ -550,6 +554,11 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     sg.world = pr->world > 1 && pr->gather ? pr->world : 1;
     auto stage = [](void* user, size_t it) -> int {
         Stage* s_ = (Stage*)user;
+        // the group uploaded by the previous call is on the device (the main stream has waited for it):
+        // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
+        if (it > 0)
+            for (size_t c_ = (it - 1) * s_->world; c_ < std::min(it * (size_t)s_->world, s_->dst.size()); ++c_)
+                PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind.data() + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
@@ -600,7 +609,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     host::XorShiftRng& rng = pr->rng;
     host::Transcript& tr = pr->tr;
     std::vector<DevBuf>&inst_lag = pr->inst_lag, &inst_coeff = pr->inst_coeff, &adv_lag = pr->adv_lag;
-    std::vector<DevBuf> adv_coeff(pk->A);
+    std::vector<DevBuf>& adv_coeff = pr->adv_coeff;     // computed during the advice phases, in the shadow of the uploads
     const F4 one = host::fr_one();
     StageTrace trace(ctx);
     Env lag{pk, nullptr, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
@@ -752,7 +761,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
 
     // ---- coefficient forms of everything the quotient reads and the proof opens
     std::vector<DevBuf> pz_coeff(pk->C), m_coeff(pk->L), phi_coeff(pk->L);
-    for (uint32_t i = 0; i < pk->A; ++i) PK_TRY(to_coeff(ctx, pk, adv_lag[i], &adv_coeff[i]));
+    for (uint32_t i = 0; i < pk->A; ++i) if (!adv_coeff[i].p) PK_TRY(to_coeff(ctx, pk, adv_lag[i], &adv_coeff[i]));
     for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(to_coeff(ctx, pk, pz_lag[c], &pz_coeff[c]));
     for (uint32_t l = 0; l < pk->L; ++l) {
         PK_TRY(to_coeff(ctx, pk, lk_m[l], &m_coeff[l]));
