@@ -104,3 +104,41 @@ def build_circuit(k: int, seed: int = 1, wide: bool = False):
             adv[3][muls[1] + 1] = adv[3][muls[1]] * adv[4][muls[1]] % R * adv[0][muls[1]] % R
             c.copy((plonk.ADVICE, 4, muls[0]), (plonk.ADVICE, 4, muls[1]))
     return c, adv, inst
+
+
+def build_rotation_circuit(k: int, seed: int = 1, window: int = 12, blinding_factors: int = 17):
+    """Keccak-like query pattern (12 rows per round, 59 unusable rows): one
+    advice column read at `window` + 2 distinct rotations, so the evaluation / multi-open stages
+    carry many (column, rotation) queries and large rotation sets.
+
+    columns: fixed 0 q_sum | 1 q_far      advice 0 a | 1 b
+    gates:   q_sum * (a + a.rot(1) + ... + a.rot(window-1) - b.rot(-3))
+             q_far * (a.rot(-5) * a.rot(window - 5) - b)
+    """
+    rng = random.Random(seed)
+    c = plonk.Circuit(k, num_fixed=2, num_advice=2, num_instance=1, blinding_factors=blinding_factors)
+    n, u = c.n, c.u
+    q_sum, q_far = c.fixed_col(0), c.fixed_col(1)
+    a, b_ = c.advice_col(0), c.advice_col(1)
+    acc = a
+    for i in range(1, window):
+        acc = acc + a.rot(i)
+    c.add_gate(q_sum * (acc - b_.rot(-3)))
+    c.add_gate(q_far * (a.rot(-5) * a.rot(window - 5) - b_))
+    adv = [[0] * n for _ in range(2)]
+    inst = [[0] * n]
+    for row in range(u):
+        adv[0][row] = rng.randrange(R)
+    for row in range(8, u - window - 2):
+        if row % 4 == 0:
+            c.fixed[0][row] = 1
+            adv[1][row - 3] = sum(adv[0][row + i] for i in range(window)) % R
+        elif row % 4 == 2:
+            c.fixed[1][row] = 1
+            adv[1][row] = adv[0][row - 5] * adv[0][row + window - 5] % R
+    c.enable_equality(plonk.ADVICE, 1)
+    c.enable_equality(plonk.INSTANCE, 0)
+    for j, row in enumerate((10, 14, 18)):
+        inst[0][j] = adv[1][row]
+        c.copy((plonk.ADVICE, 1, row), (plonk.INSTANCE, 0, j))
+    return c, adv, inst

@@ -172,3 +172,20 @@ def test_commit_batch_h2d_uploads_and_commits(ctx, cref):
     basis_pts = srs.download_g()
     assert np.array_equal(ctx.commit_batch_h2d(srs, 0, cols[:1], dev[:1], n)[0], cref.best_multiexp(cols[0], basis_pts))
     srs.destroy()
+
+
+def test_msm_2_23_closed_form_over_srs(ctx, cref):
+    """Above the BASELINE size (8 GiB of window tables): commit over g[i] = s^i G equals f(s) G in
+    both bases, single and batched."""
+    k, n, s = 23, 1 << 23, 0xABCDEF
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(s))
+    A = cref.rand_fr_stream(2323, n)
+    dA = ctx.to_device(A)
+    acc = cref.eval_polynomial(A, s)
+    want = cref.g1_mul(cref.affine_to_mont([bn254.G1_GEN]), cref.to_mont([acc]))[0]
+    assert np.array_equal(ctx.commit(srs, dA, n), want)
+    both = ctx.commit_batch(srs, [dA.ptr, dA.ptr], n)
+    assert np.array_equal(both[0], want) and np.array_equal(both[1], want)
+    ctx.ntt(dA, k)
+    assert np.array_equal(ctx.commit(srs, dA, n, lagrange=True), want)
+    srs.destroy()

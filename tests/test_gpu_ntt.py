@@ -77,3 +77,45 @@ def test_ntt_rejects_bad_sizes(zk, ctx):
     buf = ctx.alloc(64)
     with pytest.raises(zk.ZkError):
         ctx.ntt(buf, 29)
+
+
+@pytest.mark.parametrize("k,ext_k", [(4, 6), (9, 12), (11, 12), (14, 17)])
+def test_cosets_tile_the_extended_domain(ctx, cref, k, ext_k):
+    """zk_coeff_to_coset (coeff_to_extended_part): coset r = zeta * omega_ext^r of H holds the
+    extended-domain values at indices i * 2^(ext_k-k) + r; zk_fr_scatter_scaled interleaves them back."""
+    n, ne, parts = 1 << k, 1 << ext_k, 1 << (ext_k - k)
+    A = cref.rand_fr_stream(4100 + k, n)
+    dA, dE, dC, dX = ctx.to_device(A), ctx.alloc(ne * 32), ctx.alloc(n * 32), ctx.alloc(ne * 32)
+    ctx.coeff_to_extended(dA, k, ext_k, dE)
+    want = dE.download((ne, 4))
+    w_ext = bn254.omega_for_k(ext_k)
+    for r in range(parts):
+        g = bn254.FR_ZETA * pow(w_ext, r, bn254.R_MOD) % bn254.R_MOD
+        ctx.coeff_to_coset(dA, k, cref.fr_const(g), dC)
+        assert np.array_equal(dC.download((n, 4)), want[r::parts]), r
+        ctx.fr_scatter_scaled(dC, n, cref.fr_const(1), dX, parts, r)
+    assert np.array_equal(dX.download((ne, 4)), want)
+    # a scale is applied on the way: 3 * values
+    ctx.fr_scatter_scaled(dC, n, cref.fr_const(3), dX, parts, parts - 1)
+    got = cref.from_mont(dX.download((ne, 4))[parts - 1::parts][:4])
+    assert got == [3 * v % bn254.R_MOD for v in cref.from_mont(want[parts - 1::parts][:4])]
+    # in place
+    ctx.coeff_to_coset(dA, k, cref.fr_const(bn254.FR_ZETA), dA)
+    assert np.array_equal(dA.download((n, 4)), want[0::parts])
+
+
+def test_ntt_2_24_properties(ctx, cref):
+    """Above the BASELINE size (three passes): delta -> all ones, inverse round trip on random data."""
+    k, n = 24, 1 << 24
+    delta = np.zeros((n, 4), dtype=np.uint64)
+    delta[0] = cref.fr_const(1)[0]
+    d = ctx.to_device(delta)
+    ctx.ntt(d, k)
+    out = d.download((n, 4))
+    assert np.array_equal(out[::4097], np.repeat(cref.fr_const(1), out[::4097].shape[0], axis=0))
+    A = cref.rand_fr_stream(24, n)
+    d.upload(A)
+    ctx.ntt(d, k)
+    assert not np.array_equal(d.download((n, 4))[:64], A[:64])
+    ctx.ntt(d, k, inverse=True)
+    assert np.array_equal(d.download((n, 4)), A)

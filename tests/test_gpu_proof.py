@@ -189,3 +189,30 @@ def test_two_phase_proof_with_challenge(zk, ctx, cref, srs8, s_g2):
     bad = sess.finish()
     pk.destroy()
     assert not pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [], bad, s_g2)
+
+
+@pytest.mark.parametrize("multiopen", ["gwc", "shplonk"])
+def test_many_rotations_keccak_like(ctx, cref, srs8, s_g2, multiopen):
+    """One column opened at 14 distinct rotations with 17 blinding rows (the Keccak circuit's query
+    pattern): batched evaluations, rotation sets and witness polynomials of the
+    multi-open argument all see large point sets."""
+    from plonk_fixtures import build_rotation_circuit
+    circ, adv, inst = build_rotation_circuit(7, seed=3)
+    assert pv.check_witness(circ, adv, inst) is None
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], bytes(16))
+        sess.set_multiopen(1 if multiopen == "shplonk" else 0)
+        sess.advice_phase({i: plonk.column_to_mont(c) for i, c in enumerate(adv)})
+        proof = sess.finish()
+    finally:
+        pk.destroy()
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    assert pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen=multiopen)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    try:
+        assert not pv.verify(circ, vk_points, vk_repr, inst, bytes(bad), s_g2, multiopen=multiopen)
+    except AssertionError:
+        pass

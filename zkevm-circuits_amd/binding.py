@@ -285,6 +285,14 @@ class Context:
     def coeff_to_extended(self, coeffs: DeviceBuffer, k: int, ext_k: int, out: DeviceBuffer):
         self._ck(lib().zk_coeff_to_extended(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_uint32(k), ctypes.c_uint32(ext_k), ctypes.c_void_p(out.ptr)))
 
+    def coeff_to_coset(self, coeffs: DeviceBuffer, k: int, g_mont: np.ndarray, out: DeviceBuffer):
+        """out[i] = f(g * omega^i): one coset of the extended domain (coeff_to_extended_part)."""
+        self._ck(lib().zk_coeff_to_coset(self.h, ctypes.c_void_p(coeffs.ptr), ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(g_mont)), ctypes.c_void_p(out.ptr)))
+
+    def fr_scatter_scaled(self, src: DeviceBuffer, n: int, scale_mont: np.ndarray, dst: DeviceBuffer, stride: int, offset: int):
+        self._ck(lib().zk_fr_scatter_scaled(self.h, ctypes.c_void_p(src.ptr), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(scale_mont)),
+                                            ctypes.c_void_p(dst.ptr), ctypes.c_size_t(stride), ctypes.c_size_t(offset)))
+
     def extended_to_coeff(self, ext: DeviceBuffer, ext_k: int):
         self._ck(lib().zk_extended_to_coeff(self.h, ctypes.c_void_p(ext.ptr), ctypes.c_uint32(ext_k)))
 
