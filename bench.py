@@ -29,6 +29,8 @@ import torch  # noqa: E402  (device plumbing + torch.distributed only)
 K = 20
 N = 1 << K
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G), tools/ubench.hip
+MSM_WINDOWS = 16           # c = 16 signed digits at n = 2^20
 
 
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
@@ -185,6 +187,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "traffic": traffic,
                 "avg_launch_ms": round(bucket_ms, 4) if bucket_ms else None,
+                "traffic_GBps": round(traffic / (bucket_ms * 1e-3) / 1e9, 1) if (traffic and bucket_ms) else None,
+                # the binding roof (SURVEY 8d asks for both): one mixed XYZZ addition per (scalar, window) = 10
+                # Montgomery products, against the measured product peak of tools/ubench.hip
+                "alu": {"unit": "G Montgomery products/s", "peak": MULPEAK_G,
+                        "achieved": round(10.0 * N * MSM_WINDOWS / (bucket_ms * 1e-3) / 1e9, 1) if bucket_ms else None,
+                        "frac": round(10.0 * N * MSM_WINDOWS / (bucket_ms * 1e-3) / 1e9 / MULPEAK_G, 3) if bucket_ms else None},
                 "note": "integer-ALU bound (254-bit Montgomery arithmetic), see DESIGN.md; algorithmic bytes = 96 B x 2^20",
             },
             "extra": {

@@ -199,6 +199,23 @@ typedef struct zk_proof zk_proof;
 enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };
 int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* proof, int kind);
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
+/* External transcript (halo2's `T: TranscriptWrite<G1Affine, Challenge255>` argument of
+ * create_proof): by default the session runs halo2's Blake2bWrite itself and zk_proof_finish
+ * returns the proof bytes.  With a vtable every transcript operation is forwarded to the host
+ * language's own transcript object instead -- Poseidon for the aggregation layers
+ * (aggregator/src/core.rs:25-28), Keccak for EVM proofs (prover/src/common/prover/evm.rs:67) --
+ * which then also owns the proof bytes (zk_proof_finish reports length 0).  Points are 64 B
+ * affine (x || y, Montgomery limbs, identity = zeros), scalars 32 B Montgomery Fr; a callback
+ * returns 0 on success.  Call right after zk_proof_begin: what begin absorbed (vk representative,
+ * instance values) is replayed into the external transcript.                                       */
+typedef struct zk_transcript_vtable {
+    int (*common_point)(void* user, const void* affine64);
+    int (*common_scalar)(void* user, const void* fr32);
+    int (*write_point)(void* user, const void* affine64);
+    int (*write_scalar)(void* user, const void* fr32);
+    int (*squeeze_challenge)(void* user, void* fr32_out);
+} zk_transcript_vtable;
+int zk_proof_set_transcript(zk_ctx* ctx, zk_proof* proof, const zk_transcript_vtable* vtable, void* user);
 /* Multi-GPU proving: one process per GPU, every rank runs the SAME session calls on
  * the same key, witness and seed.  Rank r then commits only columns r, r + world, ... and evaluates
  * only cosets r, r + world, ... of the quotient; commitments (64 B each) and finished cosets

@@ -216,3 +216,69 @@ def test_many_rotations_keccak_like(ctx, cref, srs8, s_g2, multiopen):
         assert not pv.verify(circ, vk_points, vk_repr, inst, bytes(bad), s_g2, multiopen=multiopen)
     except AssertionError:
         pass
+
+
+class _HostBlake2bWrite:
+    """halo2's Blake2bWrite<_, G1Affine, Challenge255> kept on the host side of the ABI: what a Rust
+    shim passes as `transcript` (here the same hash, so the bytes must equal the built-in ones)."""
+
+    def __init__(self, cref):
+        import hashlib
+        self.cref = cref
+        self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.proof = bytearray()
+
+    def _point(self, raw64):
+        import numpy as np
+        return self.cref.affine_from_mont(np.frombuffer(raw64, dtype=np.uint64).reshape(1, 8))[0]
+
+    def _scalar(self, raw32):
+        import numpy as np
+        return self.cref.from_mont(np.frombuffer(raw32, dtype=np.uint64).reshape(1, 4))[0]
+
+    def common_point(self, raw64):
+        pt = self._point(raw64)
+        self.h.update(b"\x01" + (bytes(64) if pt is None else pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")))
+
+    def common_scalar(self, raw32):
+        self.h.update(b"\x02" + self._scalar(raw32).to_bytes(32, "little"))
+
+    def write_point(self, raw64):
+        self.common_point(raw64)
+        pt = self._point(raw64)
+        self.proof += bytes(32) if pt is None else (pt[0] | ((pt[1] & 1) << 255)).to_bytes(32, "little")
+
+    def write_scalar(self, raw32):
+        self.common_scalar(raw32)
+        self.proof += self._scalar(raw32).to_bytes(32, "little")
+
+    def squeeze_challenge(self):
+        self.h.update(b"\x00")
+        return self.cref.fr_const(b.fr_from_uniform_bytes(self.h.copy().digest())).tobytes()
+
+
+@pytest.mark.parametrize("multiopen", [0, 1])
+def test_external_transcript_matches_builtin(ctx, cref, srs8, multiopen):
+    """zk_proof_set_transcript: with the host's transcript object doing Blake2b, the bytes it
+    collects equal the proof of the built-in transcript (same session otherwise)."""
+    circ, adv, inst = build_circuit(7, 4, True)
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    adv_m = {i: plonk.column_to_mont(c) for i, c in enumerate(adv)}
+    inst_m = [plonk.column_to_mont(c) for c in inst]
+    try:
+        def run(external):
+            sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
+            sess.set_multiopen(multiopen)
+            tr = None
+            if external:
+                tr = _HostBlake2bWrite(cref)
+                sess.set_transcript(tr)
+            sess.advice_phase(adv_m)
+            out = sess.finish()
+            return bytes(tr.proof) if external else out, out
+        builtin, _ = run(False)
+        external, returned = run(True)
+    finally:
+        pk.destroy()
+    assert returned == b""                    # the host transcript owns the proof
+    assert len(builtin) > 500 and external == builtin

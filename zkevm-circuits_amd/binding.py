@@ -149,6 +149,14 @@ class ProvingKey:
             self.h = None
 
 
+_TR_IN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+_TR_OUT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+
+
+class _TranscriptVtable(ctypes.Structure):     # zk_transcript_vtable
+    _fields_ = [("common_point", _TR_IN), ("common_scalar", _TR_IN), ("write_point", _TR_IN), ("write_scalar", _TR_IN), ("squeeze_challenge", _TR_OUT)]
+
+
 class ProofSession:
     """begin -> advice_phase(...) per phase (returns that phase's challenges) -> finish()."""
 
@@ -164,6 +172,33 @@ class ProofSession:
     def set_multiopen(self, kind: int):
         """0 = GWC (default), 1 = SHPLONK."""
         self.ctx._ck(lib().zk_proof_set_multiopen(self.ctx.h, self.h, ctypes.c_int(kind)))
+
+    def set_transcript(self, transcript):
+        """Forward every transcript operation to `transcript`, an object with
+        common_point(bytes64) / common_scalar(bytes32) / write_point(bytes64) / write_scalar(bytes32)
+        (Montgomery limbs, as they cross the ABI) and squeeze_challenge() -> bytes32 (Montgomery Fr).
+        The object then owns the proof bytes; finish() returns b''."""
+        def wrap_in(fn, nbytes):
+            def cb(_user, ptr):
+                try:
+                    fn(ctypes.string_at(ptr, nbytes))
+                    return 0
+                except Exception as e:       # never let an exception cross the C boundary
+                    print(f"[zkmi355 transcript] callback failed: {e!r}", flush=True)
+                    return 1
+            return _TR_IN(cb)
+
+        def squeeze(_user, out_ptr):
+            try:
+                ctypes.memmove(out_ptr, bytes(transcript.squeeze_challenge()), 32)
+                return 0
+            except Exception as e:
+                print(f"[zkmi355 transcript] squeeze failed: {e!r}", flush=True)
+                return 1
+        vt = _TranscriptVtable(wrap_in(transcript.common_point, 64), wrap_in(transcript.common_scalar, 32),
+                               wrap_in(transcript.write_point, 64), wrap_in(transcript.write_scalar, 32), _TR_OUT(squeeze))
+        self._transcript = (transcript, vt)      # keep the thunks alive
+        self.ctx._ck(lib().zk_proof_set_transcript(self.ctx.h, self.h, ctypes.byref(vt), None))
 
     def set_sharding(self, rank: int, world: int, allgather_cb):
         """This rank's share of a multi-GPU proof; allgather_cb is a sharding.ALLGATHER_FN instance."""

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../include/zkmi355.h"
 #include "host_fq.hpp"
 
 namespace zk {
@@ -168,11 +169,18 @@ inline void g1_compress(const G1Affine& p, uint8_t out[32]) {
 
 // ------------------------------------------------------------------------------------ transcript
 // halo2_proofs::transcript::Blake2bWrite<_, G1Affine, Challenge255<_>>
+// halo2 Transcript / TranscriptWrite.  Built in: Blake2bWrite<_, G1Affine, Challenge255>.  With an
+// external vtable (zk_proof_set_transcript) every operation is forwarded to the host language's
+// own transcript object (Poseidon, Keccak/EVM, ...), which then also owns the proof bytes.
 struct Transcript {
     Blake2b st;
     std::vector<uint8_t> proof;
+    const zk_transcript_vtable* vt = nullptr;
+    void* user = nullptr;
+    int err = 0;                              // first non-zero status returned by an external callback
     Transcript() { st.init("Halo2-Transcript"); }
     void common_point(const G1Affine& p) {
+        if (vt) { if (int rc = vt->common_point(user, &p)) err = err ? err : rc; return; }
         uint8_t b[65];
         b[0] = 1;   // BLAKE2B_PREFIX_POINT
         if (p.is_identity()) memset(b + 1, 0, 64);
@@ -180,24 +188,32 @@ struct Transcript {
         st.update(b, 65);
     }
     void common_scalar(const F4& s) {
+        if (vt) { if (int rc = vt->common_scalar(user, &s)) err = err ? err : rc; return; }
         uint8_t b[33];
         b[0] = 2;   // BLAKE2B_PREFIX_SCALAR
         fr_to_repr(s, b + 1);
         st.update(b, 33);
     }
     void write_point(const G1Affine& p) {
+        if (vt) { if (int rc = vt->write_point(user, &p)) err = err ? err : rc; return; }
         common_point(p);
         uint8_t c[32];
         g1_compress(p, c);
         proof.insert(proof.end(), c, c + 32);
     }
     void write_scalar(const F4& s) {
+        if (vt) { if (int rc = vt->write_scalar(user, &s)) err = err ? err : rc; return; }
         common_scalar(s);
         uint8_t c[32];
         fr_to_repr(s, c);
         proof.insert(proof.end(), c, c + 32);
     }
     F4 squeeze() {
+        if (vt) {
+            F4 out = fr_zero();
+            if (int rc = vt->squeeze_challenge(user, &out)) err = err ? err : rc;
+            return out;
+        }
         const uint8_t z = 0;   // BLAKE2B_PREFIX_CHALLENGE
         st.update(&z, 1);
         uint8_t out[64];

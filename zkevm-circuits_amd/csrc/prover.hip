@@ -139,6 +139,8 @@ struct zk_proof {
     int multiopen = ZK_MULTIOPEN_GWC;
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
     // commitments and quotient cosets are split over the ranks, results exchanged through `gather`
+    std::vector<F4> absorbed;                // what zk_proof_begin fed the transcript (replayed into an external one)
+    zk_transcript_vtable ext_vt{};           // copy of the caller's vtable when an external transcript is set
     uint32_t rank = 0, world = 1;
     zk_allgather_fn gather = nullptr;
     void* gather_user = nullptr;
@@ -482,6 +484,20 @@ int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* pr, int kind) {
     return ZK_OK;
 }
 
+int zk_proof_set_transcript(zk_ctx* ctx, zk_proof* pr, const zk_transcript_vtable* vt, void* user) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && vt && vt->common_point && vt->common_scalar && vt->write_point && vt->write_scalar && vt->squeeze_challenge, "incomplete transcript vtable");
+    ZK_REQUIRE(ctx, pr->phase == 0 && !pr->tr.vt, "the transcript must be set once, before the first advice phase");
+    pr->ext_vt = *vt;
+    pr->tr.vt = &pr->ext_vt;
+    pr->tr.user = user;
+    for (const F4& s_ : pr->absorbed) pr->tr.common_scalar(s_);
+    pr->absorbed.clear();
+    pr->absorbed.shrink_to_fit();
+    if (pr->tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", pr->tr.err);
+    return ZK_OK;
+}
+
 int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* pr, uint32_t rank, uint32_t world, zk_allgather_fn gather, void* user) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, pr && world >= 1 && rank < world && (world == 1 || gather), "need rank < world and an all-gather callback");
@@ -497,10 +513,11 @@ int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, 
     const size_t n = (size_t)1 << pk->k;
     std::unique_ptr<zk_proof> pr(new zk_proof(pk, seed16));
     pr->tr.common_scalar(pk->vk_repr);
+    pr->absorbed.push_back(pk->vk_repr);
     // instances (KZG: not committed; absorbed as scalars)
     for (uint32_t i = 0; i < pk->I; ++i) {
         const F4* v = (const F4*)h_instance[i];
-        for (size_t row = 0; row < pk->u; ++row) pr->tr.common_scalar(v[row]);
+        for (size_t row = 0; row < pk->u; ++row) { pr->tr.common_scalar(v[row]); pr->absorbed.push_back(v[row]); }
         PK_TRY(upload(ctx, &pr->inst_lag[i], h_instance[i], n * 32));
         PK_TRY(to_coeff(ctx, pk, pr->inst_lag[i], &pr->inst_coeff[i]));
     }
@@ -590,6 +607,9 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         ++written;
     }
     if (num_challenges) *num_challenges = written;
+    if (pr->tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", pr->tr.err);
+    pr->absorbed.clear();
+    pr->absorbed.shrink_to_fit();
     ++pr->phase;
     return ZK_OK;
 }
@@ -1076,6 +1096,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         PK_TRY(zk_ctx_sync(ctx));
         trace.mark("multiopen (shplonk)");
+        if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", tr.err);
         *proof_len = tr.proof.size();
         if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
         memcpy(h_proof, tr.proof.data(), tr.proof.size());
@@ -1096,6 +1117,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     }
     PK_TRY(zk_ctx_sync(ctx));
     trace.mark("multiopen");
+    if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", tr.err);
     *proof_len = tr.proof.size();
     if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
     memcpy(h_proof, tr.proof.data(), tr.proof.size());
