@@ -140,10 +140,15 @@ int zk_lookup_multiplicities(zk_ctx* ctx, const void* d_inputs, const void* d_ta
 int zk_fr_random(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, uint64_t first_block, void* d_out, size_t n);
 
 /* ---- SRS: halo2_proofs::poly::kzg::commitment::ParamsKZG  -- SURVEY 8a A5 ---------------------- */
-/* Upload g (n = 2^k G1Affine) and optionally g_lagrange (may be NULL); host pointers.            */
+/* Upload g (n = 2^k G1Affine) and g_lagrange; host pointers.  h_g_lagrange may be NULL
+ * (ParamsKZG::from_parts with None): the Lagrange basis is then derived on the device.            */
 int zk_srs_create(zk_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagrange, zk_srs** out);
 /* ParamsKZG::unsafe_setup_with_s(k, s): g[i] = s^i * G, g_lagrange[i] = L_i(s) * G, on device.    */
 int zk_srs_setup_with_s(zk_ctx* ctx, uint32_t k, const void* h_s, zk_srs** out);
+/* ParamsKZG::downsize (prover/src/common/prover.rs:40-60: every layer shrinks the one params file
+ * to its own degree): the first 2^new_k points of g, with the Lagrange basis of the smaller domain
+ * recomputed on the device (g_to_lagrange: an inverse FFT over G1).                                 */
+int zk_srs_downsize(zk_ctx* ctx, const zk_srs* srs, uint32_t new_k, zk_srs** out);
 void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs);
 uint32_t zk_srs_k(const zk_srs* srs);
 const void* zk_srs_g(const zk_srs* srs);          /* device pointer, n G1Affine */

@@ -189,3 +189,41 @@ def test_msm_2_23_closed_form_over_srs(ctx, cref):
     ctx.ntt(dA, k)
     assert np.array_equal(ctx.commit(srs, dA, n, lagrange=True), want)
     srs.destroy()
+
+
+@pytest.mark.parametrize("k,small", [(1, 0), (6, 3), (11, 8)])
+def test_g_to_lagrange_and_downsize(ctx, cref, k, small):
+    """g_to_lagrange (inverse FFT over G1) against the closed form of unsafe_setup_with_s, whose
+    Lagrange basis is L_i(s) G with a known s; ParamsKZG::downsize against a fresh setup at the
+    smaller size; commit(coefficients) == commit_lagrange(evaluations) over the derived basis."""
+    s = cref.fr_const(0xD0C0FFEE)
+    full = ctx.srs_setup_with_s(k, s)
+    g, lag = full.download_g(), full.download_g_lagrange()
+    derived = ctx.srs_create(k, g)                       # no Lagrange basis supplied: derived on the device
+    assert np.array_equal(derived.download_g_lagrange(), lag)
+    shrunk, ref_small = full.downsize(small), ctx.srs_setup_with_s(small, s)
+    assert shrunk.k == small
+    assert np.array_equal(shrunk.download_g(), ref_small.download_g())
+    assert np.array_equal(shrunk.download_g_lagrange(), ref_small.download_g_lagrange())
+    n = 1 << small
+    A = cref.rand_fr_stream(77 + k, n)
+    dA = ctx.to_device(A)
+    c0 = ctx.commit(shrunk, dA, n)
+    ctx.ntt(dA, small)
+    assert np.array_equal(ctx.commit(shrunk, dA, n, lagrange=True), c0)
+    for s_ in (full, derived, shrunk, ref_small):
+        s_.destroy()
+
+
+def test_g_to_lagrange_2_16_timing(ctx, cref):
+    k = 16
+    full = ctx.srs_setup_with_s(k, cref.fr_const(12345))
+    import time
+    t0 = time.perf_counter()
+    shrunk = full.downsize(k - 1)
+    dt = time.perf_counter() - t0
+    ref = ctx.srs_setup_with_s(k - 1, cref.fr_const(12345))
+    assert np.array_equal(shrunk.download_g_lagrange(), ref.download_g_lagrange())
+    print(f"g_to_lagrange 2^{k - 1}: {dt * 1e3:.1f} ms")
+    for s_ in (full, shrunk, ref):
+        s_.destroy()

@@ -114,6 +114,12 @@ class Srs:
     def g_lagrange_ptr(self) -> Optional[int]:
         return lib().zk_srs_g_lagrange(self.h)
 
+    def downsize(self, new_k: int) -> "Srs":
+        """ParamsKZG::downsize: first 2^new_k points of g, Lagrange basis recomputed on the device."""
+        h = ctypes.c_void_p()
+        self.ctx._ck(lib().zk_srs_downsize(self.ctx.h, self.h, ctypes.c_uint32(new_k), ctypes.byref(h)))
+        return Srs(self.ctx, h)
+
     def download_g(self) -> np.ndarray:
         n = 1 << self.k
         out = np.empty((n, 8), dtype=np.uint64)

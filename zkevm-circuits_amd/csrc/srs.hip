@@ -113,10 +113,37 @@ int zk_srs_create(zk_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagr
     s->k = k;
     if (hipMalloc(&s->g, sizeof(G1Affine) * n) != hipSuccess) { delete s; return ctx->fail(ZK_ERR_OOM, "SRS allocation failed"); }
     ZK_HIP(ctx, hipMemcpyAsync(s->g, h_g, sizeof(G1Affine) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (hipMalloc(&s->g_lagrange, sizeof(G1Affine) * n) != hipSuccess) { (void)hipFree(s->g); delete s; return ctx->fail(ZK_ERR_OOM, "SRS allocation failed"); }
     if (h_g_lagrange) {
-        if (hipMalloc(&s->g_lagrange, sizeof(G1Affine) * n) != hipSuccess) { (void)hipFree(s->g); delete s; return ctx->fail(ZK_ERR_OOM, "SRS allocation failed"); }
         ZK_HIP(ctx, hipMemcpyAsync(s->g_lagrange, h_g_lagrange, sizeof(G1Affine) * n, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        // ParamsKZG::from_parts with g_lagrange = None: derive it (inverse FFT over G1, ecntt.hip)
+        int rc = g_to_lagrange(ctx, s->g, k, s->g_lagrange);
+        if (rc) { zk_srs_destroy(ctx, s); return rc; }
     }
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = s;
+    return ZK_OK;
+}
+
+// ParamsKZG::downsize: the first 2^new_k monomial-basis points with the Lagrange basis of the smaller domain
+int zk_srs_downsize(zk_ctx* ctx, const zk_srs* srs, uint32_t new_k, zk_srs** out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, srs && out, "null pointer");
+    ZK_REQUIRE(ctx, new_k <= srs->k, "downsize can only shrink the SRS");
+    const size_t n = (size_t)1 << new_k;
+    zk_srs* s = new zk_srs();
+    s->k = new_k;
+    if (hipMalloc(&s->g, sizeof(G1Affine) * n) != hipSuccess || hipMalloc(&s->g_lagrange, sizeof(G1Affine) * n) != hipSuccess) {
+        (void)hipGetLastError();
+        zk_srs_destroy(ctx, s);
+        return ctx->fail(ZK_ERR_OOM, "SRS allocation failed");
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(s->g, srs->g, sizeof(G1Affine) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = ZK_OK;
+    if (new_k == srs->k && srs->g_lagrange) ZK_HIP(ctx, hipMemcpyAsync(s->g_lagrange, srs->g_lagrange, sizeof(G1Affine) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    else rc = g_to_lagrange(ctx, s->g, new_k, s->g_lagrange);
+    if (rc) { zk_srs_destroy(ctx, s); return rc; }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = s;
     return ZK_OK;
