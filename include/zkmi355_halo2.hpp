@@ -138,6 +138,12 @@ class ParamsKZG {
         c.check(zk_srs_create(c.raw(), k, g.data(), g_lagrange.empty() ? nullptr : g_lagrange.data(), &p));
         return ParamsKZG(c, p);
     }
+    // ParamsKZG::downsize(k): g truncated, Lagrange basis of the smaller domain recomputed on the device
+    ParamsKZG downsize(uint32_t new_k) const {
+        zk_srs* p = nullptr;
+        c_.check(zk_srs_downsize(c_.raw(), srs_, new_k, &p));
+        return ParamsKZG(c_, p);
+    }
     ParamsKZG(ParamsKZG&& o) noexcept : c_(o.c_), srs_(o.srs_) { o.srs_ = nullptr; }
     ~ParamsKZG() { if (srs_) zk_srs_destroy(c_.raw(), srs_); }
     uint32_t k() const { return zk_srs_k(srs_); }
