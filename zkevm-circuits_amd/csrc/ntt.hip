@@ -119,6 +119,26 @@ __device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Fr* __restrict__ tw
         bfly29(e[1], e[3], tw29(tw, (uint32_t)(j + (1 << s)) << (log_np - 2 - s)));
     }
 }
+// (u, x) -> (u + x, u - x) for reduced operands (< 2p each, or sums of two such: x < 4p)
+__device__ __forceinline__ void bfly29_one(Fr29& u, Fr29& x) {
+    Fr29 a0 = add29(u, x), a1 = sub29k<4>(u, x);
+    normalize29(a0);
+    normalize29(a1);
+    u = a0;
+    x = a1;
+}
+// First step of a pass (s = 0): its operands come reduced from global memory and every twiddle of
+// stage 0 is omega^0 = 1, as is the j = 0 twiddle of stage 1 -- three of the four products of a
+// radix-4 step (the one of a radix-2 step) are products by one and are skipped.
+template <int R>
+__device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Fr* __restrict__ tw, int log_np) {
+    bfly29_one(e[0], e[1]);
+    if (R == 2) {
+        bfly29_one(e[2], e[3]);
+        bfly29_one(e[0], e[2]);
+        bfly29(e[1], e[3], tw29(tw, 1u << (log_np - 2)));
+    }
+}
 
 // ------------------------------------------------------------------------------ non-last pass
 // Tile = [n_p digits][T columns], element (d, c) lives at base + d*m + c with
@@ -160,7 +180,9 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
                     e[k] = L.load((dl << log_t) | c);
                 }
             }
-            if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
+            if (first) { if (r == 2) dit_first_step<2>(e, tw, log_np); else dit_first_step<1>(e, tw, log_np); }
+            else if (r == 2) dit_step<2>(e, tw, log_np, s, j);
+            else dit_step<1>(e, tw, log_np, s, j);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k >= (1 << r)) break;
@@ -221,7 +243,9 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
                     e[k] = L.load((c << log_np) | dl);
                 }
             }
-            if (r == 2) dit_step<2>(e, tw, log_np, s, j); else dit_step<1>(e, tw, log_np, s, j);
+            if (first) { if (r == 2) dit_first_step<2>(e, tw, log_np); else dit_first_step<1>(e, tw, log_np); }
+            else if (r == 2) dit_step<2>(e, tw, log_np, s, j);
+            else dit_step<1>(e, tw, log_np, s, j);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k >= (1 << r)) break;
