@@ -1,0 +1,81 @@
+"""GPU: empty inputs, misuse and error reporting of the newer C-ABI entry points (every call goes
+through ctypes into libzkmi355.so; errors must come back as status codes with a message, never as
+a crash or a silent success)."""
+import numpy as np
+import pytest
+
+from oracle import bn254
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batches_are_no_ops(zk, ctx, cref):
+    srs = ctx.srs_setup_with_s(6, cref.fr_const(5))
+    assert ctx.commit_batch(srs, [], 64).shape == (0, 8)
+    assert ctx.commit_batch_h2d(srs, 1, [], [], 64).shape == (0, 8)
+    assert ctx.poly_eval_batch([], 64, cref.fr_const(3)).shape == (0, 4)
+    out = ctx.alloc(64)
+    ctx.fr_random(bytes(32), 0, 0, out, 0)
+    m = ctx.alloc(64 * 32)
+    assert ctx.lookup_multiplicities(m, m, 0, m, 64) is None          # no usable rows: nothing can be missing
+    assert not m.download((64, 4)).any()
+    srs.destroy()
+
+
+def test_fr_random_is_a_pure_function_of_key_stream_and_counter(ctx, cref):
+    key = bytes(range(32))
+    a, b = ctx.alloc(100 * 32), ctx.alloc(100 * 32)
+    ctx.fr_random(key, 9, 1000, a, 100)
+    ctx.fr_random(key, 9, 1050, b, 50)
+    A, B = a.download((100, 4)), b.download((50, 4))
+    assert np.array_equal(A[50:], B)                                     # counter mode: block i is independent of the launch shape
+    ctx.fr_random(key, 10, 1000, b, 50)
+    assert not np.array_equal(b.download((50, 4)), A[:50])               # another stream
+    assert all(v < bn254.R_MOD for v in cref.from_mont(A))
+
+
+def test_scatter_and_coset_argument_checks(zk, ctx, cref):
+    buf = ctx.alloc(16 * 32)
+    with pytest.raises(zk.ZkError, match="offset < stride"):
+        ctx.fr_scatter_scaled(buf, 4, cref.fr_const(1), buf, 4, 4)
+    with pytest.raises(zk.ZkError, match="two-adicity"):
+        ctx.coeff_to_coset(buf, 29, cref.fr_const(1), buf)
+
+
+def test_session_misuse_is_reported(zk, ctx, cref):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from plonk_fixtures import build_circuit
+    from zkevm_circuits_amd import plonk, sharding
+    circ, adv, inst = build_circuit(6, 1, False)
+    srs = ctx.srs_setup_with_s(6, cref.fr_const(77))
+    pk = ctx.pk_create(srs, circ.blob())
+    adv_m = {i: plonk.column_to_mont(c) for i, c in enumerate(adv)}
+    inst_m = [plonk.column_to_mont(c) for c in inst]
+    try:
+        sess = ctx.proof_session(pk, inst_m, bytes(16))
+        with pytest.raises(zk.ZkError, match="rank < world"):
+            sess.set_sharding(2, 2, sharding.ALLGATHER_FN(lambda *a: 0))
+        with pytest.raises(zk.ZkError, match="unknown multi-open"):
+            sess.set_multiopen(7)
+        sess.advice_phase(adv_m)
+        with pytest.raises(zk.ZkError, match="before the first advice phase"):
+            sess.set_sharding(0, 2, sharding.ALLGATHER_FN(lambda *a: 0))
+        with pytest.raises(zk.ZkError, match="already committed"):
+            sess.advice_phase(adv_m)
+        assert len(sess.finish()) > 500
+        # a failing all-gather callback aborts the proof with a message instead of producing garbage
+        sess = ctx.proof_session(pk, inst_m, bytes(16))
+        bad = sharding.ALLGATHER_FN(lambda *a: 1)
+        sess.set_sharding(0, 2, bad)
+        with pytest.raises(zk.ZkError, match="all-gather callback failed"):
+            sess.advice_phase(adv_m)
+        sess.abort()
+        # SRS of another size than the circuit
+        other = ctx.srs_setup_with_s(7, cref.fr_const(77))
+        with pytest.raises(zk.ZkError):
+            ctx.pk_create(other, circ.blob())
+        other.destroy()
+    finally:
+        pk.destroy()
+        srs.destroy()
