@@ -76,11 +76,11 @@ __host__ __device__ __forceinline__ Fq29 neg_canon29(const Fq29& y) { return sub
 // 2 * (affine Q)  (mdbl-2008-s-1)
 __host__ __device__ __forceinline__ G1Xyzz29 dbl_affine29(const G1Affine29& q) {
     Fq29 u = add_n(q.y, q.y);                // < 2p
-    Fq29 v = mul29(u, u), w = mul29(u, v), s = mul29(q.x, v);
-    Fq29 x2 = mul29(q.x, q.x);
+    Fq29 v = sqr29(u), w = mul29(u, v), s = mul29(q.x, v);
+    Fq29 x2 = sqr29(q.x);
     Fq29 m = add_n(add29(x2, x2), x2);       // 3 x^2 < 3.1p
     G1Xyzz29 r;
-    r.x = sub_n<3>(mul29(m, m), add_n(s, s));                 // < 1.1p + 3p
+    r.x = sub_n<3>(sqr29(m), add_n(s, s));                 // < 1.1p + 3p
     r.y = sub_n<2>(mul29(m, sub_n<5>(s, r.x)), mul29(w, q.y)); // s - x3 + 5p < 6.1p
     r.zz = v;
     r.zzz = w;
@@ -91,11 +91,11 @@ __host__ __device__ __forceinline__ G1Xyzz29 dbl_affine29(const G1Affine29& q) {
 __host__ __device__ __forceinline__ G1Xyzz29 dbl29pt(const G1Xyzz29& p) {
     if (is_identity29(p)) return p;
     Fq29 u = add_n(p.y, p.y);                // < 16p
-    Fq29 v = mul29(u, u), w = mul29(u, v), s = mul29(p.x, v);   // v < 2.6p, w < 1.3p, s < 1.2p
-    Fq29 x2 = mul29(p.x, p.x);               // < 1.4p
+    Fq29 v = sqr29(u), w = mul29(u, v), s = mul29(p.x, v);   // v < 2.6p, w < 1.3p, s < 1.2p
+    Fq29 x2 = sqr29(p.x);               // < 1.4p
     Fq29 m = add_n(add29(x2, x2), x2);       // < 4.2p
     G1Xyzz29 r;
-    r.x = sub_n<3>(mul29(m, m), add_n(s, s));                   // < 1.2p + 3p
+    r.x = sub_n<3>(sqr29(m), add_n(s, s));                   // < 1.2p + 3p
     r.y = sub_n<2>(mul29(m, sub_n<5>(s, r.x)), mul29(w, p.y));  // (s - x3 + 5p) < 6.2p
     r.zz = mul29(v, p.zz);
     r.zzz = mul29(w, p.zzz);
@@ -112,9 +112,9 @@ __host__ __device__ __forceinline__ G1Xyzz29 madd29(const G1Xyzz29& p, const G1A
         if (is_zero_mod_p29<9>(rd)) return dbl_affine29(q);
         return identity29();
     }
-    Fq29 pp = mul29(pd, pd), ppp = mul29(pd, pp), qq = mul29(p.x, pp);   // < 1.5p, 1.1p, 1.1p
+    Fq29 pp = sqr29(pd), ppp = mul29(pd, pp), qq = mul29(p.x, pp);   // < 1.5p, 1.1p, 1.1p
     G1Xyzz29 r;
-    r.x = sub_n<4>(mul29(rd, rd), add_n(add29(ppp, qq), qq));            // < 1.5p + 4p
+    r.x = sub_n<4>(sqr29(rd), add_n(add29(ppp, qq), qq));            // < 1.5p + 4p
     r.y = sub_n<2>(mul29(rd, sub_n<6>(qq, r.x)), mul29(p.y, ppp));       // < 1.4p + 2p
     r.zz = mul29(p.zz, pp);
     r.zzz = mul29(p.zzz, ppp);
@@ -131,9 +131,9 @@ __host__ __device__ __forceinline__ G1Xyzz29 add29pt(const G1Xyzz29& p, const G1
         if (is_zero_mod_p29<3>(rd)) return dbl29pt(p);
         return identity29();
     }
-    Fq29 pp = mul29(pd, pd), ppp = mul29(pd, pp), qq = mul29(u1, pp);
+    Fq29 pp = sqr29(pd), ppp = mul29(pd, pp), qq = mul29(u1, pp);
     G1Xyzz29 r;
-    r.x = sub_n<4>(mul29(rd, rd), add_n(add29(ppp, qq), qq));
+    r.x = sub_n<4>(sqr29(rd), add_n(add29(ppp, qq), qq));
     r.y = sub_n<2>(mul29(rd, sub_n<6>(qq, r.x)), mul29(s1, ppp));
     r.zz = mul29(mul29(p.zz, q.zz), pp);
     r.zzz = mul29(mul29(p.zzz, q.zzz), ppp);
@@ -172,7 +172,7 @@ __device__ inline Fq29 inv29(const Fq29& a) {
         // exponent p - 2: bits of the modulus with the low limb reduced by 2 (p = ...fd47, so no borrow)
         const uint32_t limb = Fq29P::P32::M(i >> 5) - (i < 32 ? 2u : 0u);
         if ((limb >> (i & 31)) & 1) r = mul29(r, b);
-        b = mul29(b, b);
+        b = sqr29(b);
     }
     return r;
 }

@@ -175,6 +175,41 @@ __host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& 
     return t;
 }
 
+// Montgomery square: the cross products a_i a_j (i < j) are taken once against the doubled limb,
+// 45 products instead of 81 in the operand part (the reduction part is unchanged): 126 vs 162.
+// Same operand and result bounds as mul29(a, a).
+template <class P>
+__host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) {
+    uint32_t m[9], a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
+    F29<P> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a2[i] * a.l[k - i];
+        if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M(k - i);
+        m[k] = ((uint32_t)acc * P::INV) & MASK29;
+        acc += (uint64_t)m[k] * P::M(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)a2[i] * a.l[k - i];
+        if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * P::M(k - i);
+        t.l[k - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    t.l[8] = (uint32_t)acc;
+    return t;
+}
+
 using Fq29 = F29<Fq29P>;
 using Fr29 = F29<Fr29P>;
 
