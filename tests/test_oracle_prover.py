@@ -1,0 +1,43 @@
+"""CPU: the oracle's own prover (oracle/plonk_prover.py, a big-int restatement of halo2's
+create_proof) against the oracle's pairing verifier -- the whole path without a GPU.  The GPU
+session is compared byte for byte against this prover in tests/test_gpu_proof.py."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import pairing as pr  # noqa: E402
+from oracle import plonk_prover as pp  # noqa: E402
+from oracle import plonk_verifier as pv  # noqa: E402
+from plonk_fixtures import build_circuit, build_rotation_circuit  # noqa: E402
+
+S_SECRET = 0x5EC2E7
+
+
+@pytest.mark.parametrize("multiopen", ["gwc", "shplonk"])
+def test_oracle_prover_is_accepted_by_oracle_verifier(multiopen):
+    circ, adv, inst = build_circuit(5, seed=2, wide=True)
+    srs = pp.Srs(circ.k, S_SECRET)
+    vk_points, vk_repr = pp.vk_commitments(circ, srs), 0x1234567
+    proof = pp.create_proof(circ, srs, adv, inst, vk_repr, bytes(range(16)), multiopen)
+    s_g2 = pr.ec_mul(pr.G2_GEN, S_SECRET)
+    assert pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen=multiopen)
+    bad = bytearray(proof)
+    bad[40] ^= 1
+    try:
+        assert not pv.verify(circ, vk_points, vk_repr, inst, bytes(bad), s_g2, multiopen=multiopen)
+    except AssertionError:
+        pass                                  # the verifier may also refuse a malformed encoding outright
+    # another seed: other blinding, other bytes, still accepted
+    proof2 = pp.create_proof(circ, srs, adv, inst, vk_repr, bytes(16), multiopen)
+    assert proof2 != proof and pv.verify(circ, vk_points, vk_repr, inst, proof2, s_g2, multiopen=multiopen)
+
+
+def test_oracle_prover_many_rotations():
+    circ, adv, inst = build_rotation_circuit(6, seed=4, window=6, blinding_factors=10)
+    srs = pp.Srs(circ.k, S_SECRET)
+    vk_points = pp.vk_commitments(circ, srs)
+    proof = pp.create_proof(circ, srs, adv, inst, 99, bytes(16), "shplonk")
+    assert pv.verify(circ, vk_points, 99, inst, proof, pr.ec_mul(pr.G2_GEN, S_SECRET), multiopen="shplonk")
