@@ -180,6 +180,9 @@ def test_two_phase_proof_with_challenge(zk, ctx, cref, srs8, s_g2):
     proof = sess.finish()
     pk.destroy()
     assert pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [], proof, s_g2)
+    # the oracle prover squeezes the same challenges after phase 0 and arrives at the same bytes
+    from oracle import plonk_prover as pp
+    assert proof == pp.create_proof(circ, pp.Srs(k, S_SECRET), [av, bv, cv, dv], [], cref.from_mont(rep.reshape(1, 4))[0], bytes(16), "gwc")
     # a witness built with the WRONG challenge must not verify
     pk = ctx.pk_create(srs8[k], circ.blob())
     sess = ctx.proof_session(pk, [], bytes(16))
