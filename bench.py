@@ -76,10 +76,10 @@ def cpu_baseline(srs, column):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=4, help="columns submitted per commit_batch call (pipelined on the device)")
+    ap.add_argument("--batch", type=int, default=8, help="columns submitted per commit_batch call (pipelined on the device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
