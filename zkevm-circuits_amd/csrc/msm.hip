@@ -78,30 +78,46 @@ constexpr int MSM_RANGE_MAX_BITS = 11;   // <= 2048 buckets per workgroup
 // wflag[w] is raised when window w holds at least one non-zero digit: the sweeps skip the others
 // (selector / boolean / small-value columns leave most windows empty).
 template <int C>
-__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
+__device__ __forceinline__ void recode_all(const Fr& s, uint32_t (&code)[(256 + C - 1) / C]) {
     constexpr int W = (256 + C - 1) / C;      // window bits are a template parameter: every limb index below is static
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    if (i >= n) {
-#pragma unroll
-        for (int w = 0; w < W; ++w) dig[(uint64_t)w * n_pad + i] = (uint16_t)DIG_ZERO;
-        return;
-    }
-    const Fr s = from_mont(ldg(scalars + i));
-    uint32_t carry = 0;
     constexpr uint32_t mask = (1u << C) - 1, half = 1u << (C - 1);
+    uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         const int bit = w * C, limb = bit >> 5, sh = bit & 31;
         uint32_t d = limb < 8 ? (s.l[limb < 8 ? limb : 7] >> sh) : 0u;
         if (sh + C > 32 && limb + 1 < 8) d |= s.l[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
         d = (d & mask) + carry;
-        uint32_t code;
-        if (d > half) { carry = 1; const uint32_t mag = (1u << C) - d; code = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
-        else { carry = 0; code = d ? (d - 1) : DIG_ZERO; }
-        dig[(uint64_t)w * n_pad + i] = (uint16_t)code;
-        const uint64_t any = __ballot(code != DIG_ZERO);
-        if (any && (uint32_t)__builtin_ctzll(any) == (threadIdx.x & 63u)) wflag[w] = 1u;
+        if (d > half) { carry = 1; const uint32_t mag = (1u << C) - d; code[w] = mag ? (0x8000u | (mag - 1)) : DIG_ZERO; }
+        else { carry = 0; code[w] = d ? (d - 1) : DIG_ZERO; }
+    }
+}
+// One lane recodes TWO consecutive scalars and stores their digits as one 32-bit word per window:
+// a wave writes 256 contiguous bytes per row with dword stores (2-byte stores, one scalar per
+// lane, ran at a third of the rate).  n_pad is even.
+template <int C>
+__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
+    constexpr int W = (256 + C - 1) / C;
+    const uint64_t i = 2 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_pad) return;
+    uint32_t c0[W], c1[W];
+    if (i < n) recode_all<C>(from_mont(ldg(scalars + i)), c0);
+    else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) c0[w] = DIG_ZERO;
+    }
+    if (i + 1 < n) recode_all<C>(from_mont(ldg(scalars + i + 1)), c1);
+    else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) c1[w] = DIG_ZERO;
+    }
+    uint32_t* dig32 = reinterpret_cast<uint32_t*>(dig);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        dig32[((uint64_t)w * n_pad + i) >> 1] = c0[w] | (c1[w] << 16);
+        const uint64_t any = __ballot(c0[w] != DIG_ZERO || c1[w] != DIG_ZERO);
+        // one lane per wave raises the flag, and only while it still reads 0
+        if (any && (uint32_t)__builtin_ctzll(any) == (threadIdx.x & 63u) && wflag[w] == 0u) wflag[w] = 1u;
     }
 }
 static void launch_digits(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, uint64_t n_pad, uint16_t* dig, uint32_t* wflag) {
@@ -626,7 +642,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     {
         ZkProfScope ps(ctx, "msm_sort");
         ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));   // size_hist + nmulti + wflag
-        launch_digits(pl.c, dim3((unsigned)((n_pad + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
+        launch_digits(pl.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
         hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
