@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--large", action="store_true", help="vectorised builder (k >= 18, many columns)")
     ap.add_argument("--shplonk", action="store_true", help="SHPLONK multi-open instead of GWC")
+    ap.add_argument("--host-upload", action="store_true", help="sharded runs: every rank uploads every advice column (no device all-gather)")
     ap.add_argument("--pinned", action="store_true", help="advice columns in page-locked host memory (zk_host_alloc)")
     ap.add_argument("--shape", default="", help="A,F,P,L,d: circuit with this many advice / fixed / permutation columns, lookups and "
                     "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
@@ -399,7 +400,9 @@ def main():
             t0 = time.perf_counter()
         sess = ctx.proof_session(pk, inst_m, bytes(16))
         sess.set_multiopen(1 if args.shplonk else 0)
-        keep = shard.shard_session(sess) if world > 1 else None
+        keep = None
+        if world > 1:      # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
+            keep = shard.shard_session(sess) if args.host_upload else shard.shard_session_device(sess)
         sess.advice_phase({i: c for i, c in enumerate(adv_m)})
         proof = sess.finish()
         del keep

@@ -231,6 +231,12 @@ int zk_proof_set_transcript(zk_ctx* ctx, zk_proof* proof, const zk_transcript_vt
  * Call between zk_proof_begin and the first advice phase.                                          */
 typedef int (*zk_allgather_fn)(void* user, const void* h_send, size_t bytes, void* h_recv);
 int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* proof, uint32_t rank, uint32_t world, zk_allgather_fn gather, void* user);
+/* Optional, after zk_proof_set_sharding: an all-gather of DEVICE buffers (same signature, device
+ * pointers; RCCL over xGMI).  Each rank then uploads only its own 1/world of the advice columns and
+ * the ranks exchange them over the fabric, instead of every rank pulling every column over its own
+ * PCIe link.  The library drains its stream before each call; the callback must return only when
+ * d_recv is complete.                                                                              */
+int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* proof, zk_allgather_fn gather_dev, void* user);
 /* commits the advice columns of the current phase (h_cols[j] = advice column col_index[j], exactly
  * the columns of that phase) and writes the challenges that become usable after it to
  * h_challenges (32 B each, Montgomery Fr, challenge-index order)                                 */

@@ -35,7 +35,9 @@ def main():
     def prove(sharded: bool) -> bytes:
         sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
         sess.set_multiopen(multiopen)
-        keep = sharding.shard_session(sess) if sharded else None
+        keep = None
+        if sharded:
+            keep = sharding.shard_session_device(sess) if os.environ.get("ZK_TEST_DEVGATHER") == "1" else sharding.shard_session(sess)
         sess.advice_phase({i: c for i, c in enumerate(adv_m)})
         proof = sess.finish()
         del keep

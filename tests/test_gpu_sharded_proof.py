@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,k,multiopen", [(2, 7, 0), (3, 8, 1)])
-def test_sharded_session_matches_single(tmp_path, world, k, multiopen):
+@pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1)])
+def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather):
     port = 29500 + (os.getpid() % 2000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "_sharded_proof_worker.py"), str(tmp_path), str(k), str(multiopen)]
-    env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    # devgather: the advice columns are uploaded by their owning rank only and all-gathered between devices
+    env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1", ZK_TEST_DEVGATHER=str(devgather))
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     single = open(tmp_path / "proof_single.bin", "rb").read()

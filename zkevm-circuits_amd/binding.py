@@ -211,6 +211,12 @@ class ProofSession:
         self._gather_cb = allgather_cb          # keep the ctypes thunk alive
         self.ctx._ck(lib().zk_proof_set_sharding(self.ctx.h, self.h, ctypes.c_uint32(rank), ctypes.c_uint32(world), allgather_cb, None))
 
+    def set_device_gather(self, allgather_dev_cb):
+        """After set_sharding: exchange the advice columns with a device all-gather (RCCL) instead of
+        uploading every column on every rank; allgather_dev_cb is a sharding.ALLGATHER_FN over device pointers."""
+        self._gather_dev_cb = allgather_dev_cb
+        self.ctx._ck(lib().zk_proof_set_device_gather(self.ctx.h, self.h, allgather_dev_cb, None))
+
     def advice_phase(self, columns: dict) -> np.ndarray:
         """columns: {advice column index: (n, 4) u64 Montgomery array}; returns (num_challenges, 4) u64."""
         idx = sorted(columns)

@@ -144,6 +144,8 @@ struct zk_proof {
     uint32_t rank = 0, world = 1;
     zk_allgather_fn gather = nullptr;
     void* gather_user = nullptr;
+    zk_allgather_fn gather_dev = nullptr;    // optional: all-gather of DEVICE buffers (RCCL over xGMI) for the advice columns
+    void* gather_dev_user = nullptr;
     std::vector<F4> challenges;
     zk_proof(const zk_pk* k, const uint8_t* seed) : pk(k), rng(seed), inst_lag(k->I), inst_coeff(k->I), adv_lag(k->A), adv_coeff(k->A), challenges(k->chal_phase.size(), host::fr_zero()) {}
 };
@@ -506,6 +508,16 @@ int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* pr, uint32_t rank, uint32_t wor
     return ZK_OK;
 }
 
+int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* pr, zk_allgather_fn gather_dev, void* user) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && gather_dev, "null pointer");
+    ZK_REQUIRE(ctx, pr->world > 1 && pr->gather, "set the sharding (zk_proof_set_sharding) first");
+    ZK_REQUIRE(ctx, pr->phase == 0, "must be set before the first advice phase");
+    pr->gather_dev = gather_dev;
+    pr->gather_dev_user = user;
+    return ZK_OK;
+}
+
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
@@ -552,6 +564,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         zk_ctx* ctx; size_t body, tail;
         std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind;
         uint32_t world = 1;
+        std::vector<size_t> own;                                         // device-gather mode: only these columns are uploaded by this rank
         const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
     } sg{ctx, (n - pk->bf) * 32, (size_t)pk->bf * 32, {}, {}, {}};
     sg.pk = pk;
@@ -571,6 +584,13 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     sg.world = pr->world > 1 && pr->gather ? pr->world : 1;
     auto stage = [](void* user, size_t it) -> int {
         Stage* s_ = (Stage*)user;
+        if (!s_->own.empty()) {      // device-gather mode: one own column per call
+            if (it > 0) PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
+            const size_t c_ = s_->own[it];
+            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind.data() + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            return copy_stream_fence(s_->ctx);
+        }
         // the group uploaded by the previous call is on the device (the main stream has waited for it):
         // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
         if (it > 0)
@@ -591,8 +611,30 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) mine.push_back(sg.dst[c_]);
         std::vector<G1Affine> local(per), all(per * sg.world);
         memset((void*)local.data(), 0, sizeof(G1Affine) * per);
-        PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));   // MSM j reads group j of `world` columns
-        for (size_t grp = mine.size(); grp * sg.world < total; ++grp) PK_TRY(stage(&sg, grp));                   // a last group without a column of this rank
+        if (pr->gather_dev) {
+            // Device all-gather mode: this rank uploads only ITS columns (1/world of the PCIe traffic),
+            // commits them, and the ranks then exchange the columns group by group over the fabric.
+            for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) sg.own.push_back(c_);
+            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));
+            DevBuf gbuf, zero;
+            if (!gbuf.alloc((size_t)sg.world * n * 32) || !zero.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            ZK_HIP(ctx, hipMemsetAsync(zero.p, 0, n * 32, ctx->stream));
+            for (size_t grp = 0; grp * sg.world < total; ++grp) {
+                const size_t mine_c = grp * sg.world + pr->rank;
+                PK_TRY(zk_ctx_sync(ctx));                                  // own column uploaded, previous copies out of gbuf done
+                if (pr->gather_dev(pr->gather_dev_user, mine_c < total ? sg.dst[mine_c] : zero.p, n * 32, gbuf.p))
+                    return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: device all-gather callback failed");
+                for (uint32_t q_ = 0; q_ < sg.world; ++q_) {
+                    const size_t c_ = grp * sg.world + q_;
+                    if (q_ == pr->rank || c_ >= total) continue;
+                    ZK_HIP(ctx, hipMemcpyAsync(sg.dst[c_], (char*)gbuf.p + (size_t)q_ * n * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                    PK_TRY(to_coeff(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
+                }
+            }
+        } else {
+            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));   // MSM j reads group j of `world` columns
+            for (size_t grp = mine.size(); grp * sg.world < total; ++grp) PK_TRY(stage(&sg, grp));                   // a last group without a column of this rank
+        }
         PK_TRY(zk_ctx_sync(ctx));
         if (per && pr->gather(pr->gather_user, local.data(), per * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
         for (size_t c_ = 0; c_ < total; ++c_) coms[c_] = all[(c_ % sg.world) * per + c_ / sg.world];

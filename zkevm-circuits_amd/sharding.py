@@ -119,3 +119,43 @@ def shard_session(session: "binding.ProofSession", group=None):
     cb = make_allgather(group)
     session.set_sharding(dist.get_rank(group), dist.get_world_size(group), cb)
     return cb
+
+
+class _DevBytes:
+    """A raw device pointer as a 1-D uint8 array (CUDA array interface), so torch can wrap it."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def make_allgather_dev(group=None):
+    """ctypes callback for zk_proof_set_device_gather: all-gathers DEVICE buffers.  Backend nccl:
+    torch tensors over the library's own buffers go straight into RCCL (xGMI, no host copy);
+    backend gloo (single-GPU test boxes): staged through host memory."""
+    backend = dist.get_backend(group)
+    world = dist.get_world_size(group)
+
+    def gather(_user, send_ptr, nbytes, recv_ptr):
+        try:
+            t_in = torch.as_tensor(_DevBytes(send_ptr, nbytes), device="cuda")
+            t_out = torch.as_tensor(_DevBytes(recv_ptr, nbytes * world), device="cuda")
+            if backend == "nccl":
+                dist.all_gather_into_tensor(t_out, t_in, group=group)
+            else:
+                h_out = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(h_out, t_in.cpu(), group=group)
+                t_out.copy_(h_out)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            print(f"[zkmi355 sharding] device all-gather failed: {e!r}", flush=True)
+            return 1
+    return ALLGATHER_FN(gather)
+
+
+def shard_session_device(session: "binding.ProofSession", group=None):
+    """shard_session plus the device all-gather of the advice columns (each rank uploads 1/world)."""
+    cb = shard_session(session, group)
+    cb_dev = make_allgather_dev(group)
+    session.set_device_gather(cb_dev)
+    return cb, cb_dev
