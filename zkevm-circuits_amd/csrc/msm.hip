@@ -47,21 +47,6 @@ static MsmPlan make_plan(size_t n) {
     return p;
 }
 
-// signed-digit recoding of a canonical 256-bit scalar; calls f(window, bucket_in_window, negative)
-template <class Fn>
-__device__ __forceinline__ void recode(const Fr& s, int c, int W, Fn&& f) {
-    uint32_t carry = 0;
-    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-    for (int w = 0; w < W; ++w) {
-        const int bit = w * c, limb = bit >> 5, sh = bit & 31;
-        uint32_t d = limb < 8 ? (s.l[limb] >> sh) : 0u;
-        if (sh + c > 32 && limb + 1 < 8) d |= s.l[limb + 1] << (32 - sh);
-        d = (d & mask) + carry;
-        if (d > half) { carry = 1; const uint32_t mag = (1u << c) - d; if (mag) f(w, mag - 1, true); }
-        else { carry = 0; if (d) f(w, d - 1, false); }
-    }
-}
-
 // ---- sort phase --------------------------------------------------------------------------------
 // 1. k_msm_digits: every scalar leaves Montgomery form once and is recoded; digit codes go to a
 //    window-major u16 matrix dig[w][i] (row stride n_pad, multiple of 64):
