@@ -6,12 +6,14 @@
 //   1. digits    scalars leave Montgomery form (one Montgomery product by 1) and are recoded into
 //                W = ceil(256/c) signed c-bit digits, stored as a window-major u16 matrix; every
 //                non-zero digit is a (bucket, point) pair, bucket = window * 2^(c-1) + |d| - 1.
-//   2. sort      counting sort by bucket with LDS-privatised counters: workgroup (range, window)
-//                streams the digit row twice (count, scatter); no global atomics.
-//   3. buckets   buckets are ordered by size and split into tasks of <= 64 points (skew-proof);
+//   2. sort      counting sort by bucket with LDS-privatised counters: workgroup (range, window,
+//                slice) streams its quarter of the digit row twice (count, scatter); no global
+//                atomics; XCD-aware placement; empty windows are skipped.
+//   3. buckets   buckets are ordered by size and split into tasks of <= 48 points (skew-proof);
 //                one lane per task gathers R'-form affine bases (64 B each) and accumulates with
-//                mixed XYZZ additions on 29-bit limbs (8M + 2S, no inversions); multi-task
-//                buckets are tree-combined afterwards.
+//                mixed XYZZ additions on 29-bit limbs (8M + 2S, no inversions); the partials of
+//                multi-task buckets are combined per wave (segmented shuffle reduction), then
+//                per bucket.
 //   4. reduce    per window: sum_b (b+1) * B_b by running sums + LDS tree.  For SRS bases the
 //                fixed-base window tables (2^(c*w) * P_i precomputed) make every window's bucket b
 //                carry the same weight, so the W bucket arrays are folded first and ONE window is
