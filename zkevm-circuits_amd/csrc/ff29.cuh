@@ -210,6 +210,25 @@ __host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) {
     return t;
 }
 
+// a^(m-2) for a canonical 8 x 32 element in R = 2^256 Montgomery form; result in the same form.
+// The 254-step exponentiation runs on 29-bit limbs (R' domain): its dependent chain is what a
+// batch inversion waits for, and sqr29 / mul29 make it about half as long as the 32-bit CIOS one.
+template <class P29>
+__host__ __device__ inline Fp<typename P29::P32> inv_via29(const Fp<typename P29::P32>& a) {
+    using F = Fp<typename P29::P32>;
+    F t = a, one_rp = F::one();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { t = dbl(t); one_rp = dbl(one_rp); }     // x 32: R -> R'
+    F29<P29> b = unpack29<P29>(t), r = unpack29<P29>(one_rp);
+#pragma unroll 1
+    for (int i = 0; i < 254; ++i) {
+        const uint32_t limb = P29::P32::M(i >> 5) - (i < 32 ? 2u : 0u);     // bits of m - 2 (low limb >= 2: no borrow)
+        if ((limb >> (i & 31)) & 1) r = mul29(r, b);
+        b = sqr29(b);
+    }
+    return pack29_lt2p(mul29(r, unpack29<P29>(F::one())));                 // x 2^256 / 2^261: R' -> R
+}
+
 using Fq29 = F29<Fq29P>;
 using Fr29 = F29<Fr29P>;
 

@@ -6,6 +6,7 @@
 // All kernels read/write 32-byte elements as two 16-byte transactions per lane, consecutive
 // lanes on consecutive elements (fully coalesced), grid-stride where a fixed grid is needed.
 #include "ctx.hpp"
+#include "ff29.cuh"
 
 namespace zk {
 
@@ -50,7 +51,7 @@ __global__ void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ pre, uint64_
         Fr v = ldg(a + i);
         if (!v.is_zero()) acc = acc * v;
     }
-    Fr iv = inv(acc);
+    Fr iv = inv_via29<Fr29P>(acc);
     uint64_t cnt = (n - t + nt - 1) / nt;
     for (uint64_t k = cnt; k-- > 0;) {
         uint64_t i = t + k * nt;
