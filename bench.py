@@ -87,12 +87,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    shared_gpu = world > ndev           # fewer GPUs than ranks (single-GPU test box): ranks share devices, exchange over gloo
+    local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import zkevm_circuits_amd as z
 
@@ -103,9 +109,10 @@ def main():
     d_col = ctx.to_device(column)            # committed every step (read-only)
     d_work = ctx.to_device(column)           # transformed in place every step
     gather = None
-    com_t = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    xdev = "cpu" if shared_gpu else "cuda"
+    com_t = torch.zeros(64, dtype=torch.uint8, device=xdev)
     if world > 1:
-        gather = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        gather = [torch.zeros(64, dtype=torch.uint8, device=xdev) for _ in range(world)]
 
     def run_steps(count):
         """`count` steps = `count` columns: the prover commits the columns of a phase as a batch
@@ -138,7 +145,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
