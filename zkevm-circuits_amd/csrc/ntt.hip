@@ -29,6 +29,7 @@ struct NttPass {
     int log_np;     // digit size
     int log_m;      // stride of the digit (non-last)
     const Fr* tw;   // n_p/2 butterfly twiddles (omega^(n/n_p))^x, R' form
+    const Fr* out_tw = nullptr;   // non-last passes: inter-pass twiddle of every output element, in output order (R' form)
 };
 
 struct NttDomain {
@@ -39,11 +40,13 @@ struct NttDomain {
     Fr* d_lo = nullptr;       // 2^h entries, R' form
     Fr* d_hi = nullptr;       // 2^(log_n-h) entries, R' form
     Fr* d_tw[3] = {nullptr, nullptr, nullptr};
+    Fr* d_out_tw[2] = {nullptr, nullptr};
     Fr final_mul;             // (scale or 1) in R' form: last-pass output multiplier
     ~NttDomain() {
         if (d_lo) (void)hipFree(d_lo);
         if (d_hi) (void)hipFree(d_hi);
         for (auto p : d_tw) if (p) (void)hipFree(p);
+        for (auto p : d_out_tw) if (p) (void)hipFree(p);
     }
 };
 
@@ -93,6 +96,16 @@ __device__ __forceinline__ Fr two_level(const Fr* __restrict__ lo, const Fr* __r
 // both tables in R' form -> product in R' form, normalised, < 2p
 __device__ __forceinline__ Fr29 two_level29(const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, uint32_t e) {
     return mul29(unpack29<Fr29P>(ldg(lo + (e & ((1u << h) - 1)))), unpack29<Fr29P>(ldg(hi + (e >> h))));
+}
+
+// out_tw[base + d*m + c] = omega^(((blk*T + c) * d) << tw_shift): the twiddle a non-last pass applies to
+// each element it writes, tabulated once per domain in output order
+__global__ void k_build_out_twiddles(Fr* __restrict__ out_tw, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, int log_np, int log_m, int tw_shift, uint64_t n) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint64_t m = 1ull << log_m;
+    const uint32_t jpp = (uint32_t)(g & (m - 1)), d = (uint32_t)(g >> log_m) & ((1u << log_np) - 1);
+    stg(out_tw + g, pack29_lt2p(two_level29(lo, hi, h, (jpp * d) << tw_shift)));
 }
 
 // ------------------------------------------------------------------------------- butterflies
@@ -149,7 +162,8 @@ __device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Fr* __restric
 // LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
-           const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre) {
+           const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre,
+           const Fr* __restrict__ out_tw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
@@ -189,8 +203,11 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
                 const int dl = lo_d + k * hgt;
                 if (last) {
                     const uint32_t jpp = (blk << log_t) + c;
-                    const Fr29 v = mul29(e[k], two_level29(lo, hi, h, (jpp * (uint32_t)dl) << tw_shift));
-                    stg(dst + base + (uint64_t)dl * m + c, pack29_lt2p(v));
+                    const uint64_t go = base + (uint64_t)dl * m + c;
+                    // inter-pass twiddle: one load from the per-domain table in output order (one product),
+                    // or two table entries and two products when the table was not built
+                    const Fr29 v = mul29(e[k], out_tw ? unpack29<Fr29P>(ldg(out_tw + go)) : two_level29(lo, hi, h, (jpp * (uint32_t)dl) << tw_shift));
+                    stg(dst + go, pack29_lt2p(v));
                 } else {
                     L.store((dl << log_t) | c, e[k]);
                 }
@@ -336,6 +353,18 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
         if (rc) return rc;
         d->pass[p].tw = d->d_tw[p];
     }
+    // full inter-pass twiddle tables (n x 32 B per non-last pass) while the domain is not huge
+    if (P > 1 && log_n <= 24) {
+        const uint64_t n = 1ull << log_n;
+        for (int p = 0; p + 1 < P; ++p) {
+            if (hipMalloc(&d->d_out_tw[p], sizeof(Fr) * n) != hipSuccess) { (void)hipGetLastError(); d->d_out_tw[p] = nullptr; break; }
+            const NttPass& ps = d->pass[p];
+            hipLaunchKernelGGL(k_build_out_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d->d_out_tw[p], (const Fr*)d->d_lo, (const Fr*)d->d_hi, d->h,
+                               ps.log_np, ps.log_m, (int)log_n - ps.log_np - ps.log_m, n);
+            ZK_CHECK_LAUNCH(ctx);
+            d->pass[p].out_tw = d->d_out_tw[p];
+        }
+    }
     if (ctx->domains.size() > 64) ctx->domains.clear();
     ctx->domains[key] = d;
     *out = d;
@@ -433,7 +462,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
         ZkProfScope pscope(ctx, "ntt_pass");
         hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, out, ps.tw,
-                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr);
+                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw);
         ZK_CHECK_LAUNCH(ctx);
         cur = out;
     }
