@@ -25,10 +25,12 @@ constexpr int NTT_TILE = 4096;         // elements staged per workgroup (9 x 4 B
 constexpr int NTT_THREADS = 1024;
 constexpr int NTT_LDS_BYTES_PER_ELT = 36;
 
+struct Tw29;        // one butterfly twiddle split into 29-bit limbs (48 B), defined with the kernels
+
 struct NttPass {
     int log_np;     // digit size
     int log_m;      // stride of the digit (non-last)
-    const Fr* tw;   // n_p/2 butterfly twiddles (omega^(n/n_p))^x, R' form
+    const Tw29* tw; // n_p/2 butterfly twiddles (omega^(n/n_p))^x, R' form, 29-bit limbs
     const Fr* out_tw = nullptr;   // non-last passes: inter-pass twiddle of every output element, in output order (R' form)
 };
 
@@ -40,12 +42,14 @@ struct NttDomain {
     Fr* d_lo = nullptr;       // 2^h entries, R' form
     Fr* d_hi = nullptr;       // 2^(log_n-h) entries, R' form
     Fr* d_tw[3] = {nullptr, nullptr, nullptr};
+    Tw29* d_tw29[3] = {nullptr, nullptr, nullptr};
     Fr* d_out_tw[2] = {nullptr, nullptr};
     Fr final_mul;             // (scale or 1) in R' form: last-pass output multiplier
     ~NttDomain() {
         if (d_lo) (void)hipFree(d_lo);
         if (d_hi) (void)hipFree(d_hi);
         for (auto p : d_tw) if (p) (void)hipFree(p);
+        for (auto p : d_tw29) if (p) (void)hipFree((void*)p);
         for (auto p : d_out_tw) if (p) (void)hipFree(p);
     }
 };
@@ -118,12 +122,26 @@ __device__ __forceinline__ void bfly29(Fr29& u, Fr29& x, const Fr29& w) {
     u = a0;
     x = a1;
 }
-__device__ __forceinline__ Fr29 tw29(const Fr* __restrict__ tw, uint32_t idx) { return unpack29<Fr29P>(ldg(tw + idx)); }
+// butterfly twiddles are tabulated already split into 29-bit limbs (12 words = 48 B per entry, three
+// 16-byte loads): no 8 x 32 -> 9 x 29 repacking in front of every product
+struct Tw29 { uint4 q[3]; };
+__device__ __forceinline__ Fr29 tw29(const Tw29* __restrict__ tw, uint32_t idx) {
+    const uint4 a = tw[idx].q[0], b = tw[idx].q[1], c = tw[idx].q[2];
+    return Fr29{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
+}
+__global__ void k_split_twiddles(const Fr* __restrict__ in, Tw29* __restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Fr29 v = unpack29<Fr29P>(ldg(in + i));
+    out[i].q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    out[i].q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    out[i].q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
+}
 // DIT stages s (and s+1 when R == 2) on the 2^R elements at digit offsets {0, h, 2h, 3h}, h = 2^s,
 // j = digit mod h.  Radix-4 keeps both stages in registers: half the LDS round trips and barriers
 // of two radix-2 stages, same four products.
 template <int R>
-__device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Fr* __restrict__ tw, int log_np, int s, int j) {
+__device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Tw29* __restrict__ tw, int log_np, int s, int j) {
     const Fr29 w0 = tw29(tw, (uint32_t)j << (log_np - 1 - s));
     bfly29(e[0], e[1], w0);
     if (R == 2) {
@@ -144,7 +162,7 @@ __device__ __forceinline__ void bfly29_one(Fr29& u, Fr29& x) {
 // stage 0 is omega^0 = 1, as is the j = 0 twiddle of stage 1 -- three of the four products of a
 // radix-4 step (the one of a radix-2 step) are products by one and are skipped.
 template <int R>
-__device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Fr* __restrict__ tw, int log_np) {
+__device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Tw29* __restrict__ tw, int log_np) {
     bfly29_one(e[0], e[1]);
     if (R == 2) {
         bfly29_one(e[2], e[3]);
@@ -161,7 +179,7 @@ __device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Fr* __restric
 // memory: no staging copy on either side.  Steps are radix-4 (radix-2 first when log_np is odd).
 // LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ lo,
+k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
            const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre,
            const Fr* __restrict__ out_tw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -227,7 +245,7 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restric
 // output is multiplied by `fin` (1 or the inverse-transform scale, R' form), which also brings
 // the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, int log_np, int log_t,
+k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw, int log_np, int log_t,
            int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
@@ -351,7 +369,10 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
         for (uint32_t i = 0; i < log_n - (uint32_t)b; ++i) w = sqr(w);   // omega^(n/n_p)
         int rc = build_powers(ctx, w, Fr::one(), d->d_tw[p], cnt, 1);
         if (rc) return rc;
-        d->pass[p].tw = d->d_tw[p];
+        ZK_HIP(ctx, hipMalloc((void**)&d->d_tw29[p], sizeof(Tw29) * cnt));
+        hipLaunchKernelGGL(k_split_twiddles, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, (const Fr*)d->d_tw[p], d->d_tw29[p], cnt);
+        ZK_CHECK_LAUNCH(ctx);
+        d->pass[p].tw = d->d_tw29[p];
     }
     // full inter-pass twiddle tables (n x 32 B per non-last pass) while the domain is not huge
     if (P > 1 && log_n <= 24) {
