@@ -175,6 +175,25 @@ __host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& 
     return t;
 }
 
+// canonical representative of a normalised lazy value < 64 m (sums of a few dozen reduced terms):
+// quotient estimate from the bits above 2^254 (both BN254 moduli are 0.756 * 2^254, so
+// floor(t * 1354 / 1024) never exceeds floor(x / m) and misses it by at most 2), one multiple of m
+// subtracted with signed carries, then conditional subtractions.  ~half the work of multiplying
+// by one just to reduce.
+template <class P>
+__host__ __device__ __forceinline__ Fp<typename P::P32> reduce_lazy29(const F29<P>& x) {
+    const uint32_t q = ((x.l[8] >> 22) * 1354u) >> 10;
+    F29<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int64_t s_ = (int64_t)x.l[i] - (int64_t)((uint64_t)q * P::M(i)) + c;
+        r.l[i] = i < 8 ? (uint32_t)(s_ & MASK29) : (uint32_t)s_;
+        c = s_ >> 29;
+    }
+    return pack29(r);          // r < 4m: up to three conditional subtractions
+}
+
 // Montgomery square: the cross products a_i a_j (i < j) are taken once against the doubled limb,
 // 45 products instead of 81 in the operand part (the reduction part is unchanged): 126 vs 162.
 // Same operand and result bounds as mul29(a, a).

@@ -45,6 +45,7 @@ struct NttDomain {
     Tw29* d_tw29[3] = {nullptr, nullptr, nullptr};
     Fr* d_out_tw[2] = {nullptr, nullptr};
     Fr final_mul;             // (scale or 1) in R' form: last-pass output multiplier
+    bool fin_folded = false;  // final_mul is already part of the last inter-pass twiddle table: the last pass only reduces
     ~NttDomain() {
         if (d_lo) (void)hipFree(d_lo);
         if (d_hi) (void)hipFree(d_hi);
@@ -104,12 +105,15 @@ __device__ __forceinline__ Fr29 two_level29(const Fr* __restrict__ lo, const Fr*
 
 // out_tw[base + d*m + c] = omega^(((blk*T + c) * d) << tw_shift): the twiddle a non-last pass applies to
 // each element it writes, tabulated once per domain in output order
-__global__ void k_build_out_twiddles(Fr* __restrict__ out_tw, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, int log_np, int log_m, int tw_shift, uint64_t n) {
+__global__ void k_build_out_twiddles(Fr* __restrict__ out_tw, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h, int log_np, int log_m, int tw_shift, uint64_t n,
+                                     Fr fin, int apply_fin) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const uint64_t m = 1ull << log_m;
     const uint32_t jpp = (uint32_t)(g & (m - 1)), d = (uint32_t)(g >> log_m) & ((1u << log_np) - 1);
-    stg(out_tw + g, pack29_lt2p(two_level29(lo, hi, h, (jpp * d) << tw_shift)));
+    Fr29 v = two_level29(lo, hi, h, (jpp * d) << tw_shift);
+    if (apply_fin) v = mul29(v, unpack29<Fr29P>(fin));      // the transform's output scale rides on the last inter-pass twiddle
+    stg(out_tw + g, pack29_lt2p(v));
 }
 
 // ------------------------------------------------------------------------------- butterflies
@@ -246,7 +250,7 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
 // the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw, int log_np, int log_t,
-           int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre) {
+           int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre, int fin_folded) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
@@ -287,7 +291,7 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
                 const int dl = lo_d + k * hgt;
                 if (last) {
                     const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)dl << log_mid)) << log_n1);
-                    stg(dst + o, pack29_lt2p(mul29(e[k], fin29)));
+                    stg(dst + o, fin_folded ? reduce_lazy29(e[k]) : pack29_lt2p(mul29(e[k], fin29)));
                 } else {
                     L.store((c << log_np) | dl, e[k]);
                 }
@@ -381,9 +385,10 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
             if (hipMalloc(&d->d_out_tw[p], sizeof(Fr) * n) != hipSuccess) { (void)hipGetLastError(); d->d_out_tw[p] = nullptr; break; }
             const NttPass& ps = d->pass[p];
             hipLaunchKernelGGL(k_build_out_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d->d_out_tw[p], (const Fr*)d->d_lo, (const Fr*)d->d_hi, d->h,
-                               ps.log_np, ps.log_m, (int)log_n - ps.log_np - ps.log_m, n);
+                               ps.log_np, ps.log_m, (int)log_n - ps.log_np - ps.log_m, n, d->final_mul, p == P - 2 ? 1 : 0);
             ZK_CHECK_LAUNCH(ctx);
             d->pass[p].out_tw = d->d_out_tw[p];
+            if (p == P - 2) d->fin_folded = true;
         }
     }
     if (ctx->domains.size() > 64) ctx->domains.clear();
@@ -497,7 +502,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         ZkProfScope pscope(ctx, "ntt_last");
         hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
-                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr);
+                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0);
         ZK_CHECK_LAUNCH(ctx);
     }
     if (coset_post) { rc = run_distribute(*coset_post, d_data); if (rc) return rc; }
