@@ -119,3 +119,27 @@ def test_ntt_2_24_properties(ctx, cref):
     assert not np.array_equal(d.download((n, 4))[:64], A[:64])
     ctx.ntt(d, k, inverse=True)
     assert np.array_equal(d.download((n, 4)), A)
+
+
+@pytest.mark.parametrize("k", [4, 10, 13, 16])
+@pytest.mark.parametrize("pattern", ["max", "alternating", "one_hot_max", "ramp_high"])
+def test_extreme_inputs(ctx, cref, k, pattern):
+    """Inputs that maximise the magnitudes inside the lazily reduced butterflies (every element
+    r - 1, alternating 0 / r - 1, ...): forward and inverse must still match the oracle bit for bit."""
+    n, top = 1 << k, bn254.R_MOD - 1
+    if pattern == "max":
+        vals = [top] * n
+    elif pattern == "alternating":
+        vals = [top if i & 1 else 0 for i in range(n)]
+    elif pattern == "one_hot_max":
+        vals = [0] * n
+        vals[n - 1] = top
+    else:
+        vals = [(top - i) % bn254.R_MOD for i in range(n)]
+    A = cref.to_mont(vals)
+    d = ctx.to_device(A)
+    ctx.ntt(d, k)
+    want = cref.best_fft(A, bn254.omega_for_k(k), k)
+    assert np.array_equal(d.download((n, 4)), want)
+    ctx.ntt(d, k, inverse=True)
+    assert np.array_equal(d.download((n, 4)), A)

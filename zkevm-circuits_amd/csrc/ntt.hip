@@ -144,15 +144,30 @@ __global__ void k_split_twiddles(const Fr* __restrict__ in, Tw29* __restrict__ o
 // DIT stages s (and s+1 when R == 2) on the 2^R elements at digit offsets {0, h, 2h, 3h}, h = 2^s,
 // j = digit mod h.  Radix-4 keeps both stages in registers: half the LDS round trips and barriers
 // of two radix-2 stages, same four products.
+// Inside a step the sums are not carry-propagated between the two stages.  Limb bounds with
+// N = 2^29 (operands enter normalised, limbs < N; x w is normalised and < 1.4 p; the balanced
+// limbs of 2p are < 2N):  stage 1 leaves u + v < 2N and u + 2p - v < 3N; stage 2 multiplies such
+// an operand -- mul29 takes limbs up to 2^31.2 (9 N (X + N) < 2^64) -- and leaves sums < 5N < 2^32.
+// One normalisation per element at the end of the step instead of one per butterfly output.
+__device__ __forceinline__ void bfly29_lazy(Fr29& u, Fr29& x, const Fr29& w) {
+    const Fr29 v = mul29(x, w);
+    const Fr29 a0 = add29(u, v), a1 = sub29k<2>(u, v);
+    u = a0;
+    x = a1;
+}
 template <int R>
 __device__ __forceinline__ void dit_step(Fr29 (&e)[4], const Tw29* __restrict__ tw, int log_np, int s, int j) {
     const Fr29 w0 = tw29(tw, (uint32_t)j << (log_np - 1 - s));
-    bfly29(e[0], e[1], w0);
+    bfly29_lazy(e[0], e[1], w0);
     if (R == 2) {
-        bfly29(e[2], e[3], w0);
-        bfly29(e[0], e[2], tw29(tw, (uint32_t)j << (log_np - 2 - s)));
-        bfly29(e[1], e[3], tw29(tw, (uint32_t)(j + (1 << s)) << (log_np - 2 - s)));
+        bfly29_lazy(e[2], e[3], w0);
+        bfly29_lazy(e[0], e[2], tw29(tw, (uint32_t)j << (log_np - 2 - s)));
+        bfly29_lazy(e[1], e[3], tw29(tw, (uint32_t)(j + (1 << s)) << (log_np - 2 - s)));
+        normalize29(e[2]);
+        normalize29(e[3]);
     }
+    normalize29(e[0]);
+    normalize29(e[1]);
 }
 // (u, x) -> (u + x, u - x) for reduced operands (< 2p each, or sums of two such: x < 4p)
 __device__ __forceinline__ void bfly29_one(Fr29& u, Fr29& x) {
