@@ -272,17 +272,37 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restric
 }
 static_assert(SCAN_ITEMS == MSM_SLICES, "k_scan_u32_a scans MSM_SLICES entries per thread: one bucket");
 // size_hist (256 bins) -> start offset of each bin in the descending-size order
-__global__ void k_size_bins_scan(uint32_t* size_hist) {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t run = 0;
-    for (int b = SIZE_BINS - 1; b >= 0; --b) {
-        if (b == (int)TASK_CAP) size_hist[SIZE_BINS] = run;   // M: buckets with more than TASK_CAP points come first
-        const uint32_t c = size_hist[b]; size_hist[b] = run; run += c;
+// One wave.  Also picks this MSM's task size: TASK_CAP points when there is plenty of work, smaller
+// when the scalars fill only a few windows (witness columns: values below 2^64 leave 12 of 16
+// windows empty, and one lane per 32-point bucket would be 2 waves per SIMD) -- so that about
+// 2^18 tasks exist either way.  nmulti[0] = M = buckets with more points than one task,
+// nmulti[1] = the task size.
+constexpr uint32_t TASK_MIN = 8, TASK_TARGET = 1u << 18;
+__global__ void __launch_bounds__(64) k_size_bins_scan(uint32_t* size_hist, const uint32_t* __restrict__ total_points) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t total = *total_points;
+    uint32_t cap = TASK_CAP;
+    if (total < TASK_CAP * TASK_TARGET) cap = max(TASK_MIN, (total + TASK_TARGET - 1) / TASK_TARGET);
+    // descending order: position p = SIZE_BINS - 1 - bin; lane owns positions 4 lane .. 4 lane + 3
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = size_hist[SIZE_BINS - 1 - (4 * lane + k)]; sum += c[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += o; }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t bin = SIZE_BINS - 1 - (4 * lane + k);
+        if (bin == cap) size_hist[SIZE_BINS] = run;          // M: buckets with more than `cap` points come first
+        size_hist[bin] = run;
+        run += c[k];
     }
+    if (lane == 0) size_hist[SIZE_BINS + 1] = cap;
 }
 // ---- skew-proof work split ------------------------------------------------------------------------
-// A bucket with c points becomes ceil(c / TASK_CAP) tasks of <= TASK_CAP consecutive points, so no
-// lane ever walks more than TASK_CAP points whatever the scalar distribution (selector / boolean /
+// A bucket with c points becomes ceil(c / cap) tasks of <= cap consecutive points (cap <= TASK_CAP,
+// chosen per MSM by k_size_bins_scan), so no lane ever walks more than TASK_CAP points whatever the scalar distribution (selector / boolean /
 // small-value columns put n/2 points into one bucket).  Tasks are numbered along the size-ordered
 // bucket sequence (a wave still sees equal-length work); single-task buckets write their bucket
 // directly, multi-task buckets write partials that one workgroup per bucket tree-sums afterwards.
@@ -294,6 +314,7 @@ __global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __rest
     __shared__ uint32_t lh[SIZE_BINS], lbase[SIZE_BINS];
     if (threadIdx.x < SIZE_BINS) lh[threadIdx.x] = 0;
     __syncthreads();
+    const uint32_t cap = size_cursor[SIZE_BINS + 1];          // this MSM's task size (k_size_bins_scan)
     const uint32_t base = blockIdx.x * (SCAN_T * SCAN_ITEMS);
     uint32_t bin[SCAN_ITEMS], rank[SCAN_ITEMS];
 #pragma unroll
@@ -311,7 +332,7 @@ __global__ void __launch_bounds__(SCAN_T) k_order_buckets(const uint32_t* __rest
         if (i < cnt) {
             const uint32_t pos = lbase[bin[k]] + rank[k];
             order[pos] = i;
-            ntasks[pos] = (counts[i] + TASK_CAP - 1) / TASK_CAP;
+            ntasks[pos] = (counts[i] + cap - 1) / cap;
         }
     }
 }
@@ -397,8 +418,8 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
             const uint32_t mid = (lo_p + hi_p) >> 1;
             if (toff[mid] <= v) lo_p = mid; else hi_p = mid;
         }
-        const uint32_t b = order[lo_p], chunk = v - toff[lo_p];
-        const uint32_t lo = offsets[b] + chunk * TASK_CAP, hi = min(lo + TASK_CAP, offsets[b + 1]);
+        const uint32_t b = order[lo_p], chunk = v - toff[lo_p], cap = nmulti[1];
+        const uint32_t lo = offsets[b] + chunk * cap, hi = min(lo + cap, offsets[b + 1]);
         stg29(partial + v, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi));
         return;
     }
@@ -589,7 +610,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     const bool short_chain = d_table && count == 1;
     const int red_g = short_chain ? RED_G_FOLDED : RED_G_WIDE;
     const uint32_t red_blocks = ((pl.B + red_g - 1) / red_g + RED_THREADS - 1) / RED_THREADS;
-    const size_t max_tasks = (size_t)nb + ((size_t)n * pl.W) / TASK_CAP + 1;
+    const size_t max_tasks = (size_t)nb + std::max(((size_t)n * pl.W) / TASK_CAP, (size_t)TASK_TARGET) + 1;   // tasks <= points / task size + buckets
     const size_t npts29 = (size_t)nb + (size_t)pl.W * red_blocks + max_tasks + pl.B;
     if (!d_table) tab_stride = 0; else d_bases_rp = d_table;
     const int red_W = d_table ? 1 : pl.W;     // windows the weighted reduction has to handle
@@ -635,7 +656,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
         hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
-        hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist);
+        hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist, (const uint32_t*)(offsets + nb));
         hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
         hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
         hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
