@@ -88,6 +88,14 @@ struct DevBuf {
     Fr* fr() const { return (Fr*)p; }
 };
 
+// page-locked host staging (blinding rows): an asynchronous copy from pageable memory blocks the
+// host until the stream reaches it, which would serialise the upload pipeline with the enqueueing thread
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    bool alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess; }
+};
+
 struct Query { uint32_t type, idx; int32_t rot; };
 
 // ZK_PROVER_TRACE=1: wall-clock per prover stage on stderr (device drained at every mark)
@@ -562,7 +570,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     // every column are blinding values (drawn up front, in column-index = transcript order).
     struct Stage {
         zk_ctx* ctx; size_t body, tail;
-        std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind;
+        std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind_v; const F4* blind = nullptr;
         uint32_t world = 1;
         std::vector<size_t> own;                                         // device-gather mode: only these columns are uploaded by this rank
         const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
@@ -575,8 +583,12 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         sg.dst.push_back(pr->adv_lag[c].p);
         sg.lag.push_back(&pr->adv_lag[c]);
         sg.coeff.push_back(&pr->adv_coeff[c]);
-        for (uint32_t r = 0; r < pk->bf; ++r) sg.blind.push_back(pr->rng.next_fr());
+        for (uint32_t r = 0; r < pk->bf; ++r) sg.blind_v.push_back(pr->rng.next_fr());
     }
+    PinnedBuf blind_pinned;
+    if (!blind_pinned.alloc(sg.blind_v.size() * sizeof(F4))) return ctx->fail(ZK_ERR_OOM, "prover: pinned staging allocation failed");
+    memcpy(blind_pinned.p, sg.blind_v.data(), sg.blind_v.size() * sizeof(F4));
+    sg.blind = (const F4*)blind_pinned.p;
     PK_TRY(copy_stream_open(ctx));
     // Sharded session: every rank uploads every column (each GPU has its own PCIe link; all of them
     // are needed for the quotient) but commits only columns rank, rank + world, ...: the upload of
@@ -588,7 +600,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
             if (it > 0) PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
             const size_t c_ = s_->own[it];
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
-            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind.data() + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             return copy_stream_fence(s_->ctx);
         }
         // the group uploaded by the previous call is on the device (the main stream has waited for it):
@@ -598,7 +610,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
                 PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
-            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind.data() + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
         }
         return copy_stream_fence(s_->ctx);
     };
