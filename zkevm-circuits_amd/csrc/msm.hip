@@ -377,11 +377,11 @@ __global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __r
     }
 }
 // folded[b] = sum_w buckets[w*B + b]: four lanes per bucket (each takes every 4th window), LDS combine
-__global__ void __launch_bounds__(256) k_msm_fold_windows(const G1Xyzz29* __restrict__ buckets, uint32_t B, int W, G1Xyzz29* __restrict__ folded) {
+__global__ void __launch_bounds__(256) k_msm_fold_windows(const G1Xyzz29* __restrict__ buckets, uint32_t B, int W, G1Xyzz29* __restrict__ folded, const uint32_t* __restrict__ wflag) {
     __shared__ G1Xyzz29 sh[256];
     const uint32_t b = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     G1Xyzz29 acc = identity29();
-    if (b < B) for (int w = (int)q; w < W; w += 4) acc = add29pt(acc, ldg29(buckets + (uint64_t)w * B + b));
+    if (b < B) for (int w = (int)q; w < W; w += 4) if (wflag[w]) acc = add29pt(acc, ldg29(buckets + (uint64_t)w * B + b));   // empty windows were never written
     sh[threadIdx.x] = acc;
     __syncthreads();
     if (q < 2) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + 2]);
@@ -408,7 +408,7 @@ __device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ 
 __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ nmulti,
                                                      uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial,
-                                                     int log_b, uint64_t tab_stride) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
+                                                     int log_b, uint64_t tab_stride, const uint32_t* __restrict__ wflag) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
     const uint32_t M = *nmulti;
     const uint32_t Tm = M ? toff[M] : 0u;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     const uint32_t p = M + (v - Tm);
     if (p >= nbuckets) return;
     const uint32_t b = order[p];
+    if (tab_stride && wflag[b >> log_b] == 0u) return;      // empty window: the fold skips it, nothing to write
     stg29(buckets + b, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, offsets[b], offsets[b + 1]));
 }
 // ---- combining the task partials of multi-task buckets ---------------------------------------------
@@ -618,7 +619,9 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     char* bkbuf[2];
     bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
     bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
-    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count);
+    // window sums of every MSM of the batch, then one private copy of the window flags per MSM (the
+    // fold on the side stream reads them while the main stream already recodes the next column)
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count + 256 * count);
     if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -646,6 +649,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
     G1Xyzz29* folded = task_partial + max_tasks;
     G1Xyzz* wsum = wsum_all + it * pl.W;
+    uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + (size_t)pl.W * count) + it * 64;
     if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
         ZkProfScope ps(ctx, "msm_sort");
@@ -665,11 +669,12 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
     }
+    ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     {
         ZkProfScope ps(ctx, "msm_buckets");
         // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
         hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
-                           (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, pl.c - 1, (uint64_t)tab_stride);
+                           (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, pl.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
         hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
         hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
@@ -683,7 +688,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         ZkProfScope ps(ctx, "msm_reduce", ctx->stream2);
         const G1Xyzz29* red_in = buckets;
         if (d_table) {
-            hipLaunchKernelGGL(k_msm_fold_windows, dim3((pl.B + 63) / 64), dim3(256), 0, ctx->stream2, (const G1Xyzz29*)buckets, pl.B, pl.W, folded);
+            hipLaunchKernelGGL(k_msm_fold_windows, dim3((pl.B + 63) / 64), dim3(256), 0, ctx->stream2, (const G1Xyzz29*)buckets, pl.B, pl.W, folded, (const uint32_t*)wflag_it);
             red_in = folded;
         }
         if (short_chain) hipLaunchKernelGGL((k_msm_reduce<RED_G_FOLDED>), dim3(red_blocks, red_W), dim3(RED_THREADS), 0, ctx->stream2, red_in, pl.B, partial);
