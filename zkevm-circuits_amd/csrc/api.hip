@@ -68,6 +68,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream_aux) { (void)hipStreamSynchronize(ctx->stream_aux); (void)hipStreamDestroy(ctx->stream_aux); (void)hipEventDestroy(ctx->ev_aux); }
     if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); (void)hipEventDestroy(ctx->ev_copy); }
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_p2) if (e) (void)hipEventDestroy(e);

@@ -40,6 +40,9 @@ struct zk_ctx {
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;
     hipEvent_t ev_copy = nullptr;
+    // auxiliary compute stream: transforms of freshly uploaded columns run beside the commitment pipeline
+    hipStream_t stream_aux = nullptr;
+    hipEvent_t ev_aux = nullptr;
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
     std::map<uint64_t, void*> pow_tables;                         // cached two-level power tables of the coset generators
     std::vector<void*> pinned;   // small pinned host staging buffers

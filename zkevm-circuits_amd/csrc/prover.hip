@@ -180,6 +180,16 @@ int to_coeff(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff) {
     return ntt_run(ctx, coeff->fr(), pk->k, omega_inv, &ninv, nullptr, nullptr, lag.fr());
 }
 
+// to_coeff on the auxiliary stream (the caller orders that stream after the column's upload and the
+// main stream after it again): the advice phase keeps its main stream for the commitment pipeline
+int to_coeff_aux(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff) {
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream_aux;
+    const int rc = to_coeff(ctx, pk, lag, coeff);
+    ctx->stream = main_stream;
+    return rc;
+}
+
 void collect_queries(const Prog& g, std::vector<Query>* adv, std::vector<Query>* fix) {
     for (const Instr& in : g) {
         if (in.op != Q_PUSH_COL) continue;
@@ -590,6 +600,12 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     memcpy(blind_pinned.p, sg.blind_v.data(), sg.blind_v.size() * sizeof(F4));
     sg.blind = (const F4*)blind_pinned.p;
     PK_TRY(copy_stream_open(ctx));
+    if (!ctx->stream_aux) {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    }
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));                 // pooled blocks: everything enqueued so far comes first
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
     // Sharded session: every rank uploads every column (each GPU has its own PCIe link; all of them
     // are needed for the quotient) but commits only columns rank, rank + world, ...: the upload of
     // `world` columns hides one MSM.
@@ -597,22 +613,26 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     auto stage = [](void* user, size_t it) -> int {
         Stage* s_ = (Stage*)user;
         if (!s_->own.empty()) {      // device-gather mode: one own column per call
-            if (it > 0) PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
+            if (it > 0) PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
             const size_t c_ = s_->own[it];
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
-            return copy_stream_fence(s_->ctx);
+            PK_TRY(copy_stream_fence(s_->ctx));
+            ZK_HIP(s_->ctx, hipStreamWaitEvent(s_->ctx->stream_aux, s_->ctx->ev_copy, 0));
+            return ZK_OK;
         }
         // the group uploaded by the previous call is on the device (the main stream has waited for it):
         // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
         if (it > 0)
             for (size_t c_ = (it - 1) * s_->world; c_ < std::min(it * (size_t)s_->world, s_->dst.size()); ++c_)
-                PK_TRY(to_coeff(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
+                PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
         }
-        return copy_stream_fence(s_->ctx);
+        PK_TRY(copy_stream_fence(s_->ctx));
+        ZK_HIP(s_->ctx, hipStreamWaitEvent(s_->ctx->stream_aux, s_->ctx->ev_copy, 0));      // the aux stream transforms what was just uploaded
+        return ZK_OK;
     };
     std::vector<G1Affine> coms(sg.dst.size());
     if (sg.world == 1) {
@@ -651,6 +671,8 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         if (per && pr->gather(pr->gather_user, local.data(), per * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
         for (size_t c_ = 0; c_ < total; ++c_) coms[c_] = all[(c_ % sg.world) * per + c_ / sg.world];
     }
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream_aux));             // the main stream continues after the transforms
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
     trace.mark("advice upload + commits");
     for (const G1Affine& com : coms) pr->tr.write_point(com);
     uint32_t written = 0;
