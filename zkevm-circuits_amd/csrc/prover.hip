@@ -1,24 +1,30 @@
 // Host orchestration of a full PLONKish/KZG proof on top of the device kernels: the surface of
-// halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC multi-open
-// (poly::kzg::multiopen::ProverGWC), which is what BASELINE.json's north_star names.
-// External crate; reference call sites
-// [REF circuit-benchmarks/src/super_circuit.rs:109-132], [REF prover/src/common/prover/utils.rs:31,55].
+// halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC (poly::kzg::multiopen::ProverGWC,
+// what BASELINE.json's north_star names) or SHPLONK (ProverSHPLONK, what the reference's call
+// sites instantiate) multi-open.  External crate;
+// reference call sites [REF circuit-benchmarks/src/super_circuit.rs:109-132],
+// [REF prover/src/common/prover/utils.rs:31,55].
 //
 // What runs where:
-//   device : every commitment (MSM), every NTT / coset NTT, expression evaluation over the
-//            Lagrange and extended domains (quotient.hip), batch inversion, grand product /
-//            grand sum scans, polynomial evaluation, Kate division, linear combinations
-//   host   : transcript (Blake2b), RNG (XorShift), lookup multiplicity counting (hash join),
-//            program assembly, a handful of scalar field operations per challenge
+//   device : every commitment (MSM), every NTT / coset NTT, expression evaluation over Lagrange
+//            rows and over the cosets of the extended domain (quotient.hip), lookup multiplicities
+//            (lookup.hip), batch inversion, grand product / grand sum scans, the blinding
+//            polynomial (ChaCha20 counter mode), polynomial evaluation, Kate division, linear
+//            combinations
+//   host   : transcript (built-in Blake2b or the caller's object through a callback table), the
+//            blinding-row RNG (XorShift), program assembly, a handful of scalar field operations
+//            per challenge; for multi-GPU sessions the all-gather callbacks
 //
-// Protocol (one advice phase; mv-lookup/logUp lookups as in the Scroll halo2 fork, SURVEY note L):
-//   vk_repr, instances | advice commitments | theta | m commitments | beta, gamma |
-//   permutation Z commitments, lookup phi commitments | random poly | y | h pieces | x |
-//   evaluations | v | GWC witnesses.         The matching verifier is oracle/plonk_verifier.py.
+// Protocol (mv-lookup/logUp lookups as in the Scroll halo2 fork, SURVEY note L):
+//   vk_repr, instances | per phase: advice commitments, the phase's challenges | theta |
+//   m commitments | beta, gamma | permutation Z commitments | lookup phi commitments |
+//   random poly | y | h pieces | x | evaluations | GWC: v, witnesses  or  SHPLONK: y, v, h, u, pi.
+// The matching verifier is oracle/plonk_verifier.py; oracle/plonk_prover.py restates this file over
+// Python integers and the tests require both to produce the same proof bytes.
 //
-// The circuit arrives as a flat "pk blob" (zkevm-circuits_amd/plonk.py serialises it; SURVEY 8f-1
-// export format): header, permutation columns, constants, gate programs, lookup programs, fixed
-// columns and sigma columns in Lagrange form.
+// The circuit arrives as a flat "pk blob" (zkevm-circuits_amd/plonk.py serialises it; layout in
+// INTEGRATION.md, SURVEY 8f-1 export format): header, phases, permutation columns, constants, gate
+// programs, lookup programs, fixed columns and sigma columns in Lagrange form.
 #include <algorithm>
 #include <array>
 #include <unordered_map>
