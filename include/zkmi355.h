@@ -177,12 +177,13 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size
  * summed here.                                                                                   */
 int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine);
 
-/* ---- full proof: halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC multi-open
- * (poly::kzg::multiopen::ProverGWC)  -- SURVEY 8a A1, A4, K6-K11; see csrc/prover.hip ------------ */
+/* ---- full proof: halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC or SHPLONK multi-open
+ * (poly::kzg::multiopen::{ProverGWC, ProverSHPLONK})  -- SURVEY 8a A1, A4, K6-K11; csrc/prover.hip -- */
 typedef struct zk_pk zk_pk;
 /* keygen_pk over a flat circuit description (the "pk blob" of zkevm-circuits_amd/plonk.py:
- * header, permutation columns, constants, gate / lookup programs, fixed and sigma columns in
- * Lagrange form).  Commits fixed and sigma columns, builds coefficient and extended-coset forms. */
+ * header, phases, permutation columns, constants, gate / lookup programs, fixed and sigma columns
+ * in Lagrange form; layout in INTEGRATION.md).  Commits fixed and sigma columns and keeps their
+ * Lagrange and coefficient forms on the device.  srs must have the circuit's k (zk_srs_downsize).  */
 int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out);
 void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk);
 /* verifying-key side: (F + P) x 64-byte affine commitments (fixed, then sigma) and vk_repr (Fr)  */
