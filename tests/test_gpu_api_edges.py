@@ -79,3 +79,24 @@ def test_session_misuse_is_reported(zk, ctx, cref):
     finally:
         pk.destroy()
         srs.destroy()
+
+
+def test_pinned_host_columns_and_small_helpers(zk, ctx, cref):
+    """zk_host_alloc / zk_host_free (page-locked witness columns), zk_fr_powers, zk_fr_scale."""
+    n = 1 << 10
+    col = ctx.host_alloc((n, 4))
+    col[:] = cref.rand_fr_stream(31, n)
+    srs = ctx.srs_setup_with_s(10, cref.fr_const(9))
+    dev = ctx.alloc(n * 32)
+    got = ctx.commit_batch_h2d(srs, 1, [col], [dev], n)[0]
+    assert np.array_equal(got, ctx.commit(srs, ctx.to_device(np.array(col)), n, lagrange=True))
+    assert np.array_equal(dev.download((n, 4)), np.array(col))
+    ctx.host_free(col)
+    srs.destroy()
+    # powers: out[i] = mul * base^i
+    base, mul = 0x1234567, 0xABCDEF
+    out = ctx.alloc(100 * 32)
+    ctx.fr_powers(cref.fr_const(base), cref.fr_const(mul), out, 100)
+    assert [int(v) for v in cref.from_mont(out.download((100, 4)))] == [mul * pow(base, i, bn254.R_MOD) % bn254.R_MOD for i in range(100)]
+    ctx.fr_scale(out, cref.fr_const(7), 100)
+    assert [int(v) for v in cref.from_mont(out.download((100, 4)))] == [7 * mul * pow(base, i, bn254.R_MOD) % bn254.R_MOD for i in range(100)]
