@@ -1,7 +1,9 @@
 """GPU: a proving session sharded over ranks (commitments and quotient cosets split
 over the ranks, 64-byte points and finished cosets all-gathered) yields, on every rank, exactly the
 bytes of the unsharded session.  The box has one GPU, so the ranks share cuda:0 and exchange over
-gloo; the code path is the one an 8-GPU node runs with backend nccl (RCCL)."""
+gloo; the code path is the one an 8-GPU node runs with backend nccl (RCCL).  Cases: commitments
+split by column, advice columns all-gathered between devices (devgather), and -- at k >= 11, where a
+batch has fewer columns than ranks -- single MSMs split by points with host-summed partial results."""
 import os
 import subprocess
 import sys
@@ -12,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1)])
+@pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1), (2, 11, 1, 0), (3, 12, 0, 1)])
 def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather):
     port = 29500 + (os.getpid() % 2000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",

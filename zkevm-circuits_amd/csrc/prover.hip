@@ -43,6 +43,8 @@ extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, 
 extern "C" int zk_lookup_multiplicities(zk_ctx*, const void*, const void*, size_t, void*, size_t, uint64_t*);
 extern "C" int zk_coeff_to_coset(zk_ctx*, const void*, uint32_t, const void*, void*);
 extern "C" int zk_fr_scatter_scaled(zk_ctx*, const void*, size_t, const void*, void*, size_t, size_t);
+extern "C" int zk_msm_g1(zk_ctx*, const void*, const void*, size_t, void*);
+extern "C" int zk_g1_sum_host(const void*, size_t, void*);
 extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
 
 namespace {
@@ -354,6 +356,25 @@ void lagrange_masks(const zk_pk* pk, std::vector<F4>* l0, std::vector<F4>* llast
 // rank ends up with all of them in order and the transcripts stay identical.
 int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out) {
     if (pr->world <= 1 || !pr->gather) return zk_commit_batch(ctx, srs, basis, ptrs, count, n, out);
+    if (count < pr->world && n >= ((size_t)pr->world << 10)) {
+        // Fewer columns than ranks (aggregation layers: ~10 columns at k = 22..25, h pieces, the closing
+        // commitments): shard every MSM by POINTS instead -- rank r takes the r-th slice of the bases of
+        // each column, the 64-byte partial results are all-gathered (RCCL has no elliptic-curve reduction)
+        // and summed on the host.
+        const size_t base = n / pr->world, rem = n % pr->world;
+        const size_t lo = pr->rank * base + std::min<size_t>(pr->rank, rem), len = base + (pr->rank < rem ? 1 : 0);
+        const G1Affine* bases = basis ? srs->g_lagrange : srs->g;
+        std::vector<G1Affine> local(count), all(count * pr->world);
+        for (size_t i = 0; i < count; ++i)
+            PK_TRY(zk_msm_g1(ctx, (const Fr*)ptrs[i] + lo, bases + lo, len, &local[i]));
+        if (pr->gather(pr->gather_user, local.data(), count * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+        std::vector<G1Affine> parts(pr->world);
+        for (size_t i = 0; i < count; ++i) {
+            for (uint32_t q_ = 0; q_ < pr->world; ++q_) parts[q_] = all[(size_t)q_ * count + i];
+            if (zk_g1_sum_host(parts.data(), pr->world, &out[i])) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: partial sums could not be added");
+        }
+        return ZK_OK;
+    }
     const size_t per = (count + pr->world - 1) / pr->world;
     std::vector<const void*> mine;
     for (size_t i = pr->rank; i < count; i += pr->world) mine.push_back(ptrs[i]);
