@@ -16,7 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1), (2, 11, 1, 0), (3, 12, 0, 1)])
 def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather):
-    port = 29500 + (os.getpid() % 2000) + world
+    import socket
+    with socket.socket() as sock:          # a port that is free right now (cases run back to back)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "_sharded_proof_worker.py"), str(tmp_path), str(k), str(multiopen)]
     # devgather: the advice columns are uploaded by their owning rank only and all-gathered between devices
