@@ -156,7 +156,7 @@ def main():
             return ms / cnt if cnt else None
 
         bucket_ms = avg_ms("msm_buckets")
-        msm_ms = sum(avg_ms(x) or 0.0 for x in ("msm_sort", "msm_buckets"))   # reduce runs on the side stream under the next MSM
+        msm_ms = sum(avg_ms(x) or 0.0 for x in ("msm_sort", "msm_buckets", "msm_combine"))   # reduce runs on the side stream under the next MSM
         ntt_ms = (prof.get("ntt_pass", (0, 0))[0] + prof.get("ntt_last", (0, 0))[0]) / max(args.steps, 1)
         # roofline of the dominant kernel (bucket accumulation): algorithmic bytes per launch =
         # 96 B/unit (32 B scalar + 64 B affine base) x 2^20 units

@@ -675,6 +675,9 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
         hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_bases_rp, (const uint32_t*)offsets, (const uint32_t*)idx,
                            (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, pl.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
+    }
+    {
+        ZkProfScope ps(ctx, "msm_combine");
         hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
         hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
