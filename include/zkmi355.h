@@ -90,6 +90,17 @@ int zk_fr_batch_invert(zk_ctx* ctx, void* d_a, size_t n);
 int zk_ntt(zk_ctx* ctx, void* d_data, uint32_t log_n, int inverse);
 /* best_fft with an arbitrary primitive 2^log_n-th root (h_omega: one Fr), no scaling.            */
 int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega);
+/* ONE transform of size 2^log_n spread over `world` contexts, one per GPU (the
+ * 4-step split with a single all-to-all).  On entry rank r holds the residue class
+ * x[r + world * i], i < m = 2^log_n / world, in d_local; on return d_local[j1 * (m / world) + c]
+ * = X[(r * (m / world) + c) + m * j1]: every rank owns the outputs whose index mod m falls in its
+ * slice.  exchange(user, d_send, bytes_per_peer, d_recv) is an all-to-all of DEVICE buffers:
+ * block p of d_send goes to rank p, block p of d_recv comes from rank p (RCCL all_to_all_single
+ * over xGMI, see zkevm-circuits_amd/sharding.py); it must return 0 with d_recv complete.
+ * world: power of two <= 16, 2^log_n >= world^2.  inverse = 1 applies omega^-1 and 1/n.
+ * Worth it only for transforms far above 2^24: a 2^20 NTT takes 0.12 ms on one GPU.             */
+typedef int (*zk_alltoall_fn)(void* user, const void* d_send, size_t bytes_per_peer, void* d_recv);
+int zk_ntt_sharded(zk_ctx* ctx, void* d_local, uint32_t log_n, int inverse, uint32_t rank, uint32_t world, zk_alltoall_fn exchange, void* user);
 /* EvaluationDomain::coeff_to_extended: d_coeffs (2^k) -> d_out (2^ext_k): scale by zeta^i,
  * zero-pad, NTT over the extended domain.                                                       */
 int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out);

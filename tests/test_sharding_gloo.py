@@ -57,6 +57,25 @@ def _worker(rank, world, port, q):
         assert cb(None, ctypes.addressof(send), nbytes, ctypes.addressof(recv)) == 0
         for r in range(world):
             assert list(recv[r * nbytes:(r + 1) * nbytes]) == [(7 * r + i) & 0xFF for i in range(nbytes)]
+        # --- one NTT over the ranks (zk_ntt_sharded's 4-step split), the device steps stood in by the oracle:
+        # local transform of the residue class, twiddle, all-to-all, world-point transform across the rows
+        log_n = 6
+        n, m = 1 << log_n, (1 << log_n) // world
+        cols_ = m // world
+        x = cref.rand_fr_stream(31, n)
+        w_n = b.omega_for_k(log_n)
+        local = cref.from_mont(cref.best_fft(sharding.ntt_shard_input(x, rank, world), b.omega_for_k(log_n - 1), log_n - 1))
+        local = [int(v) * pow(w_n, rank * j2, b.R_MOD) % b.R_MOD for j2, v in enumerate(local)]
+        rows = [None] * world
+        dist.all_gather_object(rows, local)
+        recv = [rows[p][rank * cols_:(rank + 1) * cols_] for p in range(world)]          # block p comes from rank p
+        w_w = pow(w_n, m, b.R_MOD)
+        out = [sum(recv[i1][c] * pow(w_w, i1 * j1, b.R_MOD) for i1 in range(world)) % b.R_MOD for j1 in range(world) for c in range(cols_)]
+        full = cref.from_mont(cref.best_fft(x, w_n, log_n))
+        idx = sharding.ntt_shard_output_index(log_n, rank, world)
+        assert out == [int(full[i]) for i in idx]
+        every = np.sort(np.concatenate([sharding.ntt_shard_output_index(log_n, r, world) for r in range(world)]))
+        assert np.array_equal(every, np.arange(n))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

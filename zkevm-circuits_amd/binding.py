@@ -326,6 +326,13 @@ class Context:
     def ntt(self, data: DeviceBuffer, log_n: int, inverse: bool = False):
         self._ck(lib().zk_ntt(self.h, ctypes.c_void_p(data.ptr), ctypes.c_uint32(log_n), ctypes.c_int(1 if inverse else 0)))
 
+    def ntt_sharded(self, local: DeviceBuffer, log_n: int, rank: int, world: int, alltoall_cb, inverse: bool = False):
+        """This rank's part of ONE 2^log_n transform spread over `world` GPUs (zk_ntt_sharded):
+        in: x[rank + world * i]; out: [j1][c] = X[(rank * m / world + c) + m * j1], m = n / world.
+        alltoall_cb is a sharding.ALLTOALL_FN over device pointers."""
+        self._ck(lib().zk_ntt_sharded(self.h, ctypes.c_void_p(local.ptr), ctypes.c_uint32(log_n), ctypes.c_int(1 if inverse else 0),
+                                      ctypes.c_uint32(rank), ctypes.c_uint32(world), alltoall_cb, None))
+
     def ntt_omega(self, data: DeviceBuffer, log_n: int, omega_mont: np.ndarray):
         self._ck(lib().zk_ntt_omega(self.h, ctypes.c_void_p(data.ptr), ctypes.c_uint32(log_n), _host_ptr(np.ascontiguousarray(omega_mont))))
 

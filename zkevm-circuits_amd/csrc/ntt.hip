@@ -524,4 +524,85 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
     return ZK_OK;
 }
 
+// ---- one transform spread over several GPUs (SURVEY 8e "domain halves": the 4-step split) ------
+// n = W * m with W = world.  Write i = i1 + W * i2 and j = j2 + m * j1:
+//   X[j2 + m j1] = sum_{i1} w_W^(i1 j1) * [ w_n^(i1 j2) * sum_{i2} x[i1 + W i2] w_m^(i2 j2) ]
+// Rank i1 owns the residue class x[i1 + W i2]: a local size-m transform with the twiddle
+// w_n^(i1 j2) folded in as its output scaling, ONE all-to-all (rank c receives the j2 slice
+// [c m/W, (c+1) m/W) from everyone), and W-point butterflies across the received rows.
+template <int W>
+__global__ void __launch_bounds__(256) k_ntt_cross(const Fr* __restrict__ recv, Fr* __restrict__ out, size_t cols, const Fr* __restrict__ tw /* w_W^t, t < W/2 */, Fr scale, int scaled) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    constexpr int LOGW = W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4;
+    Fr a[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        int rev = 0;
+#pragma unroll
+        for (int b = 0; b < LOGW; ++b) rev |= ((i >> b) & 1) << (LOGW - 1 - b);
+        a[rev] = ldg(recv + (size_t)i * cols + c);
+    }
+#pragma unroll
+    for (int st = 1; st <= LOGW; ++st) {
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h) {                  // butterfly h of this stage: block h / half, lane t
+            const int half = 1 << (st - 1), t = h & (half - 1), lo = ((h >> (st - 1)) << st) + t, hi = lo + half;
+            const Fr u = a[lo];
+            const Fr v = t == 0 ? a[hi] : a[hi] * tw[t << (LOGW - st)];
+            a[lo] = u + v;
+            a[hi] = u - v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) stg(out + (size_t)j * cols + c, scaled ? a[j] * scale : a[j]);
+}
+
 }  // namespace zk
+
+using namespace zk;
+extern "C" int zk_ntt_sharded(zk_ctx* ctx, void* d_local, uint32_t log_n, int inverse, uint32_t rank, uint32_t world, zk_alltoall_fn exchange, void* user) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_local && exchange, "null pointer");
+    ZK_REQUIRE(ctx, world >= 1 && world <= 16 && (world & (world - 1)) == 0 && rank < world, "world must be a power of two <= 16, rank < world");
+    ZK_REQUIRE(ctx, log_n <= 28, "log_n exceeds the two-adicity of Fr (28)");
+    uint32_t log_w = 0;
+    while ((1u << log_w) < world) ++log_w;
+    ZK_REQUIRE(ctx, log_n >= 2 * log_w, "need n >= world^2");
+    if (world == 1) return zk_ntt(ctx, d_local, log_n, inverse);
+    const uint32_t log_m = log_n - log_w;
+    const size_t m = (size_t)1 << log_m, cols = m >> log_w;
+    Fr w_n = fr_root_of_unity(log_n), w_m = fr_root_of_unity(log_m), w_w = fr_root_of_unity(log_w);
+    if (inverse) { w_n = fr_inv_host(w_n); w_m = fr_inv_host(w_m); w_w = fr_inv_host(w_w); }
+    // steps 1 + 2: local transform over <w_m>, then element j2 times w_n^(rank * j2)
+    const Fr g = fr_pow(w_n, rank);
+    int rc = ntt_run(ctx, (Fr*)d_local, log_m, w_m, nullptr, nullptr, rank ? &g : nullptr);
+    if (rc) return rc;
+    // step 3: the exchange.  d_local is already [peer][cols]; the callback returns with d_recv complete
+    Fr* recv = (Fr*)ctx->pool_get(m * sizeof(Fr));
+    Fr* d_tw = (Fr*)ctx->pool_get(16 * sizeof(Fr));
+    if (!recv || !d_tw) { ctx->pool_put(recv, m * sizeof(Fr)); ctx->pool_put(d_tw, 16 * sizeof(Fr)); return ctx->fail(ZK_ERR_OOM, "sharded NTT: exchange buffer of %zu bytes", m * sizeof(Fr)); }
+    auto done = [&](int code) { ctx->pool_put(recv, m * sizeof(Fr)); ctx->pool_put(d_tw, 16 * sizeof(Fr)); return code; };
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
+    if (exchange(user, d_local, cols * sizeof(Fr), recv) != 0) return done(ctx->fail(ZK_ERR_INVALID_ARG, "sharded NTT: the all-to-all callback failed"));
+    // step 4: W-point transforms across the received rows, 1/n folded in for the inverse
+    Fr tw[8];
+    tw[0] = Fr::one();
+    for (uint32_t t = 1; t < (world > 1 ? world / 2 : 1); ++t) tw[t] = tw[t - 1] * w_w;
+    e = hipMemcpyAsync(d_tw, tw, sizeof(Fr) * (world / 2 ? world / 2 : 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
+    const Fr ninv = inverse ? fr_inv_host(fr_from_u64(1ull << log_n)) : Fr::one();
+    const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+    switch (world) {
+        case 2: hipLaunchKernelGGL(k_ntt_cross<2>, grid, block, 0, ctx->stream, (const Fr*)recv, (Fr*)d_local, cols, (const Fr*)d_tw, ninv, inverse); break;
+        case 4: hipLaunchKernelGGL(k_ntt_cross<4>, grid, block, 0, ctx->stream, (const Fr*)recv, (Fr*)d_local, cols, (const Fr*)d_tw, ninv, inverse); break;
+        case 8: hipLaunchKernelGGL(k_ntt_cross<8>, grid, block, 0, ctx->stream, (const Fr*)recv, (Fr*)d_local, cols, (const Fr*)d_tw, ninv, inverse); break;
+        default: hipLaunchKernelGGL(k_ntt_cross<16>, grid, block, 0, ctx->stream, (const Fr*)recv, (Fr*)d_local, cols, (const Fr*)d_tw, ninv, inverse); break;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
+    e = hipStreamSynchronize(ctx->stream);     // tw lives on this frame
+    if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
+    return done(ZK_OK);
+}

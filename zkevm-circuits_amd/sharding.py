@@ -159,3 +159,52 @@ def shard_session_device(session: "binding.ProofSession", group=None):
     cb_dev = make_allgather_dev(group)
     session.set_device_gather(cb_dev)
     return cb, cb_dev
+
+
+# ---------------------------------------------------------------- one NTT over several GPUs
+ALLTOALL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+def make_alltoall_dev(group=None):
+    """ctypes callback for zk_ntt_sharded: all-to-all of DEVICE buffers, bytes_per_peer bytes to and
+    from every rank.  Backend nccl: all_to_all_single over the library's own buffers (RCCL posts the
+    world - 1 sends/receives as one group, so all xGMI links carry traffic at once -- the transfer
+    is per-link bound, not a ring); backend gloo (single-GPU test boxes): staged through the host."""
+    backend = dist.get_backend(group)
+    world = dist.get_world_size(group)
+
+    def exchange(_user, send_ptr, bytes_per_peer, recv_ptr):
+        try:
+            total = bytes_per_peer * world
+            t_in = torch.as_tensor(_DevBytes(send_ptr, total), device="cuda")
+            t_out = torch.as_tensor(_DevBytes(recv_ptr, total), device="cuda")
+            if backend == "nccl":
+                dist.all_to_all_single(t_out, t_in, group=group)
+            else:
+                h_in = t_in.cpu()
+                blocks = [torch.empty(total, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(blocks, h_in, group=group)          # gloo has no all_to_all on every build
+                rank = dist.get_rank(group)
+                h_out = torch.cat([b[rank * bytes_per_peer:(rank + 1) * bytes_per_peer] for b in blocks])
+                t_out.copy_(h_out)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            print(f"[zkmi355 sharding] device all-to-all failed: {e!r}", flush=True)
+            return 1
+    return ALLTOALL_FN(exchange)
+
+
+def ntt_shard_input(x: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """Rows of x (n, 4) this rank holds on entry to the sharded transform: x[rank + world * i]."""
+    return np.ascontiguousarray(x[rank::world])
+
+
+def ntt_shard_output_index(log_n: int, rank: int, world: int) -> np.ndarray:
+    """Global output index of every element this rank holds after the sharded transform, in the
+    order they sit in its buffer ([j1][c], c < m / world)."""
+    m = (1 << log_n) // world
+    cols = m // world
+    j1 = np.arange(world, dtype=np.int64)[:, None]
+    c = np.arange(cols, dtype=np.int64)[None, :]
+    return (rank * cols + c + m * j1).reshape(-1)
