@@ -160,6 +160,25 @@ int zk_srs_setup_with_s(zk_ctx* ctx, uint32_t k, const void* h_s, zk_srs** out);
  * to its own degree): the first 2^new_k points of g, with the Lagrange basis of the smaller domain
  * recomputed on the device (g_to_lagrange: an inverse FFT over G1).                                 */
 int zk_srs_downsize(zk_ctx* ctx, const zk_srs* srs, uint32_t new_k, zk_srs** out);
+/* ---- SRS files: ParamsKZG::{read_custom, write_custom}; the reference loads `params{k}` through
+ * prover::utils::load_params [REF prover/src/utils.rs:39-84], default format RawBytesUnchecked
+ * [REF prover/src/utils.rs:32].  file = u32 k (LE) | g[n] | g_lagrange[n] | g2 | s_g2; G1 is 64 B
+ * (formats 1, 2: the in-memory Montgomery image) or 32 B (format 0: x canonical LE, bit 255 = parity
+ * of y); G2 is twice that and is handed through untouched (the prover never uses it).              */
+#define ZK_SERDE_PROCESSED 0
+#define ZK_SERDE_RAW 1            /* RawBytes: every point is checked (limbs < p, on the curve)      */
+#define ZK_SERDE_RAW_UNCHECKED 2
+/* 4 + 2 * 2^k * g1 + 2 * g2 bytes, the length load_params insists on; 0 for a bad k / format       */
+size_t zk_params_file_len(uint32_t k, int format);
+/* h_file: the whole file in host memory.  A length that does not match the k in its header is
+ * refused before anything is parsed, like the reference.  h_g2 / h_s_g2 (nullable) receive the two
+ * G2 encodings as they are in the file (128 B each, 64 B for Processed).                           */
+int zk_params_read(zk_ctx* ctx, const void* h_file, size_t len, int format, zk_srs** out, void* h_g2, void* h_s_g2);
+/* h_out = NULL: only *len is written (size query).  h_g2 / h_s_g2: the encodings to put in the file */
+int zk_params_write(zk_ctx* ctx, const zk_srs* srs, const void* h_g2, const void* h_s_g2, int format, void* h_out, size_t cap, size_t* len);
+/* unsafe_setup_with_s, G2 half (host only): the generator and s * generator as RawBytes
+ * (x.c0 | x.c1 | y.c0 | y.c1, Montgomery limbs; 128 B each); h_s: one Montgomery Fr                */
+int zk_g2_setup(const void* h_s, void* h_g2, void* h_s_g2);
 void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs);
 uint32_t zk_srs_k(const zk_srs* srs);
 const void* zk_srs_g(const zk_srs* srs);          /* device pointer, n G1Affine */

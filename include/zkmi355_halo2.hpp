@@ -130,7 +130,11 @@ class ParamsKZG {
     static ParamsKZG unsafe_setup_with_s(const Context& c, uint32_t k, const Fr& s) {
         zk_srs* p = nullptr;
         c.check(zk_srs_setup_with_s(c.raw(), k, s.data(), &p));
-        return ParamsKZG(c, p);
+        ParamsKZG out(c, p);
+        out.g2_.resize(128);
+        out.s_g2_.resize(128);
+        c.check(zk_g2_setup(s.data(), out.g2_.data(), out.s_g2_.data()));
+        return out;
     }
     // after ParamsKZG::read_custom on the host: g and g_lagrange in RawBytes layout
     static ParamsKZG from_points(const Context& c, uint32_t k, const std::vector<G1Affine>& g, const std::vector<G1Affine>& g_lagrange) {
@@ -138,13 +142,41 @@ class ParamsKZG {
         c.check(zk_srs_create(c.raw(), k, g.data(), g_lagrange.empty() ? nullptr : g_lagrange.data(), &p));
         return ParamsKZG(c, p);
     }
+    // ParamsKZG::read_custom(reader, format): `file` is the whole params{k} file; the G2 encodings are
+    // kept as they came (the verifier side needs them, the prover does not)
+    enum class SerdeFormat : int { Processed = ZK_SERDE_PROCESSED, RawBytes = ZK_SERDE_RAW, RawBytesUnchecked = ZK_SERDE_RAW_UNCHECKED };
+    static ParamsKZG read_custom(const Context& c, const std::vector<uint8_t>& file, SerdeFormat format = SerdeFormat::RawBytesUnchecked) {
+        zk_srs* p = nullptr;
+        std::vector<uint8_t> g2(128), s_g2(128);
+        c.check(zk_params_read(c.raw(), file.data(), file.size(), (int)format, &p, g2.data(), s_g2.data()));
+        ParamsKZG out(c, p);
+        const size_t gl = format == SerdeFormat::Processed ? 64 : 128;
+        g2.resize(gl);
+        s_g2.resize(gl);
+        out.g2_ = std::move(g2);
+        out.s_g2_ = std::move(s_g2);
+        return out;
+    }
+    // ParamsKZG::write_custom(writer, format)
+    std::vector<uint8_t> write_custom(SerdeFormat format = SerdeFormat::RawBytesUnchecked) const {
+        size_t len = 0;
+        c_.check(zk_params_write(c_.raw(), srs_, g2_.data(), s_g2_.data(), (int)format, nullptr, 0, &len));
+        std::vector<uint8_t> out(len);
+        c_.check(zk_params_write(c_.raw(), srs_, g2_.data(), s_g2_.data(), (int)format, out.data(), out.size(), &len));
+        return out;
+    }
+    const std::vector<uint8_t>& g2() const { return g2_; }
+    const std::vector<uint8_t>& s_g2() const { return s_g2_; }
     // ParamsKZG::downsize(k): g truncated, Lagrange basis of the smaller domain recomputed on the device
     ParamsKZG downsize(uint32_t new_k) const {
         zk_srs* p = nullptr;
         c_.check(zk_srs_downsize(c_.raw(), srs_, new_k, &p));
-        return ParamsKZG(c_, p);
+        ParamsKZG out(c_, p);
+        out.g2_ = g2_;
+        out.s_g2_ = s_g2_;
+        return out;
     }
-    ParamsKZG(ParamsKZG&& o) noexcept : c_(o.c_), srs_(o.srs_) { o.srs_ = nullptr; }
+    ParamsKZG(ParamsKZG&& o) noexcept : c_(o.c_), srs_(o.srs_), g2_(std::move(o.g2_)), s_g2_(std::move(o.s_g2_)) { o.srs_ = nullptr; }
     ~ParamsKZG() { if (srs_) zk_srs_destroy(c_.raw(), srs_); }
     uint32_t k() const { return zk_srs_k(srs_); }
     uint64_t n() const { return uint64_t(1) << k(); }
@@ -162,6 +194,7 @@ class ParamsKZG {
     ParamsKZG(const Context& c, zk_srs* p) : c_(c), srs_(p) {}
     const Context& c_;
     zk_srs* srs_;
+    std::vector<uint8_t> g2_, s_g2_;   // G2 generator and s * generator, file encoding
 };
 
 // plonk::keygen_pk result

@@ -74,7 +74,9 @@ int main() {
         zk::halo2::Context ctx(0);
         zk::halo2::Fr s{1, 0, 0, 0};
         auto params = zk::halo2::ParamsKZG::unsafe_setup_with_s(ctx, 4, s);
-        std::printf("ctx ok k=%u\\n", params.k());
+        auto file = params.write_custom();
+        auto back = zk::halo2::ParamsKZG::read_custom(ctx, file);
+        std::printf("ctx ok k=%u file=%zu back=%u same_g2=%d\\n", params.k(), file.size(), back.k(), (int)(back.s_g2() == params.s_g2()));
     } catch (const zk::halo2::Error& e) {
         std::printf("error %d: %s\\n", e.status, e.what());
     }
@@ -87,6 +89,6 @@ int main() {
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
     if torch.cuda.is_available():
-        assert "ctx ok k=4" in out
+        assert "ctx ok k=4 file=2308 back=4 same_g2=1" in out
     else:
         assert "error -4" in out and "no CPU fallback" in out

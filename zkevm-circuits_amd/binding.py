@@ -52,6 +52,7 @@ def lib():
         _lib.zk_srs_g.restype = ctypes.c_void_p
         _lib.zk_srs_g_lagrange.restype = ctypes.c_void_p
         _lib.zk_srs_k.restype = ctypes.c_uint32
+        _lib.zk_params_file_len.restype = ctypes.c_size_t
         _lib.zk_ctx_destroy.restype = None
         _lib.zk_srs_destroy.restype = None
         _lib.zk_pk_destroy.restype = None
@@ -424,6 +425,23 @@ class Context:
         self._ck(lib().zk_srs_create(self.h, ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(g)), gl, ctypes.byref(h)))
         return Srs(self, h)
 
+    # ---- SRS files (ParamsKZG::read_custom / write_custom): format 0 Processed, 1 RawBytes, 2 RawBytesUnchecked
+    def params_read(self, data: bytes, fmt: int = 2):
+        """-> (Srs, g2 bytes, s_g2 bytes); refuses a length that does not match the header's k."""
+        h = ctypes.c_void_p()
+        g2len = 64 if fmt == 0 else 128
+        g2, sg2 = ctypes.create_string_buffer(g2len), ctypes.create_string_buffer(g2len)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._ck(lib().zk_params_read(self.h, _host_ptr(buf), ctypes.c_size_t(buf.size), ctypes.c_int(fmt), ctypes.byref(h), g2, sg2))
+        return Srs(self, h), g2.raw, sg2.raw
+
+    def params_write(self, srs: Srs, g2: bytes, s_g2: bytes, fmt: int = 2) -> bytes:
+        need = ctypes.c_size_t()
+        self._ck(lib().zk_params_write(self.h, srs.h, g2, s_g2, ctypes.c_int(fmt), None, ctypes.c_size_t(0), ctypes.byref(need)))
+        out = np.empty(need.value, dtype=np.uint8)
+        self._ck(lib().zk_params_write(self.h, srs.h, g2, s_g2, ctypes.c_int(fmt), _host_ptr(out), ctypes.c_size_t(out.size), ctypes.byref(need)))
+        return out.tobytes()
+
     def srs_setup_with_s(self, k: int, s_mont: np.ndarray) -> Srs:
         h = ctypes.c_void_p()
         self._ck(lib().zk_srs_setup_with_s(self.h, ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(s_mont)), ctypes.byref(h)))
@@ -500,3 +518,16 @@ class Context:
 
 def version() -> str:
     return lib().zk_version().decode()
+
+
+def g2_setup(s_mont: np.ndarray):
+    """unsafe_setup_with_s, G2 half: (generator, s * generator) as 128-byte RawBytes each (host only)."""
+    g2, sg2 = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    rc = lib().zk_g2_setup(_host_ptr(np.ascontiguousarray(s_mont)), g2, sg2)
+    if rc != 0:
+        raise ZkError(f"zk_g2_setup failed: {rc}")
+    return g2.raw, sg2.raw
+
+
+def params_file_len(k: int, fmt: int = 2) -> int:
+    return int(lib().zk_params_file_len(ctypes.c_uint32(k), ctypes.c_int(fmt)))
