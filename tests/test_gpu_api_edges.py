@@ -100,3 +100,31 @@ def test_pinned_host_columns_and_small_helpers(zk, ctx, cref):
     assert [int(v) for v in cref.from_mont(out.download((100, 4)))] == [mul * pow(base, i, bn254.R_MOD) % bn254.R_MOD for i in range(100)]
     ctx.fr_scale(out, cref.fr_const(7), 100)
     assert [int(v) for v in cref.from_mont(out.download((100, 4)))] == [7 * mul * pow(base, i, bn254.R_MOD) % bn254.R_MOD for i in range(100)]
+
+
+def test_sharded_ntt_argument_checks_and_single_rank(zk, ctx, cref):
+    """zk_ntt_sharded: world must be a power of two with n >= world^2, a failing exchange callback
+    comes back as a status, and world = 1 is the ordinary transform."""
+    from zkevm_circuits_amd import sharding
+    k = 6
+    x = cref.rand_fr_stream(77, 1 << k)
+    calls = []
+
+    def exchange(_user, send, nbytes, recv):
+        calls.append(nbytes)
+        return 1
+    cb = sharding.ALLTOALL_FN(exchange)
+    buf = ctx.to_device(x)
+    for rank, world in ((0, 3), (2, 2), (0, 32)):
+        with pytest.raises(zk.ZkError, match="world"):
+            ctx.ntt_sharded(buf, k, rank, world, cb)
+    with pytest.raises(zk.ZkError, match="world\\^2"):
+        ctx.ntt_sharded(buf, 3, 0, 4, cb)
+    assert not calls
+    half = ctx.to_device(sharding.ntt_shard_input(x, 1, 2))
+    with pytest.raises(zk.ZkError, match="callback failed"):
+        ctx.ntt_sharded(half, k, 1, 2, cb)
+    assert calls == [(1 << k) // 4 * 32]
+    ctx.ntt_sharded(buf, k, 0, 1, cb)                    # one rank: no exchange at all
+    assert len(calls) == 1
+    assert np.array_equal(buf.download((1 << k, 4)), cref.best_fft(x, bn254.omega_for_k(k), k))
