@@ -7,7 +7,8 @@ NTT).  Inputs (column, SRS) are resident in HBM before the timed region starts.
 
 Multi-GPU: the prover shards by column -- rank r commits/transforms its own column,
 no data-path collective; the only exchange is the all-gather of the 64-byte commitments that a
-transcript round needs, done here every step with RCCL (`torch.distributed.all_gather`).  Weak
+transcript round needs, done here once per commitment batch with RCCL
+(`torch.distributed.all_gather_into_tensor`), as the prover does per phase.  Weak
 scaling: per-GPU work is fixed.
 
 Prints ONE JSON line (rank 0).  `value` = scalars committed per second over all ranks (Mscalar/s)
@@ -110,9 +111,9 @@ def main():
     d_work = ctx.to_device(column)           # transformed in place every step
     gather = None
     xdev = "cpu" if shared_gpu else "cuda"
-    com_t = torch.zeros(64, dtype=torch.uint8, device=xdev)
+    com_t = torch.zeros(64 * args.batch, dtype=torch.uint8, device=xdev)
     if world > 1:
-        gather = [torch.zeros(64, dtype=torch.uint8, device=xdev) for _ in range(world)]
+        gather = torch.zeros(64 * args.batch * world, dtype=torch.uint8, device=xdev)
 
     def run_steps(count):
         """`count` steps = `count` columns: the prover commits the columns of a phase as a batch
@@ -124,9 +125,10 @@ def main():
             for _ in range(b):
                 ctx.ntt(d_work, K, inverse=True)                               # b x NTT 2^20 (lagrange_to_coeff)
             if world > 1:
-                for j in range(b):
-                    com_t.copy_(torch.from_numpy(coms[j].view(np.uint8)))
-                    dist.all_gather(gather, com_t)
+                # one exchange per commitment round, as in the prover: every rank needs every
+                # commitment of the batch (64 B each) before the next transcript challenge
+                com_t[:64 * b].copy_(torch.from_numpy(np.ascontiguousarray(coms).view(np.uint8).reshape(-1)))
+                dist.all_gather_into_tensor(gather, com_t)
             done += b
 
     run_steps(args.warmup)
@@ -183,7 +185,7 @@ def main():
             "dtype": "u32x8 limbs (254-bit modular integer, Montgomery)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, 1 column per GPU", "k": K,
-                       "parallelism": f"column-sharded x{world}, all_gather(64 B commitment)/step" if world > 1 else "single GPU",
+                       "parallelism": f"column-sharded x{world}, all_gather(64 B commitment per column) once per commit batch" if world > 1 else "single GPU",
                        "columns_per_commit_batch": args.batch},
             "roofline": {
                 "kernel": "k_msm_buckets",
