@@ -344,6 +344,7 @@ def main():
     ap.add_argument("--shplonk", action="store_true", help="SHPLONK multi-open instead of GWC")
     ap.add_argument("--host-upload", action="store_true", help="sharded runs: every rank uploads every advice column (no device all-gather)")
     ap.add_argument("--pinned", action="store_true", help="advice columns in page-locked host memory (zk_host_alloc)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle's MSM / NTT at 2^k on the host and scale by the prover's counts")
     ap.add_argument("--shape", default="", help="A,F,P,L,d: circuit with this many advice / fixed / permutation columns, lookups and "
                     "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
     args = ap.parse_args()
@@ -430,6 +431,32 @@ def main():
         "multiopen": "shplonk" if args.shplonk else "gwc", "data": "synthetic-shape",
         "advice_host_memory": "pinned" if args.pinned else "pageable", "n_gpus": world,
     }
+    if args.cpu_baseline:
+        # The reference prover (Rust / Rayon) cannot be built here, and the oracle has no full prover
+        # at this size.  What can be timed on the host is what dominates halo2's create_proof: one
+        # best_multiexp and one best_fft of size 2^k in the C / OpenMP restatement, times the number
+        # of each the prover performs for this shape.  Quotient evaluation, the running products and
+        # witness synthesis are left out, so the figure is a LOWER bound for the restated CPU prover.
+        from oracle import bn254, cref
+        n = 1 << args.k
+        sc, bases = cref.rand_fr_stream(7, n), cref.srs_powers(3, min(n, 1 << 12))
+        bases = np.ascontiguousarray(np.tile(bases, (n // bases.shape[0], 1)))
+        t0 = time.perf_counter()
+        cref.best_multiexp(sc, bases, cref.usable_cpus())
+        t_msm = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cref.best_fft(sc, bn254.omega_for_k(args.k), args.k)
+        t_ntt = time.perf_counter() - t0
+        cosets = 1 << (circ.extended_k() - args.k)
+        polys = out["msm_count"] - (d - 1)                       # committed columns: advice, m / phi, Z, random
+        ntt_count = polys * (1 + cosets) + cosets               # lagrange_to_coeff + extended cosets, plus h back to coefficients
+        out["cpu_baseline"] = {
+            "kind": "port-estimate", "cores": cref.usable_cpus(), "msm_s": round(t_msm, 3), "ntt_s": round(t_ntt, 4),
+            "msm_count": out["msm_count"], "ntt_count_size_n": ntt_count,
+            "estimated_proof_s": round(out["msm_count"] * t_msm + ntt_count * t_ntt, 1),
+            "note": "C/OpenMP restatement of best_multiexp / best_fft timed once at 2^k, multiplied by the prover's MSM and "
+                    "size-n NTT counts for this shape; excludes quotient evaluation, products and synthesis (lower bound)",
+        }
     if world > 1:
         out["metric"] = f"synthetic-shape full proof wall-clock (s), {world} ranks (sharded session)"
         dist.destroy_process_group()
