@@ -373,6 +373,11 @@ def main():
         blob = circ.blob()
         adv_m = [plonk.column_to_mont(c) for c in adv]
         inst_m = [plonk.column_to_mont(c) for c in inst]
+    # halo2 hands create_proof the public inputs themselves, not an n-row column: keep the slice that
+    # holds them (the rest of the column is zero) so the transcript absorbs a handful of scalars
+    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
+    inst = [list(col[:m]) for col, m in zip(inst, npub)]
+    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
     if args.pinned:          # what a host integration would do: witness columns in page-locked memory
         pinned = {}
         for a in adv_m:
@@ -399,7 +404,7 @@ def main():
         if world > 1:
             dist.barrier()
             t0 = time.perf_counter()
-        sess = ctx.proof_session(pk, inst_m, bytes(16))
+        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
         sess.set_multiopen(1 if args.shplonk else 0)
         keep = None
         if world > 1:      # device all-gather of the advice columns unless --host-upload asks every rank to upload everything

@@ -235,6 +235,13 @@ typedef struct zk_proof zk_proof;
 enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };
 int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* proof, int kind);
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
+/* The same with halo2's instance slices as they are: h_instance[i] holds h_instance_len[i] values
+ * (not n).  Exactly those values are absorbed into the transcript -- what create_proof and
+ * verify_proof do: a circuit with a handful of public inputs absorbs a handful of scalars -- and the
+ * column is zero-padded on the device.  More values than usable rows is Error::InstanceTooLarge
+ * (status ZK_ERR_INVALID_ARG).  zk_proof_begin / zk_create_proof are the special case "every
+ * usable row is a public input".                                                                  */
+int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint32_t* h_instance_len, const uint8_t* seed16, zk_proof** out);
 /* External transcript (halo2's `T: TranscriptWrite<G1Affine, Challenge255>` argument of
  * create_proof): by default the session runs halo2's Blake2bWrite itself and zk_proof_finish
  * returns the proof bytes.  With a vtable every transcript operation is forwarded to the host

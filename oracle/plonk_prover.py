@@ -127,9 +127,14 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     sigma = circ.sigma_columns()
     rng, tr = XorShiftRng(seed16), Blake2bWrite()
 
+    # halo2 absorbs exactly the instance values it is given (KZG: QUERY_INSTANCE = false) and pads the
+    # column with zeros; more values than usable rows is Error::InstanceTooLarge.  An n-row column
+    # image stands for "every usable row is a public input".
     tr.common_scalar(vk_repr)
     for col in instance:
-        for row in range(u):
+        if u < len(col) < n:
+            raise ValueError("InstanceTooLarge")
+        for row in range(min(len(col), u)):
             tr.common_scalar(col[row])
     # ---- advice phases: blinding rows, commitments, then the phase's challenges
     adv = [list(c) for c in advice]
@@ -147,8 +152,8 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
             if cp == ph:
                 challenges[ci] = tr.squeeze()
     consts = Consts(circ.consts, challenges)
-    inst = [list(c) for c in instance]
-    lag_cols = {FIXED: circ.fixed, ADVICE: adv, INSTANCE: inst}
+    inst = [list(c) + [0] * (n - len(c)) for c in instance]
+    lag_cols ={FIXED: circ.fixed, ADVICE: adv, INSTANCE: inst}
 
     def row_lookup(row):
         return lambda t, i, rot: lag_cols[t][i][(row + rot) % n]

@@ -122,7 +122,7 @@ def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequ
     """MockProver-style check over the usable rows; returns None or a description of the failure."""
     n, u = circ.n, circ.u
     consts = Consts(circ.consts, challenges)
-    cols = {FIXED: circ.fixed, ADVICE: advice, INSTANCE: instance}
+    cols = {FIXED: circ.fixed, ADVICE: advice, INSTANCE: [list(c) + [0] * (circ.n - len(c)) for c in instance]}
     gates = [circ.compile(g) for g in circ.gates]
     lookups = [([circ.compile(e) for e in i], [circ.compile(e) for e in t]) for i, t in circ.lookups]
     for row in range(u):
@@ -261,8 +261,10 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
 
     tr = Blake2bRead(proof)
     tr.common_scalar(vk_repr)
-    for col in instance:
-        for row in range(u):
+    for col in instance:          # exactly the values given, as halo2's verify_proof does (an n-row image stands for all usable rows)
+        if u < len(col) < n:
+            return False
+        for row in range(min(len(col), u)):
             tr.common_scalar(col[row])
     # advice commitments phase by phase, each followed by that phase's challenges
     adv_com = [None] * A
@@ -322,7 +324,7 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
     def col_eval(t, i, rot):
         if t == INSTANCE:
             pt = point(rot)
-            return sum(instance[i][row] * lagrange_at(row, pt) for row in range(u) if instance[i][row]) % R
+            return sum(instance[i][row] * lagrange_at(row, pt) for row in range(min(len(instance[i]), u)) if instance[i][row]) % R
         return ev[(t, i, rot)]
 
     l0 = lagrange_at(0, x)

@@ -5,6 +5,7 @@ tampered proofs / instances must be rejected, unsatisfied witnesses must be refu
 import os
 import sys
 
+import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -328,3 +329,38 @@ def test_rotation_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8):
         pk.destroy()
     want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, cref.from_mont(rep.reshape(1, 4))[0], bytes(16), "shplonk")
     assert gpu_proof == want
+
+
+@pytest.mark.parametrize("multiopen", ["gwc", "shplonk"])
+def test_instance_slices_equal_the_oracle_prover(zk, ctx, cref, srs8, s_g2, multiopen):
+    """zk_proof_begin_instances: halo2's instance slices as they are -- exactly the given values are
+    absorbed, the column is zero-padded on the device.  Bytes equal the oracle prover's for the same
+    slices, the oracle verifier accepts them with the slices (and not with the n-row image), and
+    more values than usable rows is refused (Error::InstanceTooLarge)."""
+    from oracle import plonk_prover as pp
+    circ, adv, inst = build_circuit(6, seed=9, wide=True)
+    assert not any(inst[0][8:])
+    short = [inst[0][:8]]
+    seed = bytes((5 * i + 2) & 0xFF for i in range(16))
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        adv_m = {i: plonk.column_to_mont(c) for i, c in enumerate(adv)}
+        sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in short], seed, instance_slices=True)
+        sess.set_multiopen(1 if multiopen == "shplonk" else 0)
+        sess.advice_phase(adv_m)
+        gpu_proof = sess.finish()
+        with pytest.raises(zk.ZkError, match="InstanceTooLarge"):
+            ctx.proof_session(pk, [plonk.column_to_mont(inst[0][:circ.u + 1])], seed, instance_slices=True)
+        empty = ctx.proof_session(pk, [np.zeros((0, 4), dtype=np.uint64)], seed, instance_slices=True)   # no public input given at all
+        empty.abort()
+    finally:
+        pk.destroy()
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, short, vk_repr, seed, multiopen)
+    assert gpu_proof == want
+    assert pv.verify(circ, vk_points, vk_repr, short, gpu_proof, s_g2, multiopen=multiopen)
+    try:
+        assert not pv.verify(circ, vk_points, vk_repr, inst, gpu_proof, s_g2, multiopen=multiopen)
+    except AssertionError:
+        pass

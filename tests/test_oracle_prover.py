@@ -41,3 +41,28 @@ def test_oracle_prover_many_rotations():
     vk_points = pp.vk_commitments(circ, srs)
     proof = pp.create_proof(circ, srs, adv, inst, 99, bytes(16), "shplonk")
     assert pv.verify(circ, vk_points, 99, inst, proof, pr.ec_mul(pr.G2_GEN, S_SECRET), multiopen="shplonk")
+
+
+def test_instance_slices_are_absorbed_as_given():
+    """halo2 absorbs exactly the instance values it is handed (a circuit with 8 public inputs
+    feeds 8 scalars to the transcript), pads the column with zeros and refuses more values than
+    usable rows.  The slice proof differs from the proof over the n-row column image (other
+    transcript) and each verifies only with the instance form it was made for."""
+    circ, adv, inst = build_circuit(5, seed=3, wide=False)
+    assert not any(inst[0][8:])
+    short = [inst[0][:8]]
+    srs = pp.Srs(circ.k, S_SECRET)
+    vk_points, vk_repr = pp.vk_commitments(circ, srs), 0x7654321
+    s_g2 = pr.ec_mul(pr.G2_GEN, S_SECRET)
+    p_short = pp.create_proof(circ, srs, adv, short, vk_repr, bytes(range(16)), "shplonk")
+    p_full = pp.create_proof(circ, srs, adv, inst, vk_repr, bytes(range(16)), "shplonk")
+    assert p_short != p_full
+    assert pv.verify(circ, vk_points, vk_repr, short, p_short, s_g2, multiopen="shplonk")
+    assert pv.verify(circ, vk_points, vk_repr, inst, p_full, s_g2, multiopen="shplonk")
+    for proof, ins in ((p_short, inst), (p_full, short)):
+        try:
+            assert not pv.verify(circ, vk_points, vk_repr, ins, proof, s_g2, multiopen="shplonk")
+        except AssertionError:
+            pass
+    with pytest.raises(ValueError, match="InstanceTooLarge"):
+        pp.create_proof(circ, srs, adv, [inst[0][:circ.u + 1]], vk_repr, bytes(16), "gwc")

@@ -167,13 +167,19 @@ class _TranscriptVtable(ctypes.Structure):     # zk_transcript_vtable
 class ProofSession:
     """begin -> advice_phase(...) per phase (returns that phase's challenges) -> finish()."""
 
-    def __init__(self, ctx: "Context", pk: ProvingKey, instance: Sequence[np.ndarray], seed: bytes):
+    def __init__(self, ctx: "Context", pk: ProvingKey, instance: Sequence[np.ndarray], seed: bytes, instance_slices: bool = False):
+        """instance: (n, 4) column images (every usable row is absorbed), or -- instance_slices=True --
+        halo2's instance slices as they are: (len_i, 4) arrays, exactly len_i values absorbed each."""
         self.ctx = ctx
-        ins = [np.ascontiguousarray(a, dtype=np.uint64) for a in instance]
+        ins = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in instance]
         pi = (ctypes.c_void_p * max(len(ins), 1))(*[a.ctypes.data for a in ins])
         h = ctypes.c_void_p()
         assert len(seed) == 16
-        ctx._ck(lib().zk_proof_begin(ctx.h, pk.h, pi, ctypes.c_char_p(seed), ctypes.byref(h)))
+        if instance_slices:
+            lens = (ctypes.c_uint32 * max(len(ins), 1))(*[a.shape[0] for a in ins])
+            ctx._ck(lib().zk_proof_begin_instances(ctx.h, pk.h, pi, lens, ctypes.c_char_p(seed), ctypes.byref(h)))
+        else:
+            ctx._ck(lib().zk_proof_begin(ctx.h, pk.h, pi, ctypes.c_char_p(seed), ctypes.byref(h)))
         self.h = h
 
     def set_multiopen(self, kind: int):
@@ -505,8 +511,8 @@ class Context:
         self._ck(lib().zk_create_proof(self.h, pk.h, pa, pi, ctypes.c_char_p(seed), out, ctypes.c_size_t(cap), ctypes.byref(n)))
         return out.raw[:n.value]
 
-    def proof_session(self, pk: "ProvingKey", instance: Sequence[np.ndarray], seed: bytes = bytes(16)) -> "ProofSession":
-        return ProofSession(self, pk, instance, seed)
+    def proof_session(self, pk: "ProvingKey", instance: Sequence[np.ndarray], seed: bytes = bytes(16), instance_slices: bool = False) -> "ProofSession":
+        return ProofSession(self, pk, instance, seed, instance_slices)
 
     # ---- G1 element-wise
     def g1_affine_add(self, a: DeviceBuffer, b: DeviceBuffer, out: DeviceBuffer, n: int):

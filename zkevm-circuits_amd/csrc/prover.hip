@@ -563,23 +563,45 @@ int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* pr, zk_allgather_fn gather
     return ZK_OK;
 }
 
-int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
+// create_proof's instance handling: every PROVIDED value is absorbed (KZG: instances are not
+// committed), a column longer than the usable rows is Error::InstanceTooLarge, and the column is
+// zero-padded to n.  h_len == NULL is the full-column form: the usable rows of an n-row image.
+static int proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint32_t* h_len, const uint8_t* seed16, zk_proof** out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
     ZK_REQUIRE(ctx, pk && seed16 && out && (h_instance || !pk->I), "null pointer");
     const size_t n = (size_t)1 << pk->k;
+    if (h_len)
+        for (uint32_t i = 0; i < pk->I; ++i)
+            if (h_len[i] > pk->u) return ctx->fail(ZK_ERR_INVALID_ARG, "instance column %u has %u values, the circuit has %zu usable rows (InstanceTooLarge)", i, h_len[i], pk->u);
     std::unique_ptr<zk_proof> pr(new zk_proof(pk, seed16));
     pr->tr.common_scalar(pk->vk_repr);
     pr->absorbed.push_back(pk->vk_repr);
-    // instances (KZG: not committed; absorbed as scalars)
     for (uint32_t i = 0; i < pk->I; ++i) {
         const F4* v = (const F4*)h_instance[i];
-        for (size_t row = 0; row < pk->u; ++row) { pr->tr.common_scalar(v[row]); pr->absorbed.push_back(v[row]); }
-        PK_TRY(upload(ctx, &pr->inst_lag[i], h_instance[i], n * 32));
+        const size_t len = h_len ? h_len[i] : pk->u;
+        ZK_REQUIRE(ctx, v || !len, "null instance column");
+        for (size_t row = 0; row < len; ++row) { pr->tr.common_scalar(v[row]); pr->absorbed.push_back(v[row]); }
+        if (h_len) {
+            if (!pr->inst_lag[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
+            ZK_HIP(ctx, hipMemsetAsync(pr->inst_lag[i].p, 0, n * 32, ctx->stream));
+            if (len) PK_TRY(zk_h2d(ctx, pr->inst_lag[i].p, v, len * 32));
+        } else {
+            PK_TRY(upload(ctx, &pr->inst_lag[i], h_instance[i], n * 32));
+        }
         PK_TRY(to_coeff(ctx, pk, pr->inst_lag[i], &pr->inst_coeff[i]));
     }
     *out = pr.release();
     return ZK_OK;
+}
+int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out) {
+    return proof_begin(ctx, pk, h_instance, nullptr, seed16, out);
+}
+int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint32_t* h_instance_len, const uint8_t* seed16, zk_proof** out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && (h_instance_len || !pk->I), "null pointer");
+    static const uint32_t none = 0;
+    return proof_begin(ctx, pk, h_instance, h_instance_len ? h_instance_len : &none, seed16, out);
 }
 
 // Commits the advice columns of the current phase (h_cols[j] is advice column col_index[j]; exactly
