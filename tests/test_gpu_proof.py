@@ -364,3 +364,27 @@ def test_instance_slices_equal_the_oracle_prover(zk, ctx, cref, srs8, s_g2, mult
         assert not pv.verify(circ, vk_points, vk_repr, inst, gpu_proof, s_g2, multiopen=multiopen)
     except AssertionError:
         pass
+
+
+def test_evm_circuit_sized_proof_k14(ctx, cref, s_g2):
+    """BASELINE configs[0] is the EVM sub-circuit at k = 14 (the reference checks it with
+    MockProver; [REF circuit-benchmarks/src/evm_circuit.rs:44-60]).  Its stand-in here: a synthetic
+    circuit of that size class -- k = 14, 159 advice columns (the EVM circuit has 157), degree-5
+    gates, a lookup, 160 permutation columns -- proved through the session API with the instance
+    slice and accepted by the oracle's pairing verifier."""
+    import bench_proof
+    circ, blob, adv_m, inst_m, inst = bench_proof.build_large(ctx, 14, 53)
+    assert circ.A == 159 and circ.k == 14
+    npub = int(np.flatnonzero(inst_m[0].any(axis=1))[-1]) + 1
+    srs = ctx.srs_setup_with_s(14, np.frombuffer(plonk.fr_mont_bytes(S_SECRET), dtype=np.uint64).copy())
+    pk = ctx.pk_create(srs, blob)
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        sess = ctx.proof_session(pk, [np.ascontiguousarray(inst_m[0][:npub])], bytes(16), instance_slices=True)
+        sess.set_multiopen(1)
+        sess.advice_phase({i: c for i, c in enumerate(adv_m)})
+        proof = sess.finish()
+    finally:
+        pk.destroy()
+        srs.destroy()
+    assert pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [inst[0][:npub]], proof, s_g2, multiopen="shplonk")
