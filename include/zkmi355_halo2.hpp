@@ -222,5 +222,28 @@ inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk,
     return proof;
 }
 
+// The same with `instances: &[&[Fr]]` as halo2 takes them -- exactly these values are absorbed into
+// the transcript, the columns are zero-padded on the device -- for single-phase circuits (with
+// several phases the host re-synthesises between zk_proof_advice_phase calls).
+inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk, const std::vector<const void*>& advice_columns,
+                                         const std::vector<std::vector<Fr>>& instances, const std::array<uint8_t, 16>& rng_seed, bool shplonk = true) {
+    std::vector<const void*> ptrs;
+    std::vector<uint32_t> lens, index;
+    for (const auto& col : instances) { ptrs.push_back(col.data()); lens.push_back((uint32_t)col.size()); }
+    for (uint32_t i = 0; i < advice_columns.size(); ++i) index.push_back(i);
+    zk_proof* sess = nullptr;
+    c.check(zk_proof_begin_instances(c.raw(), pk.raw(), ptrs.data(), lens.data(), rng_seed.data(), &sess));
+    std::vector<uint8_t> proof(size_t(1) << 20);
+    size_t len = 0;
+    uint32_t num_challenges = 0;
+    std::vector<Fr> challenges(64);
+    int rc = zk_proof_set_multiopen(c.raw(), sess, shplonk ? 1 : 0);
+    if (rc == ZK_OK) rc = zk_proof_advice_phase(c.raw(), sess, index.data(), advice_columns.data(), (uint32_t)index.size(), challenges.data(), &num_challenges);
+    if (rc != ZK_OK) { zk_proof_abort(c.raw(), sess); c.check(rc); }
+    c.check(zk_proof_finish(c.raw(), sess, proof.data(), proof.size(), &len));
+    proof.resize(len);
+    return proof;
+}
+
 }  // namespace halo2
 }  // namespace zk

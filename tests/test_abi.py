@@ -74,6 +74,10 @@ int main() {
         zk::halo2::Context ctx(0);
         zk::halo2::Fr s{1, 0, 0, 0};
         auto params = zk::halo2::ParamsKZG::unsafe_setup_with_s(ctx, 4, s);
+        using namespace zk::halo2;      // the instance-slice create_proof overload must compile and link
+        auto fp = static_cast<std::vector<uint8_t> (*)(const Context&, const ProvingKey&, const std::vector<const void*>&,
+                                                       const std::vector<std::vector<Fr>>&, const std::array<uint8_t, 16>&, bool)>(&create_proof);
+        if (!fp) return 1;
         auto file = params.write_custom();
         auto back = zk::halo2::ParamsKZG::read_custom(ctx, file);
         std::printf("ctx ok k=%u file=%zu back=%u same_g2=%d\\n", params.k(), file.size(), back.k(), (int)(back.s_g2() == params.s_g2()));
