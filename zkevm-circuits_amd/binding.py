@@ -495,8 +495,8 @@ class Context:
             assert blob.dtype == np.uint8 and blob.flags["C_CONTIGUOUS"]
             self._ck(lib().zk_pk_create(self.h, srs.h, _host_ptr(blob), ctypes.c_size_t(blob.nbytes), ctypes.byref(h)))
             return ProvingKey(self, h)
-        buf = ctypes.create_string_buffer(blob, len(blob))
-        self._ck(lib().zk_pk_create(self.h, srs.h, buf, ctypes.c_size_t(len(blob)), ctypes.byref(h)))
+        view = np.frombuffer(blob, dtype=np.uint8)      # read-only view of the bytes object: no copy of a multi-GiB key
+        self._ck(lib().zk_pk_create(self.h, srs.h, _host_ptr(view), ctypes.c_size_t(view.size), ctypes.byref(h)))
         return ProvingKey(self, h)
 
     def create_proof(self, pk: "ProvingKey", advice: Sequence[np.ndarray], instance: Sequence[np.ndarray], seed: bytes = bytes(16)) -> bytes:

@@ -342,15 +342,6 @@ void push_compressed(PB& b, const std::vector<Prog>& exprs) {
 void push_perm_col(PB& b, const std::pair<uint32_t, uint32_t>& c) { b.col(c.first, c.second, 0); }
 
 // usable-row masks in Lagrange form
-void lagrange_masks(const zk_pk* pk, std::vector<F4>* l0, std::vector<F4>* llast, std::vector<F4>* lactive) {
-    const size_t n = (size_t)1 << pk->k;
-    const F4 one = host::fr_one(), zero = host::fr_zero();
-    l0->assign(n, zero); llast->assign(n, zero); lactive->assign(n, zero);
-    (*l0)[0] = one;
-    (*llast)[pk->u] = one;
-    for (size_t i = 0; i < pk->u; ++i) (*lactive)[i] = one;
-}
-
 // `count` commitments over one basis, split over the ranks of a sharded session: rank r commits
 // columns i = r, r + world, ... (pipelined batch) and the 64-byte points are all-gathered, so every
 // rank ends up with all of them in order and the transcripts stay identical.
@@ -453,32 +444,37 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
     pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F);
     pk->sigma_lag.resize(pk->P); pk->sigma_coeff.resize(pk->P);
     pk->fixed_com.resize(pk->F); pk->sigma_com.resize(pk->P);
-    for (uint32_t i = 0; i < pk->F; ++i) {
-        const uint8_t* b = r.bytes(n * 32);
-        if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated fixed column");
-        PK_TRY(upload(ctx, &pk->fixed_lag[i], b, n * 32));
-        PK_TRY(commit_lagrange(ctx, srs, pk->fixed_lag[i].fr(), n, &pk->fixed_com[i]));
-        PK_TRY(to_coeff(ctx, pk.get(), pk->fixed_lag[i], &pk->fixed_coeff[i]));
+    {   // keygen's commit_lagrange over every fixed and sigma column as ONE pipelined batch: column i + 1
+        // crosses PCIe on the copy stream while the MSM of column i runs; the coefficient forms follow
+        std::vector<const void*> h_cols;
+        std::vector<void*> d_cols;
+        for (uint32_t i = 0; i < pk->F + pk->P; ++i) {
+            const uint8_t* b = r.bytes(n * 32);
+            if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated %s column", i < pk->F ? "fixed" : "sigma");
+            DevBuf& lag = i < pk->F ? pk->fixed_lag[i] : pk->sigma_lag[i - pk->F];
+            if (!lag.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
+            h_cols.push_back(b);
+            d_cols.push_back(lag.p);
+        }
+        std::vector<G1Affine> coms(h_cols.size());
+        PK_TRY(zk_commit_batch_h2d(ctx, srs, 1, h_cols.data(), d_cols.data(), h_cols.size(), n, coms.data()));
+        for (uint32_t i = 0; i < pk->F; ++i) { pk->fixed_com[i] = coms[i]; PK_TRY(to_coeff(ctx, pk.get(), pk->fixed_lag[i], &pk->fixed_coeff[i])); }
+        for (uint32_t i = 0; i < pk->P; ++i) { pk->sigma_com[i] = coms[pk->F + i]; PK_TRY(to_coeff(ctx, pk.get(), pk->sigma_lag[i], &pk->sigma_coeff[i])); }
     }
-    for (uint32_t i = 0; i < pk->P; ++i) {
-        const uint8_t* b = r.bytes(n * 32);
-        if (!b) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated sigma column");
-        PK_TRY(upload(ctx, &pk->sigma_lag[i], b, n * 32));
-        PK_TRY(commit_lagrange(ctx, srs, pk->sigma_lag[i].fr(), n, &pk->sigma_com[i]));
-        PK_TRY(to_coeff(ctx, pk.get(), pk->sigma_lag[i], &pk->sigma_coeff[i]));
-    }
-    // l0, l_last, l_active and the X / omega^i columns
+    // l0, l_last, l_active (built on the device: a delta at row 0, a delta at row u, ones below u) and the omega^i column
     {
-        std::vector<F4> l0, ll, la;
-        lagrange_masks(pk.get(), &l0, &ll, &la);
-        PK_TRY(upload(ctx, &pk->l0_lag, l0.data(), n * 32));
-        PK_TRY(upload(ctx, &pk->llast_lag, ll.data(), n * 32));
-        PK_TRY(upload(ctx, &pk->lactive_lag, la.data(), n * 32));
+        const Fr w = fr_root_of_unity(pk->k), one = Fr::one();
+        if (!pk->l0_lag.alloc(n * 32) || !pk->llast_lag.alloc(n * 32) || !pk->lactive_lag.alloc(n * 32) || !pk->omega_lag.alloc(n * 32))
+            return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        ZK_HIP(ctx, hipMemsetAsync(pk->l0_lag.p, 0, n * 32, ctx->stream));
+        ZK_HIP(ctx, hipMemsetAsync(pk->llast_lag.p, 0, n * 32, ctx->stream));
+        ZK_HIP(ctx, hipMemsetAsync(pk->lactive_lag.p, 0, n * 32, ctx->stream));
+        PK_TRY(zk_h2d(ctx, pk->l0_lag.p, &one, 32));
+        PK_TRY(zk_h2d(ctx, (char*)pk->llast_lag.p + (size_t)pk->u * 32, &one, 32));
+        PK_TRY(zk_fr_powers(ctx, &one, &one, pk->lactive_lag.p, pk->u));          // 1 * 1^i: ones on the usable rows
         PK_TRY(to_coeff(ctx, pk.get(), pk->l0_lag, &pk->l0_coeff));
         PK_TRY(to_coeff(ctx, pk.get(), pk->llast_lag, &pk->llast_coeff));
         PK_TRY(to_coeff(ctx, pk.get(), pk->lactive_lag, &pk->lactive_coeff));
-        if (!pk->omega_lag.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        const Fr w = fr_root_of_unity(pk->k), one = Fr::one();
         PK_TRY(zk_fr_powers(ctx, &w, &one, pk->omega_lag.p, n));
         PK_TRY(zk_ctx_sync(ctx));
     }
