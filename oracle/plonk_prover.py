@@ -144,7 +144,7 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     for ph in range(max([0] + list(adv_phase) + list(chal_phase)) + 1):
         cols = [i for i in range(A) if adv_phase[i] == ph]
         for i in cols:
-            for row in range(n - bf, n):
+            for row in range(u, n):          # halo2: advice_values[n - (blinding_factors + 1)..], row u included
                 adv[i][row] = rng.next_fr()
         for i in cols:
             tr.write_point(srs.commit_lagrange(adv[i]))
@@ -153,7 +153,7 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
                 challenges[ci] = tr.squeeze()
     consts = Consts(circ.consts, challenges)
     inst = [list(c) + [0] * (n - len(c)) for c in instance]
-    lag_cols ={FIXED: circ.fixed, ADVICE: adv, INSTANCE: inst}
+    lag_cols = {FIXED: circ.fixed, ADVICE: adv, INSTANCE: inst}
 
     def row_lookup(row):
         return lambda t, i, rot: lag_cols[t][i][(row + rot) % n]

@@ -621,15 +621,15 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         by_col[c] = h_cols[j];
     }
     StageTrace trace(ctx);
-    // Column c+1 is uploaded on the copy stream while the MSM of column c runs; the last bf rows of
-    // every column are blinding values (drawn up front, in column-index = transcript order).
+    // Column c+1 is uploaded on the copy stream while the MSM of column c runs; the last bf + 1 rows
+    // (u .. n - 1) of every column are blinding values (drawn up front, in column-index = transcript order).
     struct Stage {
         zk_ctx* ctx; size_t body, tail;
         std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind_v; const F4* blind = nullptr;
         uint32_t world = 1;
         std::vector<size_t> own;                                         // device-gather mode: only these columns are uploaded by this rank
         const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
-    } sg{ctx, (n - pk->bf) * 32, (size_t)pk->bf * 32, {}, {}, {}};
+    } sg{ctx, (size_t)pk->u * 32, (size_t)(pk->bf + 1) * 32, {}, {}, {}};   // halo2: advice_values[n - (blinding_factors + 1)..] are random, row u included
     sg.pk = pk;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
@@ -638,7 +638,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         sg.dst.push_back(pr->adv_lag[c].p);
         sg.lag.push_back(&pr->adv_lag[c]);
         sg.coeff.push_back(&pr->adv_coeff[c]);
-        for (uint32_t r = 0; r < pk->bf; ++r) sg.blind_v.push_back(pr->rng.next_fr());
+        for (uint32_t r = 0; r <= pk->bf; ++r) sg.blind_v.push_back(pr->rng.next_fr());
     }
     PinnedBuf blind_pinned;
     if (!blind_pinned.alloc(sg.blind_v.size() * sizeof(F4))) return ctx->fail(ZK_ERR_OOM, "prover: pinned staging allocation failed");
