@@ -19,9 +19,62 @@
 // 1/(X^n - 1) on the coset (period 2^(ext_k-k)) before it is written.
 // HBM side: 32 B per (column, rotation) read + 32 B written per row -- the streaming-bound member
 // of the path.
+//
+// Arithmetic: the stack machine computes on nine 29-bit limbs (ff29.cuh) -- the carry-free
+// Montgomery product runs 1.6x faster than the 8 x 32 CIOS one.  Stack values stay in halo2curves'
+// R = 2^256 Montgomery form, normalised and below 2p.  mul29 divides by R' = 2^261, so a product of
+// two R-form values multiplies one operand by 32 first (a 5-bit limb shift: 64p still fits the
+// 261-bit container and 2p * 64p < 2^261 p); constants that only ever multiply (MUL_CONST, FOLD,
+// the vanishing inverses) are tabulated in R' form instead and need no shift.  Spilled stack
+// slots are packed to 8 words, so the LDS footprint is that of the 32-bit representation.
 #include "ctx.hpp"
+#include "ff29.cuh"
 
 namespace zk {
+
+using Q29 = F29<Fr29P>;
+
+// limb idx of K*p, normalised (limbs 0..7 < 2^29)
+template <class P>
+__host__ __device__ constexpr uint32_t kp_norm(int K, int idx) {
+    uint64_t carry = 0;
+    uint32_t out = 0;
+    for (int i = 0; i <= idx; ++i) {
+        const uint64_t v = (uint64_t)K * P::M(i) + carry;
+        out = i < 8 ? (uint32_t)(v & MASK29) : (uint32_t)v;
+        carry = v >> 29;
+    }
+    return out;
+}
+// r (limbs < 2^31, value < 4p) -> normalised representative below 2p: carry-propagate, then subtract
+// 2p with a signed borrow chain and keep the difference unless it went negative
+__device__ __forceinline__ Q29 q_settle(Q29 r) {
+    normalize29(r);
+    Q29 d;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int32_t s_ = (int32_t)r.l[i] - (int32_t)kp_norm<Fr29P>(2, i) + c;
+        d.l[i] = i < 8 ? ((uint32_t)s_ & MASK29) : (uint32_t)s_;
+        c = s_ >> 29;
+    }
+    const bool neg_ = (int32_t)d.l[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = neg_ ? r.l[i] : d.l[i];
+    return r;
+}
+__device__ __forceinline__ Q29 q_add(const Q29& a, const Q29& b) { return q_settle(add29(a, b)); }          // a, b < 2p
+__device__ __forceinline__ Q29 q_sub(const Q29& a, const Q29& b) { return q_settle(sub29k<2>(a, b)); }      // a - b + 2p in (0, 4p)
+// x * 32 for a normalised x < 2p: limbs stay normalised, value < 64p < 2^260
+__device__ __forceinline__ Q29 q_shl5(const Q29& x) {
+    Q29 r;
+    r.l[0] = (x.l[0] << 5) & MASK29;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.l[i] = ((x.l[i] << 5) & MASK29) | (x.l[i - 1] >> 24);
+    r.l[8] = (x.l[8] << 5) | (x.l[7] >> 24);
+    return r;
+}
+__device__ __forceinline__ Q29 q_mul(const Q29& a, const Q29& b) { return mul29(a, q_shl5(b)); }            // R-form x R-form -> R-form, < 2p
 
 enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11 };
 
@@ -44,29 +97,31 @@ struct QStack {
 
 __global__ void __launch_bounds__(Q_THREADS)
 k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const Fr* __restrict__ consts,
-                const Fr* __restrict__ t_evals, uint32_t ext_k, uint32_t k, Fr* __restrict__ out) {
+                const Fr* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
+                Fr* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     QStack st{smem};
     const uint64_t ne = 1ull << ext_k;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < ne;
     const uint32_t rot_scale = 1u << (ext_k - k);
-    Fr acc = Fr::zero();
+    const Q29 zero29 = unpack29<Fr29P>(Fr::zero());
+    Q29 acc = zero29;
     // The two topmost stack elements live in registers (t0 = top, t1 = second); element j < sp - 2
     // lives in LDS slot j.  Runs like `a b MUL c SUB` never touch LDS, and the LDS footprint per
     // lane (what bounds occupancy here) is max_depth - 2 slots.
-    Fr t0 = Fr::zero(), t1 = Fr::zero();
+    Q29 t0 = zero29, t1 = zero29;
     int sp = 0;
-    auto push = [&](const Fr& v) {
-        if (sp >= 2) st.put(sp - 2, t1);
+    auto push = [&](const Q29& v) {
+        if (sp >= 2) st.put(sp - 2, pack29_raw(t1));
         t1 = t0;
         t0 = v;
         ++sp;
     };
-    auto drop_to = [&](const Fr& top) {      // two operands consumed, `top` is the new top of stack
+    auto drop_to = [&](const Q29& top) {      // two operands consumed, `top` is the new top of stack
         --sp;
         t0 = top;
-        if (sp >= 2) t1 = st.get(sp - 2);
+        if (sp >= 2) t1 = unpack29<Fr29P>(st.get(sp - 2));
     };
     for (uint32_t pc = 0; pc < prog_len; ++pc) {
         const uint32_t op = prog[3 * pc], a = prog[3 * pc + 1], b = prog[3 * pc + 2];
@@ -75,25 +130,25 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
             case Q_PUSH_COL: {
                 const int64_t rot = (int32_t)b;
                 const uint64_t row = (i + (uint64_t)(rot * (int64_t)rot_scale)) & (ne - 1);
-                push(live ? ldg(cols[a] + row) : Fr::zero());
+                push(unpack29<Fr29P>(live ? ldg(cols[a] + row) : Fr::zero()));
                 break;
             }
-            case Q_PUSH_CONST: push(ldg(consts + a)); break;
-            case Q_ADD: drop_to(t1 + t0); break;
-            case Q_SUB: drop_to(t1 - t0); break;
-            case Q_MUL: drop_to(t1 * t0); break;
-            case Q_NEG: t0 = neg(t0); break;
-            case Q_SQUARE: t0 = sqr(t0); break;
-            case Q_DOUBLE: t0 = dbl(t0); break;
-            case Q_FOLD: acc = acc * ldg(consts + a) + t0; drop_to(t1); break;
-            case Q_MUL_CONST: t0 = t0 * ldg(consts + a); break;
-            case Q_ADD_CONST: t0 = t0 + ldg(consts + a); break;
+            case Q_PUSH_CONST: push(unpack29<Fr29P>(ldg(consts + a))); break;
+            case Q_ADD: drop_to(q_add(t1, t0)); break;
+            case Q_SUB: drop_to(q_sub(t1, t0)); break;
+            case Q_MUL: drop_to(q_mul(t1, t0)); break;
+            case Q_NEG: t0 = q_sub(zero29, t0); break;
+            case Q_SQUARE: t0 = q_mul(t0, t0); break;
+            case Q_DOUBLE: t0 = q_add(t0, t0); break;
+            case Q_FOLD: acc = q_add(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + a))), t0); drop_to(t1); break;
+            case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + a))); break;
+            case Q_ADD_CONST: t0 = q_add(t0, unpack29<Fr29P>(ldg(consts + a))); break;
             default: break;
         }
     }
     if (live) {
-        if (t_evals) acc = acc * ldg(t_evals + (i & (rot_scale - 1)));
-        stg(out + i, acc);
+        if (t_evals) acc = mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1)))));
+        stg(out + i, pack29_lt2p(acc));
     }
 }
 
@@ -149,8 +204,13 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     if (depth < 1) depth = 1;
     std::vector<Fr> tev;
     if (divide_by_vanishing) vanishing_inverses(k, ext_k, &tev);
+    // constants that multiply (MUL_CONST, FOLD) and the vanishing inverses go to the device in R' = 2^261 form too: x 32
+    auto times32 = [](Fr x) { for (int j = 0; j < 5; ++j) x = dbl(x); return x; };
+    std::vector<Fr> consts_rp((const Fr*)h_consts, (const Fr*)h_consts + num_consts);
+    for (Fr& c : consts_rp) c = times32(c);
+    for (Fr& t : tev) t = times32(t);
     const size_t prog_bytes = (size_t)num_instr * 12 + 12, col_bytes = (size_t)(num_cols ? num_cols : 1) * 8;
-    const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(Fr), tev_bytes = tev.size() * sizeof(Fr);
+    const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(Fr) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
     if (!d) return ZK_ERR_OOM;
@@ -163,6 +223,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     ZK_HIP(ctx, hipMemcpyAsync(d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (num_cols) ZK_HIP(ctx, hipMemcpyAsync(d_cols, h_col_ptrs, (size_t)num_cols * 8, hipMemcpyHostToDevice, ctx->stream));
     if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts, h_consts, (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts + num_consts, consts_rp.data(), (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     if (!tev.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_tev, tev.data(), tev_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
@@ -174,7 +235,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     }
     ZkProfScope ps(ctx, "quotient_eval");
     hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                       num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out);
+                       num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
