@@ -97,6 +97,19 @@ __global__ void k_lshladd64(uint64_t* out, uint32_t a, uint32_t b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__global__ void k_lshr64(uint64_t* out, uint32_t a, uint32_t b) {
+    uint64_t acc[CH];
+    for (int i = 0; i < CH; ++i) acc[i] = ((uint64_t)(i + threadIdx.x + b) << 40) | a;
+    for (int it = 0; it < ITERS; ++it) {
+#define S(i) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[i]));
+        BODY8(S) BODY8(S)
+#undef S
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < CH; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // field-op chains: 4 independent chains/thread
 template <class F, int OP>
 __global__ void k_field(uint64_t* out, const F* in) {
@@ -181,7 +194,7 @@ int main() {
 #define RUN(K) report(#K, time_kernel([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, out, 12345u, 678u); }), n16)
     RUN(k_fma32); RUN(k_add); RUN(k_xor); RUN(k_addco); RUN(k_addc); RUN(k_alignbit);
     RUN(k_mul_lo); RUN(k_mul_hi); RUN(k_mad24); RUN(k_mulhi24);
-    RUN(k_mad64); RUN(k_lshladd64); RUN(k_fma64);
+    RUN(k_mad64); RUN(k_lshladd64); RUN(k_lshr64); RUN(k_fma64);
     report("k_mad64_addc(pair)", time_kernel([&] { hipLaunchKernelGGL(k_mad64_addc, dim3(blocks), dim3(threads), 0, 0, out, 12345u, 678u); }), n16);
 
     // field ops
