@@ -59,6 +59,10 @@ int zk_buf_free(zk_ctx* ctx, void* d_ptr);
  * compute (zk_commit_batch_h2d, zk_proof_advice_phase); pageable memory works too, at about half. */
 int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** h_ptr);
 int zk_host_free(zk_ctx* ctx, void* h_ptr);
+/* Page-lock memory the caller already owns (e.g. the Vec<Fr> columns of a witness that is reused
+ * across proofs) instead of copying it into zk_host_alloc memory; unregister before freeing it.   */
+int zk_host_register(zk_ctx* ctx, void* h_ptr, size_t bytes);
+int zk_host_unregister(zk_ctx* ctx, void* h_ptr);
 int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int zk_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int zk_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);

@@ -92,6 +92,14 @@ def test_pinned_host_columns_and_small_helpers(zk, ctx, cref):
     assert np.array_equal(got, ctx.commit(srs, ctx.to_device(np.array(col)), n, lagrange=True))
     assert np.array_equal(dev.download((n, 4)), np.array(col))
     ctx.host_free(col)
+    # memory the caller owns, pinned in place (zk_host_register): same result, and the range can be released again
+    own = np.ascontiguousarray(cref.rand_fr_stream(32, n))
+    ctx.host_register(own)
+    got = ctx.commit_batch_h2d(srs, 1, [own], [dev], n)[0]
+    assert np.array_equal(got, ctx.commit(srs, ctx.to_device(own), n, lagrange=True))
+    ctx.host_unregister(own)
+    with pytest.raises(zk.ZkError):
+        ctx.host_unregister(own)                       # not registered any more
     srs.destroy()
     # powers: out[i] = mul * base^i
     base, mul = 0x1234567, 0xABCDEF

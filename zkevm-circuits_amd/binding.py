@@ -392,6 +392,14 @@ class Context:
         if p is not None:
             self._ck(lib().zk_host_free(self.h, ctypes.c_void_p(p)))
 
+    def host_register(self, arr: np.ndarray):
+        """Page-lock an array the caller owns (zk_host_register); pair with host_unregister(arr)."""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(lib().zk_host_register(self.h, ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._ck(lib().zk_host_unregister(self.h, ctypes.c_void_p(arr.ctypes.data)))
+
     def lookup_multiplicities(self, inputs: DeviceBuffer, table: DeviceBuffer, usable_rows: int, m: DeviceBuffer, n: int) -> Optional[int]:
         """logUp m(X) on the device; returns the lowest input row missing from the table, or None."""
         bad = ctypes.c_uint64()

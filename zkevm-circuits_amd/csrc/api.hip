@@ -124,6 +124,22 @@ int zk_host_free(zk_ctx* ctx, void* h_ptr) {
     if (h_ptr) ZK_HIP(ctx, hipHostFree(h_ptr));
     return ZK_OK;
 }
+// Pin memory the caller already owns (a Vec<Fr> of witness values): same upload behaviour as
+// zk_host_alloc memory without copying the column into it first.
+int zk_host_register(zk_ctx* ctx, void* h_ptr, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, h_ptr && bytes, "null pointer or empty range");
+    hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx->fail(ZK_ERR_HIP, "hipHostRegister of %zu bytes failed: %s", bytes, hipGetErrorString(e)); }
+    return ZK_OK;
+}
+int zk_host_unregister(zk_ctx* ctx, void* h_ptr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, h_ptr, "null pointer");
+    hipError_t e = hipHostUnregister(h_ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx->fail(ZK_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e)); }
+    return ZK_OK;
+}
 int zk_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, (d_dst && h_src) || !bytes, "null pointer");
