@@ -388,3 +388,36 @@ def test_evm_circuit_sized_proof_k14(ctx, cref, s_g2):
         pk.destroy()
         srs.destroy()
     assert pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [inst[0][:npub]], proof, s_g2, multiopen="shplonk")
+
+
+def test_shared_subexpressions_through_intermediates(ctx, cref, srs8, s_g2):
+    """The key blob exported with cross-gate common-subexpression elimination (TEE_TMP / PUSH_TMP,
+    what halo2's GraphEvaluator does with its intermediates) gives the same proof bytes as the plain
+    export and as the oracle prover, which evaluates every gate expression from scratch."""
+    from oracle import plonk_prover as pp
+    circ, adv, inst = build_circuit(6, seed=11, wide=True)
+    q_mul, a, b_, cc = circ.fixed_col(0), circ.advice_col(0), circ.advice_col(1), circ.advice_col(2)
+    circ.add_gate((q_mul * (a * b_ - cc)) * (a * b_ + 5))            # reuses a*b, a*b - c and the whole first gate
+    circ.add_gate(q_mul * ((a * b_ - cc) * (a * b_ - cc)))
+    progs = circ.compile_gates_cse()
+    ops = [op for p in progs for op, _, _ in p]
+    assert plonk.Q_TEE_TMP in ops and ops.count(plonk.Q_PUSH_TMP) >= 3
+    assert sum(len(p) for p in progs) < sum(len(circ.compile(g)) for g in circ.gates)
+    assert pv.check_witness(circ, adv, inst) is None
+    seed = bytes((7 * i + 3) & 0xFF for i in range(16))
+    proofs = []
+    for cse in (False, True):
+        pk = ctx.pk_create(srs8[circ.k], circ.blob(cse=cse))
+        try:
+            com, rep = pk.vk(circ.F + len(circ.perm_cols))
+            sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], seed)
+            sess.set_multiopen(1)
+            sess.advice_phase({i: plonk.column_to_mont(c) for i, c in enumerate(adv)})
+            proofs.append(sess.finish())
+        finally:
+            pk.destroy()
+    assert proofs[0] == proofs[1]
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, vk_repr, seed, "shplonk")
+    assert proofs[1] == want
+    assert pv.verify(circ, vk_points, vk_repr, inst, proofs[1], s_g2, multiopen="shplonk")

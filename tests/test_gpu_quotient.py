@@ -19,7 +19,7 @@ def _run_oracle(prog, cols, consts, k, ext_k, divide):
         zn, step = pow(b.FR_ZETA, 1 << k, R), pow(b.omega_for_k(ext_k), 1 << k, R)
         tev = [b.fr_inv((zn * pow(step, j, R) - 1) % R) for j in range(scale)]
     for i in range(ne):
-        st, acc = [], 0
+        st, acc, tmp = [], 0, {}
         for op, a, bb in prog:
             if op == 1:
                 rot = bb if bb < (1 << 31) else bb - (1 << 32)
@@ -34,6 +34,8 @@ def _run_oracle(prog, cols, consts, k, ext_k, divide):
             elif op == 9: acc = (acc * consts[a] + st.pop()) % R
             elif op == 10: st[-1] = st[-1] * consts[a] % R
             elif op == 11: st[-1] = (st[-1] + consts[a]) % R
+            elif op == 12: tmp[a] = st[-1]
+            elif op == 13: st.append(tmp[a])
         out.append(acc * tev[i % scale] % R if divide else acc)
     return out
 
@@ -96,3 +98,33 @@ def test_bad_programs_are_rejected(zk, ctx, cref):
     for prog in ([(zk.Q_ADD, 0, 0)], [(zk.Q_PUSH_COL, 3, 0)], [(zk.Q_PUSH_CONST, 9, 0)], [(99, 0, 0)], [(zk.Q_FOLD, 0, 0)]):
         with pytest.raises(zk.ZkError):
             ctx.quotient_eval(np.array(prog, dtype=np.uint32), [col.ptr], cref.to_mont([1]), 4, 4, out)
+
+
+@pytest.mark.parametrize("k,ext_k", [(6, 6), (7, 9)])
+def test_intermediates_shared_between_gates(zk, ctx, cref, k, ext_k):
+    """TEE_TMP / PUSH_TMP (halo2's GraphEvaluator intermediates): a product computed by one gate and
+    parked in the row's scratch is read back by later gates; same values as recomputing it."""
+    rng = random.Random(7 * k + ext_k)
+    ne = 1 << ext_k
+    cols = [[rng.randrange(R) for _ in range(ne)] for _ in range(3)]
+    consts = [rng.randrange(R) for _ in range(3)]
+    M32 = 1 << 32
+    shared = [(zk.Q_PUSH_COL, 0, 0), (zk.Q_PUSH_COL, 1, 1), (zk.Q_MUL, 0, 0), (zk.Q_PUSH_COL, 2, (-2) % M32), (zk.Q_ADD, 0, 0)]      # s = c0 * c1(+1) + c2(-2)
+    plain = (shared + [(zk.Q_PUSH_COL, 2, 0), (zk.Q_MUL, 0, 0), (zk.Q_FOLD, 0, 0)]                       # gate 1: s * c2
+             + shared + shared + [(zk.Q_MUL, 0, 0), (zk.Q_ADD_CONST, 1, 0), (zk.Q_FOLD, 0, 0)]           # gate 2: s * s + k1
+             + [(zk.Q_PUSH_COL, 1, 0)] + shared + [(zk.Q_SUB, 0, 0), (zk.Q_MUL_CONST, 2, 0), (zk.Q_FOLD, 0, 0)])   # gate 3: (c1 - s) * k2
+    with_tmp = (shared + [(zk.Q_TEE_TMP, 5, 0), (zk.Q_PUSH_COL, 2, 0), (zk.Q_MUL, 0, 0), (zk.Q_FOLD, 0, 0)]
+                + [(zk.Q_PUSH_TMP, 5, 0), (zk.Q_PUSH_TMP, 5, 0), (zk.Q_MUL, 0, 0), (zk.Q_TEE_TMP, 0, 0), (zk.Q_ADD_CONST, 1, 0), (zk.Q_FOLD, 0, 0)]
+                + [(zk.Q_PUSH_COL, 1, 0), (zk.Q_PUSH_TMP, 5, 0), (zk.Q_SUB, 0, 0), (zk.Q_MUL_CONST, 2, 0), (zk.Q_FOLD, 0, 0)])
+    dcols = [ctx.to_device(cref.to_mont(c)) for c in cols]
+    out = ctx.alloc(ne * 32)
+    want = _run_oracle(plain, cols, consts, k, ext_k, ext_k > k)
+    for prog in (plain, with_tmp):
+        ctx.quotient_eval(np.array(prog, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out, ext_k > k)
+        assert cref.from_mont(out.download((ne, 4))) == want
+    assert _run_oracle(with_tmp, cols, consts, k, ext_k, ext_k > k) == want
+    for bad, msg in (([(zk.Q_PUSH_TMP, 0, 0), (zk.Q_FOLD, 0, 0)], "read before it is written"),
+                     ([(zk.Q_TEE_TMP, 0, 0)], "bad TEE_TMP"),
+                     ([(zk.Q_PUSH_COL, 0, 0), (zk.Q_TEE_TMP, 1 << 20, 0), (zk.Q_FOLD, 0, 0)], "bad TEE_TMP")):
+        with pytest.raises(zk.ZkError, match=msg):
+            ctx.quotient_eval(np.array(bad, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out, False)

@@ -23,7 +23,7 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "zkmi355.h")
 FIELD_FR, FIELD_FQ = 0, 1
 OP_ADD, OP_SUB, OP_MUL = 0, 1, 2
 # quotient-program opcodes (csrc/quotient.hip)
-Q_END, Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_SQUARE, Q_DOUBLE, Q_FOLD, Q_MUL_CONST, Q_ADD_CONST = range(12)
+Q_END, Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_SQUARE, Q_DOUBLE, Q_FOLD, Q_MUL_CONST, Q_ADD_CONST, Q_TEE_TMP, Q_PUSH_TMP = range(14)
 
 _lib = None
 

@@ -51,7 +51,7 @@ namespace {
 
 enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECIAL = 3, CT_PERM_Z = 4, CT_SIGMA = 5, CT_LK_M = 6, CT_LK_PHI = 7, CT_RANDOM = 8, CT_H = 9 };
 enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
-enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11 };
+enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
 // abstract constant operands: user constants are [0, num_consts); challenges live above
 constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u,   // C_DELTA0 + j = beta * delta^j
                    C_CHAL0 = 0xFFFD0000u;                                                                                      // C_CHAL0 + i = user challenge i

@@ -10,6 +10,9 @@
 //      PUSH_CONST j        push consts[j]              (constants, challenges, beta/gamma/theta)
 //      ADD SUB MUL NEG SQUARE DOUBLE MUL_CONST j ADD_CONST j
 //      FOLD j              acc = acc * consts[j] + pop()     (the `acc * y + term` folding)
+//      TEE_TMP t           tmp[t] = top (stack unchanged)    -- halo2's GraphEvaluator keeps every shared
+//      PUSH_TMP t          push tmp[t]                          sub-expression as an intermediate; a value used by
+//                                                               several gates is computed once and parked here
 //      END
 //
 // One lane per extended-domain row; control flow is uniform across the grid (every lane runs the
@@ -76,10 +79,11 @@ __device__ __forceinline__ Q29 q_shl5(const Q29& x) {
 }
 __device__ __forceinline__ Q29 q_mul(const Q29& a, const Q29& b) { return mul29(a, q_shl5(b)); }            // R-form x R-form -> R-form, < 2p
 
-enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11 };
+enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
 
 constexpr int Q_THREADS = 256;
 constexpr int Q_MAX_STACK = 16;
+constexpr uint32_t Q_MAX_TMP = 4096;     // intermediates live in HBM, [slot][row]: 32 MiB per slot at 2^20 rows
 
 struct QStack {
     uint32_t* base;   // [slot][limb][lane]
@@ -98,7 +102,7 @@ struct QStack {
 __global__ void __launch_bounds__(Q_THREADS)
 k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const Fr* __restrict__ consts,
                 const Fr* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
-                Fr* __restrict__ out) {
+                Fr* __restrict__ out, Fr* tmp /* [slot][row]: the row's intermediates, written and read by its own lane */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     QStack st{smem};
     const uint64_t ne = 1ull << ext_k;
@@ -143,6 +147,8 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
             case Q_FOLD: acc = q_add(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + a))), t0); drop_to(t1); break;
             case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + a))); break;
             case Q_ADD_CONST: t0 = q_add(t0, unpack29<Fr29P>(ldg(consts + a))); break;
+            case Q_TEE_TMP: if (live) tmp[(uint64_t)a * ne + i] = pack29_raw(t0); break;                       // normalised, < 2p < 2^256
+            case Q_PUSH_TMP: push(live ? unpack29<Fr29P>(tmp[(uint64_t)a * ne + i]) : zero29); break;
             default: break;
         }
     }
@@ -153,8 +159,10 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
 }
 
 // host-side validation of a program: stack discipline and operand ranges
-static int validate_program(zk_ctx* ctx, const uint32_t* prog, uint32_t len, uint32_t ncols, uint32_t nconsts, int* max_depth) {
+static int validate_program(zk_ctx* ctx, const uint32_t* prog, uint32_t len, uint32_t ncols, uint32_t nconsts, int* max_depth, uint32_t* num_tmp) {
     int sp = 0, mx = 0;
+    std::vector<bool> defined;
+    *num_tmp = 0;
     for (uint32_t pc = 0; pc < len; ++pc) {
         const uint32_t op = prog[3 * pc], a = prog[3 * pc + 1];
         switch (op) {
@@ -165,6 +173,16 @@ static int validate_program(zk_ctx* ctx, const uint32_t* prog, uint32_t len, uin
             case Q_NEG: case Q_SQUARE: case Q_DOUBLE: if (sp < 1) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: stack underflow at pc %u", pc); break;
             case Q_MUL_CONST: case Q_ADD_CONST: if (sp < 1 || a >= nconsts) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: bad operand at pc %u", pc); break;
             case Q_FOLD: if (sp < 1 || a >= nconsts) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: bad FOLD at pc %u", pc); --sp; break;
+            case Q_TEE_TMP:
+                if (sp < 1 || a >= Q_MAX_TMP) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: bad TEE_TMP at pc %u", pc);
+                if (a >= defined.size()) defined.resize(a + 1, false);
+                defined[a] = true;
+                if (a + 1 > *num_tmp) *num_tmp = a + 1;
+                break;
+            case Q_PUSH_TMP:
+                if (a >= defined.size() || !defined[a]) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: intermediate %u read before it is written (pc %u)", a, pc);
+                ++sp;
+                break;
             default: return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: unknown opcode %u at pc %u", op, pc);
         }
         if (sp > mx) mx = sp;
@@ -199,8 +217,14 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     ZK_REQUIRE(ctx, h_program && d_out && (h_col_ptrs || !num_cols) && (h_consts || !num_consts), "null pointer");
     ZK_REQUIRE(ctx, k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     int depth = 0;
-    int rc = validate_program(ctx, h_program, num_instr, num_cols, num_consts, &depth);
+    uint32_t num_tmp = 0;
+    int rc = validate_program(ctx, h_program, num_instr, num_cols, num_consts, &depth, &num_tmp);
     if (rc) return rc;
+    Fr* d_tmp = nullptr;
+    if (num_tmp) {
+        d_tmp = (Fr*)ctx->get_scratch(SC_QTMP, ((size_t)num_tmp << ext_k) * sizeof(Fr));
+        if (!d_tmp) return ZK_ERR_OOM;
+    }
     if (depth < 1) depth = 1;
     std::vector<Fr> tev;
     if (divide_by_vanishing) vanishing_inverses(k, ext_k, &tev);
@@ -235,7 +259,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     }
     ZkProfScope ps(ctx, "quotient_eval");
     hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                       num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out);
+                       num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }

@@ -23,6 +23,7 @@ FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)
 
 FIXED, ADVICE, INSTANCE = 0, 1, 2
 Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG = 1, 2, 3, 4, 5, 6
+Q_TEE_TMP, Q_PUSH_TMP = 12, 13          # intermediates shared between gates (csrc/quotient.hip)
 BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 2
 C_CHAL0 = 0xFFFD0000   # abstract constant reference of user challenge i (csrc/prover.hip)
 
@@ -187,6 +188,73 @@ class Circuit:
         go(e)
         return out
 
+    def compile_gates_cse(self) -> List[List[Tuple[int, int, int]]]:
+        """Every gate as a postfix program, with the common-subexpression elimination halo2's
+        ``GraphEvaluator`` performs over the whole gate list: a sub-expression that holds a product
+        and occurs more than once (in the same or in different gates) is computed at its first
+        occurrence, parked with TEE_TMP, and read back with PUSH_TMP afterwards.  The gates are
+        evaluated in order in one launch, so an intermediate written by gate i is visible to gate
+        j > i.  Same values as ``compile`` gate by gate -- only cheaper."""
+        def key(x):
+            if isinstance(x, Col):
+                return ("c", x.ctype, x.index, x.rotation)
+            if isinstance(x, Const):
+                return ("k", x.value)
+            if isinstance(x, Challenge):
+                return ("h", x.index)
+            if isinstance(x, Neg):
+                return ("n", key(x.a))
+            return ("b", x.op, key(x.a), key(x.b))
+
+        def has_mul(x):
+            if isinstance(x, Bin):
+                return x.op == Q_MUL or has_mul(x.a) or has_mul(x.b)
+            return isinstance(x, Neg) and has_mul(x.a)
+
+        uses: Dict[tuple, int] = {}
+
+        def count(x):
+            kx = key(x)
+            uses[kx] = uses.get(kx, 0) + 1
+            if uses[kx] > 1:
+                return                      # its children are evaluated once only
+            if isinstance(x, Neg):
+                count(x.a)
+            elif isinstance(x, Bin):
+                count(x.a)
+                count(x.b)
+        for g in self.gates:
+            count(g)
+        slot: Dict[tuple, int] = {}
+        progs = []
+        for g in self.gates:
+            out: List[Tuple[int, int, int]] = []
+
+            def go(x):
+                kx = key(x)
+                if kx in slot:
+                    out.append((Q_PUSH_TMP, slot[kx], 0))
+                    return
+                if isinstance(x, Col):
+                    out.append((Q_PUSH_COL, colref(x.ctype, x.index), x.rotation & 0xFFFFFFFF))
+                elif isinstance(x, Const):
+                    out.append((Q_PUSH_CONST, self._const(x.value), 0))
+                elif isinstance(x, Challenge):
+                    out.append((Q_PUSH_CONST, C_CHAL0 + x.index, 0))
+                elif isinstance(x, Neg):
+                    go(x.a)
+                    out.append((Q_NEG, 0, 0))
+                else:
+                    go(x.a)
+                    go(x.b)
+                    out.append((x.op, 0, 0))
+                if uses.get(kx, 0) > 1 and has_mul(x):
+                    slot[kx] = len(slot)
+                    out.append((Q_TEE_TMP, slot[kx], 0))
+            go(g)
+            progs.append(out)
+        return progs
+
     def sigma_columns(self) -> List[List[int]]:
         """halo2 ``permutation::keygen::Assembly``: cycles of equal cells -> sigma_j(omega^i) =
         delta^j' * omega^i' of the next cell in the cycle."""
@@ -218,9 +286,10 @@ class Circuit:
         dp = [pow(FR_DELTA, j, R_MOD) for j in range(P)]
         return [[dp[mapping[j][i][0]] * wp[mapping[j][i][1]] % R_MOD for i in range(n)] for j in range(P)]
 
-    def blob(self) -> bytes:
-        """Serialise for zk_pk_create (layout documented in csrc/prover.hip)."""
-        gates = [self.compile(g) for g in self.gates]
+    def blob(self, cse: bool = False) -> bytes:
+        """Serialise for zk_pk_create (layout documented in csrc/prover.hip).  cse: share
+        sub-expressions between gates through the evaluator's intermediates (same proof bytes)."""
+        gates = self.compile_gates_cse() if cse else [self.compile(g) for g in self.gates]
         lookups = [([self.compile(e) for e in ins], [self.compile(e) for e in tabs]) for ins, tabs in self.lookups]
         sig = self.sigma_columns()
 
