@@ -228,6 +228,9 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
         a, b_, cc = (c.advice_col(3 * g + i) for i in range(3))
         c.add_gate(c.fixed_col(2 * (g % S)) * (a * b_ - cc))
         c.add_gate(c.fixed_col(2 * (g % S) + 1) * (a + b_ - cc.rot(1)))
+        if os.environ.get("ZK_BENCH_SHARED") == "1":      # gates that reuse the products of the first one (what an EVM-style circuit is full of)
+            c.add_gate((c.fixed_col(2 * (g % S)) * (a * b_ - cc)) * (a * b_ + 3))
+            c.add_gate(c.fixed_col(2 * (g % S)) * ((a * b_ - cc) * (a * b_ - cc)) * (a * b_ + 5))
     a0, b0, c0 = c.advice_col(0), c.advice_col(1), c.advice_col(2)
     hi = q_hi * (a0 * a0 + b0 - c0.rot(-1))          # degree 3, then one linear factor per extra degree
     for i in range(d - 3):
@@ -293,7 +296,7 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
     fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb][i - 2 * S] if i < 2 * S + 4 else zero_col)
     # ---- blob: header + programs, then F fixed and P sigma columns written in place (no Python-side copies)
     Pn = len(c.perm_cols)
-    gates = [c.compile(g) for g in c.gates]
+    gates = c.compile_gates_cse() if os.environ.get("ZK_BENCH_CSE") == "1" else [c.compile(g) for g in c.gates]
     lookups = [([c.compile(e) for e in ins], [c.compile(e) for e in tabs]) for ins, tabs in c.lookups]
 
     def prog(p):
