@@ -138,7 +138,9 @@ int zk_fr_prefix_sum(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
  * the instruction set: 3 x u32 per instruction {op, a, b}).  Columns are device pointers to
  * 2^ext_k Fr values each (extended-coset evaluations, or Lagrange values when ext_k == k);
  * PUSH_COL reads row (i + rot * 2^(ext_k-k)) mod 2^ext_k.  divide_by_vanishing != 0 multiplies the
- * result by 1/(X^n - 1) evaluated on the zeta-coset.  d_out must not alias any input column.     */
+ * result by 1/(X^n - 1) evaluated on the zeta-coset.  d_out must not alias any input column.
+ * TEE_TMP t / PUSH_TMP t keep GraphEvaluator-style intermediates of the row in device scratch
+ * (t < 4096, 2^ext_k x 32 B each); reading one before it is written is ZK_ERR_INVALID_ARG.          */
 int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr, const void* const* h_col_ptrs, uint32_t num_cols,
                      const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out);
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
