@@ -577,6 +577,8 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM larger than 2^31-1 points");
     const MsmPlan pl = make_plan(n);
     const uint32_t nb = (uint32_t)pl.W * pl.B;
+    // bucket offsets and task cursors are 32-bit: n * W (point, window) entries must stay below 2^32 (n <= 2^27 at 16 windows)
+    if ((uint64_t)n * pl.W >= (1ull << 32)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM of %zu points x %d windows exceeds 2^32 index entries: split it", n, pl.W);
 
     // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] (both 16-B aligned) | counts[nb] | size_hist[256] nmulti[4] wflag[64] |
     //                offsets[nb+1] | order[nb] | ntasks[nb] | toff[nb+1] | block_tot[scan_blocks_s + scan_blocks] | idx[n*W] |
