@@ -188,21 +188,7 @@ def build_large(ctx, k: int, groups: int, seed: int = 1):
         sig[ja][ra], sig[jb][rb] = sig[jb][rb].copy(), sig[ja][ra].copy()
     # the Circuit object keeps Python-int fixed columns only for the verifier's instance / gate evaluation: not needed
     # there (the verifier reads evaluations from the proof), so serialise the blob directly from the arrays
-    gates = [c.compile(g) for g in c.gates]
-    lookups = [([c.compile(e) for e in ins], [c.compile(e) for e in tabs]) for ins, tabs in c.lookups]
-    import struct
-
-    def prog(p):
-        return struct.pack("<I", len(p)) + b"".join(struct.pack("<III", *ins) for ins in p)
-    parts = [struct.pack("<12I", plonk.BLOB_MAGIC, plonk.BLOB_VERSION, k, c.bf, c.degree(), F, A, 1, P, len(c.lookups), len(gates), len(c.consts))]
-    parts.append(struct.pack("<I", 0))
-    parts += [struct.pack("<I", 0) for _ in range(A)]
-    parts += [struct.pack("<II", t, i_) for t, i_ in c.perm_cols]
-    parts += [plonk.fr_mont_bytes(v) for v in c.consts]
-    parts += [prog(g) for g in gates]
-    for ins, tabs in lookups:
-        parts.append(struct.pack("<I", len(ins)))
-        parts += [prog(p) for p in ins] + [prog(p) for p in tabs]
+    parts = [c.cs_blob()]
     parts += [f.tobytes() for f in fixed_m] + [s_.tobytes() for s_ in sig]
     inst_int = [[int(v) for v in inst[0]]]
     return c, b"".join(parts), adv_m, inst_m, inst_int
@@ -296,21 +282,7 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
     fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb][i - 2 * S] if i < 2 * S + 4 else zero_col)
     # ---- blob: header + programs, then F fixed and P sigma columns written in place (no Python-side copies)
     Pn = len(c.perm_cols)
-    gates = c.compile_gates_cse() if os.environ.get("ZK_BENCH_CSE") == "1" else [c.compile(g) for g in c.gates]
-    lookups = [([c.compile(e) for e in ins], [c.compile(e) for e in tabs]) for ins, tabs in c.lookups]
-
-    def prog(p):
-        return struct.pack("<I", len(p)) + b"".join(struct.pack("<III", *ins) for ins in p)
-    parts = [struct.pack("<12I", plonk.BLOB_MAGIC, plonk.BLOB_VERSION, k, c.bf, c.degree(), F, A, 1, Pn, len(c.lookups), len(gates), len(c.consts))]
-    parts.append(struct.pack("<I", 0))
-    parts += [struct.pack("<I", 0) for _ in range(A)]
-    parts += [struct.pack("<II", t, i_) for t, i_ in c.perm_cols]
-    parts += [plonk.fr_mont_bytes(v) for v in c.consts]
-    parts += [prog(g) for g in gates]
-    for ins, tabs in lookups:
-        parts.append(struct.pack("<I", len(ins)))
-        parts += [prog(p) for p in ins] + [prog(p) for p in tabs]
-    head = b"".join(parts)
+    head = c.cs_blob(cse=os.environ.get("ZK_BENCH_CSE") == "1")
     col_bytes = n * 32
     total = len(head) + (F + Pn) * col_bytes
     raw = np.empty(total + 8, dtype=np.uint8)

@@ -216,14 +216,31 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine);
 /* ---- full proof: halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC or SHPLONK multi-open
  * (poly::kzg::multiopen::{ProverGWC, ProverSHPLONK})  -- SURVEY 8a A1, A4, K6-K11; csrc/prover.hip -- */
 typedef struct zk_pk zk_pk;
-/* keygen_pk over a flat circuit description (the "pk blob" of zkevm-circuits_amd/plonk.py:
- * header, phases, permutation columns, constants, gate / lookup programs, fixed and sigma columns
- * in Lagrange form; layout in INTEGRATION.md).  Commits fixed and sigma columns and keeps their
- * Lagrange and coefficient forms on the device.  srs must have the circuit's k (zk_srs_downsize).  */
+/* keygen_pk over a flat circuit description (the "pk blob", version 3, filled by the Rust shim from
+ * halo2's ConstraintSystem / by zkevm-circuits_amd/plonk.py in tests: header, phases, the advice /
+ * fixed / instance query lists in registration order, permutation columns, constants, gate programs,
+ * mv-lookup arguments (one table tuple + N input tuples each, as chunk_lookups() leaves them
+ * [REF zkevm-circuits/src/super_circuit/test.rs:59]), fixed and sigma columns in Lagrange form;
+ * layout in INTEGRATION.md).  Commits fixed and sigma columns and keeps their Lagrange and
+ * coefficient forms on the device.  srs must have the circuit's k (zk_srs_downsize).  A blob whose
+ * declared degree is below what its gates and lookup arguments require (halo2
+ * ConstraintSystem::degree) is refused.                                                            */
 int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out);
 void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk);
 /* verifying-key side: (F + P) x 64-byte affine commitments (fixed, then sigma) and vk_repr (Fr)  */
 int zk_pk_vk(zk_ctx* ctx, const zk_pk* pk, void* h_commitments, void* h_vk_repr);
+/* `vk.transcript_repr()`: the scalar create_proof absorbs first (halo2 VerifyingKey::hash_into).
+ * halo2 derives it from the Debug string of the pinned verifying key -- the value the reference
+ * pins for the SuperCircuit at [REF zkevm-circuits/src/super_circuit/test.rs:70-85] -- which only
+ * the Rust side can produce: the shim computes it with upstream keygen_vk and installs it here (32 B
+ * Montgomery Fr), after which proofs of this key are proofs for the reference's own verify_proof.
+ * Without this call the key uses a stand-in (Blake2b-512 "Halo2-Verify-Key" over the
+ * constraint-system part of the blob and the compressed fixed / sigma commitments).                */
+int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk* pk, const void* h_repr_fr32);
+/* out16 = k, degree, extended k, F, A, I, permutation columns, permutation chunks, lookup arguments,
+ * phases, challenges, blinding factors, advice queries, fixed queries, commitments per proof,
+ * evaluations per proof                                                                            */
+int zk_pk_shape(zk_ctx* ctx, const zk_pk* pk, uint32_t* out16);
 /* create_proof: h_advice / h_instance are arrays of host pointers to n x 32-byte Lagrange columns;
  * seed16 seeds the XorShift blinding RNG; the proof bytes (compressed points and canonical
  * scalars, halo2 encoding) are written to h_proof.  Fails with ZK_ERR_INVALID_ARG if the witness
@@ -257,6 +274,31 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
  * affine (x || y, Montgomery limbs, identity = zeros), scalars 32 B Montgomery Fr; a callback
  * returns 0 on success.  Call right after zk_proof_begin: what begin absorbed (vk representative,
  * instance values) is replayed into the external transcript.                                       */
+/* Built-in transcripts of the session (the three the reference's call sites instantiate): Blake2b
+ * (Blake2bWrite + Challenge255, the default [REF circuit-benchmarks/src/super_circuit.rs:112]),
+ * Poseidon (snark-verifier PoseidonTranscript<NativeLoader, _> with POSEIDON_SPEC: gen_snark_shplonk
+ * [REF prover/src/common/prover/utils.rs:31], [REF aggregator/src/core.rs:91-92]) and EVM (snark-verifier
+ * EvmTranscript, Keccak-256, 64-byte big-endian points: gen_evm_proof_shplonk
+ * [REF prover/src/common/prover/evm.rs:67]).  Call right after zk_proof_begin.  A Poseidon / EVM
+ * transcript cannot absorb the identity point (as upstream): zk_proof_finish then fails.          */
+enum { ZK_TRANSCRIPT_BLAKE2B = 0, ZK_TRANSCRIPT_POSEIDON = 1, ZK_TRANSCRIPT_EVM = 2 };
+int zk_proof_set_transcript_kind(zk_ctx* ctx, zk_proof* proof, int kind);
+/* The same transcripts as host-only objects (no context, no device): what a caller needs to run
+ * halo2's verifier-side transcript logic, or to cross-check its own transcript, without Rust.
+ * Points 64 B affine Montgomery, scalars 32 B Montgomery Fr; status 0 = OK.                        */
+typedef struct zk_transcript zk_transcript;
+zk_transcript* zk_transcript_new(int kind);
+void zk_transcript_free(zk_transcript* t);
+int zk_transcript_common_point(zk_transcript* t, const void* affine64);
+int zk_transcript_common_scalar(zk_transcript* t, const void* fr32);
+int zk_transcript_write_point(zk_transcript* t, const void* affine64);
+int zk_transcript_write_scalar(zk_transcript* t, const void* fr32);
+int zk_transcript_squeeze(zk_transcript* t, void* fr32_out);
+/* bytes written so far (the proof); the pointer stays valid until the next write or free          */
+size_t zk_transcript_proof(const zk_transcript* t, const void** data);
+/* host-only hashes behind them: Keccak-256 and the Poseidon permutation (5 x 32 B Montgomery Fr)   */
+int zk_host_keccak256(const void* data, size_t len, void* out32);
+int zk_host_poseidon_permute(void* state5_fr32);
 typedef struct zk_transcript_vtable {
     int (*common_point)(void* user, const void* affine64);
     int (*common_scalar)(void* user, const void* fr32);
@@ -283,7 +325,9 @@ int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* proof, uint32_t rank, uint32_t 
 int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* proof, zk_allgather_fn gather_dev, void* user);
 /* commits the advice columns of the current phase (h_cols[j] = advice column col_index[j], exactly
  * the columns of that phase) and writes the challenges that become usable after it to
- * h_challenges (32 B each, Montgomery Fr, challenge-index order)                                 */
+ * h_challenges (32 B each, Montgomery Fr, challenge-index order).  With h_challenges given,
+ * *num_challenges must hold the buffer's capacity (in challenges) on entry -- a phase with more is
+ * refused, nothing is written -- and receives the number written (zk_pk_shape: total challenges). */
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols,
                           void* h_challenges, uint32_t* num_challenges);
 /* consumes the session (freed on success and on failure)                                         */

@@ -235,9 +235,11 @@ inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk,
     c.check(zk_proof_begin_instances(c.raw(), pk.raw(), ptrs.data(), lens.data(), rng_seed.data(), &sess));
     std::vector<uint8_t> proof(size_t(1) << 20);
     size_t len = 0;
-    uint32_t num_challenges = 0;
-    std::vector<Fr> challenges(64);
-    int rc = zk_proof_set_multiopen(c.raw(), sess, shplonk ? 1 : 0);
+    uint32_t shape[16] = {0};
+    int rc = zk_pk_shape(c.raw(), pk.raw(), shape);
+    std::vector<Fr> challenges(shape[10] ? shape[10] : 1);              // sized from the key: a phase writes every challenge it yields
+    uint32_t num_challenges = (uint32_t)challenges.size();
+    if (rc == ZK_OK) rc = zk_proof_set_multiopen(c.raw(), sess, shplonk ? 1 : 0);
     if (rc == ZK_OK) rc = zk_proof_advice_phase(c.raw(), sess, index.data(), advice_columns.data(), (uint32_t)index.size(), challenges.data(), &num_challenges);
     if (rc != ZK_OK) { zk_proof_abort(c.raw(), sess); c.check(rc); }
     c.check(zk_proof_finish(c.raw(), sess, proof.data(), proof.size(), &len));

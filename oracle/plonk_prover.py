@@ -19,37 +19,14 @@ import struct
 from typing import List, Sequence
 
 from . import bn254 as b
-from .plonk_verifier import (ADVICE, FIXED, INSTANCE, Consts, _interpolate, _queries, compress, eval_program)
+from .plonk_verifier import (ADVICE, FIXED, INSTANCE, Consts, _interpolate, _vanishing_at, compress, eval_program, shplonk_sets)
 
 R = b.R_MOD
 Q_PUSH_COL = 1
 
 
 # ------------------------------------------------------------------------------------ transcript / RNG
-class Blake2bWrite:
-    """halo2_proofs::transcript::Blake2bWrite + Challenge255 (SURVEY B.7)."""
-
-    def __init__(self):
-        self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
-        self.proof = bytearray()
-
-    def common_point(self, pt):
-        self.h.update(b"\x01" + (bytes(64) if pt is None else pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")))
-
-    def common_scalar(self, s: int):
-        self.h.update(b"\x02" + (s % R).to_bytes(32, "little"))
-
-    def write_point(self, pt):
-        self.common_point(pt)
-        self.proof += b.g1_compress(pt)
-
-    def write_scalar(self, s: int):
-        self.common_scalar(s)
-        self.proof += (s % R).to_bytes(32, "little")
-
-    def squeeze(self) -> int:
-        self.h.update(b"\x00")
-        return b.fr_from_uniform_bytes(self.h.copy().digest())
+from .transcripts import Blake2b as Blake2bWrite, make as make_transcript  # noqa: E402,F401
 
 
 class XorShiftRng:
@@ -112,7 +89,7 @@ def vk_commitments(circ, srs: Srs):
 
 # ------------------------------------------------------------------------------------ the prover
 def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]], vk_repr: int,
-                 seed16: bytes = bytes(16), multiopen: str = "gwc") -> bytes:
+                 seed16: bytes = bytes(16), multiopen: str = "gwc", transcript: str = "blake2b") -> bytes:
     n, k, u, bf, d = circ.n, circ.k, circ.u, circ.bf, circ.degree()
     A, Pn, L = circ.A, len(circ.perm_cols), len(circ.lookups)
     chunk = d - 2
@@ -122,10 +99,9 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     step = ne // n
     omega = dom.omega
     gates = [circ.compile(g) for g in circ.gates]
-    lookups = [([circ.compile(e) for e in i], [circ.compile(e) for e in t]) for i, t in circ.lookups]
-    adv_q, fix_q = _queries(circ)
+    lookups = [([circ.compile(e) for e in lk.table], [[circ.compile(e) for e in i] for i in lk.inputs]) for lk in circ.lookups]
     sigma = circ.sigma_columns()
-    rng, tr = XorShiftRng(seed16), Blake2bWrite()
+    rng, tr = XorShiftRng(seed16), make_transcript(transcript)
 
     # halo2 absorbs exactly the instance values it is given (KZG: QUERY_INSTANCE = false) and pads the
     # column with zeros; more values than usable rows is Error::InstanceTooLarge.  An n-row column
@@ -159,21 +135,22 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
         return lambda t, i, rot: lag_cols[t][i][(row + rot) % n]
 
     theta = tr.squeeze()
-    # ---- lookups, round 1: multiplicities
+    # ---- lookups, round 1 (mv_lookup::prover::Argument::prepare): theta-compressed inputs and table,
+    # multiplicities m.  A table value that occurs in several usable rows is counted at its LAST row
+    # (halo2 collects value -> row into a BTreeMap, later rows overwrite); rows >= u of m stay zero.
     lk_f, lk_t, lk_m = [], [], []
-    for ins, tabs in lookups:
-        f = [compress([eval_program(p, row_lookup(r), consts) for p in ins], theta) for r in range(n)]
+    for tabs, inputs in lookups:
+        fs = [[compress([eval_program(p, row_lookup(r), consts) for p in ins], theta) for r in range(n)] for ins in inputs]
         t = [compress([eval_program(p, row_lookup(r), consts) for p in tabs], theta) for r in range(n)]
-        first = {}
+        where = {}
         for r in range(u):
-            first.setdefault(t[r], r)
+            where[t[r]] = r
         m = [0] * n
-        for r in range(u):
-            assert f[r] in first, f"lookup input at row {r} is not in the table"
-            m[first[f[r]]] += 1
-        for r in range(u + 1, n):
-            m[r] = rng.next_fr()
-        lk_f.append(f); lk_t.append(t); lk_m.append(m)
+        for f in fs:
+            for r in range(u):
+                assert f[r] in where, f"lookup input at row {r} is not in the table"
+                m[where[f[r]]] += 1
+        lk_f.append(fs); lk_t.append(t); lk_m.append(m)
     for m in lk_m:
         tr.write_point(srs.commit_lagrange(m))
     beta, gamma = tr.squeeze(), tr.squeeze()
@@ -198,12 +175,12 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     assert C == 0 or start == 1, "permutation argument does not close"
     for z in pz:
         tr.write_point(srs.commit_lagrange(z))
-    # ---- lookups, round 2: grand sums
+    # ---- lookups, round 2 (Prepared::commit_grand_sum): phi[0] = 0, phi[r+1] = phi[r] + sum_i 1/(f_i+beta) - m/(t+beta)
     lk_phi = []
-    for f, t, m in zip(lk_f, lk_t, lk_m):
+    for fs, t, m in zip(lk_f, lk_t, lk_m):
         phi = [0] * n
         for r in range(n - 1):
-            g_ = (b.fr_inv((f[r] + beta) % R) - m[r] * b.fr_inv((t[r] + beta) % R)) % R
+            g_ = (sum(b.fr_inv((f[r] + beta) % R) for f in fs) - m[r] * b.fr_inv((t[r] + beta) % R)) % R
             phi[r + 1] = (phi[r] + g_) % R
         assert phi[u] == 0, "lookup grand sum does not close"
         for r in range(n - bf, n):
@@ -252,122 +229,119 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
                     left = left * ((v + beta * sig_ext[jj][j] + gamma) % R) % R
                     right = right * ((v + beta * pow(b.FR_DELTA, jj, R) % R * x_e[j] + gamma) % R) % R
                 acc = (acc * y + la_e[j] * (left - right)) % R
-        for l, (ins, tabs) in enumerate(lookups):
+        for l, (tabs, inputs) in enumerate(lookups):
+            # evaluation.rs: lhs = tau prod(phi_i) (phi(wX) - phi(X)),  rhs = prod(phi_i) (tau sum 1/phi_i - m)
             p0, p1, me = at(phi_ext[l]), at(phi_ext[l], 1), at(m_ext[l])
-            f = compress([eval_program(p, col_at, consts) for p in ins], theta)
-            t = compress([eval_program(p, col_at, consts) for p in tabs], theta)
+            fi = [(compress([eval_program(p, col_at, consts) for p in ins], theta) + beta) % R for ins in inputs]
+            tau = (compress([eval_program(p, col_at, consts) for p in tabs], theta) + beta) % R
+            prod = 1
+            for f in fi:
+                prod = prod * f % R
+            sum_rest = 0                       # prod(phi_i) * sum 1/phi_i as a polynomial expression
+            for a_ in range(len(fi)):
+                term = 1
+                for b_ in range(len(fi)):
+                    if b_ != a_:
+                        term = term * fi[b_] % R
+                sum_rest = (sum_rest + term) % R
+            lhs = tau * prod % R * (p1 - p0) % R
+            rhs = (tau * sum_rest - prod * me) % R
             acc = (acc * y + l0_e[j] * p0) % R
             acc = (acc * y + ll_e[j] * p0) % R
-            acc = (acc * y + la_e[j] * ((p1 - p0) * (f + beta) % R * (t + beta) - ((t + beta) - me * (f + beta)))) % R
+            acc = (acc * y + (lhs - rhs) * la_e[j]) % R
         h_ext[j] = acc * dom.t_evaluations[j % len(dom.t_evaluations)] % R
     h_coeff = dom.extended_to_coeff(h_ext)
-    h_coeff += [0] * ((d - 1) * n - len(h_coeff))
+    assert not any(h_coeff[(d - 1) * n:]), "quotient has more than d - 1 pieces: the circuit degree is too small"
+    h_coeff = h_coeff[:(d - 1) * n] + [0] * max(0, (d - 1) * n - len(h_coeff))
     pieces = [h_coeff[i * n:(i + 1) * n] for i in range(d - 1)]
     for p_ in pieces:
         tr.write_point(srs.commit(p_))
     x = tr.squeeze()
 
-    # ---- evaluations, in proof order
+    # ---- evaluations, in proof order; `queries` collects the multi-open's (polynomial, point, eval)
     point = lambda rot: x * pow(omega, rot % n, R) % R
-    opens = []          # (coefficients, rot, eval)
 
-    def open_(cf, rot, write=True):
+    def ev(cf, rot, write=True):
         e = b.eval_polynomial(cf, point(rot))
-        opens.append((cf, rot, e))
         if write:
             tr.write_scalar(e)
-    for i, rot in adv_q:
-        open_(coeff[(ADVICE, i)], rot)
-    for i, rot in fix_q:
-        open_(coeff[(FIXED, i)], rot)
-    open_(random_coeff, 0)
-    for j in range(Pn):
-        open_(sig_coeff[j], 0)
+        return e
+    adv_evals = [ev(coeff[(ADVICE, i)], rot) for i, rot in circ.advice_queries]
+    fix_evals = [ev(coeff[(FIXED, i)], rot) for i, rot in circ.fixed_queries]
+    random_eval = ev(random_coeff, 0)
+    sigma_evals = [ev(sig_coeff[j], 0) for j in range(Pn)]
+    z_evals = []
     for c in range(C):
-        open_(pz_coeff[c], 0)
-        open_(pz_coeff[c], 1)
-        if c + 1 < C:
-            open_(pz_coeff[c], rot_last)
-    for l in range(L):
-        open_(phi_coeff[l], 0)
-        open_(phi_coeff[l], 1)
-        open_(m_coeff[l], 0)
+        e0, e1 = ev(pz_coeff[c], 0), ev(pz_coeff[c], 1)
+        z_evals.append((e0, e1, ev(pz_coeff[c], rot_last) if c + 1 < C else None))
+    lk_evals = [(ev(phi_coeff[l], 0), ev(phi_coeff[l], 1), ev(m_coeff[l], 0)) for l in range(L)]
     xn = pow(x, n, R)
     hcomb = [0] * n
     for p_ in reversed(pieces):
         hcomb = [(a * xn + c_) % R for a, c_ in zip(hcomb, p_)]
-    open_(hcomb, 0, write=False)          # the verifier derives this evaluation itself
-    rots: List[int] = []
-    for _, rot, _ in opens:
-        if rot not in rots:
-            rots.append(rot)
+    h_eval = ev(hcomb, 0, write=False)          # the verifier derives this evaluation itself
 
-    def lincomb(polys, ch):               # Horner: ((p0 * ch + p1) * ch + p2) ...
-        acc_ = [0] * n
+    # halo2's order: advice, permutation products (x, wx per set, then w^last x in reverse set order),
+    # lookups, fixed, permutation sigma, h, random polynomial
+    queries = [(coeff[(ADVICE, i)], point(rot), e) for (i, rot), e in zip(circ.advice_queries, adv_evals)]
+    for c in range(C):
+        queries += [(pz_coeff[c], point(0), z_evals[c][0]), (pz_coeff[c], point(1), z_evals[c][1])]
+    for c in reversed(range(C - 1)):
+        queries.append((pz_coeff[c], point(rot_last), z_evals[c][2]))
+    for l in range(L):
+        queries += [(phi_coeff[l], point(0), lk_evals[l][0]), (phi_coeff[l], point(1), lk_evals[l][1]), (m_coeff[l], point(0), lk_evals[l][2])]
+    queries += [(coeff[(FIXED, i)], point(rot), e) for (i, rot), e in zip(circ.fixed_queries, fix_evals)]
+    queries += [(sig_coeff[j], point(0), sigma_evals[j]) for j in range(Pn)]
+    queries += [(hcomb, point(0), h_eval), (random_coeff, point(0), random_eval)]
+
+    def lincomb(polys, ch):               # sum_j ch^j * polys[j]
+        acc_, pw = [0] * n, 1
         for p_ in polys:
-            acc_ = [(a * ch + c_) % R for a, c_ in zip(acc_, p_)]
+            acc_ = [(a + pw * c_) % R for a, c_ in zip(acc_, p_)]
+            pw = pw * ch % R
         return acc_
 
     if multiopen == "gwc":
+        # poly::kzg::multiopen::gwc::ProverGWC::create_proof
         v = tr.squeeze()
-        for rot in rots:
-            batch = lincomb([cf for cf, r_, _ in opens if r_ == rot], v)
-            tr.write_point(srs.commit(b.kate_division(batch, point(rot))))
+        groups = []
+        for cf, pt, _ in queries:
+            for g_ in groups:
+                if g_[0] == pt:
+                    g_[1].append(cf)
+                    break
+            else:
+                groups.append([pt, [cf]])
+        for pt, polys in groups:
+            tr.write_point(srs.commit(b.kate_division(lincomb(polys, v), pt)))
         return bytes(tr.proof)
 
-    # ---- SHPLONK (BDFG21), the prover side of plonk_verifier._verify_shplonk
-    yy, v = tr.squeeze(), tr.squeeze()
-    polys = []          # [coefficients, [rots], [evals]] by identity of the coefficient list
-    for cf, rot, e in opens:
-        for p_ in polys:
-            if p_[0] is cf:
-                p_[1].append(rot); p_[2].append(e)
-                break
-        else:
-            polys.append([cf, [rot], [e]])
-    sets = []
-    for pi, p_ in enumerate(polys):
-        key_ = sorted(p_[1])
-        for s_ in sets:
-            if s_[0] == key_:
-                s_[1].append(pi)
-                break
-        else:
-            sets.append((key_, [pi]))
-    qfull, hset, Rset = [], [], []
-    for key_, members in sets:
-        zs = [point(r_) for r_ in key_]
-        Rk = [0] * len(key_)
-        for pi in members:
-            cf, prots, pevals = polys[pi]
-            rj = _interpolate(zs, [pevals[prots.index(r_)] for r_ in key_])
-            Rk = [(a * yy + c_) % R for a, c_ in zip(Rk, rj)]
-        qf = lincomb([polys[pi][0] for pi in members], yy)
-        hs = list(qf)
-        for t_ in range(len(Rk)):
-            hs[t_] = (hs[t_] - Rk[t_]) % R
-        for z in zs:
-            hs = b.kate_division(hs, z)
-        hs += [0] * (n - len(hs))
-        qfull.append(qf); hset.append(hs); Rset.append(Rk)
-    hpoly = lincomb(hset, v)
-    tr.write_point(srs.commit(hpoly))
+    # ---- SHPLONK (BDFG21): poly::kzg::multiopen::shplonk::ProverSHPLONK::create_proof
+    yy = tr.squeeze()
+    sets, super_points, eval_of = shplonk_sets(queries)
+    v = tr.squeeze()
+    low = []          # per set, per polynomial: r_ij(X), the interpolation of its evaluations over the set's points
+    quot = []
+    for points, members in sets:
+        rs = [_interpolate(points, [eval_of(cf, p_) for p_ in points]) for cf in members]
+        numer = lincomb([[(c_ - (r_[t] if t < len(r_) else 0)) % R for t, c_ in enumerate(cf)] for cf, r_ in zip(members, rs)], yy)
+        for z in points:
+            numer = b.kate_division(numer, z)
+        quot.append(numer + [0] * (n - len(numer)))
+        low.append(rs)
+    h_x = lincomb(quot, v)
+    tr.write_point(srs.commit(h_x))
     uu = tr.squeeze()
-    zT = 1
-    for r_ in rots:
-        zT = zT * (uu - point(r_)) % R
-    Lx = [0] * n
-    constant, cpow = 0, 1
-    for si in reversed(range(len(sets))):
-        zt = 1
-        for r_ in rots:
-            if r_ not in sets[si][0]:
-                zt = zt * (uu - point(r_)) % R
-        coef = cpow * zt % R
-        Lx = [(a + coef * c_) % R for a, c_ in zip(Lx, qfull[si])]
-        constant = (constant + coef * b.eval_polynomial(Rset[si], uu)) % R
-        cpow = cpow * v % R
-    Lx = [(a - zT * c_) % R for a, c_ in zip(Lx, hpoly)]
-    Lx[0] = (Lx[0] - constant) % R
-    tr.write_point(srs.commit(b.kate_division(Lx, uu)))
+    l_x, z_diffs, vpow = [0] * n, [], 1
+    for (points, members), rs in zip(sets, low):
+        z_i = _vanishing_at([p_ for p_ in super_points if p_ not in points], uu)
+        z_diffs.append(z_i)
+        inner = lincomb([[(c_ - (b.eval_polynomial(r_, uu) if t == 0 else 0)) % R for t, c_ in enumerate(cf)] for cf, r_ in zip(members, rs)], yy)
+        l_x = [(a + vpow * z_i % R * c_) % R for a, c_ in zip(l_x, inner)]
+        vpow = vpow * v % R
+    zt_eval = _vanishing_at(super_points, uu)
+    l_x = [(a - zt_eval * c_) % R for a, c_ in zip(l_x, h_x)]
+    assert b.eval_polynomial(l_x, uu) == 0
+    z0_inv = b.fr_inv(z_diffs[0])
+    tr.write_point(srs.commit([c_ * z0_inv % R for c_ in b.kate_division(l_x, uu)]))
     return bytes(tr.proof)

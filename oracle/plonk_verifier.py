@@ -24,56 +24,7 @@ Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG = 1, 2, 3, 4, 5, 6
 
 
 # ------------------------------------------------------------------------------------ transcript
-class Blake2bRead:
-    """halo2_proofs::transcript::Blake2bRead + Challenge255 (SURVEY B.7)."""
-
-    def __init__(self, proof: bytes):
-        self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
-        self.proof, self.pos = proof, 0
-
-    def common_point(self, pt):
-        if pt is None:
-            self.h.update(b"\x01" + bytes(64))
-        else:
-            self.h.update(b"\x01" + pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little"))
-
-    def common_scalar(self, s: int):
-        self.h.update(b"\x02" + (s % R).to_bytes(32, "little"))
-
-    def read_point(self):
-        raw = self.proof[self.pos:self.pos + 32]
-        assert len(raw) == 32, "proof truncated"
-        self.pos += 32
-        pt = decompress_g1(raw)
-        self.common_point(pt)
-        return pt
-
-    def read_scalar(self) -> int:
-        raw = self.proof[self.pos:self.pos + 32]
-        assert len(raw) == 32, "proof truncated"
-        self.pos += 32
-        s = int.from_bytes(raw, "little")
-        assert s < R, "non-canonical scalar"
-        self.common_scalar(s)
-        return s
-
-    def squeeze(self) -> int:
-        self.h.update(b"\x00")
-        return b.fr_from_uniform_bytes(self.h.copy().digest())
-
-
-def decompress_g1(raw: bytes):
-    if raw == bytes(32):
-        return None
-    v = int.from_bytes(raw, "little")
-    sign, x = v >> 255, v & ((1 << 255) - 1)
-    assert x < P
-    y2 = (x * x * x + 3) % P
-    y = pow(y2, (P + 1) // 4, P)
-    assert y * y % P == y2, "point not on curve"
-    if (y & 1) != sign:
-        y = P - y
-    return (x, y)
+from .transcripts import Blake2b as Blake2bRead, decompress_g1, make as make_transcript  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------ expressions
@@ -124,7 +75,7 @@ def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequ
     consts = Consts(circ.consts, challenges)
     cols = {FIXED: circ.fixed, ADVICE: advice, INSTANCE: [list(c) + [0] * (circ.n - len(c)) for c in instance]}
     gates = [circ.compile(g) for g in circ.gates]
-    lookups = [([circ.compile(e) for e in i], [circ.compile(e) for e in t]) for i, t in circ.lookups]
+    lookups = [([circ.compile(e) for e in lk.table], [[circ.compile(e) for e in i] for i in lk.inputs]) for lk in circ.lookups]
     for row in range(u):
         look = lambda t, i, rot: cols[t][i][(row + rot) % n]
         for gi, g in enumerate(gates):
@@ -133,45 +84,22 @@ def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequ
     for a, c in circ.copies:
         if cols[a[0]][a[1]][a[2]] != cols[c[0]][c[1]][c[2]]:
             return f"copy constraint {a} == {c} violated"
-    for li, (ins, tabs) in enumerate(lookups):
+    for li, (tabs, inputs) in enumerate(lookups):
         table = set()
         for row in range(u):
             look = lambda t, i, rot: cols[t][i][(row + rot) % n]
             table.add(tuple(eval_program(p, look, consts) for p in tabs))
-        for row in range(u):
-            look = lambda t, i, rot: cols[t][i][(row + rot) % n]
-            if tuple(eval_program(p, look, consts) for p in ins) not in table:
-                return f"lookup {li}: input at row {row} not in table"
+        for ii, ins in enumerate(inputs):
+            for row in range(u):
+                look = lambda t, i, rot: cols[t][i][(row + rot) % n]
+                if tuple(eval_program(p, look, consts) for p in ins) not in table:
+                    return f"lookup {li}, input set {ii}: input at row {row} not in table"
     return None
 
 
 # ------------------------------------------------------------------------------------ verifier
-def _queries(circ):
-    adv, fix = [], []
-
-    def scan(prog):
-        for op, a, bb in prog:
-            if op != Q_PUSH_COL:
-                continue
-            t, i = a >> 24, a & 0xFFFFFF
-            rot = bb if bb < (1 << 31) else bb - (1 << 32)
-            dst = adv if t == ADVICE else (fix if t == FIXED else None)
-            if dst is not None and (i, rot) not in dst:
-                dst.append((i, rot))
-    for g in circ.gates:
-        scan(circ.compile(g))
-    for ins, tabs in circ.lookups:
-        for e in ins:
-            scan(circ.compile(e))
-        for e in tabs:
-            scan(circ.compile(e))
-    for t, i in circ.perm_cols:
-        scan([(Q_PUSH_COL, (t << 24) | i, 0)])
-    return adv, fix
-
-
 def _interpolate(xs, ys):
-    """coefficients (low first) of the polynomial through (xs[i], ys[i])"""
+    """halo2 arithmetic::lagrange_interpolate: coefficients (low first) of the polynomial through (xs[i], ys[i])"""
     m = len(xs)
     out = [0] * m
     for a in range(m):
@@ -191,75 +119,144 @@ def _interpolate(xs, ys):
     return out
 
 
-def _verify_shplonk(tr, proof, opens, rots, point, s_g2) -> bool:
-    """SHPLONK / BDFG21 verifier for the prover's variant: sets in order of first
-    appearance, Horner powers of y inside a set and of v across sets."""
-    y, v = tr.squeeze(), tr.squeeze()
-    polys = []          # (commitment, [rots], [evals])
-    for com, rot, e in opens:
-        for p in polys:
-            if p[0] is com:
-                p[1].append(rot); p[2].append(e)
+class Com:
+    """one committed polynomial as the multi-open sees it (halo2 `CommitmentReference`: queries on the
+    same polynomial are recognised by identity, not by value)"""
+
+    def __init__(self, point):
+        self.point = point
+
+
+def shplonk_sets(queries):
+    """halo2 poly::kzg::multiopen::shplonk::construct_intermediate_sets: polynomials in order of first
+    appearance, each with the set of points it is opened at; rotation sets in order of first
+    appearance, each listing its polynomials.  queries: (object, point, eval)."""
+    polys, point_sets = [], []
+    for obj, pt, _ in queries:
+        for i, o in enumerate(polys):
+            if o is obj:
+                if pt not in point_sets[i]:
+                    point_sets[i].append(pt)
                 break
         else:
-            polys.append((com, [rot], [e]))
-    sets = []           # (sorted rots, [poly indices])
-    for pi, p in enumerate(polys):
-        key = sorted(p[1])
+            polys.append(obj)
+            point_sets.append([pt])
+    sets = []           # [sorted points, [polynomial objects]]
+    for obj, pts in zip(polys, point_sets):
+        key = sorted(pts)                  # BTreeSet<F>: ordered by canonical value
         for s_ in sets:
             if s_[0] == key:
-                s_[1].append(pi)
+                s_[1].append(obj)
                 break
         else:
-            sets.append((key, [pi]))
-    h_com = tr.read_point()
+            sets.append([key, [obj]])
+    super_points = sorted({pt for _, pt, _ in queries})
+
+    def eval_of(obj, pt):
+        return next(e for o, p_, e in queries if o is obj and p_ == pt)
+    return sets, super_points, eval_of
+
+
+def _vanishing_at(points, u):
+    acc = 1
+    for z in points:
+        acc = acc * (u - z) % R
+    return acc
+
+
+def _verify_shplonk(tr, queries, s_g2) -> bool:
+    """halo2 poly::kzg::multiopen::shplonk::VerifierSHPLONK::verify_proof (BDFG21): ascending powers of
+    y inside a rotation set and of v across the sets, everything normalised by the first set's Z_{T \\ S_0}(u)."""
+    sets, super_points, eval_of = shplonk_sets(queries)
+    y, v = tr.squeeze(), tr.squeeze()
+    h1 = tr.read_point()
     u = tr.squeeze()
-    pi_com = tr.read_point()
-    if tr.pos != len(proof):
+    h2 = tr.read_point()
+    if not tr.exhausted():
         return False
-    zT = 1
-    for r_ in rots:
-        zT = zT * (u - point(r_)) % R
-    L, cpow = None, 1
-    for key, members in reversed(sets):
-        zs = [point(r_) for r_ in key]
-        qcom, Ru = None, 0
-        for pi in members:
-            com, prots, pevals = polys[pi]
-            ys = [pevals[prots.index(r_)] for r_ in key]
-            rj = _interpolate(zs, ys)
-            rju = 0
-            for c in reversed(rj):
-                rju = (rju * u + c) % R
-            qcom = b.g1_add(b.g1_mul(qcom, y) if qcom is not None else None, com)
-            Ru = (Ru * y + rju) % R
-        zt = 1
-        for r_ in rots:
-            if r_ not in key:
-                zt = zt * (u - point(r_)) % R
-        coef = cpow * zt % R
-        term = b.g1_add(qcom, b.g1_neg(b.g1_mul(b.G1_GEN, Ru)))
-        L = b.g1_add(L, b.g1_mul(term, coef))
-        cpow = cpow * v % R
-    L = b.g1_add(L, b.g1_neg(b.g1_mul(h_com, zT)))
-    # L(X) = (X - u) pi(X):  e(L + u pi, G2) == e(pi, [s]G2)
-    lhs = b.g1_add(L, b.g1_mul(pi_com, u))
-    return pr.pairing_check([(lhs, pr.ec_neg(pr.G2_GEN)), (pi_com, s_g2)])
+    outer, r_outer, z_0, z_0_diff_inv, vpow = None, 0, 0, 0, 1
+    for i, (points, members) in enumerate(sets):
+        z_diff = _vanishing_at([p_ for p_ in super_points if p_ not in points], u)
+        if i == 0:
+            z_0 = _vanishing_at(points, u)
+            z_0_diff_inv = b.fr_inv(z_diff)
+            z_diff = 1
+        else:
+            z_diff = z_diff * z_0_diff_inv % R
+        inner, r_inner, ypow = None, 0, 1
+        for obj in members:
+            r_x = _interpolate(points, [eval_of(obj, p_) for p_ in points])
+            r_inner = (r_inner + ypow * b.eval_polynomial(r_x, u)) % R
+            inner = b.g1_add(inner, b.g1_mul(obj.point, ypow))
+            ypow = ypow * y % R
+        outer = b.g1_add(outer, b.g1_mul(inner, vpow * z_diff % R))
+        r_outer = (r_outer + vpow * r_inner % R * z_diff) % R
+        vpow = vpow * v % R
+    outer = b.g1_add(outer, b.g1_neg(b.g1_mul(b.G1_GEN, r_outer)))
+    outer = b.g1_add(outer, b.g1_neg(b.g1_mul(h1, z_0)))
+    outer = b.g1_add(outer, b.g1_mul(h2, u))
+    # e(h2, [s]) == e(outer, [1])
+    return pr.pairing_check([(outer, pr.ec_neg(pr.G2_GEN)), (h2, s_g2)])
 
 
-def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequence[int]], proof: bytes, s_g2, multiopen: str = "gwc") -> bool:
-    """vk_commitments: F fixed then P sigma affine points (int tuples); s_g2: [s]G2 of the SRS."""
+def _verify_gwc(tr, queries, s_g2) -> bool:
+    """halo2 poly::kzg::multiopen::gwc::VerifierGWC::verify_proof: queries grouped by point in order of
+    first appearance, ascending powers of v inside a group and of u across the groups."""
+    v = tr.squeeze()
+    groups = []          # [point, [(object, eval)]]
+    for obj, pt, e in queries:
+        for g_ in groups:
+            if g_[0] == pt:
+                g_[1].append((obj, e))
+                break
+        else:
+            groups.append([pt, [(obj, e)]])
+    witnesses = [tr.read_point() for _ in groups]
+    if not tr.exhausted():
+        return False
+    u = tr.squeeze()
+    left, right, upow = None, None, 1
+    for (z, members), w in zip(groups, witnesses):
+        cb, eb, vpow = None, 0, 1
+        for obj, e in members:
+            cb = b.g1_add(cb, b.g1_mul(obj.point, vpow))
+            eb = (eb + vpow * e) % R
+            vpow = vpow * v % R
+        term = b.g1_add(b.g1_add(cb, b.g1_neg(b.g1_mul(b.G1_GEN, eb))), b.g1_mul(w, z))
+        right = b.g1_add(right, b.g1_mul(term, upow))
+        left = b.g1_add(left, b.g1_mul(w, upow))
+        upow = upow * u % R
+    # e(left, [s]) == e(right, [1])
+    return pr.pairing_check([(right, pr.ec_neg(pr.G2_GEN)), (left, s_g2)])
+
+
+def default_vk_repr(circ, vk_commitments) -> int:
+    """zk_pk_create's stand-in for halo2's `vk.transcript_repr` when the caller supplies none:
+    Blake2b-512 (personal "Halo2-Verify-Key") over the constraint-system part of the key blob and the
+    compressed fixed / sigma commitments.  (halo2 hashes the Debug string of the pinned verifying key,
+    which only the Rust side can produce: the shim passes that value in through zk_pk_set_transcript_repr.)"""
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    h.update(circ.cs_blob())
+    for pt in vk_commitments:
+        h.update(b.g1_compress(pt))
+    return b.fr_from_uniform_bytes(h.digest())
+
+
+def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequence[int]], proof: bytes, s_g2, multiopen: str = "gwc",
+           transcript: str = "blake2b") -> bool:
+    """halo2_proofs::plonk::verify_proof (KZG, single circuit instance).  vk_commitments: F fixed then P
+    sigma affine points (int tuples); s_g2: [s]G2 of the SRS."""
     n, k, u, bf, d = circ.n, circ.k, circ.u, circ.bf, circ.degree()
-    F, A, I, Pn, L = circ.F, circ.A, circ.I, len(circ.perm_cols), len(circ.lookups)
+    F, A, Pn, L = circ.F, circ.A, len(circ.perm_cols), len(circ.lookups)
     chunk = d - 2
     C = (Pn + chunk - 1) // chunk if Pn else 0
     omega = b.omega_for_k(k)
     gates = [circ.compile(g) for g in circ.gates]
-    lookups = [([circ.compile(e) for e in i], [circ.compile(e) for e in t]) for i, t in circ.lookups]
-    adv_q, fix_q = _queries(circ)
-    fixed_com, sigma_com = list(vk_commitments[:F]), list(vk_commitments[F:F + Pn])
+    lookups = [([circ.compile(e) for e in lk.table], [[circ.compile(e) for e in i] for i in lk.inputs]) for lk in circ.lookups]
+    fixed_com = [Com(pt) for pt in vk_commitments[:F]]
+    sigma_com = [Com(pt) for pt in vk_commitments[F:F + Pn]]
 
-    tr = Blake2bRead(proof)
+    tr = make_transcript(transcript, proof)
     tr.common_scalar(vk_repr)
     for col in instance:          # exactly the values given, as halo2's verify_proof does (an n-row image stands for all usable rows)
         if u < len(col) < n:
@@ -274,47 +271,37 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
     for ph in range(max([0] + list(adv_phase) + list(chal_phase)) + 1):
         for i in range(A):
             if adv_phase[i] == ph:
-                adv_com[i] = tr.read_point()
+                adv_com[i] = Com(tr.read_point())
         for ci, cp in enumerate(chal_phase):
             if cp == ph:
                 challenges[ci] = tr.squeeze()
     consts = Consts(circ.consts, challenges)
     theta = tr.squeeze()
-    m_com = [tr.read_point() for _ in range(L)]
+    m_com = [Com(tr.read_point()) for _ in range(L)]
     beta, gamma = tr.squeeze(), tr.squeeze()
-    z_com = [tr.read_point() for _ in range(C)]
-    phi_com = [tr.read_point() for _ in range(L)]
-    random_com = tr.read_point()
+    z_com = [Com(tr.read_point()) for _ in range(C)]
+    phi_com = [Com(tr.read_point()) for _ in range(L)]
+    random_com = Com(tr.read_point())
     y = tr.squeeze()
     h_com = [tr.read_point() for _ in range(d - 1)]
     x = tr.squeeze()
 
     rot_last = -(bf + 1)
     point = lambda rot: x * pow(omega, rot % n, R) % R
-    opens: List[Tuple[object, int, int]] = []   # (commitment, rot, eval)
     ev: Dict[Tuple[int, int, int], int] = {}
-    for i, rot in adv_q:
-        e = tr.read_scalar(); ev[(ADVICE, i, rot)] = e; opens.append((adv_com[i], rot, e))
-    for i, rot in fix_q:
-        e = tr.read_scalar(); ev[(FIXED, i, rot)] = e; opens.append((fixed_com[i], rot, e))
-    random_eval = tr.read_scalar(); opens.append((random_com, 0, random_eval))
-    sigma_eval = []
-    for j in range(Pn):
-        e = tr.read_scalar(); sigma_eval.append(e); opens.append((sigma_com[j], 0, e))
+    adv_evals = [tr.read_scalar() for _ in circ.advice_queries]
+    for (i, rot), e in zip(circ.advice_queries, adv_evals):
+        ev[(ADVICE, i, rot)] = e
+    fix_evals = [tr.read_scalar() for _ in circ.fixed_queries]
+    for (i, rot), e in zip(circ.fixed_queries, fix_evals):
+        ev[(FIXED, i, rot)] = e
+    random_eval = tr.read_scalar()
+    sigma_eval = [tr.read_scalar() for _ in range(Pn)]
     z_eval = []
     for c in range(C):
-        e0 = tr.read_scalar(); opens.append((z_com[c], 0, e0))
-        e1 = tr.read_scalar(); opens.append((z_com[c], 1, e1))
-        el = None
-        if c + 1 < C:
-            el = tr.read_scalar(); opens.append((z_com[c], rot_last, el))
-        z_eval.append((e0, e1, el))
-    lk_eval = []
-    for l in range(L):
-        p0 = tr.read_scalar(); opens.append((phi_com[l], 0, p0))
-        p1 = tr.read_scalar(); opens.append((phi_com[l], 1, p1))
-        me = tr.read_scalar(); opens.append((m_com[l], 0, me))
-        lk_eval.append((p0, p1, me))
+        e0, e1 = tr.read_scalar(), tr.read_scalar()
+        z_eval.append((e0, e1, tr.read_scalar() if c + 1 < C else None))
+    lk_eval = [(tr.read_scalar(), tr.read_scalar(), tr.read_scalar()) for _ in range(L)]     # phi(x), phi(wx), m(x)
 
     # ---- instance evaluations are computed by the verifier (KZG: QUERY_INSTANCE = false)
     xn = pow(x, n, R)
@@ -332,7 +319,7 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
     l_blind = sum(lagrange_at(i, x) for i in range(u + 1, n)) % R
     l_active = (1 - l_last - l_blind) % R
 
-    # ---- expected numerator: same constraint order as the prover's quotient program
+    # ---- expected h(x): gates, permutation argument, lookup arguments, folded with y
     acc = 0
     def fold(term):
         nonlocal acc
@@ -353,44 +340,41 @@ def verify(circ, vk_commitments: Sequence, vk_repr: int, instance: Sequence[Sequ
                 left = left * ((v + beta * sigma_eval[j] + gamma) % R) % R
                 right = right * ((v + beta * pow(b.FR_DELTA, j, R) % R * x + gamma) % R) % R
             fold(l_active * (left - right) % R)
-    for l, (ins, tabs) in enumerate(lookups):
+    for l, (tabs, inputs) in enumerate(lookups):
+        # mv_lookup::verifier::Evaluated::expressions
         p0, p1, me = lk_eval[l]
-        f = compress([eval_program(p, col_eval, consts) for p in ins], theta)
-        t = compress([eval_program(p, col_eval, consts) for p in tabs], theta)
+        f_evals = [(compress([eval_program(p, col_eval, consts) for p in ins], theta) + beta) % R for ins in inputs]
+        tau = (compress([eval_program(p, col_eval, consts) for p in tabs], theta) + beta) % R
+        prod_fi = 1
+        for f in f_evals:
+            prod_fi = prod_fi * f % R
+        if prod_fi == 0 or tau == 0:
+            return False                      # batch_invert / invert().unwrap() of the Rust verifier
+        sum_inv_fi = sum(b.fr_inv(f) for f in f_evals) % R
+        lhs = tau * prod_fi % R * (p1 - p0) % R
+        rhs = tau * prod_fi % R * (sum_inv_fi - me * b.fr_inv(tau)) % R
         fold(l0 * p0 % R)
         fold(l_last * p0 % R)
-        fold(l_active * (((p1 - p0) * (f + beta) % R * (t + beta) - ((t + beta) - me * (f + beta))) % R) % R)
+        fold((lhs - rhs) * l_active % R)
     h_eval = acc * b.fr_inv((xn - 1) % R) % R
     # commitment to h(X) = sum_i x^(n i) h_i(X)
     hc = None
     for com in reversed(h_com):
         hc = b.g1_add(b.g1_mul(hc, xn) if hc is not None else None, com)
-    opens.append((hc, 0, h_eval))
+    h_obj = Com(hc)
 
-    rots = []
-    for _, rot, _ in opens:
-        if rot not in rots:
-            rots.append(rot)
+    # ---- the multi-open queries, in halo2's order: advice, permutation products, lookups, fixed,
+    # permutation sigma, then h and the random polynomial
+    queries = [(adv_com[i], point(rot), e) for (i, rot), e in zip(circ.advice_queries, adv_evals)]
+    for c in range(C):
+        queries += [(z_com[c], point(0), z_eval[c][0]), (z_com[c], point(1), z_eval[c][1])]
+    for c in reversed(range(C - 1)):
+        queries.append((z_com[c], point(rot_last), z_eval[c][2]))
+    for l in range(L):
+        queries += [(phi_com[l], point(0), lk_eval[l][0]), (phi_com[l], point(1), lk_eval[l][1]), (m_com[l], point(0), lk_eval[l][2])]
+    queries += [(fixed_com[i], point(rot), e) for (i, rot), e in zip(circ.fixed_queries, fix_evals)]
+    queries += [(sigma_com[j], point(0), sigma_eval[j]) for j in range(Pn)]
+    queries += [(h_obj, point(0), h_eval), (random_com, point(0), random_eval)]
     if multiopen == "shplonk":
-        return _verify_shplonk(tr, proof, opens, rots, point, s_g2)
-    # ---- GWC: one witness per distinct point, in order of first appearance
-    v = tr.squeeze()
-    witnesses = [tr.read_point() for _ in rots]
-    if tr.pos != len(proof):
-        return False
-    uch = tr.squeeze()
-    lhs, rhs, upow = None, None, 1
-    for rot, W in zip(rots, witnesses):
-        cb, eb = None, 0
-        for com, r_, e in opens:
-            if r_ != rot:
-                continue
-            cb = b.g1_add(b.g1_mul(cb, v) if cb is not None else None, com)
-            eb = (eb * v + e) % R
-        z = point(rot)
-        term = b.g1_add(b.g1_add(cb, b.g1_neg(b.g1_mul(b.G1_GEN, eb))), b.g1_mul(W, z))
-        lhs = b.g1_add(lhs, b.g1_mul(term, upow))
-        rhs = b.g1_add(rhs, b.g1_mul(W, upow))
-        upow = upow * uch % R
-    # e(lhs, G2) == e(rhs, [s]G2)
-    return pr.pairing_check([(lhs, pr.ec_neg(pr.G2_GEN)), (rhs, s_g2)])
+        return _verify_shplonk(tr, queries, s_g2)
+    return _verify_gwc(tr, queries, s_g2)

@@ -142,3 +142,49 @@ def build_rotation_circuit(k: int, seed: int = 1, window: int = 12, blinding_fac
         inst[0][j] = adv[1][row]
         c.copy((plonk.ADVICE, 1, row), (plonk.INSTANCE, 0, j))
     return c, adv, inst
+
+
+def build_multi_lookup_circuit(k: int, seed: int = 1, n_inputs: int = 3, input_degree: int = 1, gate_degree: int = 3, blinding_factors: int = 5):
+    """mv-lookup shapes of the reference: several `lookup_any` calls into the same table are merged
+    into arguments with several input tuples and split again by degree (`chunk_lookups`
+    [REF zkevm-circuits/src/super_circuit/test.rs:59]); the EVM circuit alone registers >= 80 of them
+    [REF zkevm-circuits/src/evm_circuit/execution.rs:978-1014].
+
+    columns: fixed  0 q | 1 t_a | 2 t_b | 3 t_c (second table, one column)
+             advice 2 i, 2 i + 1 = input pair i (x_i, y_i) | 2 n_inputs = z | 2 n_inputs + 1 = w
+    lookups: (x_i, y_i) or (q x_i, q y_i) in (t_a, t_b), for every i   -- merged by table, chunked by degree
+             (z) in (t_c)                                              -- a second table
+    gate:    q * (x_0^(gate_degree - 1) - w)                           -- fixes the circuit degree
+    The table holds duplicate rows (the multiplicity of a duplicated value goes to one row only).
+    """
+    rng = random.Random(seed)
+    A = 2 * n_inputs + 2
+    c = plonk.Circuit(k, num_fixed=4, num_advice=A, num_instance=0, blinding_factors=blinding_factors)
+    n, u = c.n, c.u
+    q, t_a, t_b, t_c = (c.fixed_col(i) for i in range(4))
+    x0, w = c.advice_col(0), c.advice_col(A - 1)
+    pw = x0
+    for _ in range(gate_degree - 2):
+        pw = pw * x0
+    c.add_gate(q * (pw - w))
+    for i in range(n_inputs):
+        xi, yi = c.advice_col(2 * i), c.advice_col(2 * i + 1)
+        ins = [q * xi, q * yi] if input_degree == 2 else [xi, yi]
+        c.lookup_any("pairs", ins, [t_a, t_b])
+    c.lookup_any("single", [c.advice_col(A - 2)], [t_c])
+    c.chunk_lookups()
+    tab = [(0, 0)] + [(i, (i * i * 7 + 1) % R) for i in range(1, 20)]
+    tab += tab[3:9]                                   # duplicate rows
+    for row in range(u):
+        c.fixed[1][row], c.fixed[2][row] = tab[row] if row < len(tab) else (0, 0)
+        c.fixed[3][row] = (row * 5 + 2) % 23
+    adv = [[0] * n for _ in range(A)]
+    for row in range(u):
+        on = rng.random() < 0.7
+        c.fixed[0][row] = 1 if on else 0
+        for i in range(n_inputs):
+            pick = tab[rng.randrange(len(tab))] if (on or input_degree == 1) and rng.random() < 0.8 else (0, 0)
+            adv[2 * i][row], adv[2 * i + 1][row] = pick
+        adv[A - 2][row] = c.fixed[3][rng.randrange(u)]
+        adv[A - 1][row] = pow(adv[0][row], gate_degree - 1, R) if on else rng.randrange(R)
+    return c, adv, []

@@ -102,14 +102,15 @@ def test_fr_random_chacha(ctx, cref, n, first):
 
 @pytest.mark.parametrize("n,usable,distinct", [(64, 58, 10), (4096, 4090, 300), (1 << 16, (1 << 16) - 6, 50000)])
 def test_lookup_multiplicities(ctx, cref, n, usable, distinct):
-    """zk_lookup_multiplicities == dict-based count; duplicates credit the lowest table row; misses are reported."""
+    """zk_lookup_multiplicities == dict-based count; a value held by several table rows credits the LAST of them
+    (halo2 mv_lookup: value -> row collected into a BTreeMap, later rows overwrite); misses are reported."""
     rng = random.Random(n)
     pool = [rng.randrange(bn254.R_MOD) for _ in range(distinct)]
     table = [pool[rng.randrange(distinct)] if i >= distinct else pool[i] for i in range(n)]      # every pool value present, with repeats
     inputs = [pool[rng.randrange(distinct)] for _ in range(n)]
     first = {}
     for i in range(usable):
-        first.setdefault(table[i], i)
+        first[table[i]] = i
     want = [0] * n
     for r_ in range(usable):
         want[first[inputs[r_]]] += 1

@@ -421,3 +421,161 @@ def test_shared_subexpressions_through_intermediates(ctx, cref, srs8, s_g2):
     want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, vk_repr, seed, "shplonk")
     assert proofs[1] == want
     assert pv.verify(circ, vk_points, vk_repr, inst, proofs[1], s_g2, multiopen="shplonk")
+
+
+def _session_proof(ctx, pk, adv, inst, seed, multiopen, transcript_kind=None, slices=False):
+    sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], seed, instance_slices=slices)
+    if transcript_kind is not None:
+        sess.set_transcript_kind(transcript_kind)
+    sess.set_multiopen(1 if multiopen == "shplonk" else 0)
+    sess.advice_phase({i: plonk.column_to_mont(c) for i, c in enumerate(adv)})
+    return sess.finish()
+
+
+@pytest.mark.parametrize("n_inputs,input_degree,gate_degree,multiopen", [(1, 2, 3, "shplonk"), (2, 1, 3, "gwc"), (3, 1, 5, "shplonk"), (5, 1, 9, "shplonk")])
+def test_merged_and_chunked_lookups_equal_the_oracle_prover(zk, ctx, cref, srs8, s_g2, n_inputs, input_degree, gate_degree, multiopen):
+    """mv-lookup arguments as halo2's chunk_lookups() leaves them [REF zkevm-circuits/src/super_circuit/test.rs:59]:
+    1, 2 and 5 input tuples in one argument, a table whose inputs overflow into a second argument, a
+    second table, duplicate table rows.  The first shape has no gate above degree 3: the circuit
+    degree (5) comes from the lookup's required_degree alone."""
+    from oracle import plonk_prover as pp
+    from plonk_fixtures import build_multi_lookup_circuit
+    circ, adv, inst = build_multi_lookup_circuit(6, seed=10 + n_inputs, n_inputs=n_inputs, input_degree=input_degree, gate_degree=gate_degree)
+    assert pv.check_witness(circ, adv, inst) is None
+    seed = bytes(range(1, 17))
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        shape = pk.shape()
+        assert (shape["degree"], shape["L"], shape["advice_queries"]) == (circ.degree(), len(circ.lookups), len(circ.advice_queries))
+        gpu_proof = _session_proof(ctx, pk, adv, inst, seed, multiopen)
+        bad = [list(col) for col in adv]
+        bad[1][3] = (bad[1][3] + 1) % b.R_MOD                 # an input pair that is not in the table
+        with pytest.raises(zk.ZkError, match="not in the table"):
+            _session_proof(ctx, pk, bad, inst, seed, multiopen)
+    finally:
+        pk.destroy()
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    assert vk_repr == pv.default_vk_repr(circ, vk_points)
+    want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, vk_repr, seed, multiopen)
+    first_diff = next((i for i, (x, y) in enumerate(zip(gpu_proof, want)) if x != y), None)
+    assert len(gpu_proof) == len(want) and first_diff is None, f"proofs differ from byte {first_diff} (32-byte item {first_diff // 32 if first_diff is not None else -1})"
+    assert pv.verify(circ, vk_points, vk_repr, inst, gpu_proof, s_g2, multiopen=multiopen)
+
+
+def test_declared_degree_below_the_lookup_degree_is_refused(zk, ctx, srs8):
+    """halo2's cs.degree() counts mv_lookup::Argument::required_degree; a blob that declares less
+    would lose the top of the quotient (d - 1 pieces), so zk_pk_create recomputes it and refuses."""
+    import struct
+    from plonk_fixtures import build_multi_lookup_circuit
+    circ, _, _ = build_multi_lookup_circuit(6, seed=3, n_inputs=1, input_degree=2, gate_degree=3)
+    assert circ.degree() == 5 and max(g.degree() for g in circ.gates) == 3
+    blob = bytearray(circ.blob())
+    blob[16:20] = struct.pack("<I", 4)
+    with pytest.raises(zk.ZkError, match="declared degree 4 is below"):
+        ctx.pk_create(srs8[circ.k], bytes(blob))
+
+
+def test_hostile_blobs_are_refused(zk, ctx, srs8):
+    """header counts are checked against the blob before anything is sized by them"""
+    import struct
+    circ, _, _ = build_circuit(6, 1, False)
+    blob = circ.blob()
+    for field, value in ((6, 0xFFFFFF), (5, 0x7FFFFFFF), (8, 0xFFFFFFFF), (11, 0xFFFFFFFF), (10, 0xFFFFFFF0), (9, 0x40000000)):
+        bad = bytearray(blob)
+        bad[4 * field:4 * field + 4] = struct.pack("<I", value)
+        with pytest.raises(zk.ZkError):
+            ctx.pk_create(srs8[circ.k], bytes(bad))
+    for cut in (40, 200, len(circ.cs_blob()) - 3, len(blob) - 32):
+        with pytest.raises(zk.ZkError):
+            ctx.pk_create(srs8[circ.k], blob[:cut])
+    bad = bytearray(blob)
+    bad[4:8] = struct.pack("<I", 2)                               # an older blob version
+    with pytest.raises(zk.ZkError, match="version"):
+        ctx.pk_create(srs8[circ.k], bytes(bad))
+
+
+def test_caller_supplied_transcript_repr(ctx, cref, srs8, s_g2):
+    """halo2 absorbs vk.transcript_repr() first [REF zkevm-circuits/src/super_circuit/test.rs:70-85];
+    the Rust side computes it and installs it with zk_pk_set_transcript_repr.  With the value the
+    reference pins for the SuperCircuit as the stand-in: the proof is the oracle prover's proof for
+    that representative and verifies only under it."""
+    from oracle import plonk_prover as pp
+    circ, adv, inst = build_circuit(6, seed=9, wide=False)
+    pinned = 0x1b3d158be8148c9e8ac9fce6eff2c576027c356ee1ff68ad7662d61556d5a7d7
+    seed = bytes(16)
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    try:
+        com, rep0 = pk.vk(circ.F + len(circ.perm_cols))
+        default = _session_proof(ctx, pk, adv, inst, seed, "shplonk")
+        pk.set_transcript_repr(cref.to_mont([pinned])[0])
+        _, rep1 = pk.vk(circ.F + len(circ.perm_cols))
+        proof = _session_proof(ctx, pk, adv, inst, seed, "shplonk")
+    finally:
+        pk.destroy()
+    vk_points = cref.affine_from_mont(com)
+    assert cref.from_mont(rep1.reshape(1, 4))[0] == pinned and cref.from_mont(rep0.reshape(1, 4))[0] == pv.default_vk_repr(circ, vk_points)
+    assert proof != default
+    assert proof == pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, pinned, seed, "shplonk")
+    assert pv.verify(circ, vk_points, pinned, inst, proof, s_g2, multiopen="shplonk")
+    try:
+        assert not pv.verify(circ, vk_points, pinned, inst, default, s_g2, multiopen="shplonk")
+    except AssertionError:
+        pass
+
+
+@pytest.mark.parametrize("kind,name", [(1, "poseidon"), (2, "evm")])
+def test_poseidon_and_evm_transcripts_equal_the_oracle_prover(ctx, cref, srs8, s_g2, kind, name):
+    """gen_snark_shplonk (Poseidon transcript) and gen_evm_proof_shplonk (Keccak transcript, 64-byte
+    big-endian points) [REF prover/src/common/prover/utils.rs:31], [REF prover/src/common/prover/evm.rs:67]:
+    the session with the built-in transcript produces the oracle prover's bytes, and the oracle
+    verifier accepts them with the same transcript only."""
+    from oracle import plonk_prover as pp
+    circ, adv, inst = build_circuit(6, seed=13, wide=True)
+    short = [inst[0][:8]]
+    seed = bytes(range(16))
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        proof = _session_proof(ctx, pk, adv, short, seed, "shplonk", transcript_kind=kind, slices=True)
+        blake = _session_proof(ctx, pk, adv, short, seed, "shplonk", slices=True)
+    finally:
+        pk.destroy()
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, short, vk_repr, seed, "shplonk", transcript=name)
+    assert proof == want and proof != blake
+    if kind == 2:
+        assert len(proof) > len(blake)            # uncompressed points
+    assert pv.verify(circ, vk_points, vk_repr, short, proof, s_g2, multiopen="shplonk", transcript=name)
+
+
+def test_degree_three_circuit(ctx, cref, srs8, s_g2):
+    """cs.degree() = 3 (only the permutation argument sets it): one column per permutation chunk,
+    two quotient pieces, extended domain 2n"""
+    import random
+    from oracle import plonk_prover as pp
+    k = 5
+    circ = plonk.Circuit(k, num_fixed=1, num_advice=3, num_instance=0, blinding_factors=5)
+    q, a, b_, c_ = circ.fixed_col(0), circ.advice_col(0), circ.advice_col(1), circ.advice_col(2)
+    circ.add_gate(q * (a + b_ - c_))
+    rng = random.Random(1)
+    adv = [[0] * circ.n for _ in range(3)]
+    for row in range(circ.u):
+        circ.fixed[0][row] = row % 2
+        adv[0][row], adv[1][row] = rng.randrange(b.R_MOD), rng.randrange(b.R_MOD)
+        adv[2][row] = (adv[0][row] + adv[1][row]) % b.R_MOD if row % 2 else rng.randrange(b.R_MOD)
+    adv[0][4] = adv[2][3]
+    adv[2][5] = (adv[0][5] + adv[1][5]) % b.R_MOD
+    circ.copy((plonk.ADVICE, 2, 3), (plonk.ADVICE, 0, 4))
+    circ.enable_equality(plonk.ADVICE, 1)
+    assert circ.degree() == 3 and pv.check_witness(circ, adv, []) is None
+    pk = ctx.pk_create(srs8[k], circ.blob())
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        assert pk.shape()["C"] == 3
+        proof = _session_proof(ctx, pk, adv, [], bytes(16), "shplonk")
+    finally:
+        pk.destroy()
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+    assert proof == pp.create_proof(circ, pp.Srs(k, S_SECRET), adv, [], vk_repr, bytes(16), "shplonk")
+    assert pv.verify(circ, vk_points, vk_repr, [], proof, s_g2, multiopen="shplonk")

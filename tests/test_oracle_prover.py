@@ -66,3 +66,47 @@ def test_instance_slices_are_absorbed_as_given():
             pass
     with pytest.raises(ValueError, match="InstanceTooLarge"):
         pp.create_proof(circ, srs, adv, [inst[0][:circ.u + 1]], vk_repr, bytes(16), "gwc")
+
+
+@pytest.mark.parametrize("n_inputs,input_degree,gate_degree,multiopen", [(1, 2, 3, "shplonk"), (2, 1, 3, "shplonk"), (3, 1, 5, "gwc"), (5, 1, 9, "shplonk")])
+def test_merged_and_chunked_lookups(n_inputs, input_degree, gate_degree, multiopen):
+    """mv-lookup arguments with several input tuples per table (halo2 `chunk_lookups`): 1, 2 and 5
+    input sets in one argument, a table whose inputs overflow into a second argument, a second
+    table, duplicate table rows; the first case has no gate above degree 3, so the circuit degree
+    comes from the lookup alone (required_degree)."""
+    from plonk_fixtures import build_multi_lookup_circuit
+    circ, adv, inst = build_multi_lookup_circuit(5, seed=n_inputs, n_inputs=n_inputs, input_degree=input_degree, gate_degree=gate_degree)
+    shapes = sorted(len(lk.inputs) for lk in circ.lookups)
+    want = {(1, 2, 3): (5, [1, 1]), (2, 1, 3): (5, [1, 2]), (3, 1, 5): (5, [1, 1, 2]), (5, 1, 9): (9, [1, 5])}[(n_inputs, input_degree, gate_degree)]
+    assert (circ.degree(), shapes) == want
+    assert pv.check_witness(circ, adv, inst) is None
+    srs = pp.Srs(circ.k, S_SECRET)
+    vk_points = pp.vk_commitments(circ, srs)
+    vk_repr = pv.default_vk_repr(circ, vk_points)
+    s_g2 = pr.ec_mul(pr.G2_GEN, S_SECRET)
+    proof = pp.create_proof(circ, srs, adv, inst, vk_repr, bytes(range(16)), multiopen)
+    assert pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen=multiopen)
+    # an input that is not in the table cannot be proved
+    bad = [list(col) for col in adv]
+    bad[1][3] = (bad[1][3] + 1) % pv.R
+    assert pv.check_witness(circ, bad, inst) is not None
+    with pytest.raises(AssertionError):
+        pp.create_proof(circ, srs, bad, inst, vk_repr, bytes(16), multiopen)
+
+
+@pytest.mark.parametrize("kind", ["poseidon", "evm"])
+def test_poseidon_and_evm_transcripts(kind):
+    """gen_snark_shplonk's Poseidon transcript and gen_evm_proof_shplonk's Keccak transcript
+    [REF prover/src/common/prover/utils.rs:31], [REF prover/src/common/prover/evm.rs:67]"""
+    circ, adv, inst = build_circuit(5, seed=6, wide=False)
+    short = [inst[0][:8]]
+    srs = pp.Srs(circ.k, S_SECRET)
+    vk_points, vk_repr = pp.vk_commitments(circ, srs), 0xABCDEF
+    s_g2 = pr.ec_mul(pr.G2_GEN, S_SECRET)
+    proof = pp.create_proof(circ, srs, adv, short, vk_repr, bytes(range(16)), "shplonk", transcript=kind)
+    assert pv.verify(circ, vk_points, vk_repr, short, proof, s_g2, multiopen="shplonk", transcript=kind)
+    other = "evm" if kind == "poseidon" else "poseidon"
+    try:
+        assert not pv.verify(circ, vk_points, vk_repr, short, proof, s_g2, multiopen="shplonk", transcript=other)
+    except AssertionError:
+        pass

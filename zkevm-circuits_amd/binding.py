@@ -57,6 +57,10 @@ def lib():
         _lib.zk_srs_destroy.restype = None
         _lib.zk_pk_destroy.restype = None
         _lib.zk_proof_abort.restype = None
+        _lib.zk_transcript_new.restype = ctypes.c_void_p
+        _lib.zk_transcript_free.restype = None
+        _lib.zk_transcript_free.argtypes = [ctypes.c_void_p]
+        _lib.zk_transcript_proof.restype = ctypes.c_size_t
     return _lib
 
 
@@ -150,10 +154,75 @@ class ProvingKey:
         self.ctx._ck(lib().zk_pk_vk(self.ctx.h, self.h, _host_ptr(com), _host_ptr(rep)))
         return com[:num_commitments], rep
 
+    def set_transcript_repr(self, repr_mont: np.ndarray):
+        """install halo2's `vk.transcript_repr()` ((4,) u64 Montgomery Fr): the first scalar every proof absorbs"""
+        r = np.ascontiguousarray(repr_mont, dtype=np.uint64).reshape(4)
+        self.ctx._ck(lib().zk_pk_set_transcript_repr(self.ctx.h, self.h, _host_ptr(r)))
+
+    def shape(self) -> dict:
+        out = (ctypes.c_uint32 * 16)()
+        self.ctx._ck(lib().zk_pk_shape(self.ctx.h, self.h, out))
+        names = ["k", "degree", "extended_k", "F", "A", "I", "P", "C", "L", "phases", "challenges", "blinding_factors",
+                 "advice_queries", "fixed_queries", "commitments", "evaluations"]
+        return dict(zip(names, list(out)))
+
     def destroy(self):
         if self.h:
             lib().zk_pk_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+TRANSCRIPT_BLAKE2B, TRANSCRIPT_POSEIDON, TRANSCRIPT_EVM = 0, 1, 2
+
+
+class HostTranscript:
+    """zk_transcript: the library's Blake2b / Poseidon / EVM transcript as a host-only object (no GPU)."""
+
+    def __init__(self, kind: int):
+        self.h = lib().zk_transcript_new(ctypes.c_int(kind))
+        if not self.h:
+            raise ZkError(f"unknown transcript kind {kind}")
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise ZkError(f"transcript operation failed with status {rc}")
+
+    def common_point(self, affine64: bytes): self._ck(lib().zk_transcript_common_point(ctypes.c_void_p(self.h), ctypes.c_char_p(bytes(affine64))))
+    def common_scalar(self, fr32: bytes): self._ck(lib().zk_transcript_common_scalar(ctypes.c_void_p(self.h), ctypes.c_char_p(bytes(fr32))))
+    def write_point(self, affine64: bytes): self._ck(lib().zk_transcript_write_point(ctypes.c_void_p(self.h), ctypes.c_char_p(bytes(affine64))))
+    def write_scalar(self, fr32: bytes): self._ck(lib().zk_transcript_write_scalar(ctypes.c_void_p(self.h), ctypes.c_char_p(bytes(fr32))))
+
+    def squeeze_challenge(self) -> bytes:
+        out = ctypes.create_string_buffer(32)
+        self._ck(lib().zk_transcript_squeeze(ctypes.c_void_p(self.h), out))
+        return out.raw
+
+    def proof(self) -> bytes:
+        p = ctypes.c_void_p()
+        n = lib().zk_transcript_proof(ctypes.c_void_p(self.h), ctypes.byref(p))
+        return ctypes.string_at(p.value, n) if n else b""
+
+    def close(self):
+        if self.h:
+            lib().zk_transcript_free(ctypes.c_void_p(self.h))
+            self.h = None
+
+
+def host_keccak256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    rc = lib().zk_host_keccak256(ctypes.c_char_p(data), ctypes.c_size_t(len(data)), out)
+    if rc != 0:
+        raise ZkError(f"zk_host_keccak256 failed with status {rc}")
+    return out.raw
+
+
+def host_poseidon_permute(state_mont: np.ndarray) -> np.ndarray:
+    """(5, 4) u64 Montgomery Fr in and out: one permutation of the transcript's Poseidon (T 5, R_F 8, R_P 60)"""
+    st = np.ascontiguousarray(state_mont, dtype=np.uint64).reshape(5, 4).copy()
+    rc = lib().zk_host_poseidon_permute(_host_ptr(st))
+    if rc != 0:
+        raise ZkError(f"zk_host_poseidon_permute failed with status {rc}")
+    return st
 
 
 _TR_IN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
@@ -170,7 +239,7 @@ class ProofSession:
     def __init__(self, ctx: "Context", pk: ProvingKey, instance: Sequence[np.ndarray], seed: bytes, instance_slices: bool = False):
         """instance: (n, 4) column images (every usable row is absorbed), or -- instance_slices=True --
         halo2's instance slices as they are: (len_i, 4) arrays, exactly len_i values absorbed each."""
-        self.ctx = ctx
+        self.ctx, self.pk = ctx, pk
         ins = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in instance]
         pi = (ctypes.c_void_p * max(len(ins), 1))(*[a.ctypes.data for a in ins])
         h = ctypes.c_void_p()
@@ -185,6 +254,10 @@ class ProofSession:
     def set_multiopen(self, kind: int):
         """0 = GWC (default), 1 = SHPLONK."""
         self.ctx._ck(lib().zk_proof_set_multiopen(self.ctx.h, self.h, ctypes.c_int(kind)))
+
+    def set_transcript_kind(self, kind: int):
+        """built-in transcript: TRANSCRIPT_BLAKE2B (default), TRANSCRIPT_POSEIDON or TRANSCRIPT_EVM"""
+        self.ctx._ck(lib().zk_proof_set_transcript_kind(self.ctx.h, self.h, ctypes.c_int(kind)))
 
     def set_transcript(self, transcript):
         """Forward every transcript operation to `transcript`, an object with
@@ -230,8 +303,11 @@ class ProofSession:
         cols = [np.ascontiguousarray(columns[i], dtype=np.uint64) for i in idx]
         ci = (ctypes.c_uint32 * max(len(idx), 1))(*idx)
         pc = (ctypes.c_void_p * max(len(idx), 1))(*[c.ctypes.data for c in cols])
-        out = np.zeros((64, 4), dtype=np.uint64)
-        cnt = ctypes.c_uint32()
+        cap = getattr(self, "_challenge_cap", None)
+        if cap is None:
+            cap = self._challenge_cap = max(1, self.pk.shape()["challenges"])      # sized from the key, never guessed
+        out = np.zeros((cap, 4), dtype=np.uint64)
+        cnt = ctypes.c_uint32(cap)
         self.ctx._ck(lib().zk_proof_advice_phase(self.ctx.h, self.h, ci, pc, ctypes.c_uint32(len(idx)), _host_ptr(out), ctypes.byref(cnt)))
         return out[:cnt.value].copy()
 

@@ -195,7 +195,7 @@ typedef int (*MsmStageFn)(void* user, size_t it);
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
                   size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user);
-int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
+int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1
 int copy_stream_open(zk_ctx* ctx);      // copy stream starts after everything enqueued on the main stream so far
 int copy_stream_fence(zk_ctx* ctx);     // main stream continues after everything enqueued on the copy stream so far

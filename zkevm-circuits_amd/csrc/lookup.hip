@@ -1,12 +1,15 @@
 // Lookup multiplicities m(X) of the logUp ("mv-lookup") argument on the device.
 //
 // Reference behaviour (halo2, Scroll fork, plonk/mv_lookup/prover.rs `Argument::prepare`, SURVEY
-// Appendix B.6): after the input and table expressions are theta-compressed, m[i] counts how many
-// usable input rows carry the value of table row i; when a value occurs in several table rows the
-// first one takes the whole count; an input that is not in the table is a prover error.
+// Appendix B.6): after the table expressions and every input tuple of the argument are
+// theta-compressed, m[i] counts how many usable input rows -- over ALL input tuples -- carry the
+// value of table row i; when a value occurs in several table rows the LAST one takes the whole
+// count (the upstream code collects value -> row into a BTreeMap, so later rows overwrite earlier
+// ones; any choice yields a valid proof); an input that is not in the table is a prover error
+// (Error::ConstraintSystemFailure).
 //
-// Device form: an open-addressing hash table over the usable table rows (slot = lowest row index
-// with that value, settled with atomicCAS / atomicMin), then one probe sequence per input row
+// Device form: an open-addressing hash table over the usable table rows (slot = highest row index
+// with that value, settled with atomicCAS / atomicMax), then one probe sequence per input row
 // (atomicAdd on the owning row's counter).  Values are canonical Montgomery residues, so equality
 // of the eight limbs is equality in Fr.  2 n slots for n rows: expected probe length < 1.5.
 #include "ctx.hpp"
@@ -34,7 +37,7 @@ __global__ void __launch_bounds__(256) k_lk_insert(const Fr* __restrict__ table,
     const bool active = row < rows;
     const Fr key = active ? ldg(table + row) : Fr::zero();
     // Fixed tables are padded with long runs of one default row.  Equal values inside a wave are
-    // represented by their first lane (the lowest row) only, so a run of a million equal rows
+    // represented by their last lane (the highest row) only, so a run of a million equal rows
     // sends 1/64 of the probes to that value's slot instead of hammering one L2 line.
     bool rep = false;
     uint64_t todo = __ballot(active);
@@ -44,18 +47,18 @@ __global__ void __launch_bounds__(256) k_lk_insert(const Fr* __restrict__ table,
 #pragma unroll
         for (int i = 0; i < 8; ++i) diff |= key.l[i] ^ __shfl(key.l[i], src);
         const uint64_t same = __ballot(diff == 0) & todo;
-        if ((int)lane == src) rep = true;
+        if ((int)lane == 63 - (int)__builtin_clzll(same)) rep = true;
         todo &= ~same;
     }
     if (!rep) return;
     uint32_t h = fr_hash(key) & mask;
     for (;;) {
-        // look before touching the slot atomically: a value that is already owned by a lower row
+        // look before touching the slot atomically: a value that is already owned by a higher row
         // costs one load and no atomic
         uint32_t old = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == LK_EMPTY) old = atomicCAS(&slots[h], LK_EMPTY, row);
         if (old == LK_EMPTY) return;
-        if (fr_same(ldg(table + old), key)) { if (row < old) atomicMin(&slots[h], row); return; }   // duplicate value: lowest row owns it
+        if (fr_same(ldg(table + old), key)) { if (row > old) atomicMax(&slots[h], row); return; }   // duplicate value: highest row owns it (LK_EMPTY never reappears: rows < 2^31)
         h = (h + 1) & mask;
     }
 }
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(LK_COUNT_THREADS) k_lk_count(const Fr* __restr
     for (uint32_t i = threadIdx.x; i < LK_BLOCK_SLOTS; i += blockDim.x)
         if (t_key[i] != LK_EMPTY) atomicAdd(&counts[t_key[i]], t_cnt[i]);
 }
-// m[i] = counts[i] as a Montgomery residue for i < rows, 0 for rows <= i < n (the caller overwrites the blinding rows)
+// m[i] = counts[i] as a Montgomery residue for i < rows, 0 for rows <= i < n (halo2 leaves the unusable rows of m at zero)
 __global__ void __launch_bounds__(256) k_lk_to_fr(const uint32_t* __restrict__ counts, uint32_t rows, Fr* __restrict__ m, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -116,7 +119,9 @@ __global__ void __launch_bounds__(256) k_lk_to_fr(const uint32_t* __restrict__ c
 // Enqueues the whole computation on the context's stream; d_status (one u32 on the device, set to
 // 0xFFFFFFFF by the caller) receives the lowest offending input row.  No synchronisation: the
 // prover runs every lookup of a proof back to back and reads all status words at once.
-int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status) {
+// d_inputs: `num_inputs` theta-compressed input vectors looked up in the same table (mv-lookup
+// arguments carry one or more input tuples).
+int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status) {
     uint32_t cap = 16;
     while (cap < 2 * usable_rows) cap <<= 1;
     // scratch: slots[cap] | counts[usable_rows]   (reused by the next enqueue: same stream, so ordered)
@@ -128,8 +133,9 @@ int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_t
     const uint32_t rows = (uint32_t)usable_rows;
     if (rows) {
         hipLaunchKernelGGL(k_lk_insert, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_table, rows, slots, cap - 1);
-        hipLaunchKernelGGL(k_lk_count, dim3((rows + LK_COUNT_THREADS - 1) / LK_COUNT_THREADS), dim3(LK_COUNT_THREADS), 0, ctx->stream, d_inputs, d_table, rows,
-                           (const uint32_t*)slots, cap - 1, counts, d_status);
+        for (size_t i = 0; i < num_inputs; ++i)
+            hipLaunchKernelGGL(k_lk_count, dim3((rows + LK_COUNT_THREADS - 1) / LK_COUNT_THREADS), dim3(LK_COUNT_THREADS), 0, ctx->stream, d_inputs[i], d_table, rows,
+                               (const uint32_t*)slots, cap - 1, counts, d_status);
         ZK_CHECK_LAUNCH(ctx);
     }
     hipLaunchKernelGGL(k_lk_to_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)counts, rows, d_m, (uint64_t)n);
@@ -149,7 +155,8 @@ extern "C" int zk_lookup_multiplicities(zk_ctx* ctx, const void* d_inputs, const
     uint32_t* status = (uint32_t*)ctx->get_scratch(SC_TMP2, 64);
     if (!status) return ZK_ERR_OOM;
     ZK_HIP(ctx, hipMemsetAsync(status, 0xFF, 4, ctx->stream));
-    int rc = lookup_multiplicities_enqueue(ctx, (const Fr*)d_inputs, (const Fr*)d_table, usable_rows, (Fr*)d_m, n, status);
+    const Fr* one_input = (const Fr*)d_inputs;
+    int rc = lookup_multiplicities_enqueue(ctx, &one_input, 1, (const Fr*)d_table, usable_rows, (Fr*)d_m, n, status);
     if (rc) return rc;
     uint32_t st = LK_EMPTY;
     ZK_HIP(ctx, hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -22,9 +22,12 @@
 // The matching verifier is oracle/plonk_verifier.py; oracle/plonk_prover.py restates this file over
 // Python integers and the tests require both to produce the same proof bytes.
 //
-// The circuit arrives as a flat "pk blob" (zkevm-circuits_amd/plonk.py serialises it; layout in
-// INTEGRATION.md, SURVEY 8f-1 export format): header, phases, permutation columns, constants, gate
-// programs, lookup programs, fixed columns and sigma columns in Lagrange form.
+// The circuit arrives as a flat "pk blob" (zkevm-circuits_amd/plonk.py serialises it, the Rust shim
+// fills it from halo2's ConstraintSystem; layout in INTEGRATION.md, SURVEY 8f-1 export format):
+// header, phases, the advice / fixed / instance query lists in halo2's registration order (the order
+// of the evaluations in the proof), permutation columns, constants, gate programs, lookup arguments
+// (one table tuple and one or more input tuples each, as chunk_lookups() leaves them), fixed columns
+// and sigma columns in Lagrange form.
 #include <algorithm>
 #include <array>
 #include <unordered_map>
@@ -32,7 +35,7 @@
 #include <chrono>
 #include <cstdlib>
 #include "ctx.hpp"
-#include "host_util.hpp"
+#include "host_hash.hpp"
 
 using namespace zk;
 using zk::host::F4;
@@ -93,6 +96,13 @@ struct DevBuf {
         if (owner) { p = owner->pool_get(n); return p != nullptr; }
         return hipMalloc(&p, n ? n : 1) == hipSuccess;
     }
+    // plain hipMalloc / hipFree even inside a PoolScope (buffers that outlive the session, e.g. the key's coset cache)
+    bool alloc_unpooled(size_t n) {
+        release();
+        bytes = n;
+        owner = nullptr;
+        return hipMalloc(&p, n ? n : 1) == hipSuccess;
+    }
     Fr* fr() const { return (Fr*)p; }
 };
 
@@ -127,7 +137,7 @@ struct zk_pk {
     std::vector<std::pair<uint32_t, uint32_t>> perm_cols;
     std::vector<F4> consts;
     std::vector<Prog> gates;
-    struct Lookup { std::vector<Prog> inputs, tables; };
+    struct Lookup { std::vector<Prog> tables; std::vector<std::vector<Prog>> inputs; };      // mv_lookup::Argument: table_expressions, inputs_expressions
     std::vector<Lookup> lookups;
     std::vector<Query> adv_q, fix_q;         // evaluation queries, in proof order
     uint32_t num_phases = 1;
@@ -138,11 +148,13 @@ struct zk_pk {
     DevBuf omega_lag, l0_lag, llast_lag, lactive_lag, l0_coeff, llast_coeff, lactive_coeff;
     // cosets of the key's own columns (fixed, sigma, l0 / l_last / l_active, X), filled by the first
     // proof and reused by later ones when they fit the budget (ZK_PK_COSET_CACHE_GB, default 96):
-    // part_cache[r][column reference]
+    // part_cache[r][column reference].  Plain device allocations owned by the key (a slot appears
+    // only once it is filled).  A key serves one proving thread at a time, as its context does.
     mutable std::vector<std::unordered_map<uint32_t, DevBuf>> part_cache;
     mutable int part_cache_state = -1;       // -1 undecided, 0 off, 1 on
     std::vector<G1Affine> fixed_com, sigma_com;
-    F4 vk_repr;
+    F4 vk_repr;                              // vk.transcript_repr: the default, or what zk_pk_set_transcript_repr installed
+    std::vector<Query> inst_q;               // instance queries (verifier side; carried for the vk)
     const zk_srs* srs = nullptr;
 };
 
@@ -174,8 +186,35 @@ struct Reader {
     const uint8_t* p; size_t left; bool ok = true;
     uint32_t u32() { if (left < 4) { ok = false; return 0; } uint32_t v; memcpy(&v, p, 4); p += 4; left -= 4; return v; }
     const uint8_t* bytes(size_t n) { if (left < n) { ok = false; return nullptr; } const uint8_t* r = p; p += n; left -= n; return r; }
-    Prog prog() { Prog g; uint32_t len = u32(); for (uint32_t i = 0; i < len && ok; ++i) { Instr in; in.op = u32(); in.a = u32(); in.b = u32(); g.push_back(in); } return g; }
+    // a count of records of `each` bytes that the rest of the blob can actually hold (a truncated or
+    // hostile header must not drive allocations)
+    uint32_t count(size_t each) { const uint32_t c = u32(); if (ok && (size_t)c * each > left) ok = false; return ok ? c : 0; }
+    Prog prog() { Prog g; const uint32_t len = count(12); g.reserve(len); for (uint32_t i = 0; i < len && ok; ++i) { Instr in; in.op = u32(); in.a = u32(); in.b = u32(); g.push_back(in); } return g; }
+    void queries(std::vector<Query>* out, uint32_t type, uint32_t ncols) {
+        const uint32_t cnt = count(8);
+        for (uint32_t i = 0; i < cnt && ok; ++i) { const uint32_t c = u32(); const int32_t rot = (int32_t)u32(); if (c >= ncols) ok = false; out->push_back(Query{type, c, rot}); }
+    }
 };
+
+// Degree of a postfix program as halo2's Expression::degree computes it (columns 1, constants and
+// challenges 0, sums the maximum, products the sum); -1 on a malformed program.
+int program_degree(const Prog& g, std::vector<int>* tmp_degree) {
+    std::vector<int> st;
+    for (const Instr& in : g) {
+        switch (in.op) {
+            case Q_PUSH_COL: st.push_back(1); break;
+            case Q_PUSH_CONST: st.push_back(0); break;
+            case Q_ADD: case Q_SUB: if (st.size() < 2) return -1; { const int b_ = st.back(); st.pop_back(); st.back() = std::max(st.back(), b_); } break;
+            case Q_MUL: if (st.size() < 2) return -1; { const int b_ = st.back(); st.pop_back(); st.back() += b_; } break;
+            case Q_NEG: case Q_DOUBLE: case Q_ADD_CONST: case Q_MUL_CONST: if (st.empty()) return -1; break;
+            case Q_SQUARE: if (st.empty()) return -1; st.back() *= 2; break;
+            case Q_TEE_TMP: if (st.empty()) return -1; if (in.a >= tmp_degree->size()) tmp_degree->resize(in.a + 1, 0); (*tmp_degree)[in.a] = st.back(); break;
+            case Q_PUSH_TMP: if (in.a >= tmp_degree->size()) return -1; st.push_back((*tmp_degree)[in.a]); break;
+            default: return -1;
+        }
+    }
+    return st.size() == 1 ? st[0] : -1;
+}
 
 int commit_lagrange(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 1, d_vals, n, out); }
 int commit_coeff(zk_ctx* ctx, const zk_srs* srs, const Fr* d_vals, size_t n, G1Affine* out) { return zk_commit(ctx, srs, 0, d_vals, n, out); }
@@ -196,18 +235,6 @@ int to_coeff_aux(zk_ctx* ctx, const zk_pk* pk, const DevBuf& lag, DevBuf* coeff)
     const int rc = to_coeff(ctx, pk, lag, coeff);
     ctx->stream = main_stream;
     return rc;
-}
-
-void collect_queries(const Prog& g, std::vector<Query>* adv, std::vector<Query>* fix) {
-    for (const Instr& in : g) {
-        if (in.op != Q_PUSH_COL) continue;
-        const uint32_t type = in.a >> 24, idx = in.a & 0xFFFFFF;
-        std::vector<Query>* dst = type == CT_ADVICE ? adv : (type == CT_FIXED ? fix : nullptr);
-        if (!dst) continue;
-        bool seen = false;
-        for (const Query& q : *dst) if (q.idx == idx && q.rot == (int32_t)in.b) { seen = true; break; }
-        if (!seen) dst->push_back(Query{type, idx, (int32_t)in.b});
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,47 +425,88 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
     Reader r{(const uint8_t*)h_blob, blob_len};
     if (r.u32() != 0x4B505A4Bu) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic");
     const uint32_t version = r.u32();
-    if (version != 1u && version != 2u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: unsupported version %u", version);
+    if (version != 3u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: unsupported version %u (this library reads version 3)", version);
     std::unique_ptr<zk_pk> pk(new zk_pk());
     pk->srs = srs;
     pk->k = r.u32(); pk->bf = r.u32(); pk->d = r.u32(); pk->F = r.u32(); pk->A = r.u32(); pk->I = r.u32(); pk->P = r.u32(); pk->L = r.u32();
     const uint32_t ngates = r.u32(), nconsts = r.u32();
-    if (!r.ok || pk->k < 2 || pk->d < 4 || pk->d > 17) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad header (k=%u, degree=%u)", pk->k, pk->d);
+    // halo2: cs.degree() >= 3 (the permutation argument); the extended domain has at most 2^28 rows
+    if (!r.ok || pk->k < 2 || pk->k > 27 || pk->d < 3 || pk->d > 17) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad header (k=%u, degree=%u)", pk->k, pk->d);
     // commit_lagrange needs the Lagrange basis of exactly this domain (halo2: ParamsKZG::downsize)
     if (pk->k != srs->k) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS is for k=%u but the circuit has k=%u: downsize the SRS first", srs->k, pk->k);
     const size_t n = (size_t)1 << pk->k;
     if (pk->bf + 2 >= n) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many blinding rows");
     if (!srs->g_lagrange) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS has no Lagrange basis");
+    // every count of the header is checked against what the blob can hold before anything is sized by it
+    if ((size_t)pk->A * 4 > r.left || (size_t)pk->P * 8 > r.left || (size_t)nconsts * 32 > r.left || (size_t)ngates * 4 > r.left || (size_t)pk->L * 8 > r.left ||
+        ((size_t)pk->F + pk->P) > r.left / (n * 32) || pk->A > 0xFFFFFFu || pk->F > 0xFFFFFFu || pk->I > 0xFFFFFFu)
+        return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: header counts exceed the blob (%zu bytes)", blob_len);
     pk->u = (uint32_t)n - pk->bf - 1;
     pk->chunk = pk->d - 2;
     pk->C = pk->P ? (pk->P + pk->chunk - 1) / pk->chunk : 0;
     pk->ext_k = pk->k;
     while (((size_t)1 << pk->ext_k) < n * (pk->d - 1)) ++pk->ext_k;
+    if (pk->ext_k > 28) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: extended domain 2^%u exceeds the two-adicity of Fr", pk->ext_k);
     pk->adv_phase.assign(pk->A, 0);
-    if (version >= 2) {   // phases: [num_challenges][A x advice phase][num_challenges x challenge phase]
-        const uint32_t nch = r.u32();
+    {   // phases: [num_challenges][A x advice phase][num_challenges x challenge phase]
+        const uint32_t nch = r.count(4);
         if (nch > 4096) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many challenges");
-        for (uint32_t i = 0; i < pk->A; ++i) { pk->adv_phase[i] = r.u32(); if (pk->adv_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->adv_phase[i] + 1; }
-        for (uint32_t i = 0; i < nch; ++i) { pk->chal_phase.push_back(r.u32()); if (pk->chal_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->chal_phase[i] + 1; }
+        for (uint32_t i = 0; i < pk->A && r.ok; ++i) { pk->adv_phase[i] = r.u32(); if (pk->adv_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->adv_phase[i] + 1; }
+        for (uint32_t i = 0; i < nch && r.ok; ++i) { pk->chal_phase.push_back(r.u32()); if (pk->chal_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->chal_phase[i] + 1; }
         if (!r.ok || pk->num_phases > 16) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad phase table");
     }
-    for (uint32_t i = 0; i < pk->P; ++i) { uint32_t t = r.u32(), x = r.u32(); pk->perm_cols.push_back({t, x}); }
-    for (uint32_t i = 0; i < nconsts; ++i) { const uint8_t* b = r.bytes(32); F4 v; if (b) memcpy(v.l, b, 32); pk->consts.push_back(v); }
-    for (uint32_t i = 0; i < ngates; ++i) pk->gates.push_back(r.prog());
-    for (uint32_t i = 0; i < pk->L; ++i) {
+    // cs.advice_queries / fixed_queries / instance_queries: (column, rotation) in registration order
+    r.queries(&pk->adv_q, CT_ADVICE, pk->A);
+    r.queries(&pk->fix_q, CT_FIXED, pk->F);
+    r.queries(&pk->inst_q, CT_INSTANCE, pk->I);
+    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad query lists");
+    for (uint32_t i = 0; i < pk->P && r.ok; ++i) { uint32_t t = r.u32(), x = r.u32(); pk->perm_cols.push_back({t, x}); }
+    for (uint32_t i = 0; i < nconsts && r.ok; ++i) { const uint8_t* b = r.bytes(32); F4 v; if (b) memcpy(v.l, b, 32); pk->consts.push_back(v); }
+    for (uint32_t i = 0; i < ngates && r.ok; ++i) pk->gates.push_back(r.prog());
+    for (uint32_t i = 0; i < pk->L && r.ok; ++i) {
         zk_pk::Lookup lk;
-        const uint32_t m = r.u32();
-        for (uint32_t j = 0; j < m; ++j) lk.inputs.push_back(r.prog());
-        for (uint32_t j = 0; j < m; ++j) lk.tables.push_back(r.prog());
+        const uint32_t m = r.u32(), ninputs = r.count(4);
+        if (!r.ok || m == 0 || ninputs == 0 || (size_t)m * 4 > r.left || (size_t)m * ninputs > r.left / 4) { r.ok = false; break; }
+        for (uint32_t j = 0; j < m && r.ok; ++j) lk.tables.push_back(r.prog());
+        for (uint32_t a = 0; a < ninputs && r.ok; ++a) {
+            lk.inputs.emplace_back();
+            for (uint32_t j = 0; j < m && r.ok; ++j) lk.inputs.back().push_back(r.prog());
+        }
         pk->lookups.push_back(std::move(lk));
     }
-    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated");
-    // evaluation queries: gates, lookups, then permutation columns at rotation 0
-    for (const Prog& g : pk->gates) collect_queries(g, &pk->adv_q, &pk->fix_q);
-    for (const auto& lk : pk->lookups) { for (const Prog& g : lk.inputs) collect_queries(g, &pk->adv_q, &pk->fix_q); for (const Prog& g : lk.tables) collect_queries(g, &pk->adv_q, &pk->fix_q); }
-    for (const auto& pc : pk->perm_cols) {
-        Prog one{{Q_PUSH_COL, colref(pc.first, pc.second), 0}};
-        collect_queries(one, &pk->adv_q, &pk->fix_q);
+    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated or malformed constraint system");
+    const size_t cs_len = blob_len - r.left;        // the constraint-system part: everything before the column data
+    // The degree the blob declares must cover what its own programs need (halo2 ConstraintSystem::degree:
+    // permutation argument 3, mv_lookup::Argument::required_degree, every gate polynomial): with a
+    // smaller one the quotient would not fit its d - 1 pieces and the proof would be rejected.
+    {
+        uint32_t need = 3;
+        std::vector<int> tmp_deg;
+        for (const Prog& g : pk->gates) {
+            const int dg = program_degree(g, &tmp_deg);
+            if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed gate program");
+            need = std::max(need, (uint32_t)dg);
+        }
+        for (const auto& lk : pk->lookups) {
+            std::vector<int> none;
+            int table_degree = 0, inputs_degree = 0;
+            for (const Prog& g : lk.tables) { const int dg = program_degree(g, &none); if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup table program"); table_degree = std::max(table_degree, dg); }
+            for (const auto& in : lk.inputs) {
+                int one = 0;
+                for (const Prog& g : in) { const int dg = program_degree(g, &none); if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup input program"); one = std::max(one, dg); }
+                inputs_degree += one;
+            }
+            need = std::max(need, std::max((uint32_t)(3 + lk.inputs.size()), (uint32_t)(table_degree + inputs_degree + 2)));
+        }
+        if (pk->d < need) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: declared degree %u is below the %u its gates and lookup arguments require", pk->d, need);
+    }
+    for (const auto& pc : pk->perm_cols) {          // halo2: enable_equality queries the column at Rotation::cur()
+        if (pc.first > CT_INSTANCE) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad permutation column type %u", pc.first);
+        if (pc.first == CT_INSTANCE) continue;
+        const std::vector<Query>& qs = pc.first == CT_ADVICE ? pk->adv_q : pk->fix_q;
+        bool seen = false;
+        for (const Query& q : qs) if (q.idx == pc.second && q.rot == 0) { seen = true; break; }
+        if (!seen) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: permutation column (%u, %u) is not queried at rotation 0", pc.first, pc.second);
     }
     // fixed + sigma columns
     pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F);
@@ -478,14 +546,14 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         PK_TRY(zk_fr_powers(ctx, &w, &one, pk->omega_lag.p, n));
         PK_TRY(zk_ctx_sync(ctx));
     }
-    // vk_repr: hash of the circuit shape and the fixed / sigma commitments
+    // Default vk.transcript_repr: Blake2b-512 ("Halo2-Verify-Key") over the whole constraint-system
+    // part of the blob and the compressed fixed / sigma commitments.  halo2's own value hashes the Debug
+    // string of the pinned verifying key, which only the Rust side can produce: the shim installs it
+    // with zk_pk_set_transcript_repr, and then proofs are made for exactly the reference's verifier.
     {
         host::Blake2b hsh;
         hsh.init("Halo2-Verify-Key");
-        const uint32_t hdr[10] = {pk->k, pk->bf, pk->d, pk->F, pk->A, pk->I, pk->P, pk->L, ngates, nconsts};
-        hsh.update(hdr, sizeof hdr);
-        if (!pk->adv_phase.empty()) hsh.update(pk->adv_phase.data(), pk->adv_phase.size() * 4);
-        if (!pk->chal_phase.empty()) hsh.update(pk->chal_phase.data(), pk->chal_phase.size() * 4);
+        hsh.update(h_blob, cs_len);
         for (const auto& c : pk->fixed_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
         for (const auto& c : pk->sigma_com) { uint8_t b[32]; host::g1_compress(c, b); hsh.update(b, 32); }
         uint8_t dg[64];
@@ -494,6 +562,28 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
     }
     PK_TRY(zk_ctx_sync(ctx));
     *out = pk.release();
+    return ZK_OK;
+}
+
+// halo2 absorbs `vk.transcript_repr()` first [REF zkevm-circuits/src/super_circuit/test.rs:70-85 pins its
+// value for the SuperCircuit]; the caller that holds the real VerifyingKey passes that scalar here.
+int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk* pk, const void* h_repr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && h_repr, "null pointer");
+    memcpy(pk->vk_repr.l, h_repr, 32);
+    return ZK_OK;
+}
+
+// Shape of a key, for callers that size buffers from it: out[0..15] = k, degree, extended k, F, A, I,
+// P (permutation columns), C (permutation chunks), L (lookup arguments), phases, challenges,
+// blinding factors, advice queries, fixed queries, commitments in a proof, evaluations in a proof.
+int zk_pk_shape(zk_ctx* ctx, const zk_pk* pk, uint32_t* out16) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && out16, "null pointer");
+    const uint32_t evals = (uint32_t)pk->adv_q.size() + (uint32_t)pk->fix_q.size() + 1 + pk->P + (pk->C ? 3 * pk->C - 1 : 0) + 3 * pk->L;
+    const uint32_t v[16] = {pk->k, pk->d, pk->ext_k, pk->F, pk->A, pk->I, pk->P, pk->C, pk->L, pk->num_phases, (uint32_t)pk->chal_phase.size(), pk->bf,
+                            (uint32_t)pk->adv_q.size(), (uint32_t)pk->fix_q.size(), pk->A + 2 * pk->L + pk->C + 1 + (pk->d - 1), evals};
+    memcpy(out16, v, sizeof v);
     return ZK_OK;
 }
 
@@ -538,6 +628,18 @@ int zk_proof_set_transcript(zk_ctx* ctx, zk_proof* pr, const zk_transcript_vtabl
     pr->absorbed.clear();
     pr->absorbed.shrink_to_fit();
     if (pr->tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", pr->tr.err);
+    return ZK_OK;
+}
+
+// Built-in transcripts: Blake2b (default), Poseidon (gen_snark_shplonk) or Keccak / EVM
+// (gen_evm_proof_shplonk).  Same rule as zk_proof_set_transcript: right after zk_proof_begin; what
+// begin absorbed is replayed into the chosen transcript.
+int zk_proof_set_transcript_kind(zk_ctx* ctx, zk_proof* pr, int kind) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && (kind == ZK_TRANSCRIPT_BLAKE2B || kind == ZK_TRANSCRIPT_POSEIDON || kind == ZK_TRANSCRIPT_EVM), "unknown transcript kind");
+    ZK_REQUIRE(ctx, pr->phase == 0 && !pr->tr.vt, "the transcript must be chosen once, before the first advice phase");
+    pr->tr.reset(kind);
+    for (const F4& s_ : pr->absorbed) pr->tr.common_scalar(s_);
     return ZK_OK;
 }
 
@@ -603,7 +705,8 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
 // Commits the advice columns of the current phase (h_cols[j] is advice column col_index[j]; exactly
 // the columns of this phase, each n x 32 B Lagrange values; rows >= n - bf are replaced by blinding
 // values) and squeezes the challenges that become available after it into h_challenges (Fr each,
-// in challenge-index order); *num_challenges receives how many were written.
+// in challenge-index order).  When h_challenges is given, *num_challenges holds its capacity (in
+// challenges) on entry; on return it holds how many the phase produced.
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
@@ -611,8 +714,11 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     const zk_pk* pk = pr->pk;
     if (pr->phase >= pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "all %u advice phases are already committed", pk->num_phases);
     const size_t n = (size_t)1 << pk->k;
-    uint32_t expected = 0;
+    uint32_t expected = 0, phase_challenges = 0;
     for (uint32_t i = 0; i < pk->A; ++i) expected += pk->adv_phase[i] == pr->phase;
+    for (uint32_t cp : pk->chal_phase) phase_challenges += cp == pr->phase;
+    if (h_challenges && (!num_challenges || *num_challenges < phase_challenges))
+        return ctx->fail(ZK_ERR_INVALID_ARG, "phase %u yields %u challenges: pass a buffer for at least that many and its capacity in *num_challenges", pr->phase, phase_challenges);
     if (ncols != expected) return ctx->fail(ZK_ERR_INVALID_ARG, "phase %u has %u advice columns, %u were passed", pr->phase, expected, ncols);
     std::vector<const void*> by_col(pk->A, nullptr);
     for (uint32_t j = 0; j < ncols; ++j) {
@@ -696,6 +802,9 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
             DevBuf gbuf, zero;
             if (!gbuf.alloc((size_t)sg.world * n * 32) || !zero.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
             ZK_HIP(ctx, hipMemsetAsync(zero.p, 0, n * 32, ctx->stream));
+            // the transforms of this rank's own columns still run on the auxiliary stream and share the NTT
+            // scratch with the ones enqueued below on the main stream: finish them first
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
             for (size_t grp = 0; grp * sg.world < total; ++grp) {
                 const size_t mine_c = grp * sg.world + pr->rank;
                 PK_TRY(zk_ctx_sync(ctx));                                  // own column uploaded, previous copies out of gbuf done
@@ -756,27 +865,33 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     Env lag{pk, nullptr, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
 
-    // ---- lookups, round 1: multiplicities m.  Every lookup is enqueued back to back (theta-compression,
-    // device hash join, blinding rows); one download of the status words, one pipelined batch of commits.
-    std::vector<DevBuf> lk_f(pk->L), lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
+    // ---- lookups, round 1 (mv_lookup::prover::Argument::prepare): theta-compressed table and input tuples,
+    // multiplicities m over ALL input tuples of the argument.  Every lookup is enqueued back to back
+    // (compression programs, device hash join); one download of the status words, one pipelined batch
+    // of commits.  The unusable rows of m stay zero, as upstream leaves them.
+    std::vector<std::vector<DevBuf>> lk_f(pk->L);
+    std::vector<DevBuf> lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
     if (pk->L) {
         DevBuf status;
         if (!status.alloc((size_t)pk->L * 4)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         ZK_HIP(ctx, hipMemsetAsync(status.p, 0xFF, (size_t)pk->L * 4, ctx->stream));
-        const size_t nblind = n - pk->u - 1;
-        std::vector<F4> blind((size_t)pk->L * nblind);
         std::vector<const void*> mptrs(pk->L);
         for (uint32_t l = 0; l < pk->L; ++l) {
             const auto& lk = pk->lookups[l];
-            PB pf, pt;
-            push_compressed(pf, lk.inputs); pf.fold(C_ONE);
+            PB pt;
             push_compressed(pt, lk.tables); pt.fold(C_ONE);
-            if (!lk_f[l].alloc(n * 32) || !lk_t[l].alloc(n * 32) || !lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            PK_TRY(run_program(ctx, lag, pf.g, lk_f[l].p));
+            if (!lk_t[l].alloc(n * 32) || !lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
             PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
-            PK_TRY(lookup_multiplicities_enqueue(ctx, lk_f[l].fr(), lk_t[l].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l));
-            for (size_t i = 0; i < nblind; ++i) blind[l * nblind + i] = rng.next_fr();
-            ZK_HIP(ctx, hipMemcpyAsync((char*)lk_m[l].p + ((size_t)pk->u + 1) * 32, blind.data() + l * nblind, nblind * 32, hipMemcpyHostToDevice, ctx->stream));
+            lk_f[l].resize(lk.inputs.size());
+            std::vector<const Fr*> fptrs;
+            for (size_t a = 0; a < lk.inputs.size(); ++a) {
+                PB pf;
+                push_compressed(pf, lk.inputs[a]); pf.fold(C_ONE);
+                if (!lk_f[l][a].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                PK_TRY(run_program(ctx, lag, pf.g, lk_f[l][a].p));
+                fptrs.push_back(lk_f[l][a].fr());
+            }
+            PK_TRY(lookup_multiplicities_enqueue(ctx, fptrs.data(), fptrs.size(), lk_t[l].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l));
             mptrs[l] = lk_m[l].p;
         }
         std::vector<uint32_t> st(pk->L);
@@ -843,35 +958,40 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
     }
     trace.mark("permutation Z");
-    // ---- lookups, round 2: grand sums phi, again enqueued back to back with one closing check and one commit batch
+    // ---- lookups, round 2 (Prepared::commit_grand_sum): phi[0] = 0, phi[i+1] = phi[i] + sum_a 1/(f_a[i]+beta) - m[i]/(t[i]+beta),
+    // the last bf rows random; enqueued back to back with one closing check and one commit batch
     if (pk->L) {
-        // g[i] = 1/(f+beta) - m/(t+beta)  via one batch inversion of (f+beta) and (t+beta)
+        size_t max_inputs = 1;
+        for (const auto& lk : pk->lookups) max_inputs = std::max(max_inputs, lk.inputs.size());
         DevBuf inv, g, closing_d;
-        if (!inv.alloc(2 * n * 32) || !g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        if (!inv.alloc((max_inputs + 1) * n * 32) || !g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         std::vector<F4> blind((size_t)pk->L * pk->bf);
         std::vector<const void*> pptrs(pk->L);
         for (uint32_t l = 0; l < pk->L; ++l) {
             DevBuf phi;
             if (!phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            const size_t N = lk_f[l].size();
+            // inv = [t + beta | f_0 + beta | ... | f_{N-1} + beta], inverted in one batch
             Env e2 = lag;
-            // program over explicit buffers: use CT_LK_PHI slots 0/1 as scratch references for f and t
-            std::vector<DevBuf> ft(2);
-            ft[0] = std::move(lk_f[l]); ft[1] = std::move(lk_t[l]);
+            std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
+            ft[0] = std::move(lk_t[l]);
+            for (size_t a = 0; a < N; ++a) ft[1 + a] = std::move(lk_f[l][a]);
             e2.lk_phi = &ft;
-            PB a, b;
-            a.col(CT_LK_PHI, 0).addc(C_BETA).fold(C_ONE);
-            b.col(CT_LK_PHI, 1).addc(C_BETA).fold(C_ONE);
-            PK_TRY(run_program(ctx, e2, a.g, inv.p));
-            PK_TRY(run_program(ctx, e2, b.g, (char*)inv.p + n * 32));
-            PK_TRY(zk_fr_batch_invert(ctx, inv.p, 2 * n));
-            // g = inv_f - m * inv_t
-            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, (char*)inv.p + n * 32, g.p, n));
-            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, inv.p, g.p, g.p, n));
+            for (size_t a = 0; a <= N; ++a) {
+                PB pb;
+                pb.col(CT_LK_PHI, (uint32_t)a).addc(C_BETA).fold(C_ONE);
+                PK_TRY(run_program(ctx, e2, pb.g, (char*)inv.p + a * n * 32));
+            }
+            PK_TRY(zk_fr_batch_invert(ctx, inv.p, (N + 1) * n));
+            // g = sum_a inv_f_a - m * inv_t
+            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, inv.p, g.p, n));
+            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, (char*)inv.p + n * 32, g.p, g.p, n));
+            for (size_t a = 1; a < N; ++a) PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_ADD, g.p, (char*)inv.p + (1 + a) * n * 32, g.p, n));
             PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
             ZK_HIP(ctx, hipMemcpyAsync((char*)closing_d.p + (size_t)l * 32, (char*)phi.p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
             for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
             ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
-            lk_f[l].release(); lk_t[l].release(); ft.clear();                   // f, t are not needed again (the quotient recomputes them on its cosets)
+            ft.clear(); lk_f[l].clear();                                        // f, t are not needed again (the quotient recomputes them on its cosets)
             pptrs[l] = phi.p;
             lk_phi[l] = std::move(phi);
         }
@@ -928,18 +1048,57 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             q.op(Q_SUB).op(Q_MUL).fold(C_Y);
         }
     }
+    // lookup identities (plonk::evaluation, mv-lookup): with phi_a = f_a + beta and tau = t + beta,
+    //   l_active * ( tau * prod_a phi_a * (phi(wX) - phi(X))  -  prod_a phi_a * (tau * sum_a 1/phi_a - m) )
+    // An argument with several input tuples parks tau and the phi_a of a row in intermediates (slots
+    // above the ones the gate programs use) and forms sum_a prod_{b != a} phi_b from them.
+    uint32_t tmp_base = 0;
+    for (const Instr& in : q.g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
     for (uint32_t l = 0; l < pk->L; ++l) {
         const auto& lk = pk->lookups[l];
+        const uint32_t N = (uint32_t)lk.inputs.size();
         q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
         q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
-        // l_active * ( (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta)) )
         q.col(CT_SPECIAL, SP_LACTIVE);
-        q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
-        push_compressed(q, lk.inputs); q.addc(C_BETA).op(Q_MUL);
-        push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
+        if (N == 1) {
+            // (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta))
+            q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
+            push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
+            push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
+            push_compressed(q, lk.tables); q.addc(C_BETA);
+            q.col(CT_LK_M, l); push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
+            q.op(Q_SUB).op(Q_SUB).op(Q_MUL).fold(C_Y);
+            continue;
+        }
+        const uint32_t t_tau = tmp_base, t_phi = tmp_base + 1;          // reused by every multi-input lookup: a row's values are consumed right away
+        auto tmp = [&](uint32_t op, uint32_t slot) { q.g.push_back({op, slot, 0}); };
+        // prod = phi_0 * ... * phi_{N-1}, each factor parked on the way
+        for (uint32_t a = 0; a < N; ++a) {
+            push_compressed(q, lk.inputs[a]); q.addc(C_BETA);
+            tmp(Q_TEE_TMP, t_phi + a);
+            if (a) q.op(Q_MUL);
+        }
+        tmp(Q_TEE_TMP, t_phi + N);                                       // prod
+        // lhs = tau * prod * (phi(wX) - phi(X))
         push_compressed(q, lk.tables); q.addc(C_BETA);
-        q.col(CT_LK_M, l); push_compressed(q, lk.inputs); q.addc(C_BETA).op(Q_MUL);
-        q.op(Q_SUB).op(Q_SUB).op(Q_MUL).fold(C_Y);
+        tmp(Q_TEE_TMP, t_tau);
+        q.op(Q_MUL);
+        q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB).op(Q_MUL);
+        // rhs = tau * sum_a prod_{b != a} phi_b - prod * m
+        for (uint32_t a = 0; a < N; ++a) {
+            bool first = true;
+            for (uint32_t b2 = 0; b2 < N; ++b2) {
+                if (b2 == a) continue;
+                tmp(Q_PUSH_TMP, t_phi + b2);
+                if (!first) q.op(Q_MUL);
+                first = false;
+            }
+            if (a) q.op(Q_ADD);
+        }
+        tmp(Q_PUSH_TMP, t_tau); q.op(Q_MUL);
+        tmp(Q_PUSH_TMP, t_phi + N); q.col(CT_LK_M, l).op(Q_MUL);
+        q.op(Q_SUB);
+        q.op(Q_SUB).op(Q_MUL).fold(C_Y);
     }
     // The extended domain is evaluated one coset at a time (g_r = zeta * omega_ext^r, r < 2^(ext_k-k)):
     // every column the program reads is taken to that coset with a size-n transform of its
@@ -988,18 +1147,22 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
           if (!sharded || r_ % pr->world == pr->rank) {
             for (size_t i = 0; i < refs.size(); ++i) {
                 void* dst = part_buf[i].p;
-                if (cache_on && of_key(refs[i])) {
-                    DevBuf& slot = pk->part_cache[r_][refs[i]];
-                    part_of[refs[i]] = slot.p;
-                    if (slot.p) continue;                 // computed by an earlier proof
-                    if (!slot.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-                    dst = slot.p;
+                DevBuf fresh;                             // a cache slot being filled: published only once it holds the coset
+                const bool cached = cache_on && of_key(refs[i]);
+                if (cached) {
+                    auto it = pk->part_cache[r_].find(refs[i]);
+                    if (it != pk->part_cache[r_].end()) { part_of[refs[i]] = it->second.p; continue; }   // computed by an earlier proof
+                    if (!fresh.alloc_unpooled(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");   // lives as long as the key, not the session's pool
+                    dst = fresh.p;
                 }
                 part_of[refs[i]] = dst;
-                if (refs[i] == colref(CT_SPECIAL, SP_X)) { PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n)); continue; }   // X on the coset: g * omega^i
-                const Fr* cf = coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
-                if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
-                PK_TRY(zk_coeff_to_coset(ctx, cf, k, &g, dst));
+                if (refs[i] == colref(CT_SPECIAL, SP_X)) PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n));   // X on the coset: g * omega^i
+                else {
+                    const Fr* cf = coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
+                    if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
+                    PK_TRY(zk_coeff_to_coset(ctx, cf, k, &g, dst));
+                }
+                if (cached) pk->part_cache[r_][refs[i]] = std::move(fresh);
             }
             trace.mark("  quotient: cosets of the columns");
             PK_TRY(run_program(ctx, part, q.g, hpart.p));
@@ -1036,43 +1199,53 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
 
     trace.mark("h commits");
     const F4 x = tr.squeeze();
-    // ---- evaluations
+    // ---- evaluations, written in halo2's order: advice queries, fixed queries, the random polynomial,
+    // the permutation's sigma polynomials, per permutation set Z(x), Z(wx) (and Z(w^last x) for all but
+    // the last set), per lookup phi(x), phi(wx), m(x)
     const F4 w = [&] { Fr t = fr_root_of_unity(k); F4 r; memcpy(r.l, &t, 32); return r; }();
     const F4 w_inv = host::fr_inv(w);
     auto rotate = [&](int32_t rot) { F4 p = x; const F4 b = rot >= 0 ? w : w_inv; for (int32_t i = 0; i < (rot >= 0 ? rot : -rot); ++i) p = host::fr_mul(p, b); return p; };
+    const int64_t nn = (int64_t)n;
+    auto norm_rot = [&](int32_t rot) { return (int32_t)((((int64_t)rot % nn) + nn) % nn); };    // rotations are points: x w^rot, rot mod n
     struct Open { const Fr* poly; int32_t rot; F4 eval; };
-    std::vector<Open> opens;
+    std::vector<Open> evals;
     auto eval_at = [&](const Fr* coeffs, int32_t rot, F4* out) -> int { const F4 pt = rotate(rot); return zk_poly_eval(ctx, coeffs, n, &pt, out); };
-    // every (polynomial, rotation) the proof opens, in transcript order; evaluated in one batch per point
-    for (const Query& qy : pk->adv_q) opens.push_back({adv_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
-    for (const Query& qy : pk->fix_q) opens.push_back({pk->fixed_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
-    opens.push_back({random_coeff.fr(), 0, host::fr_zero()});
-    for (uint32_t j = 0; j < pk->P; ++j) opens.push_back({pk->sigma_coeff[j].fr(), 0, host::fr_zero()});
+    for (const Query& qy : pk->adv_q) evals.push_back({adv_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
+    const size_t e_fix = evals.size();
+    for (const Query& qy : pk->fix_q) evals.push_back({pk->fixed_coeff[qy.idx].fr(), qy.rot, host::fr_zero()});
+    const size_t e_random = evals.size();
+    evals.push_back({random_coeff.fr(), 0, host::fr_zero()});
+    const size_t e_sigma = evals.size();
+    for (uint32_t j = 0; j < pk->P; ++j) evals.push_back({pk->sigma_coeff[j].fr(), 0, host::fr_zero()});
+    std::vector<size_t> e_pz(pk->C);
     for (uint32_t c = 0; c < pk->C; ++c) {
-        for (int32_t rot : {0, 1}) opens.push_back({pz_coeff[c].fr(), rot, host::fr_zero()});
-        if (c + 1 < pk->C) opens.push_back({pz_coeff[c].fr(), rot_last, host::fr_zero()});
+        e_pz[c] = evals.size();
+        for (int32_t rot : {0, 1}) evals.push_back({pz_coeff[c].fr(), rot, host::fr_zero()});
+        if (c + 1 < pk->C) evals.push_back({pz_coeff[c].fr(), rot_last, host::fr_zero()});
     }
+    const size_t e_lk = evals.size();
     for (uint32_t l = 0; l < pk->L; ++l) {
-        for (int32_t rot : {0, 1}) opens.push_back({phi_coeff[l].fr(), rot, host::fr_zero()});
-        opens.push_back({m_coeff[l].fr(), 0, host::fr_zero()});
+        for (int32_t rot : {0, 1}) evals.push_back({phi_coeff[l].fr(), rot, host::fr_zero()});
+        evals.push_back({m_coeff[l].fr(), 0, host::fr_zero()});
     }
-    {
+    {   // one batched multi-polynomial reduction per distinct point
         std::vector<int32_t> distinct;
-        for (const Open& o : opens) if (std::find(distinct.begin(), distinct.end(), o.rot) == distinct.end()) distinct.push_back(o.rot);
+        for (const Open& o : evals) if (std::find(distinct.begin(), distinct.end(), norm_rot(o.rot)) == distinct.end()) distinct.push_back(norm_rot(o.rot));
         for (int32_t rot : distinct) {
             std::vector<const void*> ptrs;
             std::vector<size_t> where;
-            for (size_t i = 0; i < opens.size(); ++i) if (opens[i].rot == rot) { ptrs.push_back(opens[i].poly); where.push_back(i); }
+            for (size_t i = 0; i < evals.size(); ++i) if (norm_rot(evals[i].rot) == rot) { ptrs.push_back(evals[i].poly); where.push_back(i); }
             std::vector<F4> vals(ptrs.size());
-            const F4 pt = rotate(rot);
+            const F4 pt = rotate(evals[where[0]].rot);
             PK_TRY(zk_poly_eval_batch(ctx, ptrs.data(), ptrs.size(), n, &pt, vals.data()));
-            for (size_t j = 0; j < where.size(); ++j) opens[where[j]].eval = vals[j];
+            for (size_t j = 0; j < where.size(); ++j) evals[where[j]].eval = vals[j];
         }
-        for (const Open& o : opens) tr.write_scalar(o.eval);
+        for (const Open& o : evals) tr.write_scalar(o.eval);
     }
     trace.mark("evaluations");
     // h(X) = sum_i x^(n i) h_i(X): opened at x, the verifier derives its expected value itself
     DevBuf hcomb;
+    F4 h_eval;
     {
         if (!hcomb.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         F4 xn = x;
@@ -1081,36 +1254,58 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         std::vector<const void*> cols;
         for (uint32_t i = pieces; i-- > 0;) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(h.fr() + (size_t)i * n); }
         PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &xn, 1, k, k, 0, hcomb.p));
-        F4 e; PK_TRY(eval_at(hcomb.fr(), 0, &e));
-        opens.push_back({hcomb.fr(), 0, e});   // not written: the verifier recomputes it
+        PK_TRY(eval_at(hcomb.fr(), 0, &h_eval));
     }
     trace.mark("h recombination");
-    std::vector<int32_t> rots;
-    for (const Open& o : opens) if (std::find(rots.begin(), rots.end(), o.rot) == rots.end()) rots.push_back(o.rot);
+    // ---- the multi-open's queries in halo2's order (plonk::prover::create_proof): advice, permutation
+    // products (x and wx per set, then w^last x for all but the last set in REVERSE set order), lookups,
+    // fixed, permutation sigma, then h and the random polynomial
+    std::vector<Open> queries;
+    for (size_t i = 0; i < e_fix; ++i) queries.push_back(evals[i]);
+    for (uint32_t c = 0; c < pk->C; ++c) { queries.push_back(evals[e_pz[c]]); queries.push_back(evals[e_pz[c] + 1]); }
+    for (uint32_t c = pk->C > 1 ? pk->C - 1 : 0; c-- > 0;) queries.push_back(evals[e_pz[c] + 2]);
+    for (size_t i = e_lk; i < evals.size(); ++i) queries.push_back(evals[i]);
+    for (size_t i = e_fix; i < e_random; ++i) queries.push_back(evals[i]);
+    for (size_t i = e_sigma; i < e_sigma + pk->P; ++i) queries.push_back(evals[i]);
+    queries.push_back({hcomb.fr(), 0, h_eval});
+    queries.push_back(evals[e_random]);
+    for (Open& o : queries) o.rot = norm_rot(o.rot);
+    auto point_of = [&](int32_t nrot) { return rotate(nrot > nn / 2 ? (int32_t)(nrot - nn) : nrot); };
+    // sum_j ch^j * polys[j] on the device: Horner from the last polynomial down (FOLD multiplies the accumulator by ch)
+    auto lincomb = [&](const std::vector<const void*>& polys, const F4& ch, void* d_out) -> int {
+        std::vector<uint32_t> words;
+        std::vector<const void*> cols;
+        for (size_t j = polys.size(); j-- > 0;) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(polys[j]); }
+        return zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &ch, 1, k, k, 0, d_out);
+    };
     DevBuf batch, wit;
     if (!batch.alloc(n * 32) || !wit.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
     if (pr->multiopen == ZK_MULTIOPEN_SHPLONK) {
-        // ---- SHPLONK / BDFG21 (poly::kzg::multiopen::ProverSHPLONK): what the reference's
-        // call sites instantiate.  Two commitments whatever the number of polynomials and points.
-        const F4 y = tr.squeeze(), v = tr.squeeze();
-        // distinct polynomials with their (rotation, eval) lists, grouped into rotation sets
+        // ---- SHPLONK / BDFG21 (poly::kzg::multiopen::shplonk::ProverSHPLONK::create_proof): what
+        // the reference's call sites instantiate.  Two commitments whatever the number of polynomials and points.
+        const F4 y = tr.squeeze();
+        // construct_intermediate_sets: polynomials in order of first appearance with their point sets;
+        // rotation sets in order of first appearance, each listing its polynomials
         struct PolyQ { const Fr* poly; std::vector<int32_t> rots; std::vector<F4> evals; };
         std::vector<PolyQ> polys;
-        for (const Open& o : opens) {
+        for (const Open& o : queries) {
             auto it = std::find_if(polys.begin(), polys.end(), [&](const PolyQ& p) { return p.poly == o.poly; });
             if (it == polys.end()) { polys.push_back({o.poly, {}, {}}); it = polys.end() - 1; }
-            it->rots.push_back(o.rot); it->evals.push_back(o.eval);
+            if (std::find(it->rots.begin(), it->rots.end(), o.rot) == it->rots.end()) { it->rots.push_back(o.rot); it->evals.push_back(o.eval); }
         }
         struct Set { std::vector<int32_t> rots; std::vector<size_t> members; };
         std::vector<Set> sets;
+        std::vector<int32_t> super;                  // every point that is opened somewhere
         for (size_t pi = 0; pi < polys.size(); ++pi) {
             std::vector<int32_t> key = polys[pi].rots;
             std::sort(key.begin(), key.end());
             auto it = std::find_if(sets.begin(), sets.end(), [&](const Set& s_) { return s_.rots == key; });
             if (it == sets.end()) { sets.push_back({key, {}}); it = sets.end() - 1; }
             it->members.push_back(pi);
+            for (int32_t r_ : key) if (std::find(super.begin(), super.end(), r_) == super.end()) super.push_back(r_);
         }
-        // r_j(X): interpolation of poly j's evaluations over its set's points (degree < |S|), host side
+        const F4 v = tr.squeeze();
+        // r_ij(X): interpolation of polynomial j's evaluations over its set's points (degree < |S|), host side
         auto interpolate = [&](const std::vector<F4>& xs, const std::vector<F4>& ys) {
             const size_t m = xs.size();
             std::vector<F4> out(m, host::fr_zero());
@@ -1131,32 +1326,32 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         };
         auto eval_small = [&](const std::vector<F4>& c, const F4& at) { F4 acc = host::fr_zero(); for (size_t t = c.size(); t-- > 0;) acc = host::fr_add(host::fr_mul(acc, at), c[t]); return acc; };
         std::vector<DevBuf> qfull(sets.size()), hset(sets.size());
-        std::vector<std::vector<F4>> Rset(sets.size());
+        std::vector<std::vector<F4>> Rset(sets.size());       // R_i(X) = sum_j y^j r_ij(X)
         DevBuf tmp;
         if (!tmp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         for (size_t si = 0; si < sets.size(); ++si) {
             const Set& st = sets[si];
             std::vector<F4> zs;
-            for (int32_t r_ : st.rots) zs.push_back(rotate(r_));
-            // Qfull_i = Horner over the set's polynomials with y;  R_i = same combination of the r_j
-            std::vector<uint32_t> words;
-            std::vector<const void*> cols;
+            for (int32_t r_ : st.rots) zs.push_back(point_of(r_));
+            // N_i(X) = sum_j y^j (P_ij(X) - r_ij(X)):  Qfull_i = sum_j y^j P_ij on the device, R_i on the host
+            std::vector<const void*> members;
             std::vector<F4> R(st.rots.size(), host::fr_zero());
+            F4 ypow = host::fr_one();
             for (size_t pi : st.members) {
-                words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u});
-                cols.push_back(polys[pi].poly);
+                members.push_back(polys[pi].poly);
                 std::vector<F4> ys(st.rots.size());
                 for (size_t a = 0; a < st.rots.size(); ++a) {
                     const size_t where = std::find(polys[pi].rots.begin(), polys[pi].rots.end(), st.rots[a]) - polys[pi].rots.begin();
                     ys[a] = polys[pi].evals[where];
                 }
                 const std::vector<F4> rj = interpolate(zs, ys);
-                for (size_t t = 0; t < R.size(); ++t) R[t] = host::fr_add(host::fr_mul(R[t], y), rj[t]);
+                for (size_t t = 0; t < R.size(); ++t) R[t] = host::fr_add(R[t], host::fr_mul(ypow, rj[t]));
+                ypow = host::fr_mul(ypow, y);
             }
             Rset[si] = R;
             if (!qfull[si].alloc(n * 32) || !hset[si].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &y, 1, k, k, 0, qfull[si].p));
-            // h_i = (Qfull_i - R_i) / prod (X - z): subtract R_i from the low coefficients, divide point by point
+            PK_TRY(lincomb(members, y, qfull[si].p));
+            // Q_i = N_i / prod (X - z): subtract R_i from the low coefficients, divide point by point
             PK_TRY(zk_d2d(ctx, hset[si].p, qfull[si].p, n * 32));
             std::vector<F4> low(R.size());
             PK_TRY(zk_d2h(ctx, low.data(), hset[si].p, R.size() * 32));
@@ -1170,29 +1365,30 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 ZK_HIP(ctx, hipMemsetAsync((char*)hset[si].p + len * 32, 0, (n - len) * 32, ctx->stream));
             }
         }
-        // h = Horner over the sets with v; commit
+        // h = sum_i v^i Q_i; commit
         {
-            std::vector<uint32_t> words;
-            std::vector<const void*> cols;
-            for (size_t si = 0; si < sets.size(); ++si) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(hset[si].p); }
-            PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &v, 1, k, k, 0, batch.p));
+            std::vector<const void*> qs;
+            for (size_t si = 0; si < sets.size(); ++si) qs.push_back(hset[si].p);
+            PK_TRY(lincomb(qs, v, batch.p));
             G1Affine com;
             PK_TRY(commit_coeff(ctx, srs, batch.fr(), n, &com));
             tr.write_point(com);
         }
         const F4 u = tr.squeeze();
-        // L(X) = sum_i c_i Z_{T\\S_i}(u) (Qfull_i(X) - R_i(u)) - Z_T(u) h(X),  c_i = v^(s-1-i);   pi = L / (X - u)
+        // L(X) = sum_i v^i Z_{T \ S_i}(u) (Qfull_i(X) - R_i(u)) - Z_T(u) h(X);  the proof's second point commits to
+        // L(X) / (X - u), normalised by 1 / Z_{T \ S_0}(u) (the verifier scales the first set's term to one)
         std::vector<F4> coef(sets.size() + 1);
-        F4 zT = host::fr_one(), constant = host::fr_zero(), cpow = host::fr_one();
-        for (int32_t r_ : rots) zT = host::fr_mul(zT, host::fr_sub(u, rotate(r_)));
-        for (size_t si = sets.size(); si-- > 0;) {
-            F4 zt = host::fr_one();
-            for (int32_t r_ : rots) if (std::find(sets[si].rots.begin(), sets[si].rots.end(), r_) == sets[si].rots.end()) zt = host::fr_mul(zt, host::fr_sub(u, rotate(r_)));
-            coef[si] = host::fr_mul(cpow, zt);
+        F4 zT = host::fr_one(), constant = host::fr_zero(), vpow = host::fr_one(), z0_inv = host::fr_one();
+        for (int32_t r_ : super) zT = host::fr_mul(zT, host::fr_sub(u, point_of(r_)));
+        for (size_t si = 0; si < sets.size(); ++si) {
+            F4 zdiff = host::fr_one();
+            for (int32_t r_ : super) if (std::find(sets[si].rots.begin(), sets[si].rots.end(), r_) == sets[si].rots.end()) zdiff = host::fr_mul(zdiff, host::fr_sub(u, point_of(r_)));
+            if (si == 0) z0_inv = host::fr_inv(zdiff);
+            coef[si] = host::fr_mul(host::fr_mul(vpow, zdiff), z0_inv);
             constant = host::fr_add(constant, host::fr_mul(coef[si], eval_small(Rset[si], u)));
-            cpow = host::fr_mul(cpow, v);
+            vpow = host::fr_mul(vpow, v);
         }
-        coef[sets.size()] = zT;
+        coef[sets.size()] = host::fr_mul(zT, z0_inv);
         {
             std::vector<uint32_t> words;
             std::vector<const void*> cols;
@@ -1217,20 +1413,22 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         PK_TRY(zk_ctx_sync(ctx));
         trace.mark("multiopen (shplonk)");
-        if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", tr.err);
+        if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "transcript failed with status %d (external callback, or the identity point in a Poseidon / EVM transcript)", tr.err);
         *proof_len = tr.proof.size();
         if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
         memcpy(h_proof, tr.proof.data(), tr.proof.size());
         return ZK_OK;
     }
-    // ---- GWC multi-open: one witness per distinct point, in order of first appearance
+    // ---- GWC multi-open (poly::kzg::multiopen::gwc::ProverGWC::create_proof): one witness per distinct
+    // point in order of first appearance, the point's polynomials combined with ascending powers of v
     const F4 v = tr.squeeze();
+    std::vector<int32_t> rots;
+    for (const Open& o : queries) if (std::find(rots.begin(), rots.end(), o.rot) == rots.end()) rots.push_back(o.rot);
     for (int32_t rot : rots) {
-        std::vector<uint32_t> words;
-        std::vector<const void*> cols;
-        for (const Open& o : opens) if (o.rot == rot) { words.insert(words.end(), {Q_PUSH_COL, (uint32_t)cols.size(), 0u, Q_FOLD, 0u, 0u}); cols.push_back(o.poly); }
-        PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), cols.data(), (uint32_t)cols.size(), &v, 1, k, k, 0, batch.p));
-        const F4 z = rotate(rot);
+        std::vector<const void*> members;
+        for (const Open& o : queries) if (o.rot == rot) members.push_back(o.poly);
+        PK_TRY(lincomb(members, v, batch.p));
+        const F4 z = point_of(rot);
         PK_TRY(zk_kate_division(ctx, batch.p, n, &z, wit.p));
         G1Affine com;
         PK_TRY(commit_coeff(ctx, srs, wit.fr(), n - 1, &com));
@@ -1238,10 +1436,70 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     }
     PK_TRY(zk_ctx_sync(ctx));
     trace.mark("multiopen");
-    if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "external transcript callback failed with status %d", tr.err);
+    if (tr.err) return ctx->fail(ZK_ERR_INVALID_ARG, "transcript failed with status %d (external callback, or the identity point in a Poseidon / EVM transcript)", tr.err);
     *proof_len = tr.proof.size();
     if (tr.proof.size() > proof_cap) return ctx->fail(ZK_ERR_INVALID_ARG, "proof buffer too small: need %zu bytes", tr.proof.size());
     memcpy(h_proof, tr.proof.data(), tr.proof.size());
+    return ZK_OK;
+}
+
+// ---- host-only transcript objects and hashes (no context, no device) -----------------------------
+struct zk_transcript { host::Transcript tr; };
+zk_transcript* zk_transcript_new(int kind) {
+    if (kind != ZK_TRANSCRIPT_BLAKE2B && kind != ZK_TRANSCRIPT_POSEIDON && kind != ZK_TRANSCRIPT_EVM) return nullptr;
+    zk_transcript* t = new (std::nothrow) zk_transcript();
+    if (t) t->tr.reset(kind);
+    return t;
+}
+void zk_transcript_free(zk_transcript* t) { delete t; }
+static int transcript_status(zk_transcript* t) { const int e = t->tr.err; t->tr.err = 0; return e; }
+int zk_transcript_common_point(zk_transcript* t, const void* affine64) {
+    if (!t || !affine64) return ZK_ERR_INVALID_ARG;
+    G1Affine p; memcpy((void*)&p, affine64, 64);
+    t->tr.common_point(p);
+    return transcript_status(t);
+}
+int zk_transcript_common_scalar(zk_transcript* t, const void* fr32) {
+    if (!t || !fr32) return ZK_ERR_INVALID_ARG;
+    F4 s_; memcpy(s_.l, fr32, 32);
+    t->tr.common_scalar(s_);
+    return transcript_status(t);
+}
+int zk_transcript_write_point(zk_transcript* t, const void* affine64) {
+    if (!t || !affine64) return ZK_ERR_INVALID_ARG;
+    G1Affine p; memcpy((void*)&p, affine64, 64);
+    if (t->tr.kind != ZK_TRANSCRIPT_BLAKE2B && p.is_identity()) return ZK_ERR_INVALID_ARG;
+    t->tr.write_point(p);
+    return transcript_status(t);
+}
+int zk_transcript_write_scalar(zk_transcript* t, const void* fr32) {
+    if (!t || !fr32) return ZK_ERR_INVALID_ARG;
+    F4 s_; memcpy(s_.l, fr32, 32);
+    t->tr.write_scalar(s_);
+    return transcript_status(t);
+}
+int zk_transcript_squeeze(zk_transcript* t, void* fr32_out) {
+    if (!t || !fr32_out) return ZK_ERR_INVALID_ARG;
+    const F4 c = t->tr.squeeze();
+    memcpy(fr32_out, c.l, 32);
+    return transcript_status(t);
+}
+size_t zk_transcript_proof(const zk_transcript* t, const void** data) {
+    if (!t) return 0;
+    if (data) *data = t->tr.proof.data();
+    return t->tr.proof.size();
+}
+int zk_host_keccak256(const void* data, size_t len, void* out32) {
+    if ((!data && len) || !out32) return ZK_ERR_INVALID_ARG;
+    host::keccak256((const uint8_t*)data, len, (uint8_t*)out32);
+    return ZK_OK;
+}
+int zk_host_poseidon_permute(void* state5_fr32) {
+    if (!state5_fr32) return ZK_ERR_INVALID_ARG;
+    F4 st[host::PoseidonSpec::T];
+    memcpy(st, state5_fr32, sizeof st);
+    host::PoseidonSpec::get().permute(st);
+    memcpy(state5_fr32, st, sizeof st);
     return ZK_OK;
 }
 

@@ -24,7 +24,7 @@ FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)
 FIXED, ADVICE, INSTANCE = 0, 1, 2
 Q_PUSH_COL, Q_PUSH_CONST, Q_ADD, Q_SUB, Q_MUL, Q_NEG = 1, 2, 3, 4, 5, 6
 Q_TEE_TMP, Q_PUSH_TMP = 12, 13          # intermediates shared between gates (csrc/quotient.hip)
-BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 2
+BLOB_MAGIC, BLOB_VERSION = 0x4B505A4B, 3
 C_CHAL0 = 0xFFFD0000   # abstract constant reference of user challenge i (csrc/prover.hip)
 
 
@@ -98,8 +98,28 @@ def colref(ctype: int, index: int) -> int:
     return (ctype << 24) | index
 
 
+class Lookup:
+    """halo2 `mv_lookup::Argument`: one table tuple and one or more input tuples looked up in it
+    (`inputs_expressions: Vec<Vec<Expression>>`; `chunk_lookups()` merges the inputs that share a
+    table and splits them again so that the argument's degree stays within the circuit's)."""
+
+    def __init__(self, name: str, table: Sequence[Expr], inputs: Sequence[Sequence[Expr]]):
+        self.name, self.table, self.inputs = name, list(table), [list(i) for i in inputs]
+        assert all(len(i) == len(self.table) for i in self.inputs)
+
+    def required_degree(self) -> int:
+        """halo2 mv_lookup::Argument::required_degree: the grand-sum identity
+        l_active * (tau * prod phi_i * (phi(wX) - phi(X)) - ...) has degree table + sum(inputs) + 2."""
+        table_degree = max(e.degree() for e in self.table)
+        inputs_degree = sum(max(e.degree() for e in i) for i in self.inputs)
+        return max(3 + len(self.inputs), table_degree + inputs_degree + 2)
+
+
 class Circuit:
-    """Shape + fixed assignment + copy constraints of one PLONKish circuit."""
+    """Shape + fixed assignment + copy constraints of one PLONKish circuit (mirror of halo2's
+    `ConstraintSystem` + keygen `Assembly`).  Column queries are registered in call order, as
+    halo2's `query_advice / query_fixed / enable_equality` do: that order is the order of the
+    evaluations in the proof, so it is part of the exported key blob."""
 
     def __init__(self, k: int, num_fixed: int, num_advice: int, num_instance: int, blinding_factors: int = 5):
         self.k, self.n = k, 1 << k
@@ -107,7 +127,9 @@ class Circuit:
         self.bf = blinding_factors
         self.u = self.n - self.bf - 1          # rows [0, u) are usable
         self.gates: List[Expr] = []
-        self.lookups: List[Tuple[List[Expr], List[Expr]]] = []
+        self.lookups: List[Lookup] = []
+        self.lookups_map: Dict[str, Lookup] = {}      # halo2 `lookups_map`: table identifier -> tracker, until chunk_lookups()
+        self.minimum_degree = 1
         self.perm_cols: List[Tuple[int, int]] = []
         self.copies: List[Tuple[Tuple[int, int, int], Tuple[int, int, int]]] = []
         self.fixed = [[0] * self.n for _ in range(num_fixed)]
@@ -115,17 +137,81 @@ class Circuit:
         self._const_index: Dict[int, int] = {}
         self.advice_phase = [0] * num_advice      # halo2 FirstPhase = 0, SecondPhase = 1, ...
         self.challenge_phase: List[int] = []      # challenge i is squeezed after this phase
+        self.advice_queries: List[Tuple[int, int]] = []      # (column, rotation), registration order
+        self.fixed_queries: List[Tuple[int, int]] = []
+        self.instance_queries: List[Tuple[int, int]] = []
 
     # -- columns
     def fixed_col(self, i, rot=0): return Col(FIXED, i, rot)
     def advice_col(self, i, rot=0): return Col(ADVICE, i, rot)
     def instance_col(self, i, rot=0): return Col(INSTANCE, i, rot)
 
+    def _register(self, e: Expr):
+        """halo2 query_*_index: first use of a (column, rotation) pair appends it to the query list"""
+        if isinstance(e, Col):
+            lst = {FIXED: self.fixed_queries, ADVICE: self.advice_queries, INSTANCE: self.instance_queries}[e.ctype]
+            if (e.index, e.rotation) not in lst:
+                lst.append((e.index, e.rotation))
+        elif isinstance(e, Neg):
+            self._register(e.a)
+        elif isinstance(e, Bin):
+            self._register(e.a)
+            self._register(e.b)
+
     # -- constraints
-    def add_gate(self, e: Expr): self.gates.append(e)
-    def add_lookup(self, inputs: Sequence[Expr], tables: Sequence[Expr]):
+    def add_gate(self, e: Expr):
+        self._register(e)
+        self.gates.append(e)
+
+    def add_lookup(self, inputs: Sequence[Expr], tables: Sequence[Expr], name: str = "lookup"):
+        """one lookup argument with one input tuple (what `lookup_any` yields when nothing is merged)"""
         assert len(inputs) == len(tables)
-        self.lookups.append((list(inputs), list(tables)))
+        for e in list(inputs) + list(tables):
+            self._register(e)
+        self.lookups.append(Lookup(name, tables, [inputs]))
+
+    def lookup_any(self, name: str, inputs: Sequence[Expr], tables: Sequence[Expr]):
+        """halo2 `ConstraintSystem::lookup_any` of the mv-lookup fork: lookups into the same table
+        expressions are collected under one tracker; `chunk_lookups()` turns the trackers into
+        arguments [REF zkevm-circuits/src/evm_circuit/execution.rs:978-1014]."""
+        assert len(inputs) == len(tables)
+        for e in list(inputs) + list(tables):
+            self._register(e)
+        ident = repr([self.compile(t) for t in tables])
+        if ident in self.lookups_map:
+            self.lookups_map[ident].inputs.append(list(inputs))
+        else:
+            self.lookups_map[ident] = Lookup(name, tables, [inputs])
+
+    def chunk_lookups(self):
+        """halo2 `ConstraintSystem::chunk_lookups` [REF zkevm-circuits/src/super_circuit/test.rs:59],
+        [REF aggregator/src/aggregation/config.rs:223]: fix the circuit degree at (next power of two of
+        the largest gate / single-lookup degree - 1) + 1, then greedily pack the inputs of every table into
+        as few arguments as that degree allows."""
+        if not self.lookups_map:
+            return self
+        max_gate_degree = max([g.degree() for g in self.gates] + [0])
+        max_single = 0
+        for v in self.lookups_map.values():
+            base = max(3, max(e.degree() for e in v.table) + 2)
+            max_single = max(max_single, base + max(max(e.degree() for e in i) for i in v.inputs))
+        required = max(max_gate_degree, max_single)
+        required = 1 << max(required - 2, 0).bit_length()            # (required - 1).next_power_of_two()
+        self.minimum_degree = max(self.minimum_degree, required + 1)
+        for key in sorted(self.lookups_map):
+            v = self.lookups_map[key]
+            args = [Lookup(v.name, v.table, [])]
+            for inp in v.inputs:
+                cur = max(e.degree() for e in inp)
+                for a in args:
+                    if a.required_degree() + cur <= self.minimum_degree:
+                        a.inputs.append(list(inp))
+                        break
+                else:
+                    args.append(Lookup(v.name, v.table, [inp]))
+            self.lookups += [a for a in args if a.inputs]
+        self.lookups_map = {}
+        return self
 
     def challenge_usable_after(self, phase: int) -> "Challenge":
         self.challenge_phase.append(phase)
@@ -137,6 +223,7 @@ class Circuit:
     def enable_equality(self, ctype: int, index: int):
         if (ctype, index) not in self.perm_cols:
             self.perm_cols.append((ctype, index))
+            self._register(Col(ctype, index, 0))       # halo2: enable_equality queries the column at Rotation::cur()
 
     def copy(self, a: Tuple[int, int, int], b: Tuple[int, int, int]):
         """(ctype, index, row) == (ctype, index, row)"""
@@ -147,10 +234,15 @@ class Circuit:
 
     # -- derived shape
     def degree(self) -> int:
-        d = 4 if self.lookups else 3
+        """halo2 `ConstraintSystem::degree`: permutation argument 3, every lookup's required
+        degree, every gate polynomial, and the minimum degree set by chunk_lookups()."""
+        assert not self.lookups_map, "call chunk_lookups() before the circuit is used"
+        d = 3
+        for lk in self.lookups:
+            d = max(d, lk.required_degree())
         for g in self.gates:
             d = max(d, g.degree())
-        return max(d, 4)
+        return max(d, self.minimum_degree)
 
     def extended_k(self) -> int:
         ek = self.k
@@ -286,27 +378,39 @@ class Circuit:
         dp = [pow(FR_DELTA, j, R_MOD) for j in range(P)]
         return [[dp[mapping[j][i][0]] * wp[mapping[j][i][1]] % R_MOD for i in range(n)] for j in range(P)]
 
-    def blob(self, cse: bool = False) -> bytes:
-        """Serialise for zk_pk_create (layout documented in csrc/prover.hip).  cse: share
-        sub-expressions between gates through the evaluator's intermediates (same proof bytes)."""
+    def cs_blob(self, cse: bool = False) -> bytes:
+        """The constraint-system part of the key blob (everything but the column data): what the
+        default `vk.transcript_repr` of zk_pk_create hashes together with the key's commitments."""
         gates = self.compile_gates_cse() if cse else [self.compile(g) for g in self.gates]
-        lookups = [([self.compile(e) for e in ins], [self.compile(e) for e in tabs]) for ins, tabs in self.lookups]
-        sig = self.sigma_columns()
+        lookups = [([self.compile(e) for e in lk.table], [[self.compile(e) for e in i] for i in lk.inputs]) for lk in self.lookups]
 
         def prog(p):
             return struct.pack("<I", len(p)) + b"".join(struct.pack("<III", *ins) for ins in p)
+
+        def queries(q):
+            return struct.pack("<I", len(q)) + b"".join(struct.pack("<Ii", c, r) for c, r in q)
 
         out = [struct.pack("<12I", BLOB_MAGIC, BLOB_VERSION, self.k, self.bf, self.degree(), self.F, self.A, self.I,
                            len(self.perm_cols), len(self.lookups), len(gates), len(self.consts))]
         out.append(struct.pack("<I", len(self.challenge_phase)))
         out += [struct.pack("<I", p) for p in self.advice_phase]
         out += [struct.pack("<I", p) for p in self.challenge_phase]
+        out += [queries(self.advice_queries), queries(self.fixed_queries), queries(self.instance_queries)]
         out += [struct.pack("<II", t, i) for t, i in self.perm_cols]
         out += [fr_mont_bytes(c) for c in self.consts]
         out += [prog(g) for g in gates]
-        for ins, tabs in lookups:
-            out.append(struct.pack("<I", len(ins)))
-            out += [prog(p) for p in ins] + [prog(p) for p in tabs]
+        for tabs, inputs in lookups:
+            out.append(struct.pack("<II", len(tabs), len(inputs)))
+            out += [prog(p) for p in tabs]
+            for ins in inputs:
+                out += [prog(p) for p in ins]
+        return b"".join(out)
+
+    def blob(self, cse: bool = False) -> bytes:
+        """Serialise for zk_pk_create (layout documented in INTEGRATION.md).  cse: share
+        sub-expressions between gates through the evaluator's intermediates (same proof bytes)."""
+        sig = self.sigma_columns()
+        out = [self.cs_blob(cse)]
         out += [column_to_mont(col).tobytes() for col in self.fixed]
         out += [column_to_mont(col).tobytes() for col in sig]
         return b"".join(out)
