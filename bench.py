@@ -3,20 +3,29 @@
 
 A "step" is one pass of the hot path over one column: KZG-commit a 2^20-row column
 (`commit_lagrange` = one 2^20 MSM over g_lagrange) and transform it (`lagrange_to_coeff` = one 2^20
-NTT).  Inputs (column, SRS) are resident in HBM before the timed region starts.
+NTT).  Inputs are resident in HBM before the timed region starts.  The steps walk a ROTATING set of
+16 distinct columns to commit and 16 distinct columns to transform (1 GiB, beyond the 256 MiB
+Infinity Cache), so no step finds its input in a cache the previous step filled.
 
-Multi-GPU: the prover shards by column -- rank r commits/transforms its own column,
-no data-path collective; the only exchange is the all-gather of the 64-byte commitments that a
-transcript round needs, done here once per commitment batch with RCCL
-(`torch.distributed.all_gather_into_tensor`), as the prover does per phase.  Weak
-scaling: per-GPU work is fixed.
+`python bench.py --gpus N` launches itself as N ranks (torch.distributed.run, one rank per GPU,
+backend nccl = RCCL) when it was not started under a launcher already.  Multi-GPU: the
+prover shards by column -- rank r commits / transforms its own columns, no data-path collective;
+the only exchange is the all-gather of the 64-byte commitments that a transcript round needs, done
+once per commitment batch (`all_gather_into_tensor`), as the prover does per phase.  Weak scaling.
 
 Prints ONE JSON line (rank 0).  `value` = scalars committed per second over all ranks (Mscalar/s)
-with the step's NTT included in the time; the MSM-only and NTT-only rates are under "extra".
+with the step's NTT included in the time.  On one GPU the line also carries
+  * `roofline` (dominant kernel, k_msm_buckets) and `rooflines` (every kernel class of the path),
+  * `cpu_baseline` (the C oracle on the host cores),
+  * `proof`: BASELINE's headline metric -- full-proof wall-clock of the SuperCircuit-shape circuit
+    (k = 20) and of the Keccak-shape circuit (k = 18), each verified by the oracle's pairing verifier
+    (synthetic-shape: the reference's witnesses need its Rust + Go toolchain).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,68 +33,51 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (device plumbing + torch.distributed only)
-
 K = 20
 N = 1 << K
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G), tools/ubench.hip
-MSM_WINDOWS = 16           # c = 16 signed digits at n = 2^20
-
-
+NCOL = 16                  # rotating set: 16 x 32 MiB committed + 16 x 32 MiB transformed
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G) of the library's own product routine (tools/ubench.hip)
+MAD_PEAK_T = 30.4          # measured v_mad_u64_u32 lane-ops/s (T), tools/ubench.hip: the hardware-side bound
+MADS_PER_PRODUCT = 161     # v_mad_u64_u32 per 9 x 29-bit Montgomery product
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
-def fr_mont(v: int) -> np.ndarray:
-    """Montgomery image (R = 2^256) of a small integer, as 4 x u64 limbs."""
-    x = (v << 256) % R_MOD
-    return np.array([(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
-
-
-def synth_column(seed: int) -> np.ndarray:
-    """n canonical Montgomery-form Fr values (252-bit uniform: always < r)."""
-    rng = np.random.default_rng(seed)
-    a = rng.integers(0, 1 << 63, size=(N, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(N, 4), dtype=np.uint64)
-    a[:, 3] &= np.uint64((1 << 60) - 1)
-    return a
-
-
-def cpu_baseline(srs, column):
-    """Oracle (C restatement of halo2's best_multiexp + best_fft, OpenMP) on the host cores:
-    one 2^20 MSM + one 2^20 NTT = exactly one bench step.  Reported, never the target."""
-    from oracle import bn254, cref
-
-    bases = srs.download_g_lagrange()
-    threads = cref.num_threads()
-    t0 = time.perf_counter()
-    cref.best_multiexp(column, bases, threads)
-    t1 = time.perf_counter()
-    cref.best_fft(column, bn254.omega_for_k(K), K)
-    t2 = time.perf_counter()
-    return {
-        "value": round(N / (t2 - t0) / 1e6, 4),
-        "unit": "Mscalar/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"one full step on the host: MSM 2^20 ({t1 - t0:.2f} s) + NTT 2^20 ({t2 - t1:.2f} s), C oracle (halo2 best_multiexp/best_fft restated), OpenMP {threads} threads",
-        "msm_s": round(t1 - t0, 3),
-        "ntt_s": round(t2 - t1, 3),
-    }
+def relaunch_under_launcher(args) -> int:
+    """`--gpus N` without a launcher: start N ranks of this script (one per GPU) and relay their output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_proof:
+        cmd.append("--no-proof")
+    return subprocess.call(cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proof", action="store_true", help="skip the full-proof section (N = 1 only)")
     ap.add_argument("--batch", type=int, default=8, help="columns submitted per commit_batch call (pipelined on the device)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_launcher(args))
+
+    import numpy as np
+    import torch  # device plumbing + torch.distributed only
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -103,17 +95,29 @@ def main():
 
     import zkevm_circuits_amd as z
 
+    def fr_mont(v: int) -> np.ndarray:
+        x = (v << 256) % R_MOD
+        return np.array([(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+
+    def synth_column(seed: int) -> np.ndarray:
+        """n canonical Montgomery-form Fr values (252-bit uniform: always < r): dense scalars, every window occupied"""
+        rng = np.random.default_rng(seed)
+        a = rng.integers(0, 1 << 63, size=(N, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(N, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+
     stream = torch.cuda.current_stream().cuda_stream
     ctx = z.Context(local_rank, stream=stream if stream else None)
     srs = ctx.srs_setup_with_s(K, fr_mont(0xC0FFEE))
-    column = synth_column(1234 + rank)
-    d_col = ctx.to_device(column)            # committed every step (read-only)
-    d_work = ctx.to_device(column)           # transformed in place every step
+    first_column = synth_column(1000 * (rank + 1))
+    d_cols = [ctx.to_device(first_column if i == 0 else synth_column(1000 * (rank + 1) + i)) for i in range(NCOL)]       # committed (read-only)
+    d_work = [ctx.to_device(synth_column(5000 * (rank + 1) + i)) for i in range(NCOL)]                                   # transformed in place
     gather = None
     xdev = "cpu" if shared_gpu else "cuda"
     com_t = torch.zeros(64 * args.batch, dtype=torch.uint8, device=xdev)
     if world > 1:
         gather = torch.zeros(64 * args.batch * world, dtype=torch.uint8, device=xdev)
+    cursor = [0]
 
     def run_steps(count):
         """`count` steps = `count` columns: the prover commits the columns of a phase as a batch
@@ -121,9 +125,11 @@ def main():
         done = 0
         while done < count:
             b = min(args.batch, count - done)
-            coms = ctx.commit_batch(srs, [d_col.ptr] * b, N, lagrange=True)   # b x MSM 2^20
-            for _ in range(b):
-                ctx.ntt(d_work, K, inverse=True)                               # b x NTT 2^20 (lagrange_to_coeff)
+            ids = [(cursor[0] + j) % NCOL for j in range(b)]
+            cursor[0] += b
+            coms = ctx.commit_batch(srs, [d_cols[i].ptr for i in ids], N, lagrange=True)    # b x MSM 2^20, b distinct columns
+            for i in ids:
+                ctx.ntt(d_work[i], K, inverse=True)                                           # b x NTT 2^20 (lagrange_to_coeff), b distinct buffers
             if world > 1:
                 # one exchange per commitment round, as in the prover: every rank needs every
                 # commitment of the batch (64 B each) before the next transcript challenge
@@ -157,20 +163,45 @@ def main():
             ms, cnt = prof.get(name, (0.0, 0))
             return ms / cnt if cnt else None
 
+        def hbm_roof(kernel, alg_bytes, ms, note, products=None):
+            """roofline record of one kernel class: algorithmic bytes per launch / measured launch time
+            against the HBM peak (the metric's roof) plus, where given, the integer-ALU roof that binds"""
+            if not ms:
+                return None
+            ach = alg_bytes / (ms * 1e-3) / 1e9
+            rec = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                   "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "note": note}
+            if products:
+                gps = products / (ms * 1e-3) / 1e9
+                rec["alu"] = {"unit": "G Montgomery products/s", "achieved": round(gps, 1), "peak_own_routine": MULPEAK_G, "frac_own_routine": round(gps / MULPEAK_G, 3),
+                              "peak_v_mad_u64_u32": round(MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT, 1), "frac_v_mad_u64_u32": round(gps / (MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT), 3)}
+            return rec
+
+        plan = ctx.msm_plan(srs, N) if hasattr(ctx, "msm_plan") else {"c": 16, "windows": 16}
+        windows = plan["windows"]
         bucket_ms = avg_ms("msm_buckets")
-        msm_ms = sum(avg_ms(x) or 0.0 for x in ("msm_sort", "msm_buckets", "msm_combine"))   # reduce runs on the side stream under the next MSM
+        sort_ms, comb_ms, red_ms = avg_ms("msm_sort") or 0.0, avg_ms("msm_combine") or 0.0, avg_ms("msm_reduce") or 0.0
+        msm_pipelined_ms = sort_ms + (bucket_ms or 0.0) + comb_ms            # the reduction runs on the side stream under the next MSM
+        msm_lone_ms = msm_pipelined_ms + red_ms                              # what one MSM alone costs: nothing to hide the reduction under
         ntt_ms = (prof.get("ntt_pass", (0, 0))[0] + prof.get("ntt_last", (0, 0))[0]) / max(args.steps, 1)
-        # roofline of the dominant kernel (bucket accumulation): algorithmic bytes per launch =
-        # 96 B/unit (32 B scalar + 64 B affine base) x 2^20 units
-        alg_bytes = 96.0 * N
-        achieved = alg_bytes / (bucket_ms * 1e-3) / 1e9 if bucket_ms else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("msm_buckets_bytes_per_launch")
             except Exception:
                 traffic = None
+        main_roof = hbm_roof("k_msm_buckets", 96.0 * N, bucket_ms,
+                             "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 (SURVEY 8d); integer-ALU bound: one mixed XYZZ addition "
+                             f"(10 Montgomery products) per (scalar, window), {windows} windows", products=10.0 * N * windows)
+        if main_roof:
+            main_roof["traffic"] = traffic            # PMC FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, from the committed rocprofv3 pass (profiles/); null until measured this round
+            main_roof["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc pass of this command)" if traffic else None
+        rooflines = [r for r in (
+            main_roof,
+            hbm_roof("k_ntt_pass + k_ntt_last (one 2^20 transform)", 64.0 * N, ntt_ms,
+                     "algorithmic bytes = 64 B x 2^20 (read once, write once); VALU-issue bound: 10.5 M Montgomery products per transform", products=N * K / 2.0),
+        ) if r]
         out = {
             "metric": "MSM Mscalar/s (step = KZG commit of one 2^20 column: MSM 2^20 + NTT 2^20)",
             "value": round(world * N * args.steps / elapsed / 1e6, 3),
@@ -184,29 +215,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u32x8 limbs (254-bit modular integer, Montgomery)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, 1 column per GPU", "k": K,
-                       "parallelism": f"column-sharded x{world}, all_gather(64 B commitment per column) once per commit batch" if world > 1 else "single GPU",
-                       "columns_per_commit_batch": args.batch},
-            "roofline": {
-                "kernel": "k_msm_buckets",
-                "bound": "hbm",
-                "achieved": round(achieved, 2) if achieved else None,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                "traffic": traffic,
-                "avg_launch_ms": round(bucket_ms, 4) if bucket_ms else None,
-                "traffic_GBps": round(traffic / (bucket_ms * 1e-3) / 1e9, 1) if (traffic and bucket_ms) else None,
-                # the binding roof (SURVEY 8d asks for both): one mixed XYZZ addition per (scalar, window) = 10
-                # Montgomery products, against the measured product peak of tools/ubench.hip
-                "alu": {"unit": "G Montgomery products/s", "peak": MULPEAK_G,
-                        "achieved": round(10.0 * N * MSM_WINDOWS / (bucket_ms * 1e-3) / 1e9, 1) if bucket_ms else None,
-                        "frac": round(10.0 * N * MSM_WINDOWS / (bucket_ms * 1e-3) / 1e9 / MULPEAK_G, 3) if bucket_ms else None},
-                "note": "integer-ALU bound (254-bit Montgomery arithmetic), see DESIGN.md; algorithmic bytes = 96 B x 2^20",
-            },
+            "config": {"workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, 1 column per step per GPU", "k": K,
+                       "parallelism": f"column-sharded x{world}, all_gather(64 B commitment per column) once per commit batch, backend {'gloo (ranks share a GPU)' if shared_gpu else 'nccl (RCCL)'}" if world > 1 else "single GPU",
+                       "columns_per_commit_batch": args.batch, "rotating_columns": f"{NCOL} committed + {NCOL} transformed, 32 MiB each (1 GiB working set)",
+                       "msm_window_bits": plan.get("c"), "msm_windows": windows},
+            "roofline": main_roof,
+            "rooflines": rooflines,
             "extra": {
-                "msm_only_ms": round(msm_ms, 4),
-                "msm_only_mscalar_per_s": round(N / (msm_ms * 1e-3) / 1e6, 2) if msm_ms else None,
+                "msm_pipelined_ms": round(msm_pipelined_ms, 4),
+                "msm_pipelined_mscalar_per_s": round(N / (msm_pipelined_ms * 1e-3) / 1e6, 2) if msm_pipelined_ms else None,
+                "msm_lone_ms": round(msm_lone_ms, 4),
+                "msm_reduce_ms_on_side_stream": round(red_ms, 4),
                 "ntt_only_ms": round(ntt_ms, 4),
                 "ntt_gfieldop_per_s": round(1.5 * N * K / (ntt_ms * 1e-3) / 1e9, 2) if ntt_ms else None,
                 "ntt_algorithmic_GBps": round(64.0 * N / (ntt_ms * 1e-3) / 1e9, 1) if ntt_ms else None,
@@ -214,11 +233,84 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(srs, column)
+            out["cpu_baseline"] = cpu_baseline(srs, first_column)
+        for b_ in d_cols + d_work:
+            b_.free()
+        srs.destroy()
+        if world == 1 and not args.no_proof:
+            out["proof"] = proof_section(ctx)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(srs, column):
+    """Oracle (C restatement of halo2's best_multiexp + best_fft, OpenMP) on the host cores:
+    one 2^20 MSM + one 2^20 NTT = exactly one bench step.  Reported, never the target."""
+    from oracle import bn254, cref
+
+    bases = srs.download_g_lagrange()
+    threads = cref.num_threads()
+    t0 = time.perf_counter()
+    cref.best_multiexp(column, bases, threads)
+    t1 = time.perf_counter()
+    cref.best_fft(column, bn254.omega_for_k(K), K)
+    t2 = time.perf_counter()
+    return {
+        "value": round(N / (t2 - t0) / 1e6, 4),
+        "unit": "Mscalar/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"one full step on the host: MSM 2^20 ({t1 - t0:.2f} s) + NTT 2^20 ({t2 - t1:.2f} s), C oracle (halo2 best_multiexp/best_fft restated), OpenMP {threads} threads",
+        "msm_s": round(t1 - t0, 3),
+        "ntt_s": round(t2 - t1, 3),
+    }
+
+
+def proof_section(ctx):
+    """BASELINE's headline metric on one GPU: full-proof wall-clock of the SuperCircuit-shape circuit
+    (config 4 stand-in, k = 20: 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9)
+    and of the Keccak-shape circuit (config 3 stand-in, k = 18: 59 unusable rows, 13-rotation gates,
+    degree 9), SHPLONK + Blake2b as at [REF circuit-benchmarks/src/super_circuit.rs:117-132]; each proof
+    is checked by the oracle's pairing verifier.  The quotient evaluator's roofline comes from the
+    same run: bytes = 32 x n x (distinct (column, rotation) reads + 1 write) per coset launch."""
+    import bench_proof as bp
+
+    out = {}
+    for name, build in (("keccak_shape_k18", lambda: bp.build_keccak_shape(ctx, 18)),
+                        ("supercircuit_shape_k20", lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9))):
+        try:
+            t0 = time.perf_counter()
+            circ, blob, adv_m, inst_m, inst = build()
+            t_build = time.perf_counter() - t0
+            ctx.prof_reset()
+            ctx.prof_enable(True)
+            rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=2, verify=True, pinned=True, t_build=t_build)
+            ctx.prof_enable(False)
+            prof = {nm: ctx.prof_get(nm) for nm in ctx.prof_names()}
+            n = 1 << circ.k
+            d, P, L = circ.degree(), len(circ.perm_cols), len(circ.lookups)
+            C = (P + d - 3) // (d - 2) if P else 0
+            # distinct (column, rotation) operands of the quotient program: the circuit's own queries, sigma, Z (x, wx, w^last x),
+            # phi (x, wx) and m per lookup, l_0 / l_last / l_active / X
+            reads = len(circ.advice_queries) + len(circ.fixed_queries) + len(circ.instance_queries) + P + (3 * C - 1 if C else 0) + 3 * L + 4
+            q_ms, q_cnt = prof.get("quotient_eval", (0.0, 0))
+            cosets = 1 << (circ.extended_k() - circ.k)
+            # the coset launches of the quotient are the largest programs: take the per-launch time of the 2 x cosets slowest class = total / count is
+            # diluted by the small helper programs, so the record reports the whole scope and the share of the big launches separately
+            rec["quotient_eval_scope"] = {"launches": int(q_cnt), "total_ms": round(q_ms, 2)}
+            qbig = prof.get("quotient_coset", (0.0, 0))
+            if qbig[1]:
+                ms = qbig[0] / qbig[1]
+                alg = 32.0 * n * (reads + 1)
+                rec["roofline_quotient"] = {"kernel": "k_quotient_eval (one coset of the extended domain)", "bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1),
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 3),
+                                            "distinct_column_rotation_reads": reads, "algorithmic_bytes_per_launch": int(alg), "cosets_per_proof": cosets}
+            out[name] = rec
+        except Exception as e:           # the MSM / NTT line must survive a failure of the proof section
+            out[name] = {"error": repr(e)}
+    return out
 
 
 if __name__ == "__main__":

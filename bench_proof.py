@@ -194,6 +194,115 @@ def build_large(ctx, k: int, groups: int, seed: int = 1):
     return c, b"".join(parts), adv_m, inst_m, inst_int
 
 
+def assemble_blob(ctx, c, F: int, fixed_of, copies):
+    """key blob of circuit `c` with F fixed columns given as Montgomery arrays (fixed_of(i)) and the
+    sigma columns of `copies`, written in place (no Python-side copies of the columns)"""
+    n = c.n
+    Pn = len(c.perm_cols)
+    head = c.cs_blob(cse=os.environ.get("ZK_BENCH_CSE") == "1")
+    col_bytes = n * 32
+    total = len(head) + (F + Pn) * col_bytes
+    raw = np.empty(total + 8, dtype=np.uint8)
+    shift = (-(raw.ctypes.data + len(head))) % 8       # columns 8-byte aligned in memory (u64 views below)
+    blob = raw[shift:shift + total]
+    blob[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+    off = len(head)
+    for i in range(F):
+        blob[off:off + col_bytes] = fixed_of(i).view(np.uint8).reshape(-1)
+        off += col_bytes
+    pos = {pc: j for j, pc in enumerate(c.perm_cols)}
+    omega_m = np.frombuffer(plonk.fr_mont_bytes(c.omega()), dtype=np.uint64).copy()
+    sig_view = [blob[off + j * col_bytes: off + (j + 1) * col_bytes].view(np.uint64).reshape(n, 4) for j in range(Pn)]
+    tmp = ctx.alloc(col_bytes)
+    for j in range(Pn):
+        ctx.fr_powers(omega_m, np.frombuffer(plonk.fr_mont_bytes(pow(plonk.FR_DELTA, j, R)), dtype=np.uint64).copy(), tmp, n)
+        sig_view[j][:] = tmp.download((n, 4))
+    tmp.free()
+    for (ta_, ia, ra), (tb_, ib, rb) in copies:
+        ja, jb = pos[(ta_, ia)], pos[(tb_, ib)]
+        va, vb = sig_view[ja][ra].copy(), sig_view[jb][rb].copy()
+        sig_view[ja][ra], sig_view[jb][rb] = vb, va
+    return blob
+
+
+def build_keccak_shape(ctx, k: int, pairs: int = 48, window: int = 12, lookups: int = 7, d: int = 9, seed: int = 1):
+    """SURVEY 8d config 3 stand-in (Keccak circuit, k = 18): the packed-multi Keccak circuit at 12
+    rows per round has 59 unusable rows [REF zkevm-circuits/src/keccak_circuit/keccak_packed_multi.rs:59-68]
+    -- i.e. some column is queried at dozens of rotations --, maximum degree 9
+    [REF zkevm-circuits/src/keccak_circuit/param.rs:1] and a handful of table lookups.  Shape used
+    here: `pairs` column pairs (a_j, b_j), all with distinct data;
+        q_sum * (a + a.rot(1) + ... + a.rot(window-1) - b.rot(-3))        window + 1 rotations of a_j
+        q_far * (a.rot(-5) * a.rot(window-5) - b)
+        q_hi * (a_0^2 - b_0.rot(1)) * (a_0 + 1)...(a_0 + d - 3)           degree d
+        `lookups` lookups (q_lk * a_j) in a 4096-row table
+    58 blinding factors (59 unusable rows), copy constraints into the instance column."""
+    rng = np.random.default_rng(seed)
+    A, F = 2 * pairs, 5
+    c = plonk.Circuit(k, num_fixed=F, num_advice=A, num_instance=1, blinding_factors=58)
+    c.fixed = None
+    n, u = c.n, c.u
+    q_sum, q_far, q_lk, t_a, q_hi = (c.fixed_col(i) for i in range(F))
+    for j in range(pairs):
+        a, b_ = c.advice_col(2 * j), c.advice_col(2 * j + 1)
+        acc = a
+        for i in range(1, window):
+            acc = acc + a.rot(i)
+        c.add_gate(q_sum * (acc - b_.rot(-3)))
+        c.add_gate(q_far * (a.rot(-5) * a.rot(window - 5) - b_))
+    a0, b0 = c.advice_col(0), c.advice_col(1)
+    hi = q_hi * (a0 * a0 - b0.rot(1))
+    for i in range(d - 3):
+        hi = hi * (a0 + (i + 1))
+    c.add_gate(hi)
+    for l in range(lookups):
+        c.add_lookup([q_lk * c.advice_col(2 * (l % pairs))], [t_a])
+    for j in range(min(6, pairs)):
+        c.enable_equality(plonk.ADVICE, 2 * j + 1)
+    c.enable_equality(plonk.INSTANCE, 0)
+    assert c.degree() == d, (c.degree(), d)
+    tab_n = min(4096, u)
+    rows = np.arange(8, u - window - 2)
+    r0, r2, r3 = rows[rows % 4 == 0], rows[rows % 4 == 2], rows[rows % 4 == 3]
+    a_v = np.zeros((pairs, n), dtype=np.uint64)
+    a_v[:, :u] = rng.integers(0, tab_n, size=(pairs, u), dtype=np.uint64)
+    b_v = np.zeros((pairs, n), dtype=np.uint64)
+    for i in range(window):
+        b_v[:, r0 - 3] += a_v[:, r0 + i]
+    b_v[:, r2] = a_v[:, r2 - 5] * a_v[:, r2 + window - 5]
+    b_v[0, r3 + 1] = a_v[0, r3] * a_v[0, r3]                  # the degree-d gate reads pair 0 only
+    inst = np.zeros((1, n), dtype=np.uint64)
+    pub = r2[:4]
+    inst[0, :pub.size] = b_v[0, pub]
+    copies = [((plonk.ADVICE, 1, int(r_)), (plonk.INSTANCE, 0, j)) for j, r_ in enumerate(pub)]
+    for j in range(1, min(6, pairs)):                         # tie equal cells of different columns together
+        b_v[j, r2[10 + j]] = b_v[0, r2[10]]
+        a_v[j, r2[10 + j] - 5], a_v[j, r2[10 + j] + window - 5] = a_v[0, r2[10] - 5], a_v[0, r2[10] + window - 5]
+        copies.append(((plonk.ADVICE, 1, int(r2[10])), (plonk.ADVICE, 2 * j + 1, int(r2[10 + j]))))
+    # the changed a cells feed rotation sums: recompute the sums of the touched pairs
+    for j in range(1, min(6, pairs)):
+        b_v[j, r0 - 3] = 0
+        for i in range(window):
+            b_v[j, r0 - 3] += a_v[j, r0 + i]
+        b_v[j, r2] = a_v[j, r2 - 5] * a_v[j, r2 + window - 5]
+    c.copies = copies
+    adv_m = []
+    for j in range(pairs):
+        adv_m.append(to_mont_gpu(ctx, small_to_limbs(a_v[j])))
+        adv_m.append(to_mont_gpu(ctx, small_to_limbs(b_v[j])))
+    inst_m = [to_mont_gpu(ctx, small_to_limbs(inst[0]))]
+
+    def sel(rows_):
+        v = np.zeros(n, dtype=np.uint64)
+        v[rows_] = 1
+        return to_mont_gpu(ctx, small_to_limbs(v))
+    ta = np.zeros(n, dtype=np.uint64)
+    ta[:tab_n] = np.arange(tab_n, dtype=np.uint64)
+    fixed_m = [sel(r0), sel(r2), sel(np.arange(u)), to_mont_gpu(ctx, small_to_limbs(ta)), sel(r3)]
+    blob = assemble_blob(ctx, c, F, lambda i: fixed_m[i], copies)
+    inst_int = [[int(v) for v in inst[0]]]
+    return c, blob, adv_m, inst_m, inst_int
+
+
 def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: int = 8, seed: int = 1):
     """SURVEY 8d config 4 stand-in: a circuit with the SuperCircuit's *shape* (A advice, F fixed,
     P permutation columns, L lookups, max degree d).  Same ingredients as `build_large`; to keep
@@ -280,33 +389,79 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
     tb = np.zeros(n, dtype=np.uint64); tb[1:tab_n] = ti[1:] * ti[1:] + 3
     f_ta, f_tb = to_mont_gpu(ctx, small_to_limbs(ta)), to_mont_gpu(ctx, small_to_limbs(tb))
     fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb][i - 2 * S] if i < 2 * S + 4 else zero_col)
-    # ---- blob: header + programs, then F fixed and P sigma columns written in place (no Python-side copies)
-    Pn = len(c.perm_cols)
-    head = c.cs_blob(cse=os.environ.get("ZK_BENCH_CSE") == "1")
-    col_bytes = n * 32
-    total = len(head) + (F + Pn) * col_bytes
-    raw = np.empty(total + 8, dtype=np.uint8)
-    shift = (-(raw.ctypes.data + len(head))) % 8       # columns 8-byte aligned in memory (u64 views below)
-    blob = raw[shift:shift + total]
-    blob[:len(head)] = np.frombuffer(head, dtype=np.uint8)
-    off = len(head)
-    for i in range(F):
-        blob[off:off + col_bytes] = fixed_of(i).view(np.uint8).reshape(-1)
-        off += col_bytes
-    pos = {pc: j for j, pc in enumerate(c.perm_cols)}
-    omega_m = np.frombuffer(plonk.fr_mont_bytes(c.omega()), dtype=np.uint64).copy()
-    sig_view = [blob[off + j * col_bytes: off + (j + 1) * col_bytes].view(np.uint64).reshape(n, 4) for j in range(Pn)]
-    tmp = ctx.alloc(col_bytes)
-    for j in range(Pn):
-        ctx.fr_powers(omega_m, np.frombuffer(plonk.fr_mont_bytes(pow(plonk.FR_DELTA, j, R)), dtype=np.uint64).copy(), tmp, n)
-        sig_view[j][:] = tmp.download((n, 4))
-    tmp.free()
-    for (ta_, ia, ra), (tb_, ib, rb) in copies:
-        ja, jb = pos[(ta_, ia)], pos[(tb_, ib)]
-        va, vb = sig_view[ja][ra].copy(), sig_view[jb][rb].copy()
-        sig_view[ja][ra], sig_view[jb][rb] = vb, va
+    blob = assemble_blob(ctx, c, F, fixed_of, copies)
     inst_int = [[int(v) for v in inst[0]]]
     return c, blob, adv_m, inst_m, inst_int
+
+
+def proof_bench(ctx, k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=3, verify=True, pinned=False, t_build=0.0,
+                session_hook=None, barrier=None, report=True, world=1, transcript_kind=None):
+    """keygen_pk + `repeat` proving sessions of one circuit; returns the result record (None on
+    ranks that do not report).  Verified afterwards by the oracle's pairing verifier."""
+    # halo2 hands create_proof the public inputs themselves, not an n-row column: keep the slice that
+    # holds them (the rest of the column is zero) so the transcript absorbs a handful of scalars
+    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
+    inst = [list(col[:m]) for col, m in zip(inst, npub)]
+    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
+    if pinned:          # what a host integration would do: witness columns in page-locked memory
+        pin = {}
+        for a in adv_m:
+            if id(a) not in pin:
+                pin[id(a)] = ctx.host_alloc(a.shape)
+                pin[id(a)][:] = a
+        adv_m = [pin[id(a)] for a in adv_m]
+    S = 0x5EC2E7
+    s_mont = np.frombuffer(plonk.fr_mont_bytes(S), dtype=np.uint64).copy()
+    t0 = time.perf_counter()
+    srs = ctx.srs_setup_with_s(k, s_mont)
+    ctx.sync()
+    t_srs = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pk = ctx.pk_create(srs, blob)
+    ctx.sync()
+    t_keygen = time.perf_counter() - t0
+    times = []
+    proof = b""
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        if barrier:
+            barrier()
+            t0 = time.perf_counter()
+        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+        if transcript_kind is not None:
+            sess.set_transcript_kind(transcript_kind)
+        sess.set_multiopen(1 if shplonk else 0)
+        keep = session_hook(sess) if session_hook else None
+        sess.advice_phase({i: c for i, c in enumerate(adv_m)})
+        proof = sess.finish()
+        del keep
+        if barrier:
+            barrier()
+        times.append(time.perf_counter() - t0)
+    if not report:
+        pk.destroy(); srs.destroy()
+        return None
+    ok = None
+    if verify:
+        from oracle import cref, pairing as pr, plonk_verifier as pv
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        kinds = {None: "blake2b", 0: "blake2b", 1: "poseidon", 2: "evm"}
+        ok = bool(pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst, proof, pr.ec_mul(pr.G2_GEN, S),
+                            multiopen="shplonk" if shplonk else "gwc", transcript=kinds[transcript_kind]))
+    pk.destroy(); srs.destroy()
+    d = circ.degree()
+    return {
+        "metric": "synthetic-shape full proof wall-clock (s), 1x MI355X",
+        "value": round(min(times), 4), "unit": "s", "higher_is_better": False,
+        "k": k, "advice": circ.A, "fixed": circ.F, "instance": circ.I, "permutation_columns": len(circ.perm_cols),
+        "lookups": len(circ.lookups), "gates": len(circ.gates), "degree": d, "extended_k": circ.extended_k(),
+        "advice_queries": len(circ.advice_queries), "fixed_queries": len(circ.fixed_queries), "blinding_factors": circ.bf,
+        "proof_bytes": len(proof), "create_proof_s": [round(t, 4) for t in times], "keygen_pk_s": round(t_keygen, 4),
+        "srs_setup_s": round(t_srs, 4), "host_circuit_build_s": round(t_build, 2), "verified_by_oracle": ok,
+        "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + d - 3) // (d - 2) + 1 + (d - 1) + (2 if shplonk else 0),
+        "multiopen": "shplonk" if shplonk else "gwc", "data": "synthetic-shape",
+        "advice_host_memory": "pinned" if pinned else "pageable", "n_gpus": world,
+    }
 
 
 def main():
@@ -320,6 +475,7 @@ def main():
     ap.add_argument("--host-upload", action="store_true", help="sharded runs: every rank uploads every advice column (no device all-gather)")
     ap.add_argument("--pinned", action="store_true", help="advice columns in page-locked host memory (zk_host_alloc)")
     ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle's MSM / NTT at 2^k on the host and scale by the prover's counts")
+    ap.add_argument("--keccak", action="store_true", help="Keccak-circuit stand-in (SURVEY 8d config 3): 59 unusable rows, 13-rotation gates, degree 9")
     ap.add_argument("--shape", default="", help="A,F,P,L,d: circuit with this many advice / fixed / permutation columns, lookups and "
                     "max degree (SURVEY 8d config 4 stand-in: 1000,150,150,100,9)")
     args = ap.parse_args()
@@ -338,7 +494,9 @@ def main():
         dist.init_process_group(backend="nccl" if torch.cuda.device_count() >= world else "gloo")
     ctx = z.Context(device)
     t0 = time.perf_counter()
-    if args.shape:
+    if args.keccak:
+        circ, blob, adv_m, inst_m, inst = build_keccak_shape(ctx, args.k)
+    elif args.shape:
         sa, sf, sp, sl, sd = (int(v) for v in args.shape.split(","))
         circ, blob, adv_m, inst_m, inst = build_shape(ctx, args.k, sa, sf, sp, sl, sd)
     elif args.large:
@@ -348,69 +506,16 @@ def main():
         blob = circ.blob()
         adv_m = [plonk.column_to_mont(c) for c in adv]
         inst_m = [plonk.column_to_mont(c) for c in inst]
-    # halo2 hands create_proof the public inputs themselves, not an n-row column: keep the slice that
-    # holds them (the rest of the column is zero) so the transcript absorbs a handful of scalars
-    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
-    inst = [list(col[:m]) for col, m in zip(inst, npub)]
-    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
-    if args.pinned:          # what a host integration would do: witness columns in page-locked memory
-        pinned = {}
-        for a in adv_m:
-            if id(a) not in pinned:
-                pinned[id(a)] = ctx.host_alloc(a.shape)
-                pinned[id(a)][:] = a
-        adv_m = [pinned[id(a)] for a in adv_m]
     t_build = time.perf_counter() - t0
-
-    S = 0x5EC2E7
-    s_mont = np.frombuffer(plonk.fr_mont_bytes(S), dtype=np.uint64).copy()
-    t0 = time.perf_counter()
-    srs = ctx.srs_setup_with_s(args.k, s_mont)
-    ctx.sync()
-    t_srs = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    pk = ctx.pk_create(srs, blob)
-    ctx.sync()
-    t_keygen = time.perf_counter() - t0
-    times = []
-    proof = b""
-    for _ in range(args.repeat):
-        t0 = time.perf_counter()
-        if world > 1:
-            dist.barrier()
-            t0 = time.perf_counter()
-        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
-        sess.set_multiopen(1 if args.shplonk else 0)
-        keep = None
-        if world > 1:      # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
-            keep = shard.shard_session(sess) if args.host_upload else shard.shard_session_device(sess)
-        sess.advice_phase({i: c for i, c in enumerate(adv_m)})
-        proof = sess.finish()
-        del keep
-        if world > 1:
-            dist.barrier()
-        times.append(time.perf_counter() - t0)
+    hook = None
+    if world > 1:      # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
+        hook = (lambda sess: shard.shard_session(sess)) if args.host_upload else (lambda sess: shard.shard_session_device(sess))
+    out = proof_bench(ctx, args.k, circ, blob, adv_m, inst_m, inst, shplonk=args.shplonk, repeat=args.repeat, verify=not args.no_verify, pinned=args.pinned,
+                      t_build=t_build, session_hook=hook, barrier=(dist.barrier if world > 1 else None), report=(rank == 0), world=world)
     if world > 1 and rank != 0:
         dist.destroy_process_group()
         return
-    ok = None
-    if not args.no_verify:
-        from oracle import cref, pairing as pr, plonk_verifier as pv
-        com, rep = pk.vk(circ.F + len(circ.perm_cols))
-        ok = bool(pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst, proof, pr.ec_mul(pr.G2_GEN, S),
-                            multiopen="shplonk" if args.shplonk else "gwc"))
     d = circ.degree()
-    out = {
-        "metric": "synthetic-shape full proof wall-clock (s), 1x MI355X",
-        "value": round(min(times), 4), "unit": "s", "higher_is_better": False,
-        "k": args.k, "advice": circ.A, "fixed": circ.F, "instance": circ.I, "permutation_columns": len(circ.perm_cols),
-        "lookups": len(circ.lookups), "gates": len(circ.gates), "degree": d, "extended_k": circ.extended_k(),
-        "proof_bytes": len(proof), "create_proof_s": [round(t, 4) for t in times], "keygen_pk_s": round(t_keygen, 4),
-        "srs_setup_s": round(t_srs, 4), "host_circuit_build_s": round(t_build, 2), "verified_by_oracle": ok,
-        "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + d - 3) // (d - 2) + 1 + (d - 1),
-        "multiopen": "shplonk" if args.shplonk else "gwc", "data": "synthetic-shape",
-        "advice_host_memory": "pinned" if args.pinned else "pageable", "n_gpus": world,
-    }
     if args.cpu_baseline:
         # The reference prover (Rust / Rayon) cannot be built here, and the oracle has no full prover
         # at this size.  What can be timed on the host is what dominates halo2's create_proof: one

@@ -207,6 +207,11 @@ int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* c
 /* best_multiexp over HOST slices, exactly the reference signature (copies in, computes, copies
  * the affine result out).                                                                        */
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine);
+/* Introspection: Pippenger window size (bits) and window count that commitments of n points over
+ * this SRS use -- with the SRS's fixed-base window tables all windows share one bucket set (c = 20,
+ * 13 windows at k = 20); without them (tables beyond ZK_MSM_TABLE_GB, default 32 GiB per basis)
+ * one bucket set per window (c <= 16).                                                            */
+int zk_msm_plan(const zk_srs* srs, size_t n, int* window_bits, int* windows);
 
 /* Host-only: out = sum of n affine points (no context, no device).  Used to finish a point-sharded
  * MSM: each rank's 64-byte partial result is all-gathered as bytes (RCCL has no EC reduce op) and

@@ -476,6 +476,11 @@ class Context:
     def host_unregister(self, arr: np.ndarray):
         self._ck(lib().zk_host_unregister(self.h, ctypes.c_void_p(arr.ctypes.data)))
 
+    def msm_plan(self, srs, n: int) -> dict:
+        c, w = ctypes.c_int(), ctypes.c_int()
+        self._ck(lib().zk_msm_plan(srs.h, ctypes.c_size_t(n), ctypes.byref(c), ctypes.byref(w)))
+        return {"c": c.value, "windows": w.value}
+
     def lookup_multiplicities(self, inputs: DeviceBuffer, table: DeviceBuffer, usable_rows: int, m: DeviceBuffer, n: int) -> Optional[int]:
         """logUp m(X) on the device; returns the lowest input row missing from the table, or None."""
         bad = ctypes.c_uint64()

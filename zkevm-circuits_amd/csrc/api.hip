@@ -273,15 +273,8 @@ int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, 
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
-    const G1Affine* brp = nullptr;
-    int rc = srs_bases_rp(ctx, srs, basis, &brp);
-    if (rc) return rc;
-    const G1Affine* tab = nullptr;
-    size_t stride = 0;
-    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
-    if (rc) return rc;
     const Fr* sp = (const Fr*)d_scalars;
-    return msm_batch_tab(ctx, &sp, 1, b, brp, tab, stride, n, (G1Affine*)h_out_affine);
+    return msm_batch_srs(ctx, srs, basis, &sp, 1, n, (G1Affine*)h_out_affine);
 }
 // Sum of n affine points on the HOST (no device, no context): combines the per-rank partial
 // results of a point-sharded MSM after they were all-gathered as raw bytes (RCCL has no
@@ -348,14 +341,7 @@ int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* c
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
-    const G1Affine* brp = nullptr;
-    int rc = srs_bases_rp(ctx, srs, basis, &brp);
-    if (rc) return rc;
-    const G1Affine* tab = nullptr;
-    size_t stride = 0;
-    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
-    if (rc) return rc;
-    return msm_batch_tab(ctx, (const Fr* const*)d_scalar_ptrs, count, b, brp, tab, stride, n, (G1Affine*)h_out_affine, stage, stage_user);
+    return msm_batch_srs(ctx, srs, basis, (const Fr* const*)d_scalar_ptrs, count, n, (G1Affine*)h_out_affine, stage, stage_user);
 }
 int copy_stream_open(zk_ctx* ctx) {
     if (!ctx->stream_copy) {

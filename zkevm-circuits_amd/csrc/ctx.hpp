@@ -80,6 +80,7 @@ struct zk_ctx {
     }
     // per-kernel HIP-event profiling (zk_prof_*): off by default
     bool prof_on = false;
+    const char* prof_tag = nullptr;      // when set, zk_quotient_eval books its launch under this name (the prover tags the big coset programs)
     struct ProfEntry { double ms = 0; uint64_t count = 0; };
     std::map<std::string, ProfEntry> prof;
     struct ProfPending { const char* name; hipEvent_t a, b; };
@@ -194,6 +195,7 @@ int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const 
 typedef int (*MsmStageFn)(void* user, size_t it);
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
                   size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
+int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user);
 int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1

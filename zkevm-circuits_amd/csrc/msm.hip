@@ -18,6 +18,13 @@
 //                fixed-base window tables (2^(c*w) * P_i precomputed) make every window's bucket b
 //                carry the same weight, so the W bucket arrays are folded first and ONE window is
 //                reduced.  Runs on a side stream: in a batch it hides under the next MSM.
+//   M. merged    with window tables (SRS bases) all windows share ONE bucket set: every non-zero
+//                digit of every window is an entry (bucket, table index w * 2^k + i); the window
+//                size is then free of the bucket-count / window-count trade-off (c = 20 at 2^20:
+//                13 windows instead of 16, 2^19 buckets of ~26 entries), nothing is folded, and
+//                the entries are sorted by a two-level counting sort (partition by the high
+//                bucket bits while the digits are produced, then an LDS counting sort per
+//                partition) that touches every entry a constant number of times.
 //   5. tail      window sums go to the host: Horner over the windows (c doublings each; a
 //                dependent doubling chain is issue-bound on one GPU lane) and the affine
 //                normalisation; with window tables only the normalisation is left.
@@ -195,6 +202,111 @@ __global__ void __launch_bounds__(1024) k_msm_lds_sweep(const uint16_t* __restri
             if (SCATTER) idx[pos] = (uint32_t)(v * 16 + 2 * j + hi) | ((code & 0x8000u) ? NEG_BIT : 0u);
         }
         v = vn;
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) counts[(gbase + t) * MSM_SLICES + sl] = lds[t];
+    }
+}
+
+// ---- merged-window sort (SRS bases with window tables) -------------------------------------------
+// Window bits C up to 22: digit magnitudes no longer fit the u16 codes of the per-window path.
+// code = 0xFFFFFFFF for a zero digit, else bit 31 = sign, bits 0..21 = |d| - 1 (the bucket).
+constexpr int MSM_M_MIN_C = 8, MSM_M_MAX_C = 22;
+constexpr uint32_t MSM_M_MAX_BINS = 1u << (MSM_M_MAX_C - 1 - MSM_RANGE_MAX_BITS);     // 1024 partitions of 2048 buckets
+constexpr uint32_t MSM_M_CHUNK = 2048;                                                   // scalars per workgroup of the partition passes
+constexpr uint32_t CODE_ZERO = 0xFFFFFFFFu;
+template <int C>
+__device__ __forceinline__ void recode_wide(const Fr& s, uint32_t (&code)[(256 + C - 1) / C]) {
+    constexpr int W = (256 + C - 1) / C;
+    constexpr uint32_t mask = (1u << C) - 1, half = 1u << (C - 1);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * C, limb = bit >> 5, sh = bit & 31;
+        uint32_t d = limb < 8 ? (s.l[limb < 8 ? limb : 7] >> sh) : 0u;
+        if (sh + C > 32 && limb + 1 < 8) d |= s.l[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
+        d = (d & mask) + carry;
+        if (d > half) { carry = 1; const uint32_t mag = (1u << C) - d; code[w] = mag ? (NEG_BIT | (mag - 1)) : CODE_ZERO; }
+        else { carry = 0; code[w] = d ? (d - 1) : CODE_ZERO; }
+    }
+}
+// LDS counter update shared by the partition and the per-partition passes: lanes of the wave that
+// hit the leader's slot share ONE atomic (runs of equal scalars put the same bucket in every lane,
+// and 64 atomics on one LDS word serialise); the rest go alone.  Returns the lane's position.
+__device__ __forceinline__ uint32_t lds_take(uint32_t* lds, uint32_t slot, bool active) {
+    const uint64_t act = __ballot(active);
+    if (!active) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lead = __shfl(slot, (int)__builtin_ctzll(act));
+    const uint64_t same = __ballot(slot == lead);          // only active lanes reach this ballot
+    if (slot == lead) {
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        uint32_t pos = 0;
+        if (rank == 0) pos = atomicAdd(&lds[slot], (uint32_t)__popcll(same));
+        return __shfl(pos, (int)__builtin_ctzll(same)) + rank;
+    }
+    return atomicAdd(&lds[slot], 1u);
+}
+// Partition passes.  Workgroup g owns scalars [g * CHUNK, (g + 1) * CHUNK) and recodes them twice:
+//   COUNT   hist[bin * nwg + g] = entries of this chunk whose bucket falls into partition `bin`
+//   SCATTER the same entries go to entries[cursor++], cursors starting at the scanned histogram:
+//           entry = (bucket & (2^range_bits - 1)) << 32 | sign | (w * tab_stride + i)
+// (recoding again costs one Montgomery product per scalar; keeping the digits would cost a write
+// and a read of W words per scalar).
+template <int C, bool SCATTER>
+__global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
+                                                          uint64_t* __restrict__ entries, uint64_t tab_stride) {
+    constexpr int W = (256 + C - 1) / C;
+    __shared__ uint32_t lds[MSM_M_MAX_BINS];
+    const uint32_t nbins = 1u << (C - 1 - range_bits), nwg = gridDim.x, g = blockIdx.x;
+    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = SCATTER ? hist_off[(uint64_t)t * nwg + g] : 0u;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)g * MSM_M_CHUNK, hi = min(n, lo + MSM_M_CHUNK);
+    const uint32_t rmask = (1u << range_bits) - 1u;
+    for (uint64_t base = lo; base < hi; base += blockDim.x) {          // uniform trip count: the ballots below see whole waves
+        const uint64_t i = base + threadIdx.x;
+        const bool live = i < hi;
+        uint32_t code[W];
+        if (live) recode_wide<C>(from_mont(ldg(scalars + i)), code);
+        else {
+#pragma unroll
+            for (int w = 0; w < W; ++w) code[w] = CODE_ZERO;
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const bool nz = code[w] != CODE_ZERO;
+            if (!__ballot(nz)) continue;
+            const uint32_t bucket = code[w] & 0x3FFFFFu;
+            const uint32_t pos = lds_take(lds, bucket >> range_bits, nz);
+            if (SCATTER && nz) entries[pos] = ((uint64_t)(bucket & rmask) << 32) | (uint64_t)((uint32_t)((uint64_t)w * tab_stride + i) | (code[w] & NEG_BIT));
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) hist[(uint64_t)t * nwg + g] = lds[t];
+    }
+}
+// Per-partition LDS counting sort: workgroup (bin, slice) streams its quarter of the partition's
+// entries; counters are laid out [bucket][slice] exactly as in the per-window path, so the same
+// scans produce every (bucket, slice) cursor.
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_msm_m_bin(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ hist_off, uint32_t nwg, int range_bits,
+                                                    uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx) {
+    __shared__ uint32_t lds[1 << MSM_RANGE_MAX_BITS];
+    const uint32_t bin = blockIdx.x / MSM_SLICES, sl = blockIdx.x % MSM_SLICES, range = 1u << range_bits;
+    const uint64_t gbase = (uint64_t)bin << range_bits;
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[(gbase + t) * MSM_SLICES + sl] : 0u;
+    __syncthreads();
+    const uint32_t lo = hist_off[(uint64_t)bin * nwg], hi = hist_off[(uint64_t)(bin + 1) * nwg];     // the scan's closing entry holds the total
+    const uint32_t per = (hi - lo + MSM_SLICES - 1) / MSM_SLICES;
+    const uint32_t s0 = min(hi, lo + sl * per), s1 = min(hi, s0 + per);
+    for (uint32_t base = s0; base < s1; base += blockDim.x) {
+        const uint32_t e = base + threadIdx.x;
+        const bool live = e < s1;
+        const uint64_t ent = live ? entries[e] : 0ull;
+        const uint32_t pos = lds_take(lds, (uint32_t)(ent >> 32), live);
+        if (SCATTER && live) idx[pos] = (uint32_t)ent;
     }
     if (!SCATTER) {
         __syncthreads();
@@ -523,7 +635,7 @@ __device__ __forceinline__ G1Xyzz29 mul_small(const G1Xyzz29& p, uint32_t k) {
     return k ? acc : identity29();
 }
 
-constexpr int RED_G_WIDE = 8, RED_G_FOLDED = 2;
+constexpr int RED_G_WIDE = 8, RED_G_FOLDED = 2, RED_G_MERGED = 16;
 constexpr int RED_THREADS = 256;
 // grid: (groups_per_window / RED_THREADS, W); each block writes one partial per (window, block)
 // G = buckets folded per lane: 8 keeps the work low when W windows are reduced; 2 keeps the
@@ -714,29 +826,194 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it * pl.W, red_W, pl.c, h_out + it);
     return ZK_OK;
 }
+// ---- merged-window MSM over an SRS window table ----------------------------------------------------
+static MsmPlan make_plan_merged(uint32_t k_srs) {
+    int c = (int)k_srs;
+    if (c < MSM_M_MIN_C) c = MSM_M_MIN_C;
+    if (c > MSM_M_MAX_C) c = MSM_M_MAX_C;
+    if (const char* e = getenv("ZK_MSM_C")) { const int v = atoi(e); if (v >= MSM_M_MIN_C && v <= MSM_M_MAX_C) c = v; }   // measurement knob
+    MsmPlan p;
+    p.c = c;
+    p.W = (256 + c - 1) / c;
+    p.B = 1u << (c - 1);
+    return p;
+}
+template <bool SCATTER>
+static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride) {
+#define ZK_PART_CASE(C) case C: hipLaunchKernelGGL((k_msm_m_partition<C, SCATTER>), grid, dim3(256), 0, st, scalars, n, range_bits, hist, hist_off, entries, tab_stride); break;
+    switch (c) {
+        ZK_PART_CASE(8) ZK_PART_CASE(9) ZK_PART_CASE(10) ZK_PART_CASE(11) ZK_PART_CASE(12) ZK_PART_CASE(13) ZK_PART_CASE(14) ZK_PART_CASE(15)
+        ZK_PART_CASE(16) ZK_PART_CASE(17) ZK_PART_CASE(18) ZK_PART_CASE(19) ZK_PART_CASE(20) ZK_PART_CASE(21) ZK_PART_CASE(22)
+    }
+#undef ZK_PART_CASE
+}
+// d_table: [W][tab_stride] affine points, table[w][i] = 2^(c w) * P_i in R' form, built for plan `pl`.
+// Same pipelining as msm_batch_tab: the reduction of MSM i runs on the side stream under MSM i + 1.
+int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_table, size_t tab_stride, const MsmPlan& pl,
+                     size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user) {
+    if (count == 0) return ZK_OK;
+    if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
+    const uint32_t nb = pl.B;
+    const uint64_t max_entries = (uint64_t)n * pl.W;
+    // table indices carry the sign in bit 31, cursors are 32-bit
+    if ((uint64_t)pl.W * tab_stride >= (1ull << 31) || max_entries >= (1ull << 32)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM of %zu points x %d windows exceeds the 32-bit entry space: split it", n, pl.W);
+    int range_bits = pl.c - 1;
+    if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
+    const uint32_t nbins = nb >> range_bits;
+    const uint32_t nwg = (uint32_t)((n + MSM_M_CHUNK - 1) / MSM_M_CHUNK);
+    const uint32_t hist_cnt = nbins * nwg;
+    const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+    const uint32_t scan_blocks_s = (nb + SCAN_T - 1) / SCAN_T;
+    const uint32_t scan_blocks_h = (hist_cnt + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+    // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] | counts[nb] | size_hist[256] nmulti[4] pad[64] | offsets[nb+1] | order[nb] |
+    //                ntasks[nb] | toff[nb+1] | block_tot[...] | hist[hist_cnt] | hist_off[hist_cnt + 1] | idx[n W] | (8-B aligned) entries[n W] u64
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
+    const size_t words = head_words + 4 + 2 * max_entries;
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
+    if (!ws) return ZK_ERR_OOM;
+    uint32_t* slice_counts = ws;
+    uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
+    uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
+    uint32_t* size_hist = counts + nb;
+    uint32_t* nmulti = size_hist + SIZE_BINS;
+    uint32_t* offsets = nmulti + 4 + 64;
+    uint32_t* order = offsets + nb + 1;
+    uint32_t* ntasks = order + nb;
+    uint32_t* toff = ntasks + nb;
+    uint32_t* block_tot = toff + nb + 1;
+    uint32_t* block_tot2 = block_tot + scan_blocks_s;
+    uint32_t* block_tot3 = block_tot2 + scan_blocks;
+    uint32_t* hist = block_tot3 + scan_blocks_h;
+    uint32_t* hist_off = hist + hist_cnt;
+    uint32_t* idx = hist_off + hist_cnt + 1;
+    uint64_t* entries = reinterpret_cast<uint64_t*>(ws + ((head_words + 3) & ~(size_t)3));
+    const bool lone = count == 1;                 // a lone MSM waits for its reduction: shorter chains
+    const int red_g = lone ? RED_G_WIDE : RED_G_MERGED;
+    const uint32_t red_blocks = ((nb + red_g - 1) / red_g + RED_THREADS - 1) / RED_THREADS;
+    const size_t max_tasks = (size_t)nb + std::max((size_t)(max_entries / TASK_CAP), (size_t)TASK_TARGET) + 1;
+    const size_t npts29 = (size_t)nb + red_blocks + max_tasks;
+    char* bkbuf[2];
+    bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
+    bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count);
+    if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
+    if (!ctx->stream2) {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
+            ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
+        }
+    }
+    if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
+    for (size_t it = 0; it < count; ++it) {
+        const int par = (int)(it & 1);
+        const Fr* d_scalars = d_scalar_ptrs[it];
+        G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
+        G1Xyzz29* partial = buckets + nb;
+        G1Xyzz29* task_partial = partial + red_blocks;
+        if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
+        {
+            ZkProfScope ps(ctx, "msm_sort");
+            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
+            // 1. partition by the high bucket bits while recoding: histogram, scan, scatter
+            launch_partition<false>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, hist_cnt, hist_off, (const uint32_t*)block_tot3);
+            launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride);
+            ZK_CHECK_LAUNCH(ctx);
+            // 2. counting sort inside every partition: counts, scans (bucket offsets, size bins, task split), scatter
+            hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
+            hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
+            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist, (const uint32_t*)(offsets + nb));
+            hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
+            ZK_CHECK_LAUNCH(ctx);
+        }
+        {
+            ZkProfScope ps(ctx, "msm_buckets");
+            // idx already holds table indices: no window offset, no per-window skip (tab_stride = 0)
+            hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_table, (const uint32_t*)offsets, (const uint32_t*)idx,
+                               (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, 0, (uint64_t)0, (const uint32_t*)nullptr);
+        }
+        {
+            ZkProfScope ps(ctx, "msm_combine");
+            hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
+            hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
+                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
+            hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
+                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
+            ZK_CHECK_LAUNCH(ctx);
+        }
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_p1[par], 0));
+        {   // weighted bucket sum on the side stream: hides under the next MSM
+            ZkProfScope ps(ctx, "msm_reduce", ctx->stream2);
+            if (lone) hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks, 1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, nb, partial);
+            else hipLaunchKernelGGL((k_msm_reduce<RED_G_MERGED>), dim3(red_blocks, 1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, nb, partial);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)partial, red_blocks, wsum_all + it);
+            ZK_CHECK_LAUNCH(ctx);
+        }
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], ctx->stream2));
+        if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+    }
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
+    if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
+    std::vector<G1Xyzz> hw(count);
+    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+    return ZK_OK;
+}
+// commitments over an SRS basis: the merged-window path when the basis has (or can get) its window
+// table, the per-window path otherwise
+int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user) {
+    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
+    const G1Affine* brp = nullptr;
+    int rc = srs_bases_rp(ctx, srs, basis, &brp);
+    if (rc) return rc;
+    const G1Affine* tab = nullptr;
+    size_t stride = 0;
+    rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
+    if (rc) return rc;
+    if (tab) return msm_batch_merged(ctx, d_scalar_ptrs, count, tab, stride, make_plan_merged(srs->k), n, h_out, stage, stage_user);
+    return msm_batch_tab(ctx, d_scalar_ptrs, count, b, brp, nullptr, 0, n, h_out, stage, stage_user);
+}
 int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
     return msm_batch_tab(ctx, d_scalar_ptrs, count, d_bases, d_bases_rp, nullptr, 0, n, h_out);
 }
-// Window table of an SRS basis for MSMs of n points, built on first use and cached on the zk_srs;
-// *out stays nullptr when the table would be too large or the plan does not match the cached one.
+// Window table of an SRS basis (table[w][i] = 2^(c w) * P_i for the merged-window plan of the SRS's
+// own k), built on first use and cached on the zk_srs; *out stays nullptr when the table would be
+// too large (beyond ZK_MSM_TABLE_GB, default 32 GiB per basis) or the MSM is tiny.
 int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const G1Affine** out, size_t* stride) {
     *out = nullptr;
     *stride = 0;
     zk_srs* s = const_cast<zk_srs*>(srs);
-    const MsmPlan pl = make_plan(n);
+    const MsmPlan pl = make_plan_merged(s->k);
     const uint64_t ns = 1ull << s->k;
     const size_t bytes = sizeof(G1Affine) * ns * pl.W;
-    if (n < 1024 || bytes > ((size_t)24 << 30)) return ZK_OK;
+    const char* env = getenv("ZK_MSM_TABLE_GB");
+    const double cap_gb = env ? atof(env) : 32.0;
+    if (n < 64 || (double)bytes > cap_gb * (double)(1ull << 30) || (uint64_t)pl.W * ns >= (1ull << 31)) return ZK_OK;
+    if (s->tab[basis] && s->tab_c[basis] != pl.c) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(s->tab[basis]); s->tab[basis] = nullptr; }   // plan changed (measurement knob)
     if (!s->tab[basis]) {
         const G1Affine* rp = nullptr;
         int rc = srs_bases_rp(ctx, srs, basis, &rp);
         if (rc) return rc;
-        if (hipMalloc(&s->tab[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tab[basis] = nullptr; return ZK_OK; }   // no memory: fall back silently
+        if (hipMalloc(&s->tab[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tab[basis] = nullptr; return ZK_OK; }   // no memory: per-window path
         s->tab_c[basis] = pl.c;
         hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tab[basis]);
         ZK_CHECK_LAUNCH(ctx);
     }
-    if (s->tab_c[basis] != pl.c) return ZK_OK;
     *out = s->tab[basis];
     *stride = ns;
     return ZK_OK;
@@ -765,3 +1042,17 @@ int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out
 }
 
 }  // namespace zk
+
+// window size / window count the commitments over this SRS use for an MSM of n points (introspection for benches)
+extern "C" int zk_msm_plan(const zk_srs* srs, size_t n, int* window_bits, int* windows) {
+    if (!srs || !window_bits || !windows) return ZK_ERR_INVALID_ARG;
+    const uint64_t ns = 1ull << srs->k;
+    const zk::MsmPlan m = zk::make_plan_merged(srs->k);
+    const char* env = getenv("ZK_MSM_TABLE_GB");
+    const double cap_gb = env ? atof(env) : 32.0;
+    const bool merged = n >= 64 && (double)(sizeof(zk::G1Affine) * ns * m.W) <= cap_gb * (double)(1ull << 30) && (uint64_t)m.W * ns < (1ull << 31);
+    const zk::MsmPlan pl = merged ? m : zk::make_plan(n);
+    *window_bits = pl.c;
+    *windows = pl.W;
+    return ZK_OK;
+}

@@ -1165,7 +1165,10 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 if (cached) pk->part_cache[r_][refs[i]] = std::move(fresh);
             }
             trace.mark("  quotient: cosets of the columns");
-            PK_TRY(run_program(ctx, part, q.g, hpart.p));
+            ctx->prof_tag = "quotient_coset";
+            const int rc_q = run_program(ctx, part, q.g, hpart.p);
+            ctx->prof_tag = nullptr;
+            PK_TRY(rc_q);
             trace.mark("  quotient: program");
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);

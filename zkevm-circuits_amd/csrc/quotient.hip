@@ -257,7 +257,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 8 * Q_THREADS * 4));
         attr_set = true;
     }
-    ZkProfScope ps(ctx, "quotient_eval");
+    ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
     hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
                        num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
     ZK_CHECK_LAUNCH(ctx);
