@@ -227,3 +227,68 @@ def test_g_to_lagrange_2_16_timing(ctx, cref):
     print(f"g_to_lagrange 2^{k - 1}: {dt * 1e3:.1f} ms")
     for s_ in (full, shrunk, ref):
         s_.destroy()
+
+
+@pytest.mark.parametrize("k", [10, 14, 16])
+def test_commit_paths_agree_with_the_oracle(ctx, cref, k):
+    """Commitments over an SRS take the merged-window path (one bucket set for all windows, over the
+    SRS's window table) or, for columns hinted as small-valued, the per-window path; both must give
+    best_multiexp's point for every scalar distribution, alone and mixed inside one pipelined batch,
+    over both bases, also for n < 2^k."""
+    n = 1 << k
+    rng = random.Random(k)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(0xABCDE + k))
+    kinds = {
+        "dense": cref.rand_fr_stream(70 + k, n),
+        "small30": cref.to_mont([rng.randrange(1 << 30) for _ in range(n)]),
+        "bytes": cref.to_mont([rng.randrange(256) for _ in range(n)]),
+        "boolean": cref.to_mont([rng.randrange(2) for _ in range(n)]),
+        "all_equal": cref.to_mont([0x1234567] * n),
+        "zero": cref.to_mont([0] * n),
+        "mostly_small": cref.to_mont([rng.randrange(R) if rng.random() < 0.01 else rng.randrange(1 << 16) for _ in range(n)]),
+        "extremes": cref.to_mont([rng.choice([R - 1, 5, 1 << 253, (1 << 20) - 1, 1 << 19]) for _ in range(n)]),
+    }
+    names = list(kinds)
+    bufs = [ctx.to_device(kinds[nm]) for nm in names]
+    ptrs = [b_.ptr for b_ in bufs]
+    for lagrange in (True, False):
+        basis = srs.download_g_lagrange() if lagrange else srs.download_g()
+        want = np.stack([cref.best_multiexp(kinds[nm], basis) for nm in names])
+        for hint in (None, [0] * len(names), [1] * len(names), [i % 2 for i in range(len(names))], [(i + 1) % 2 for i in range(len(names))]):
+            got = ctx.commit_batch(srs, ptrs, n, lagrange=lagrange, narrow=hint)
+            bad = [nm for nm, g_, w_ in zip(names, got, want) if not np.array_equal(g_, w_)]
+            assert not bad, f"hint {hint}, lagrange {lagrange}: {bad} differ from best_multiexp"
+        single = np.stack([ctx.commit(srs, b_, n, lagrange=lagrange) for b_ in bufs])
+        assert np.array_equal(single, want)
+        m = n - 3                                           # a witness polynomial of the multi-open has n - 1 coefficients
+        got = ctx.commit_batch(srs, ptrs[:2], m, lagrange=lagrange, narrow=[0, 1])
+        assert np.array_equal(got, np.stack([cref.best_multiexp(kinds[nm][:m], basis[:m]) for nm in names[:2]]))
+    plan = ctx.msm_plan(srs, n)
+    assert plan["c"] == max(8, min(k, 22)) and plan["windows"] == (256 + plan["c"] - 1) // plan["c"]
+    srs.destroy()
+
+
+def test_skewed_columns_stay_fast_on_both_paths(ctx, cref):
+    """selector-like and constant columns at 2^18 on the merged and the per-window path: one bucket
+    (or one partition of the sort) receives everything; the run time must stay flat"""
+    import time
+    k, n = 18, 1 << 18
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(77))
+    dense = ctx.to_device(cref.rand_fr_stream(5, n))
+    cols = {"boolean": cref.to_mont([i & 1 for i in range(n)]), "all_equal": cref.to_mont([R - 2] * n), "bytes": cref.to_mont([i % 251 for i in range(n)])}
+    basis = srs.download_g_lagrange()
+    ctx.commit_batch(srs, [dense.ptr], n, lagrange=True, narrow=[0])        # tables built, clocks up
+    ctx.commit_batch(srs, [dense.ptr], n, lagrange=True, narrow=[1])
+    t0 = time.perf_counter()
+    ctx.commit_batch(srs, [dense.ptr] * 4, n, lagrange=True, narrow=[0] * 4)
+    t_dense = (time.perf_counter() - t0) / 4
+    for name, col in cols.items():
+        buf = ctx.to_device(col)
+        want = cref.best_multiexp(col, basis)
+        for hint in (0, 1):
+            t0 = time.perf_counter()
+            got = ctx.commit_batch(srs, [buf.ptr] * 4, n, lagrange=True, narrow=[hint] * 4)
+            dt = (time.perf_counter() - t0) / 4
+            assert all(np.array_equal(g_, want) for g_ in got), (name, hint)
+            assert dt < 4 * t_dense + 2e-3, f"{name} on path {hint}: {dt * 1e3:.2f} ms per MSM against {t_dense * 1e3:.2f} ms for dense scalars"
+    srs.destroy()

@@ -409,6 +409,9 @@ def test_shared_subexpressions_through_intermediates(ctx, cref, srs8, s_g2):
     for cse in (False, True):
         pk = ctx.pk_create(srs8[circ.k], circ.blob(cse=cse))
         try:
+            # two exports of the SAME circuit: the caller holds one vk.transcript_repr for both (the stand-in
+            # the library derives hashes the exported programs, which differ)
+            pk.set_transcript_repr(cref.to_mont([0x5EED5EED])[0])
             com, rep = pk.vk(circ.F + len(circ.perm_cols))
             sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], seed)
             sess.set_multiopen(1)
@@ -450,7 +453,8 @@ def test_merged_and_chunked_lookups_equal_the_oracle_prover(zk, ctx, cref, srs8,
         assert (shape["degree"], shape["L"], shape["advice_queries"]) == (circ.degree(), len(circ.lookups), len(circ.advice_queries))
         gpu_proof = _session_proof(ctx, pk, adv, inst, seed, multiopen)
         bad = [list(col) for col in adv]
-        bad[1][3] = (bad[1][3] + 1) % b.R_MOD                 # an input pair that is not in the table
+        row = next(r for r in range(circ.u) if circ.fixed[0][r] == 1)      # an enabled row (the degree-2 inputs are gated by q)
+        bad[1][row] = (bad[1][row] + 1) % b.R_MOD             # an input pair that is not in the table
         with pytest.raises(zk.ZkError, match="not in the table"):
             _session_proof(ctx, pk, bad, inst, seed, multiopen)
     finally:

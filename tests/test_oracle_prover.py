@@ -88,7 +88,8 @@ def test_merged_and_chunked_lookups(n_inputs, input_degree, gate_degree, multiop
     assert pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen=multiopen)
     # an input that is not in the table cannot be proved
     bad = [list(col) for col in adv]
-    bad[1][3] = (bad[1][3] + 1) % pv.R
+    row = next(r for r in range(circ.u) if circ.fixed[0][r] == 1)
+    bad[1][row] = (bad[1][row] + 1) % pv.R
     assert pv.check_witness(circ, bad, inst) is not None
     with pytest.raises(AssertionError):
         pp.create_proof(circ, srs, bad, inst, vk_repr, bytes(16), multiopen)

@@ -1,6 +1,7 @@
 // C ABI glue (include/zkmi355.h): context, device memory, timers, and the NTT / MSM entry points.
 #include "ctx.hpp"
 #include "host_fq.hpp"
+#include "host_util.hpp"
 
 namespace zk {
 
@@ -68,6 +69,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream2b) { (void)hipStreamSynchronize(ctx->stream2b); (void)hipStreamDestroy(ctx->stream2b); }
     if (ctx->stream_aux) { (void)hipStreamSynchronize(ctx->stream_aux); (void)hipStreamDestroy(ctx->stream_aux); (void)hipEventDestroy(ctx->ev_aux); }
     if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); (void)hipEventDestroy(ctx->ev_copy); }
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
@@ -304,6 +306,12 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
     if (!ctx) return ZK_ERR_INVALID_ARG;
     return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr);
 }
+// The same with a hint per column (nullable): narrow[i] != 0 says column i holds small integers
+// (selectors, bytes, counters, lookup multiplicities) -- see zkmi355.h.
+int zk_commit_batch_hint(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, void* h_out_affine) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr, narrow);
+}
 // Same, for columns that still live in host memory: column i + 1 is uploaded on the copy stream
 // while the MSM of column i runs.  d_cols[i] (n x 32 B each) receive the uploaded columns.
 int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* h_cols, void* const* d_cols, size_t count, size_t n, void* h_out_affine) {
@@ -318,7 +326,9 @@ int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* c
         ZK_HIP(s->ctx, hipMemcpyAsync(s->d[it], s->h[it], s->bytes, hipMemcpyHostToDevice, s->ctx->stream_copy));
         return zk::copy_stream_fence(s->ctx);
     };
-    return zk::commit_batch_staged(ctx, srs, basis, (const void* const*)d_cols, count, n, h_out_affine, fn, &st);
+    std::vector<uint8_t> narrow(count);
+    zk::sample_narrow(h_cols, count, n, narrow.data());
+    return zk::commit_batch_staged(ctx, srs, basis, (const void* const*)d_cols, count, n, h_out_affine, fn, &st, narrow.data());
 }
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
@@ -336,12 +346,29 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size
 }  // extern "C"
 
 namespace zk {
-int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user) {
-    ZK_REQUIRE(ctx, srs && h_out_affine && (d_scalar_ptrs || !count), "null pointer");
+// Which columns fill only a few Pippenger windows?  Witness columns are mostly small integers
+// (bytes, flags, counters, selectors) and those take the per-window MSM path, which never touches
+// the bucket sets of empty windows; only a sample is inspected (the choice affects speed, never the
+// result).  Columns are in Montgomery form: a sampled value is converted back before it is judged.
+void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow) {
+    const size_t samples = n < 1024 ? n : 1024, step = n / (samples ? samples : 1);
+    for (size_t c = 0; c < count; ++c) {
+        const host::F4* col = (const host::F4*)h_cols[c];
+        bool small = col != nullptr;
+        for (size_t i = 0; small && i < samples; ++i) {
+            const host::F4 v = host::fr_canon(col[i * step + (i * 7 + c) % (step ? step : 1)]);
+            small = (v.l[1] | v.l[2] | v.l[3]) == 0;
+        }
+        narrow[c] = small ? 1 : 0;
+    }
+}
+int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
+    if (count == 0) return ZK_OK;            // an empty batch (a circuit without permutation columns or lookups) commits nothing
+    ZK_REQUIRE(ctx, srs && h_out_affine && d_scalar_ptrs, "null pointer");
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
-    return msm_batch_srs(ctx, srs, basis, (const Fr* const*)d_scalar_ptrs, count, n, (G1Affine*)h_out_affine, stage, stage_user);
+    return msm_batch_srs(ctx, srs, basis, (const Fr* const*)d_scalar_ptrs, count, n, (G1Affine*)h_out_affine, stage, stage_user, narrow);
 }
 int copy_stream_open(zk_ctx* ctx) {
     if (!ctx->stream_copy) {

@@ -35,7 +35,7 @@ struct zk_ctx {
     // scratch arenas, grown on demand (never shrunk): index = purpose
     zk::Scratch scratch[12];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
-    hipStream_t stream2 = nullptr;
+    hipStream_t stream2 = nullptr, stream2b = nullptr;
     hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;
@@ -149,6 +149,7 @@ struct zk_srs {
     zk::G1Affine* g_lagrange_rp = nullptr;
     // lazily built fixed-base window tables [W][2^k] (R' form) and the window size they were built for
     zk::G1Affine* tab[2] = {nullptr, nullptr};
+    zk::G1Affine* tabn[2] = {nullptr, nullptr};   // per-window tables (c <= 16) for the columns that fill few windows
     int tab_c[2] = {0, 0};
 };
 
@@ -195,8 +196,10 @@ int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const 
 typedef int (*MsmStageFn)(void* user, size_t it);
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
                   size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
-int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
-int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user);
+int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr,
+                  const uint8_t* narrow = nullptr /*per column: scalars fill few windows*/);
+int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow = nullptr);
+void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = every sampled value is below 2^64
 int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1
 int copy_stream_open(zk_ctx* ctx);      // copy stream starts after everything enqueued on the main stream so far

@@ -680,6 +680,97 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* 
     if (threadIdx.x == 0) stg(out + w, to_std_xyzz(sh[0]));
 }
 
+// ---- weighted bucket sum of the merged path: sum_b (b + 1) * B_b over 2^19 .. 2^21 buckets -----------
+// With b = g * G + j:  sum_b b B_b = sum_g [sum_j j B_{gG+j}] + G * sum_g g S_g,  S_g = sum_j B_{gG+j}:
+// every level turns `count` points into count / G group sums with two short running sums per lane
+// (2 G additions, no scalar multiplication) and one partial of the local weighted sums per
+// workgroup; the last level (<= 1024 points, one workgroup) lifts its lanes by g * G directly.
+//   result = U + A_1 + G (A_2 + G (A_3 + ... G A_last)),   U = sum of all buckets.
+// About 2.3 additions per bucket in total, against one ~19-bit scalar multiplication per lane
+// before: the reduction of a merged MSM costs a sixth of its accumulation instead of a fifth.
+constexpr int WS_G = 8;
+constexpr uint32_t WS_LAST_MAX = 1024;
+constexpr int WS_MAX_LEVELS = 8;
+__device__ __forceinline__ G1Xyzz29 block_sum29(G1Xyzz29 v, G1Xyzz29* sh) {      // 256 threads; result valid in thread 0
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    const G1Xyzz29 r = sh[0];
+    __syncthreads();
+    return r;
+}
+template <bool LAST>
+__global__ void __launch_bounds__(256) k_wsum_level(const G1Xyzz29* __restrict__ in, uint32_t count, G1Xyzz29* __restrict__ S_out, G1Xyzz29* __restrict__ Tpart, G1Xyzz29* __restrict__ U_out) {
+    __shared__ G1Xyzz29 sh[256];
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, groups = (count + WS_G - 1) / WS_G;
+    G1Xyzz29 acc = identity29(), run = identity29();
+    if (g < groups) {
+        const uint32_t b0 = g * WS_G, b1 = min(b0 + WS_G, count);
+        for (uint32_t b = b1; b-- > b0;) { acc = add29pt(acc, run); run = add29pt(run, ldg29(in + b)); }     // acc = sum_j j * in[b0 + j]
+        if (LAST) { if (b0) acc = add29pt(acc, mul_small(run, b0)); }
+        else stg29(S_out + g, run);
+    }
+    const G1Xyzz29 t = block_sum29(acc, sh);
+    if (threadIdx.x == 0) stg29(Tpart + blockIdx.x, t);
+    if (LAST) {
+        const G1Xyzz29 u = block_sum29(run, sh);
+        if (threadIdx.x == 0) stg29(U_out, u);
+    }
+}
+struct WsumPlan { int levels; uint32_t off[WS_MAX_LEVELS], cnt[WS_MAX_LEVELS]; };      // Tpart ranges per level
+__global__ void __launch_bounds__(256) k_wsum_final(const G1Xyzz29* __restrict__ Tpart, WsumPlan pl, const G1Xyzz29* __restrict__ U, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz29 sh[256];
+    G1Xyzz29 T = identity29();
+    for (int lv = pl.levels - 1; lv >= 0; --lv) {
+        G1Xyzz29 a = identity29();
+        for (uint32_t i = threadIdx.x; i < pl.cnt[lv]; i += 256) a = add29pt(a, ldg29(Tpart + pl.off[lv] + i));
+        a = block_sum29(a, sh);
+        if (threadIdx.x == 0) {
+            if (lv != pl.levels - 1) { for (int d = 1; d < WS_G; d <<= 1) T = dbl29pt(T); }       // * G
+            T = add29pt(T, a);
+        }
+    }
+    if (threadIdx.x == 0) stg(out, to_std_xyzz(add29pt(T, ldg29(U))));
+}
+// enqueue the whole reduction of `buckets[nb]` on stream `st`; scratch: >= nb / 4 + 1024 points
+static int wsum_enqueue(zk_ctx* ctx, hipStream_t st, const G1Xyzz29* buckets, uint32_t nb, G1Xyzz29* scratch, G1Xyzz* out) {
+    WsumPlan pl;
+    pl.levels = 0;
+    uint32_t tparts = 0, count = nb;
+    // layout of scratch: [U][Tparts ...][S level 1][S level 2]...
+    uint32_t t_total = 1;
+    for (uint32_t c_ = nb; ; ) {
+        const uint32_t groups = (c_ + WS_G - 1) / WS_G;
+        t_total += c_ <= WS_LAST_MAX ? 1 : (groups + 255) / 256;
+        if (c_ <= WS_LAST_MAX) break;
+        c_ = groups;
+    }
+    G1Xyzz29* U = scratch;
+    G1Xyzz29* Tpart = scratch + 1;
+    G1Xyzz29* S = scratch + t_total;
+    const G1Xyzz29* in = buckets;
+    while (count > WS_LAST_MAX) {
+        if (pl.levels >= WS_MAX_LEVELS - 1) return ctx->fail(ZK_ERR_UNSUPPORTED, "bucket reduction: too many levels");
+        const uint32_t groups = (count + WS_G - 1) / WS_G, blocks = (groups + 255) / 256;
+        pl.off[pl.levels] = tparts; pl.cnt[pl.levels] = blocks;
+        hipLaunchKernelGGL((k_wsum_level<false>), dim3(blocks), dim3(256), 0, st, in, count, S, Tpart + tparts, (G1Xyzz29*)nullptr);
+        tparts += blocks;
+        ++pl.levels;
+        in = S;
+        S += groups;
+        count = groups;
+    }
+    pl.off[pl.levels] = tparts; pl.cnt[pl.levels] = 1;
+    hipLaunchKernelGGL((k_wsum_level<true>), dim3(1), dim3(256), 0, st, in, count, (G1Xyzz29*)nullptr, Tpart + tparts, U);
+    ++pl.levels;
+    hipLaunchKernelGGL(k_wsum_final, dim3(1), dim3(256), 0, st, (const G1Xyzz29*)Tpart, pl, (const G1Xyzz29*)U, out);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
 // bases_rp: device bases already in R' form (SRS cache) or nullptr -> converted into scratch
 // d_table (nullable): fixed-base window table for exactly this plan (W windows of tab_stride points)
 int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, const G1Affine* d_table, size_t tab_stride,
@@ -826,6 +917,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it * pl.W, red_W, pl.c, h_out + it);
     return ZK_OK;
 }
+#define PK_TRY_MSM(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 // ---- merged-window MSM over an SRS window table ----------------------------------------------------
 static MsmPlan make_plan_merged(uint32_t k_srs) {
     int c = (int)k_srs;
@@ -849,10 +941,30 @@ static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars
 }
 // d_table: [W][tab_stride] affine points, table[w][i] = 2^(c w) * P_i in R' form, built for plan `pl`.
 // Same pipelining as msm_batch_tab: the reduction of MSM i runs on the side stream under MSM i + 1.
+// narrow[it] != 0 (with d_table_n, the per-window table of plan pl_n): column `it` is expected to fill
+// only a few windows (witness columns of small values, selectors, lookup multiplicities) and takes the
+// per-window path -- bucket sets of empty windows are never touched there, whereas the merged path
+// always pays for its 2^(c-1) shared buckets.  The two paths alternate freely inside one pipelined batch.
 int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_table, size_t tab_stride, const MsmPlan& pl,
-                     size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user) {
+                     size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const G1Affine* d_table_n = nullptr, const MsmPlan* pl_n = nullptr, const uint8_t* narrow = nullptr) {
     if (count == 0) return ZK_OK;
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
+    bool any_narrow = false;
+    if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] != 0;
+    // ---- per-window ("narrow") path: sizes and workspace, as in msm_batch_tab with a window table
+    const MsmPlan pn = any_narrow ? *pl_n : MsmPlan{4, 64, 8};
+    const uint32_t nbN = (uint32_t)pn.W * pn.B;
+    const uint32_t scan_blocks_N = (nbN + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), scan_blocks_sN = (nbN + SCAN_T - 1) / SCAN_T;
+    const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
+    const size_t dig_words = (size_t)(n_pad * pn.W + 1) / 2 + 4;
+    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * pn.W;
+    const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
+    if (any_narrow && (uint64_t)n * pn.W >= (1ull << 32)) any_narrow = false;
+    int range_bits_N = pn.c - 1;
+    if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
+    const uint32_t red_blocks_N = ((pn.B + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
+    const size_t max_tasks_N = (size_t)nbN + std::max(((size_t)n * pn.W) / TASK_CAP, (size_t)TASK_TARGET) + 1;
+    const size_t npts29_N = any_narrow ? (size_t)nbN + red_blocks_N + max_tasks_N + pn.B : 0;
     const uint32_t nb = pl.B;
     const uint64_t max_entries = (uint64_t)n * pl.W;
     // table indices carry the sign in bit 31, cursors are 32-bit
@@ -868,7 +980,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] | counts[nb] | size_hist[256] nmulti[4] pad[64] | offsets[nb+1] | order[nb] |
     //                ntasks[nb] | toff[nb+1] | block_tot[...] | hist[hist_cnt] | hist_off[hist_cnt + 1] | idx[n W] | (8-B aligned) entries[n W] u64
     const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
-    const size_t words = head_words + 4 + 2 * max_entries;
+    const size_t words = std::max(head_words + 4 + 2 * max_entries, words_N);
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* slice_counts = ws;
@@ -887,15 +999,14 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     uint32_t* hist_off = hist + hist_cnt;
     uint32_t* idx = hist_off + hist_cnt + 1;
     uint64_t* entries = reinterpret_cast<uint64_t*>(ws + ((head_words + 3) & ~(size_t)3));
-    const bool lone = count == 1;                 // a lone MSM waits for its reduction: shorter chains
-    const int red_g = lone ? RED_G_WIDE : RED_G_MERGED;
-    const uint32_t red_blocks = ((nb + red_g - 1) / red_g + RED_THREADS - 1) / RED_THREADS;
+    const uint32_t red_pts = nb / 4 + 1024;       // scratch of the weighted bucket sum (group sums of every level, partials)
     const size_t max_tasks = (size_t)nb + std::max((size_t)(max_entries / TASK_CAP), (size_t)TASK_TARGET) + 1;
-    const size_t npts29 = (size_t)nb + red_blocks + max_tasks;
+    const size_t npts29 = std::max((size_t)nb + red_pts + max_tasks, npts29_N);
     char* bkbuf[2];
     bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
     bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
-    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count);
+    // one window sum per MSM, then one private copy of the window flags per MSM of the per-window path
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count + 256 * count);
     if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -904,14 +1015,88 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
         }
     }
+    // The reductions of consecutive MSMs alternate between two side streams: each is a chain of short
+    // launches (latency, not throughput), and with witness columns that fill few windows it can take
+    // longer than the sort + accumulation of the next column.
+    if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
     for (size_t it = 0; it < count; ++it) {
         const int par = (int)(it & 1);
+        hipStream_t side = par ? ctx->stream2b : ctx->stream2;
         const Fr* d_scalars = d_scalar_ptrs[it];
         G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
         G1Xyzz29* partial = buckets + nb;
-        G1Xyzz29* task_partial = partial + red_blocks;
+        G1Xyzz29* task_partial = partial + red_pts;
         if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
+        if (any_narrow && narrow[it]) {
+            // ---- per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with
+            // empty windows skipped, bucket accumulation, fold of the occupied windows, one window reduced
+            uint32_t* slice_countsN = ws;
+            uint32_t* slice_offN = slice_countsN + (size_t)nbN * MSM_SLICES;
+            uint32_t* countsN = slice_offN + (size_t)nbN * MSM_SLICES + 4;
+            uint32_t* size_histN = countsN + nbN;
+            uint32_t* nmultiN = size_histN + SIZE_BINS;
+            uint32_t* wflag = nmultiN + 4;
+            uint32_t* offsetsN = wflag + 64;
+            uint32_t* orderN = offsetsN + nbN + 1;
+            uint32_t* ntasksN = orderN + nbN;
+            uint32_t* toffN = ntasksN + nbN;
+            uint32_t* block_totN = toffN + nbN + 1;
+            uint32_t* block_tot2N = block_totN + scan_blocks_sN;
+            uint32_t* idxN = block_tot2N + scan_blocks_N;
+            uint16_t* dig = reinterpret_cast<uint16_t*>(ws + ((head_words_N + 3) & ~(size_t)3));
+            G1Xyzz29* partialN = buckets + nbN;
+            G1Xyzz29* task_partialN = partialN + red_blocks_N;
+            G1Xyzz29* folded = task_partialN + max_tasks_N;
+            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
+            const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
+            {
+                ZkProfScope ps(ctx, "msm_sort");
+                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
+                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
+                hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
+                ZK_CHECK_LAUNCH(ctx);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_totN, scan_blocks_sN, slice_offN, nbN * MSM_SLICES, offsetsN + nbN);
+                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_sN), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_countsN, nbN, slice_offN, (const uint32_t*)block_totN, offsetsN, countsN, size_histN);
+                hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_histN, (const uint32_t*)(offsetsN + nbN));
+                hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)countsN, nbN, size_histN, orderN, ntasksN);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasksN, nbN, toffN, block_tot2N);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2N, scan_blocks_N, toffN, nbN, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, nbN, toffN, (const uint32_t*)block_tot2N);
+                ZK_CHECK_LAUNCH(ctx);
+                hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)slice_offN, idxN, (const uint32_t*)wflag, (uint32_t)pn.W);
+                ZK_CHECK_LAUNCH(ctx);
+            }
+            ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            {
+                ZkProfScope ps(ctx, "msm_buckets_narrow");
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)offsetsN, (const uint32_t*)idxN,
+                                   (const uint32_t*)orderN, (const uint32_t*)toffN, (const uint32_t*)nmultiN, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
+            }
+            {
+                ZkProfScope ps(ctx, "msm_combine");
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)toffN, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3((nbN + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
+                hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
+                ZK_CHECK_LAUNCH(ctx);
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
+            ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
+            {
+                ZkProfScope ps(ctx, "msm_reduce_narrow", side);
+                hipLaunchKernelGGL(k_msm_fold_windows, dim3((pn.B + 63) / 64), dim3(256), 0, side, (const G1Xyzz29*)buckets, pn.B, pn.W, folded, (const uint32_t*)wflag_it);
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)folded, pn.B, partialN);
+                ZK_CHECK_LAUNCH(ctx);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, red_blocks_N, wsum_all + it);
+                ZK_CHECK_LAUNCH(ctx);
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
+            if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+            continue;
+        }
         {
             ZkProfScope ps(ctx, "msm_sort");
             ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
@@ -954,16 +1139,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_CHECK_LAUNCH(ctx);
         }
         ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
-        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_p1[par], 0));
-        {   // weighted bucket sum on the side stream: hides under the next MSM
-            ZkProfScope ps(ctx, "msm_reduce", ctx->stream2);
-            if (lone) hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks, 1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, nb, partial);
-            else hipLaunchKernelGGL((k_msm_reduce<RED_G_MERGED>), dim3(red_blocks, 1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)buckets, nb, partial);
-            ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, ctx->stream2, (const G1Xyzz29*)partial, red_blocks, wsum_all + it);
-            ZK_CHECK_LAUNCH(ctx);
+        ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
+        {   // weighted bucket sum on a side stream: hides under the next MSMs
+            ZkProfScope ps(ctx, "msm_reduce", side);
+            PK_TRY_MSM(wsum_enqueue(ctx, side, buckets, nb, partial, wsum_all + it));
         }
-        ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], ctx->stream2));
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
         if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
     }
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
@@ -974,9 +1155,33 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
     return ZK_OK;
 }
+// Per-window table of an SRS basis (plan make_plan(2^k): c = k - 4 <= 16), for the columns that fill
+// few windows; built on first use like the merged one.
+static int srs_window_table_narrow(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const G1Affine** out, MsmPlan* plan) {
+    *out = nullptr;
+    zk_srs* s = const_cast<zk_srs*>(srs);
+    const uint64_t ns = 1ull << s->k;
+    const MsmPlan pl = make_plan(ns);
+    *plan = pl;
+    const size_t bytes = sizeof(G1Affine) * ns * pl.W;
+    const char* env = getenv("ZK_MSM_TABLE_GB");
+    const double cap_gb = env ? atof(env) : 32.0;
+    if (n < 1024 || (double)bytes > cap_gb * (double)(1ull << 30)) return ZK_OK;
+    if (!s->tabn[basis]) {
+        const G1Affine* rp = nullptr;
+        int rc = srs_bases_rp(ctx, srs, basis, &rp);
+        if (rc) return rc;
+        if (hipMalloc(&s->tabn[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tabn[basis] = nullptr; return ZK_OK; }
+        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tabn[basis]);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    *out = s->tabn[basis];
+    return ZK_OK;
+}
 // commitments over an SRS basis: the merged-window path when the basis has (or can get) its window
-// table, the per-window path otherwise
-int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user) {
+// table -- columns flagged `narrow` take the per-window path over their own table --, the plain
+// per-window path otherwise.  ZK_MSM_NARROW=0 / 1 overrides the flags (measurement knob).
+int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     const G1Affine* brp = nullptr;
     int rc = srs_bases_rp(ctx, srs, basis, &brp);
@@ -985,8 +1190,15 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
     size_t stride = 0;
     rc = srs_window_table(ctx, srs, basis, n, &tab, &stride);
     if (rc) return rc;
-    if (tab) return msm_batch_merged(ctx, d_scalar_ptrs, count, tab, stride, make_plan_merged(srs->k), n, h_out, stage, stage_user);
-    return msm_batch_tab(ctx, d_scalar_ptrs, count, b, brp, nullptr, 0, n, h_out, stage, stage_user);
+    if (!tab) return msm_batch_tab(ctx, d_scalar_ptrs, count, b, brp, nullptr, 0, n, h_out, stage, stage_user);
+    std::vector<uint8_t> forced;
+    if (const char* e = getenv("ZK_MSM_NARROW")) { forced.assign(count, (uint8_t)(atoi(e) != 0)); narrow = forced.data(); }
+    bool any = false;
+    if (narrow) for (size_t i = 0; i < count; ++i) any |= narrow[i] != 0;
+    const G1Affine* tabn = nullptr;
+    MsmPlan pln{};
+    if (any) { rc = srs_window_table_narrow(ctx, srs, basis, n, &tabn, &pln); if (rc) return rc; }
+    return msm_batch_merged(ctx, d_scalar_ptrs, count, tab, stride, make_plan_merged(srs->k), n, h_out, stage, stage_user, tabn, &pln, tabn ? narrow : nullptr);
 }
 int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
     return msm_batch_tab(ctx, d_scalar_ptrs, count, d_bases, d_bases_rp, nullptr, 0, n, h_out);

@@ -372,8 +372,9 @@ void push_perm_col(PB& b, const std::pair<uint32_t, uint32_t>& c) { b.col(c.firs
 // `count` commitments over one basis, split over the ranks of a sharded session: rank r commits
 // columns i = r, r + world, ... (pipelined batch) and the 64-byte points are all-gathered, so every
 // rank ends up with all of them in order and the transcripts stay identical.
-int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out) {
-    if (pr->world <= 1 || !pr->gather) return zk_commit_batch(ctx, srs, basis, ptrs, count, n, out);
+int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out, bool narrow = false) {
+    const std::vector<uint8_t> hint(count, narrow ? 1 : 0);
+    if (pr->world <= 1 || !pr->gather) return commit_batch_staged(ctx, srs, basis, ptrs, count, n, out, nullptr, nullptr, hint.data());
     if (count < pr->world && n >= ((size_t)pr->world << 10)) {
         // Fewer columns than ranks (aggregation layers: ~10 columns at k = 22..25, h pieces, the closing
         // commitments): shard every MSM by POINTS instead -- rank r takes the r-th slice of the bases of
@@ -398,7 +399,7 @@ int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis
     for (size_t i = pr->rank; i < count; i += pr->world) mine.push_back(ptrs[i]);
     std::vector<G1Affine> local(per), all(per * pr->world);
     memset((void*)local.data(), 0, sizeof(G1Affine) * per);
-    PK_TRY(zk_commit_batch(ctx, srs, basis, mine.data(), mine.size(), n, local.data()));
+    PK_TRY(commit_batch_staged(ctx, srs, basis, mine.data(), mine.size(), n, local.data(), nullptr, nullptr, hint.data()));
     if (per && pr->gather(pr->gather_user, local.data(), per * sizeof(G1Affine), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
     for (size_t i = 0; i < count; ++i) out[i] = all[(i % pr->world) * per + i / pr->world];
     return ZK_OK;
@@ -786,19 +787,22 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         return ZK_OK;
     };
     std::vector<G1Affine> coms(sg.dst.size());
+    std::vector<uint8_t> narrow(sg.src.size());
+    sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of small values take the per-window MSM path
     if (sg.world == 1) {
-        PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg));
+        PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg, narrow.data()));
     } else {
         const size_t total = sg.dst.size(), per = (total + sg.world - 1) / sg.world;
         std::vector<const void*> mine;
-        for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) mine.push_back(sg.dst[c_]);
+        std::vector<uint8_t> mine_narrow;
+        for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) { mine.push_back(sg.dst[c_]); mine_narrow.push_back(narrow[c_]); }
         std::vector<G1Affine> local(per), all(per * sg.world);
         memset((void*)local.data(), 0, sizeof(G1Affine) * per);
         if (pr->gather_dev) {
             // Device all-gather mode: this rank uploads only ITS columns (1/world of the PCIe traffic),
             // commits them, and the ranks then exchange the columns group by group over the fabric.
             for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) sg.own.push_back(c_);
-            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));
+            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg, mine_narrow.data()));
             DevBuf gbuf, zero;
             if (!gbuf.alloc((size_t)sg.world * n * 32) || !zero.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
             ZK_HIP(ctx, hipMemsetAsync(zero.p, 0, n * 32, ctx->stream));
@@ -818,7 +822,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
                 }
             }
         } else {
-            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg));   // MSM j reads group j of `world` columns
+            PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg, mine_narrow.data()));   // MSM j reads group j of `world` columns
             for (size_t grp = mine.size(); grp * sg.world < total; ++grp) PK_TRY(stage(&sg, grp));                   // a last group without a column of this rank
         }
         PK_TRY(zk_ctx_sync(ctx));
@@ -900,7 +904,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (st[l] != 0xFFFFFFFFu) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %u is not in the table (witness does not satisfy the circuit)", l, st[l]);
         trace.mark("  lookup: m (all lookups)");
         std::vector<G1Affine> coms(pk->L);
-        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data(), true));      // multiplicities are small counts
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup m");
