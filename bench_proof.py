@@ -473,6 +473,7 @@ def main():
     ap.add_argument("--large", action="store_true", help="vectorised builder (k >= 18, many columns)")
     ap.add_argument("--shplonk", action="store_true", help="SHPLONK multi-open instead of GWC")
     ap.add_argument("--host-upload", action="store_true", help="sharded runs: every rank uploads every advice column (no device all-gather)")
+    ap.add_argument("--rccl", action="store_true", help="sharded runs: exchange through the library's own RCCL communicator (zk_comm_init) instead of torch.distributed callbacks")
     ap.add_argument("--pinned", action="store_true", help="advice columns in page-locked host memory (zk_host_alloc)")
     ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle's MSM / NTT at 2^k on the host and scale by the prover's counts")
     ap.add_argument("--keccak", action="store_true", help="Keccak-circuit stand-in (SURVEY 8d config 3): 59 unusable rows, 13-rotation gates, degree 9")
@@ -508,7 +509,10 @@ def main():
         inst_m = [plonk.column_to_mont(c) for c in inst]
     t_build = time.perf_counter() - t0
     hook = None
-    if world > 1:      # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
+    if world > 1 and args.rccl:
+        shard.comm_init_from_torch(ctx)
+        hook = lambda sess: sess.set_sharding_comm()
+    elif world > 1:    # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
         hook = (lambda sess: shard.shard_session(sess)) if args.host_upload else (lambda sess: shard.shard_session_device(sess))
     out = proof_bench(ctx, args.k, circ, blob, adv_m, inst_m, inst, shplonk=args.shplonk, repeat=args.repeat, verify=not args.no_verify, pinned=args.pinned,
                       t_build=t_build, session_hook=hook, barrier=(dist.barrier if world > 1 else None), report=(rank == 0), world=world)

@@ -102,6 +102,8 @@ int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega)
  * block p of d_send goes to rank p, block p of d_recv comes from rank p (RCCL all_to_all_single
  * over xGMI, see zkevm-circuits_amd/sharding.py); it must return 0 with d_recv complete.
  * world: power of two <= 16, 2^log_n >= world^2.  inverse = 1 applies omega^-1 and 1/n.
+ * exchange == NULL: the context's own RCCL communicator does the all-to-all (zk_comm_init), with
+ * no host synchronisation between the local transform, the exchange and the cross butterflies.
  * Worth it only for transforms far above 2^24: a 2^20 NTT takes 0.12 ms on one GPU.             */
 typedef int (*zk_alltoall_fn)(void* user, const void* d_send, size_t bytes_per_peer, void* d_recv);
 int zk_ntt_sharded(zk_ctx* ctx, void* d_local, uint32_t log_n, int inverse, uint32_t rank, uint32_t world, zk_alltoall_fn exchange, void* user);
@@ -329,6 +331,22 @@ int zk_proof_set_transcript(zk_ctx* ctx, zk_proof* proof, const zk_transcript_vt
  * Call between zk_proof_begin and the first advice phase.                                          */
 typedef int (*zk_allgather_fn)(void* user, const void* h_send, size_t bytes, void* h_recv);
 int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* proof, uint32_t rank, uint32_t world, zk_allgather_fn gather, void* user);
+/* ---- collectives inside the library: RCCL over xGMI, one process per GPU (csrc/comm.hip) ----------
+ * For host languages without a collective library of their own (the Rust shim): rank 0 makes a
+ * 128-byte unique id (zk_comm_unique_id) and hands it to every rank by any out-of-band channel;
+ * zk_comm_init joins the communicator (ncclCommInitRank) on the context's device.  After that
+ *   zk_proof_set_sharding_comm   shards a proving session over the communicator: commitments
+ *                                all-gathered per transcript round, advice columns and finished
+ *                                quotient cosets device to device, everything stream-ordered;
+ *   zk_ntt_sharded(.., NULL, NULL) uses one grouped ncclSend / ncclRecv all-to-all;
+ *   zk_comm_allgather / _alltoall  are the raw collectives over device buffers.
+ * librccl is loaded on first use; a single-GPU deployment never needs it.                          */
+int zk_comm_unique_id(void* out128);
+int zk_comm_init(zk_ctx* ctx, const void* id128, uint32_t rank, uint32_t world);
+int zk_comm_destroy(zk_ctx* ctx);
+int zk_comm_allgather(zk_ctx* ctx, const void* d_send, size_t bytes, void* d_recv);
+int zk_comm_alltoall(zk_ctx* ctx, const void* d_send, size_t bytes_per_peer, void* d_recv);
+int zk_proof_set_sharding_comm(zk_ctx* ctx, zk_proof* proof);
 /* Optional, after zk_proof_set_sharding: an all-gather of DEVICE buffers (same signature, device
  * pointers; RCCL over xGMI).  Each rank then uploads only its own 1/world of the advice columns and
  * the ranks exchange them over the fabric, instead of every rank pulling every column over its own

@@ -96,3 +96,30 @@ int main() {
         assert "ctx ok k=4 file=2308 back=4 same_g2=1" in out
     else:
         assert "error -4" in out and "no CPU fallback" in out
+
+
+def test_rust_ffi_block_matches_the_header():
+    """shim/halo2_proofs/src/zkmi355/ffi.rs (the Rust side of the boundary; cannot be compiled here)
+    declares a subset of include/zkmi355.h: every function must exist in the header with the same
+    number of parameters, and the library must export it."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    rust = open(os.path.join(root, "shim", "halo2_proofs", "src", "zkmi355", "ffi.rs")).read()
+    header = open(os.path.join(root, "include", "zkmi355.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    block = rust[rust.index('extern "C" {'):]
+    fns = re.findall(r"pub fn (zk_\w+)\((.*?)\)", block, flags=re.S)
+    assert len(fns) >= 20
+    import zkevm_circuits_amd as z
+    lib = z.lib()
+    for name, params in fns:
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert m, f"{name} is declared in ffi.rs but not in zkmi355.h"
+        n_rust = len([p_ for p_ in params.split(",") if p_.strip()])
+        c_params = m.group(1).strip()
+        n_c = 0 if c_params in ("", "void") else len(c_params.split(","))
+        assert n_rust == n_c, f"{name}: {n_rust} parameters in ffi.rs, {n_c} in the header"
+        assert hasattr(lib, name), f"{name} is not exported by libzkmi355.so"
+    # the vtable has the header's five callbacks in the header's order
+    order = re.findall(r"pub (\w+): unsafe extern", rust)
+    assert order == ["common_point", "common_scalar", "write_point", "write_scalar", "squeeze_challenge"]

@@ -291,6 +291,10 @@ class ProofSession:
         self._gather_cb = allgather_cb          # keep the ctypes thunk alive
         self.ctx._ck(lib().zk_proof_set_sharding(self.ctx.h, self.h, ctypes.c_uint32(rank), ctypes.c_uint32(world), allgather_cb, None))
 
+    def set_sharding_comm(self):
+        """shard this session over the context's own RCCL communicator (Context.comm_init)"""
+        self.ctx._ck(lib().zk_proof_set_sharding_comm(self.ctx.h, self.h))
+
     def set_device_gather(self, allgather_dev_cb):
         """After set_sharding: exchange the advice columns with a device all-gather (RCCL) instead of
         uploading every column on every rank; allgather_dev_cb is a sharding.ALLGATHER_FN over device pointers."""
@@ -475,6 +479,28 @@ class Context:
 
     def host_unregister(self, arr: np.ndarray):
         self._ck(lib().zk_host_unregister(self.h, ctypes.c_void_p(arr.ctypes.data)))
+
+    # ---- in-library RCCL collectives (csrc/comm.hip)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        out = ctypes.create_string_buffer(128)
+        rc = lib().zk_comm_unique_id(out)
+        if rc != 0:
+            raise ZkError(f"zk_comm_unique_id failed with status {rc} (librccl missing?)")
+        return out.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._ck(lib().zk_comm_init(self.h, ctypes.c_char_p(unique_id), ctypes.c_uint32(rank), ctypes.c_uint32(world)))
+
+    def comm_destroy(self):
+        self._ck(lib().zk_comm_destroy(self.h))
+
+    def comm_allgather(self, send: DeviceBuffer, nbytes: int, recv: DeviceBuffer):
+        self._ck(lib().zk_comm_allgather(self.h, ctypes.c_void_p(send.ptr), ctypes.c_size_t(nbytes), ctypes.c_void_p(recv.ptr)))
+
+    def comm_alltoall(self, send: DeviceBuffer, bytes_per_peer: int, recv: DeviceBuffer):
+        self._ck(lib().zk_comm_alltoall(self.h, ctypes.c_void_p(send.ptr), ctypes.c_size_t(bytes_per_peer), ctypes.c_void_p(recv.ptr)))
 
     def msm_plan(self, srs, n: int) -> dict:
         c, w = ctypes.c_int(), ctypes.c_int()

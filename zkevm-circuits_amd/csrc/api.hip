@@ -68,6 +68,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& s : ctx->scratch) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    zk::comm_release(ctx);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->stream2b) { (void)hipStreamSynchronize(ctx->stream2b); (void)hipStreamDestroy(ctx->stream2b); }
     if (ctx->stream_aux) { (void)hipStreamSynchronize(ctx->stream_aux); (void)hipStreamDestroy(ctx->stream_aux); (void)hipEventDestroy(ctx->ev_aux); }

@@ -33,7 +33,7 @@ struct zk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
     // scratch arenas, grown on demand (never shrunk): index = purpose
-    zk::Scratch scratch[12];
+    zk::Scratch scratch[13];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
     hipStream_t stream2 = nullptr, stream2b = nullptr;
     hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
@@ -43,6 +43,9 @@ struct zk_ctx {
     // auxiliary compute stream: transforms of freshly uploaded columns run beside the commitment pipeline
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_aux = nullptr;
+    // RCCL communicator of this rank (comm.hip; opaque here so that rccl.h stays out of the other translation units)
+    void* comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 1;
     std::map<uint64_t, std::shared_ptr<zk::NttDomain>> domains;   // key: log_n | kind << 8
     std::map<uint64_t, void*> pow_tables;                         // cached two-level power tables of the coset generators
     std::vector<void*> pinned;   // small pinned host staging buffers
@@ -171,7 +174,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);
@@ -202,6 +205,11 @@ int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* c
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = every sampled value is below 2^64
 int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1
+bool comm_ready(const zk_ctx* ctx);                                                              // comm.hip: in-library RCCL collectives
+int comm_allgather_dev(zk_ctx* ctx, const void* d_send, size_t bytes, void* d_recv);             // stream-ordered, no host sync
+int comm_allgather_host(zk_ctx* ctx, const void* h_send, size_t bytes, void* h_recv);           // small host buffers, returns complete
+int comm_alltoall_dev(zk_ctx* ctx, const void* d_send, size_t bytes_per_peer, void* d_recv);
+void comm_release(zk_ctx* ctx);
 int copy_stream_open(zk_ctx* ctx);      // copy stream starts after everything enqueued on the main stream so far
 int copy_stream_fence(zk_ctx* ctx);     // main stream continues after everything enqueued on the copy stream so far
 }  // namespace zk

@@ -563,7 +563,8 @@ __global__ void __launch_bounds__(256) k_ntt_cross(const Fr* __restrict__ recv, 
 using namespace zk;
 extern "C" int zk_ntt_sharded(zk_ctx* ctx, void* d_local, uint32_t log_n, int inverse, uint32_t rank, uint32_t world, zk_alltoall_fn exchange, void* user) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, d_local && exchange, "null pointer");
+    ZK_REQUIRE(ctx, d_local, "null pointer");
+    ZK_REQUIRE(ctx, exchange || world == 1 || (comm_ready(ctx) && ctx->comm_world == world && ctx->comm_rank == rank), "no all-to-all callback and no matching communicator (zk_comm_init)");
     ZK_REQUIRE(ctx, world >= 1 && world <= 16 && (world & (world - 1)) == 0 && rank < world, "world must be a power of two <= 16, rank < world");
     ZK_REQUIRE(ctx, log_n <= 28, "log_n exceeds the two-adicity of Fr (28)");
     uint32_t log_w = 0;
@@ -583,9 +584,17 @@ extern "C" int zk_ntt_sharded(zk_ctx* ctx, void* d_local, uint32_t log_n, int in
     Fr* d_tw = (Fr*)ctx->pool_get(16 * sizeof(Fr));
     if (!recv || !d_tw) { ctx->pool_put(recv, m * sizeof(Fr)); ctx->pool_put(d_tw, 16 * sizeof(Fr)); return ctx->fail(ZK_ERR_OOM, "sharded NTT: exchange buffer of %zu bytes", m * sizeof(Fr)); }
     auto done = [&](int code) { ctx->pool_put(recv, m * sizeof(Fr)); ctx->pool_put(d_tw, 16 * sizeof(Fr)); return code; };
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
-    if (exchange(user, d_local, cols * sizeof(Fr), recv) != 0) return done(ctx->fail(ZK_ERR_INVALID_ARG, "sharded NTT: the all-to-all callback failed"));
+    hipError_t e = hipSuccess;
+    if (exchange) {
+        e = hipStreamSynchronize(ctx->stream);       // a callback runs on the caller's own stream
+        if (e != hipSuccess) return done(ctx->fail(ZK_ERR_HIP, "sharded NTT: %s", hipGetErrorString(e)));
+        if (exchange(user, d_local, cols * sizeof(Fr), recv) != 0) return done(ctx->fail(ZK_ERR_INVALID_ARG, "sharded NTT: the all-to-all callback failed"));
+    } else {
+        // in-library RCCL: W - 1 grouped send / receive pairs on this stream, no host synchronisation between
+        // the local transform, the exchange and the cross butterflies
+        rc = comm_alltoall_dev(ctx, d_local, cols * sizeof(Fr), recv);
+        if (rc) return done(rc);
+    }
     // step 4: W-point transforms across the received rows, 1/n folded in for the inverse
     Fr tw[8];
     tw[0] = Fr::one();

@@ -172,6 +172,7 @@ struct zk_proof {
     uint32_t rank = 0, world = 1;
     zk_allgather_fn gather = nullptr;
     void* gather_user = nullptr;
+    bool use_comm = false;                   // exchanges go through the context's RCCL communicator (zk_proof_set_sharding_comm)
     zk_allgather_fn gather_dev = nullptr;    // optional: all-gather of DEVICE buffers (RCCL over xGMI) for the advice columns
     void* gather_dev_user = nullptr;
     std::vector<F4> challenges;
@@ -649,6 +650,27 @@ int zk_proof_set_sharding(zk_ctx* ctx, zk_proof* pr, uint32_t rank, uint32_t wor
     ZK_REQUIRE(ctx, pr && world >= 1 && rank < world && (world == 1 || gather), "need rank < world and an all-gather callback");
     ZK_REQUIRE(ctx, pr->phase == 0, "sharding must be set before the first advice phase");
     pr->rank = rank; pr->world = world; pr->gather = gather; pr->gather_user = user;
+    return ZK_OK;
+}
+
+// Sharded session over the context's own RCCL communicator (zk_comm_init): rank and world come from it,
+// commitments are all-gathered through a device staging buffer, advice columns and finished quotient
+// cosets device to device over xGMI -- no callback, no host-language collective needed.
+static int comm_gather_host_thunk(void* user, const void* send, size_t bytes, void* recv) { return comm_allgather_host((zk_ctx*)user, send, bytes, recv); }
+static int comm_gather_dev_thunk(void* user, const void* d_send, size_t bytes, void* d_recv) {
+    zk_ctx* c = (zk_ctx*)user;
+    const int rc = comm_allgather_dev(c, d_send, bytes, d_recv);
+    return rc ? rc : (hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZK_ERR_HIP);     // the callback contract: complete on return
+}
+int zk_proof_set_sharding_comm(zk_ctx* ctx, zk_proof* pr) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr, "null pointer");
+    ZK_REQUIRE(ctx, comm_ready(ctx), "no communicator on this context: call zk_comm_init first");
+    ZK_REQUIRE(ctx, pr->phase == 0, "sharding must be set before the first advice phase");
+    pr->rank = ctx->comm_rank; pr->world = ctx->comm_world;
+    pr->gather = comm_gather_host_thunk; pr->gather_user = ctx;
+    pr->gather_dev = comm_gather_dev_thunk; pr->gather_dev_user = ctx;
+    pr->use_comm = true;
     return ZK_OK;
 }
 
@@ -1141,7 +1163,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         const bool sharded = pr->world > 1 && pr->gather;
         const Fr one_fr = Fr::one();
         std::vector<uint8_t> send, recv;
-        DevBuf rtmp;
+        DevBuf rtmp, gbuf;
         if (sharded) {
             send.assign(n * 32, 0);
             recv.resize((size_t)pr->world * n * 32);
@@ -1181,7 +1203,16 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &vinv, h.p, nparts, r_));
           }
             g = g * w_ext;
-            if (sharded && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
+            if (sharded && pr->use_comm && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
+                // in-library RCCL: the finished cosets go device to device, stream-ordered (no host copy, no synchronisation)
+                const uint32_t round0 = r_ - r_ % pr->world;
+                if (!gbuf.p && !gbuf.alloc((size_t)pr->world * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                PK_TRY(comm_allgather_dev(ctx, hpart.p, n * 32, gbuf.p));
+                for (uint32_t q_ = 0; q_ < pr->world; ++q_) {
+                    if (q_ == pr->rank || round0 + q_ >= nparts) continue;
+                    PK_TRY(zk_fr_scatter_scaled(ctx, (char*)gbuf.p + (size_t)q_ * n * 32, n, &one_fr, h.p, nparts, round0 + q_));
+                }
+            } else if (sharded && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
                 const uint32_t round0 = r_ - r_ % pr->world;                        // first coset of this round
                 if (round0 + pr->rank < nparts) PK_TRY(zk_d2h(ctx, send.data(), hpart.p, n * 32));
                 if (pr->gather(pr->gather_user, send.data(), n * 32, recv.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");

@@ -208,3 +208,17 @@ def ntt_shard_output_index(log_n: int, rank: int, world: int) -> np.ndarray:
     j1 = np.arange(world, dtype=np.int64)[:, None]
     c = np.arange(cols, dtype=np.int64)[None, :]
     return (rank * cols + c + m * j1).reshape(-1)
+
+
+def comm_init_from_torch(ctx):
+    """Joins the library's OWN RCCL communicator (zk_comm_init, csrc/comm.hip) using torch.distributed only
+    as the out-of-band channel for rank 0's 128-byte unique id -- what a Rust caller does with a file or
+    an environment variable.  Afterwards `session.set_sharding_comm()` / `zk_ntt_sharded(.., NULL, NULL)`
+    exchange their data inside the library, stream-ordered, without these Python callbacks."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], rank, world)
+    return rank, world
