@@ -288,15 +288,22 @@ def proof_section(ctx):
     import bench_proof as bp
 
     out = {}
-    for name, build in (("keccak_shape_k18", lambda: bp.build_keccak_shape(ctx, 18)),
-                        ("supercircuit_shape_k20", lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9))):
+    # (name, builder, proofs per key, transcript): the recursion shape is BASELINE config 5's stand-in -- k = 22, 9 advice
+    # columns, FOUR sequential proofs sharing one proving key, Poseidon transcript as gen_snark_shplonk uses
+    # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
+    for name, build, repeat, tkind in (("keccak_shape_k18", lambda: bp.build_keccak_shape(ctx, 18), 2, None),
+                                       ("recursion_shape_k22", lambda: bp.build_large(ctx, 22, 3), 4, 1),
+                                       ("supercircuit_shape_k20", lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 2, None)):
         try:
             t0 = time.perf_counter()
             circ, blob, adv_m, inst_m, inst = build()
             t_build = time.perf_counter() - t0
             ctx.prof_reset()
             ctx.prof_enable(True)
-            rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=2, verify=True, pinned=True, t_build=t_build)
+            rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=True, t_build=t_build, transcript_kind=tkind)
+            if tkind == 1:
+                rec["transcript"] = "poseidon"
+                rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
             ctx.prof_enable(False)
             prof = {nm: ctx.prof_get(nm) for nm in ctx.prof_names()}
             n = 1 << circ.k

@@ -364,6 +364,29 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_inde
 int zk_proof_finish(zk_ctx* ctx, zk_proof* proof, void* h_proof, size_t proof_cap, size_t* proof_len);
 void zk_proof_abort(zk_ctx* ctx, zk_proof* proof);
 
+/* ---- host-only wire formats and aggregation arithmetic (csrc/wire.hip, csrc/host_pairing.hpp) ------
+ * No context, no device.  SerdeFormat codes: 0 Processed, 1 RawBytes, 2 RawBytesUnchecked.          */
+/* instances <-> concatenated 32-byte big-endian words [REF prover/src/proof.rs:77-85,126-138]         */
+int zk_host_instances_encode(const void* fr_mont, size_t n, void* out_be);
+int zk_host_instances_decode(const void* in_be, size_t n, void* fr_mont_out);
+/* G1 points in halo2curves' SerdeFormat: 32 B compressed (Processed) or 64 B Montgomery limbs       */
+int zk_host_g1_encode(const void* affine64, size_t n, int format, void* out);
+int zk_host_g1_decode(const void* in, size_t n, int format, void* affine64_out);
+/* halo2 VerifyingKey::write / read [REF prover/src/io.rs:97-106]: k and the commitment count as u32
+ * big-endian, fixed then permutation commitments, then the selector assignments packed 8 rows/byte  */
+int zk_host_vk_write(uint32_t k, const void* fixed_commitments, uint32_t num_fixed, const void* perm_commitments, uint32_t num_perm,
+                     const uint8_t* selectors_packed, uint32_t num_selectors, int format, void* out, size_t cap, size_t* len);
+int zk_host_vk_read(const void* in, size_t in_len, int format, uint32_t num_perm, uint32_t num_selectors, uint32_t* k, uint32_t* num_fixed,
+                    void* fixed_commitments, size_t fixed_cap, void* perm_commitments, uint8_t* selectors_packed);
+/* BN254 optimal-ate pairing product: prod e(P_i, Q_i) == 1 ?  (G2: 128 B = x.c0, x.c1, y.c0, y.c1)   */
+int zk_host_pairing_check(const void* g1_points, const void* g2_points, size_t n, int* ok);
+/* aggregation layers between two GPU proofs [REF aggregator/src/core.rs:48-147]: combine the child
+ * snarks' KZG accumulators with powers of a Poseidon-transcript challenge (KzgAs::create_proof,
+ * no blinding), decide e(lhs, g2) == e(rhs, s_g2), encode the result as 12 limbs of 88 bits          */
+int zk_host_accumulate(const void* lhs_in, const void* rhs_in, size_t n, void* lhs_out, void* rhs_out, void* r_out);
+int zk_host_accumulator_check(const void* lhs, const void* rhs, const void* g2, const void* s_g2, int* ok);
+int zk_host_accumulator_limbs(const void* lhs, const void* rhs, void* out12_fr);
+
 /* ---- G1 element-wise (tests of the group law; halo2curves G1 Add / Double / Mul) --------------- */
 /* out[i] = a[i] + b[i], all affine (n x 64 B) */
 int zk_g1_affine_add_vec(zk_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);
