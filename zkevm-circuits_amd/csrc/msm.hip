@@ -1142,7 +1142,16 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
         {   // weighted bucket sum on a side stream: hides under the next MSMs
             ZkProfScope ps(ctx, "msm_reduce", side);
-            PK_TRY_MSM(wsum_enqueue(ctx, side, buckets, nb, partial, wsum_all + it));
+            if (count == 1) {
+                // a lone MSM waits for its reduction: one launch with a scalar multiplication per lane has the shorter
+                // dependent chain (about 60 additions against 150 over the levels below), at twice the work
+                const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;      // <= nb / 2048 + 1 partials: fits red_pts
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, nb, partial);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partial, rb, wsum_all + it);
+                ZK_CHECK_LAUNCH(ctx);
+            } else {
+                PK_TRY_MSM(wsum_enqueue(ctx, side, buckets, nb, partial, wsum_all + it));
+            }
         }
         ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
         if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
