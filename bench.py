@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the full-proof section (N = 1 only)")
-    ap.add_argument("--batch", type=int, default=8, help="columns submitted per commit_batch call (pipelined on the device)")
+    ap.add_argument("--batch", type=int, default=16, help="columns submitted per commit_batch call (pipelined on the device; a prover phase commits tens to a thousand)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

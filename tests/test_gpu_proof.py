@@ -583,3 +583,59 @@ def test_degree_three_circuit(ctx, cref, srs8, s_g2):
     vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
     assert proof == pp.create_proof(circ, pp.Srs(k, S_SECRET), adv, [], vk_repr, bytes(16), "shplonk")
     assert pv.verify(circ, vk_points, vk_repr, [], proof, s_g2, multiopen="shplonk")
+
+
+def test_degree_classes_leave_the_proof_unchanged(ctx, cref, srs8):
+    """The quotient is evaluated class by class (constraints of degree g only on the (g - 1) n points they
+    need); h, and with it every proof byte, must equal the single-domain evaluation that halo2's
+    evaluate_h performs (ZK_QUOTIENT_SPLIT=0) -- on a circuit whose constraints spread over all classes
+    (gates of degree 2, 3, 5 and 9, a lookup, a chunked permutation)."""
+    import random
+    k = 6
+    circ = plonk.Circuit(k, num_fixed=3, num_advice=6, num_instance=0, blinding_factors=5)
+    q, t_a, one_hot = circ.fixed_col(0), circ.fixed_col(1), circ.fixed_col(2)
+    a, b_, c_, d_, e_, f_ = (circ.advice_col(i) for i in range(6))
+    circ.add_gate(q * (a + b_.rot(1) - d_))                      # degree 2: a single coset
+    circ.add_gate(q * (a * b_ - c_))                             # degree 3
+    circ.add_gate(q * (a * b_ - c_) * (a + 1) * (b_ + 2))        # degree 5
+    hi = q * (e_ * e_ - f_)
+    for i in range(6):
+        hi = hi * (e_ + (i + 1))
+    circ.add_gate(hi)                                            # degree 9: the full extended domain
+    circ.add_lookup([one_hot * a], [t_a])
+    for col in range(6):
+        circ.enable_equality(plonk.ADVICE, col)
+    rng = random.Random(5)
+    n, u = circ.n, circ.u
+    adv = [[0] * n for _ in range(6)]
+    for row in range(u):
+        circ.fixed[1][row] = row % 16
+    for row in range(u):
+        circ.fixed[0][row] = 1 if row + 1 < u else 0
+        circ.fixed[2][row] = row % 2
+    for row in range(u):
+        adv[0][row] = rng.randrange(16)
+        adv[1][row] = rng.randrange(b.R_MOD)
+        adv[4][row] = rng.randrange(b.R_MOD)
+        adv[5][row] = adv[4][row] * adv[4][row] % b.R_MOD
+    for row in range(u):
+        adv[2][row] = adv[0][row] * adv[1][row] % b.R_MOD
+        adv[3][row] = (adv[0][row] + adv[1][(row + 1) % n]) % b.R_MOD if circ.fixed[0][row] else 0
+    adv[5][7] = adv[5][3] = adv[4][3] * adv[4][3] % b.R_MOD
+    adv[4][7] = adv[4][3]
+    circ.copy((plonk.ADVICE, 5, 3), (plonk.ADVICE, 5, 7))
+    assert circ.degree() == 9 and pv.check_witness(circ, adv, []) is None
+    from oracle import plonk_prover as pp
+    proofs = {}
+    for mode in ("1", "0"):
+        os.environ["ZK_QUOTIENT_SPLIT"] = mode
+        try:
+            pk = ctx.pk_create(srs8[k], circ.blob())
+            _, rep = pk.vk(circ.F + len(circ.perm_cols))
+            proofs[mode] = _session_proof(ctx, pk, adv, [], bytes(range(16)), "shplonk")
+            pk.destroy()
+        finally:
+            os.environ.pop("ZK_QUOTIENT_SPLIT", None)
+    assert proofs["1"] == proofs["0"]
+    want = pp.create_proof(circ, pp.Srs(k, S_SECRET), adv, [], cref.from_mont(rep.reshape(1, 4))[0], bytes(range(16)), "shplonk")
+    assert proofs["1"] == want

@@ -82,6 +82,7 @@ struct zk_ctx {
         pool_bytes = 0;
     }
     // per-kernel HIP-event profiling (zk_prof_*): off by default
+    bool ntt_attr_set = false, quotient_attr_set = false;   // hipFuncSetAttribute (large dynamic LDS) is per device: remembered per context, not per process
     bool prof_on = false;
     const char* prof_tag = nullptr;      // when set, zk_quotient_eval books its launch under this name (the prover tags the big coset programs)
     struct ProfEntry { double ms = 0; uint64_t count = 0; };

@@ -294,7 +294,21 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_msm_m_bin(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ hist_off, uint32_t nwg, int range_bits,
                                                     uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx) {
     __shared__ uint32_t lds[1 << MSM_RANGE_MAX_BITS];
-    const uint32_t bin = blockIdx.x / MSM_SLICES, sl = blockIdx.x % MSM_SLICES, range = 1u << range_bits;
+    // Workgroups go to the 8 XCDs round-robin by linear id.  The MSM_SLICES workgroups of a partition write
+    // interleaved 4-byte runs into the same lines of `idx` (cursors are laid out [bucket][slice]); placed on
+    // ONE XCD they merge those lines in its L2 instead of evicting four partial copies (the L2s are not
+    // coherent with each other): id = xcd + 8 * (MSM_SLICES * group + slice), partition = 8 * group + xcd.
+    const uint32_t nbins_ = gridDim.x / MSM_SLICES;
+    uint32_t bin, sl;
+    if ((nbins_ & 7u) == 0) {
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        sl = slot % MSM_SLICES;
+        bin = (slot / MSM_SLICES) * 8u + xcd;
+    } else {
+        bin = blockIdx.x / MSM_SLICES;
+        sl = blockIdx.x % MSM_SLICES;
+    }
+    const uint32_t range = 1u << range_bits;
     const uint64_t gbase = (uint64_t)bin << range_bits;
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) lds[t] = SCATTER ? offsets[(gbase + t) * MSM_SLICES + sl] : 0u;
     __syncthreads();
@@ -702,9 +716,28 @@ __device__ __forceinline__ G1Xyzz29 block_sum29(G1Xyzz29 v, G1Xyzz29* sh) {     
     __syncthreads();
     return r;
 }
+// two sums over the workgroup at once: the additions of a tree level are independent, so the pair costs one
+// dependent addition per level, not two
+__device__ __forceinline__ void block_sum29x2(G1Xyzz29& a, G1Xyzz29& b, G1Xyzz29* sh) {       // sh: 2 x 256 points
+    sh[threadIdx.x] = a;
+    sh[256 + threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const G1Xyzz29 x = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
+            const G1Xyzz29 y = add29pt(sh[256 + threadIdx.x], sh[256 + threadIdx.x + off]);
+            sh[threadIdx.x] = x;
+            sh[256 + threadIdx.x] = y;
+        }
+        __syncthreads();
+    }
+    a = sh[0];
+    b = sh[256];
+    __syncthreads();
+}
 template <bool LAST>
 __global__ void __launch_bounds__(256) k_wsum_level(const G1Xyzz29* __restrict__ in, uint32_t count, G1Xyzz29* __restrict__ S_out, G1Xyzz29* __restrict__ Tpart, G1Xyzz29* __restrict__ U_out) {
-    __shared__ G1Xyzz29 sh[256];
+    __shared__ G1Xyzz29 sh[LAST ? 512 : 256];
     const uint32_t g = blockIdx.x * 256 + threadIdx.x, groups = (count + WS_G - 1) / WS_G;
     G1Xyzz29 acc = identity29(), run = identity29();
     if (g < groups) {
@@ -713,27 +746,35 @@ __global__ void __launch_bounds__(256) k_wsum_level(const G1Xyzz29* __restrict__
         if (LAST) { if (b0) acc = add29pt(acc, mul_small(run, b0)); }
         else stg29(S_out + g, run);
     }
-    const G1Xyzz29 t = block_sum29(acc, sh);
-    if (threadIdx.x == 0) stg29(Tpart + blockIdx.x, t);
     if (LAST) {
-        const G1Xyzz29 u = block_sum29(run, sh);
-        if (threadIdx.x == 0) stg29(U_out, u);
+        block_sum29x2(acc, run, sh);
+        if (threadIdx.x == 0) { stg29(Tpart + blockIdx.x, acc); stg29(U_out, run); }
+    } else {
+        const G1Xyzz29 t = block_sum29(acc, sh);
+        if (threadIdx.x == 0) stg29(Tpart + blockIdx.x, t);
     }
 }
 struct WsumPlan { int levels; uint32_t off[WS_MAX_LEVELS], cnt[WS_MAX_LEVELS]; };      // Tpart ranges per level
+// wave w sums the partials of level w (and w + 4) with a shuffle tree, all levels at once; lane 0 of
+// wave 0 then folds them:  T = U + A_0 + G (A_1 + G (A_2 + ...))
 __global__ void __launch_bounds__(256) k_wsum_final(const G1Xyzz29* __restrict__ Tpart, WsumPlan pl, const G1Xyzz29* __restrict__ U, G1Xyzz* __restrict__ out) {
-    __shared__ G1Xyzz29 sh[256];
-    G1Xyzz29 T = identity29();
-    for (int lv = pl.levels - 1; lv >= 0; --lv) {
+    __shared__ G1Xyzz29 A[WS_MAX_LEVELS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (int lv = (int)wave; lv < pl.levels; lv += 4) {
         G1Xyzz29 a = identity29();
-        for (uint32_t i = threadIdx.x; i < pl.cnt[lv]; i += 256) a = add29pt(a, ldg29(Tpart + pl.off[lv] + i));
-        a = block_sum29(a, sh);
-        if (threadIdx.x == 0) {
-            if (lv != pl.levels - 1) { for (int d = 1; d < WS_G; d <<= 1) T = dbl29pt(T); }       // * G
-            T = add29pt(T, a);
-        }
+        for (uint32_t i = lane; i < pl.cnt[lv]; i += 64) a = add29pt(a, ldg29(Tpart + pl.off[lv] + i));
+        for (int off = 32; off > 0; off >>= 1) a = add29pt(a, shfl_down_pt(a, off));
+        if (lane == 0) A[lv] = a;
     }
-    if (threadIdx.x == 0) stg(out, to_std_xyzz(add29pt(T, ldg29(U))));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G1Xyzz29 T = A[pl.levels - 1];
+        for (int lv = pl.levels - 2; lv >= 0; --lv) {
+            for (int d = 1; d < WS_G; d <<= 1) T = dbl29pt(T);       // * G
+            T = add29pt(T, A[lv]);
+        }
+        stg(out, to_std_xyzz(add29pt(T, ldg29(U))));
+    }
 }
 // enqueue the whole reduction of `buckets[nb]` on stream `st`; scratch: >= nb / 4 + 1024 points
 static int wsum_enqueue(zk_ctx* ctx, hipStream_t st, const G1Xyzz29* buckets, uint32_t nb, G1Xyzz29* scratch, G1Xyzz* out) {

@@ -255,6 +255,7 @@ k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
     }
 }
 
+__host__ __device__ __forceinline__ int ntt_row_pad(int log_np) { return log_np >= 8 ? 8 : 0; }     // <= 16 rows per tile then: at most 128 extra elements
 // ----------------------------------------------------------------------------------- last pass
 // Rows of n_P contiguous elements; tile = T rows i1 = blk*T + c (row stride = midN * n_P) at a
 // fixed middle digit `mid`.  LDS layout [c][d].  Same step structure as the other passes: the
@@ -268,8 +269,11 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
            int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre, int fin_folded) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tile = 1 << (log_np + log_t);
-    Lds29 L{smem, tile};
     const int T = 1 << log_t;
+    // rows are padded by 8 words: the last step reads with c fastest (coalesced output), and with a row
+    // stride that is a multiple of the 32 banks the T rows of a wave would collide on every bank
+    const int row = (1 << log_np) + ntt_row_pad(log_np);
+    Lds29 L{smem, T * row};
     const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
     const Fr29 fin29 = unpack29<Fr29P>(fin);
 
@@ -294,7 +298,7 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
                     e[k] = unpack29<Fr29P>(ldg(src + gi));
                     if (pre) e[k] = mul29(e[k], unpack29<Fr29P>(ldg(pre + gi)));     // only when this is the only pass
                 } else {
-                    e[k] = L.load((c << log_np) | dl);
+                    e[k] = L.load(c * row + dl);
                 }
             }
             if (first) { if (r == 2) dit_first_step<2>(e, tw, log_np); else dit_first_step<1>(e, tw, log_np); }
@@ -308,7 +312,7 @@ k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restr
                     const uint64_t o = i1 + (((uint64_t)mid + ((uint64_t)dl << log_mid)) << log_n1);
                     stg(dst + o, fin_folded ? reduce_lazy29(e[k]) : pack29_lt2p(mul29(e[k], fin29)));
                 } else {
-                    L.store((c << log_np) | dl, e[k]);
+                    L.store(c * row + dl, e[k]);
                 }
             }
         }
@@ -412,12 +416,11 @@ static int get_domain(zk_ctx* ctx, uint32_t log_n, const Fr& omega, const Fr* sc
     return ZK_OK;
 }
 
-static bool g_attr_set = false;
 static int set_lds_attr(zk_ctx* ctx) {
-    if (g_attr_set) return ZK_OK;
+    if (ctx->ntt_attr_set) return ZK_OK;
     ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT));
-    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT));
-    g_attr_set = true;
+    ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT));
+    ctx->ntt_attr_set = true;
     return ZK_OK;
 }
 
@@ -516,7 +519,7 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
         const int tile = 1 << (ps.log_np + log_t);
         const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
         ZkProfScope pscope(ctx, "ntt_last");
-        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
+        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
                            ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0);
         ZK_CHECK_LAUNCH(ctx);
     }

@@ -57,7 +57,8 @@ enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
 enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
 // abstract constant operands: user constants are [0, num_consts); challenges live above
 constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u,   // C_DELTA0 + j = beta * delta^j
-                   C_CHAL0 = 0xFFFD0000u;                                                                                      // C_CHAL0 + i = user challenge i
+                   C_CHAL0 = 0xFFFD0000u,                                                                                      // C_CHAL0 + i = user challenge i
+                   C_YPOW0 = 0xFFFC0000u;                                                                                      // C_YPOW0 + g = y^g (folding constraints that are g positions apart)
 
 inline uint32_t colref(uint32_t type, uint32_t idx) { return (type << 24) | idx; }
 
@@ -294,6 +295,7 @@ bool resolve_const(const Env& e, uint32_t ref, F4* out) {
     }
     if (ref >= C_DELTA0 && ref - C_DELTA0 < e.beta_delta.size()) { *out = e.beta_delta[ref - C_DELTA0]; return true; }
     if (ref >= C_CHAL0 && ref - C_CHAL0 < e.challenges.size()) { *out = e.challenges[ref - C_CHAL0]; return true; }
+    if (ref >= C_YPOW0 && ref < C_CHAL0) { *out = host::fr_pow(e.y, ref - C_YPOW0); return true; }
     return false;
 }
 int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
@@ -1055,15 +1057,19 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         PK_TRY(to_coeff(ctx, pk, lk_phi[l], &phi_coeff[l]));
     }
     trace.mark("coefficient forms");
-    // ---- the quotient program: gates, permutation, lookups, each folded with y
+    // ---- the quotient's constraints in halo2's order: gates, permutation, lookups (folded with y below)
+    std::vector<Prog> cons;
     PB q;
-    for (const Prog& g : pk->gates) { q.append(g); q.fold(C_Y); }
+    auto end_c = [&] { cons.push_back(std::move(q.g)); q.g.clear(); };
+    for (const Prog& g : pk->gates) cons.push_back(g);
     const int32_t rot_last = -(int32_t)(pk->bf + 1);
     if (pk->C) {
-        q.col(CT_SPECIAL, SP_L0).cst(C_ONE).col(CT_PERM_Z, 0).op(Q_SUB).op(Q_MUL).fold(C_Y);                                   // l0 (1 - Z_0)
-        q.col(CT_SPECIAL, SP_LLAST).col(CT_PERM_Z, pk->C - 1).op(Q_SQUARE).col(CT_PERM_Z, pk->C - 1).op(Q_SUB).op(Q_MUL).fold(C_Y);   // l_last (Z^2 - Z)
-        for (uint32_t c = 1; c < pk->C; ++c)
-            q.col(CT_SPECIAL, SP_L0).col(CT_PERM_Z, c).col(CT_PERM_Z, c - 1, rot_last).op(Q_SUB).op(Q_MUL).fold(C_Y);          // l0 (Z_c - Z_{c-1}(w^last X))
+        q.col(CT_SPECIAL, SP_L0).cst(C_ONE).col(CT_PERM_Z, 0).op(Q_SUB).op(Q_MUL); end_c();                                   // l0 (1 - Z_0)
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_PERM_Z, pk->C - 1).op(Q_SQUARE).col(CT_PERM_Z, pk->C - 1).op(Q_SUB).op(Q_MUL); end_c();   // l_last (Z^2 - Z)
+        for (uint32_t c = 1; c < pk->C; ++c) {
+            q.col(CT_SPECIAL, SP_L0).col(CT_PERM_Z, c).col(CT_PERM_Z, c - 1, rot_last).op(Q_SUB).op(Q_MUL);          // l0 (Z_c - Z_{c-1}(w^last X))
+            end_c();
+        }
         for (uint32_t c = 0; c < pk->C; ++c) {
             const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
             q.col(CT_SPECIAL, SP_LACTIVE);
@@ -1071,7 +1077,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SIGMA, j).mulc(C_BETA).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
             q.col(CT_PERM_Z, c, 0);
             for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SPECIAL, SP_X).mulc(C_DELTA0 + j).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
-            q.op(Q_SUB).op(Q_MUL).fold(C_Y);
+            q.op(Q_SUB).op(Q_MUL); end_c();
         }
     }
     // lookup identities (plonk::evaluation, mv-lookup): with phi_a = f_a + beta and tau = t + beta,
@@ -1079,12 +1085,13 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // An argument with several input tuples parks tau and the phi_a of a row in intermediates (slots
     // above the ones the gate programs use) and forms sum_a prod_{b != a} phi_b from them.
     uint32_t tmp_base = 0;
-    for (const Instr& in : q.g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
+    for (const Prog& g : pk->gates) for (const Instr& in : g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
+    const bool gates_share_tmps = tmp_base != 0;
     for (uint32_t l = 0; l < pk->L; ++l) {
         const auto& lk = pk->lookups[l];
         const uint32_t N = (uint32_t)lk.inputs.size();
-        q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
-        q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL).fold(C_Y);
+        q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL); end_c();
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL); end_c();
         q.col(CT_SPECIAL, SP_LACTIVE);
         if (N == 1) {
             // (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta))
@@ -1093,7 +1100,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
             push_compressed(q, lk.tables); q.addc(C_BETA);
             q.col(CT_LK_M, l); push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
-            q.op(Q_SUB).op(Q_SUB).op(Q_MUL).fold(C_Y);
+            q.op(Q_SUB).op(Q_SUB).op(Q_MUL); end_c();
             continue;
         }
         const uint32_t t_tau = tmp_base, t_phi = tmp_base + 1;          // reused by every multi-input lookup: a row's values are consumed right away
@@ -1124,7 +1131,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         tmp(Q_PUSH_TMP, t_tau); q.op(Q_MUL);
         tmp(Q_PUSH_TMP, t_phi + N); q.col(CT_LK_M, l).op(Q_MUL);
         q.op(Q_SUB);
-        q.op(Q_SUB).op(Q_MUL).fold(C_Y);
+        q.op(Q_SUB).op(Q_MUL); end_c();
     }
     // The extended domain is evaluated one coset at a time (g_r = zeta * omega_ext^r, r < 2^(ext_k-k)):
     // every column the program reads is taken to that coset with a size-n transform of its
@@ -1132,12 +1139,56 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // the result, divided by the vanishing polynomial -- a constant g_r^n - 1 on a coset of H --
     // lands at stride 2^(ext_k-k) in the extended buffer.  Live memory is one n-row block per
     // column instead of 2^(ext_k-k) of them: what lets 10^3-column circuits fit.
-    DevBuf h;
-    if (!h.alloc(ne * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+    //
+    // Degree classes.  h = (sum_i y^(K-1-i) g_i) / (X^n - 1) is linear in the constraints, and a constraint of
+    // degree g only needs (g - 1) n evaluation points, i.e. the cosets r that are multiples of
+    // 2^(E - e), e = ceil(log2(g - 1)), E = ext_k - k: the extended domain of size 2^(k+e) is the union of
+    // exactly those cosets.  The constraints are therefore grouped by e; class e is evaluated on its 2^e
+    // cosets only, brought to coefficient form over its own (smaller) extended domain and added to h.  A
+    // column that occurs only in low-degree constraints needs 2^e coset transforms instead of 2^E, and the
+    // low-degree part of the program runs over 2^e n rows instead of 2^E n.  The polynomial h -- and with
+    // it every proof byte -- is the same as when everything is evaluated on the full extended domain
+    // (what halo2's evaluate_h does); how much is saved depends on the circuit's degree profile.
+    const uint32_t E = ext_k - k, K = (uint32_t)cons.size();
+    const bool sharded = pr->world > 1 && pr->gather;
+    const char* split_env = getenv("ZK_QUOTIENT_SPLIT");
+    const bool split = !(split_env && atoi(split_env) == 0) && !sharded && !gates_share_tmps;     // intermediates shared between gates tie their rows together
+    std::vector<uint32_t> cls(K, E);
     {
-        std::vector<uint32_t> refs;
-        for (const Instr& in : q.g) if (in.op == Q_PUSH_COL && std::find(refs.begin(), refs.end(), in.a) == refs.end()) refs.push_back(in.a);
-        const uint32_t nparts = 1u << (ext_k - k);
+        std::vector<int> tmp_deg;
+        for (uint32_t i = 0; i < K; ++i) {
+            const int dg = program_degree(cons[i], &tmp_deg);
+            if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: malformed constraint program %u", i);
+            if ((uint32_t)dg > pk->d) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: constraint %u has degree %d above the circuit degree %u", i, dg, pk->d);
+            uint32_t e = 0;
+            while (e < E && ((uint32_t)1 << e) < (uint32_t)std::max(dg - 1, 1)) ++e;
+            cls[i] = split ? e : E;
+        }
+    }
+    struct QClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; DevBuf h; };
+    std::vector<QClass> qc(E + 1);
+    for (uint32_t i = 0; i < K; ++i) {
+        QClass& c = qc[cls[i]];
+        c.prog.insert(c.prog.end(), cons[i].begin(), cons[i].end());
+        c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
+        c.last = i;
+        c.used = true;
+    }
+    std::vector<uint32_t> refs;          // every column any class reads
+    for (QClass& c : qc)
+        for (const Instr& in : c.prog)
+            if (in.op == Q_PUSH_COL) {
+                if (std::find(c.refs.begin(), c.refs.end(), in.a) == c.refs.end()) c.refs.push_back(in.a);
+                if (std::find(refs.begin(), refs.end(), in.a) == refs.end()) refs.push_back(in.a);
+            }
+    for (uint32_t e = 0; e <= E; ++e)
+        if (qc[e].used || e == E) {
+            if (!qc[e].h.alloc(((size_t)n << e) * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            if (!qc[e].used) ZK_HIP(ctx, hipMemsetAsync(qc[e].h.p, 0, ((size_t)n << e) * 32, ctx->stream));
+        }
+    DevBuf& h = qc[E].h;
+    {
+        const uint32_t nparts = 1u << E;
         auto of_key = [](uint32_t ref) { const uint32_t t = ref >> 24; return t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL; };
         if (pk->part_cache_state < 0) {       // decide once: do the key's own cosets fit the budget?
             size_t key_cols = 0;
@@ -1160,7 +1211,6 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         Fr g = fr_zeta();
         // sharded session: rank q evaluates cosets q, q + world, ...; after every round of `world`
         // cosets the (already divided) results are all-gathered and interleaved into h on every rank
-        const bool sharded = pr->world > 1 && pr->gather;
         const Fr one_fr = Fr::one();
         std::vector<uint8_t> send, recv;
         DevBuf rtmp, gbuf;
@@ -1171,7 +1221,14 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         for (uint32_t r_ = 0; r_ < nparts; ++r_) {
           if (!sharded || r_ % pr->world == pr->rank) {
+            // classes whose extended domain contains this coset, and the columns they read
+            std::vector<uint32_t> active;
+            for (uint32_t e = 0; e <= E; ++e) if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0) active.push_back(e);
+            part_of.clear();
             for (size_t i = 0; i < refs.size(); ++i) {
+                bool needed = false;
+                for (uint32_t e : active) needed |= std::find(qc[e].refs.begin(), qc[e].refs.end(), refs[i]) != qc[e].refs.end();
+                if (!needed) continue;
                 void* dst = part_buf[i].p;
                 DevBuf fresh;                             // a cache slot being filled: published only once it holds the coset
                 const bool cached = cache_on && of_key(refs[i]);
@@ -1191,16 +1248,23 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 if (cached) pk->part_cache[r_][refs[i]] = std::move(fresh);
             }
             trace.mark("  quotient: cosets of the columns");
-            ctx->prof_tag = "quotient_coset";
-            const int rc_q = run_program(ctx, part, q.g, hpart.p);
-            ctx->prof_tag = nullptr;
-            PK_TRY(rc_q);
-            trace.mark("  quotient: program");
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
             const Fr vinv = fr_inv_host(gn - Fr::one());
-            if (sharded) PK_TRY(zk_fr_scale(ctx, hpart.p, &vinv, n));            // peers receive the finished values
-            PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &vinv, h.p, nparts, r_));
+            for (uint32_t e : active) {
+                ctx->prof_tag = "quotient_coset";
+                const int rc_q = run_program(ctx, part, qc[e].prog, hpart.p);
+                ctx->prof_tag = nullptr;
+                PK_TRY(rc_q);
+                // class e lags (K - 1 - last) positions behind the end of the constraint list: its sum still takes y^(K-1-last)
+                const F4 yp = host::fr_pow(lag.y, K - 1 - qc[e].last);
+                Fr scale;
+                memcpy((void*)&scale, yp.l, 32);
+                scale = scale * vinv;
+                if (sharded) PK_TRY(zk_fr_scale(ctx, hpart.p, &scale, n));            // peers receive the finished values (one class in sharded sessions)
+                PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &scale, qc[e].h.p, (size_t)1 << e, r_ >> (E - e)));
+            }
+            trace.mark("  quotient: program");
           }
             g = g * w_ext;
             if (sharded && pr->use_comm && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
@@ -1224,7 +1288,17 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             }
         }
     }
+    // every class back to coefficients over its own extended domain; the smaller ones are added into h
+    for (uint32_t e = 0; e < E; ++e) {
+        if (!qc[e].used) continue;
+        PK_TRY(zk_extended_to_coeff(ctx, qc[e].h.p, k + e));
+    }
     PK_TRY(zk_extended_to_coeff(ctx, h.p, ext_k));
+    for (uint32_t e = 0; e < E; ++e) {
+        if (!qc[e].used) continue;
+        PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_ADD, h.p, qc[e].h.p, h.p, n << e));
+        qc[e].h.release();
+    }
     trace.mark("quotient eval + ifft");
     const uint32_t pieces = pk->d - 1;
     {

@@ -252,10 +252,9 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
     const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 8 * Q_THREADS * 4;    // the two topmost elements are in registers
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->quotient_attr_set) {
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 8 * Q_THREADS * 4));
-        attr_set = true;
+        ctx->quotient_attr_set = true;
     }
     ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
     hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
