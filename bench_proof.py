@@ -376,6 +376,15 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
     copies += [((plonk.ADVICE, 1, int(r0)), (plonk.INSTANCE, 0, j)) for j, r0 in enumerate(pub)]
     c.copies = copies
     data_m = [[to_mont_gpu(ctx, small_to_limbs(data[t, i])) for i in range(3)] for t in range(D)]
+    if os.environ.get("ZK_BENCH_DENSE") == "1":
+        # a witness with field-sized cells: the third row of every 3-row region is read by no constraint; fill it
+        # (one row in three of every column) with uniform field elements, so that no column is "small-valued"
+        free = rows + 2
+        for t in range(D):
+            for i in range(3):
+                limbs = rng.integers(0, 1 << 63, size=(free.size, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(free.size, 4), dtype=np.uint64)
+                limbs[:, 3] &= np.uint64((1 << 60) - 1)
+                data_m[t][i][free] = limbs
     zero_col = np.zeros((n, 4), dtype=np.uint64)
     adv_m = [data_m[(col // 3) % D][col % 3] if col < 3 * groups else zero_col for col in range(A)]
     inst_m = [to_mont_gpu(ctx, small_to_limbs(inst[0]))]
@@ -395,7 +404,7 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
 
 
 def proof_bench(ctx, k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=3, verify=True, pinned=False, t_build=0.0,
-                session_hook=None, barrier=None, report=True, world=1, transcript_kind=None):
+                session_hook=None, barrier=None, report=True, world=1, transcript_kind=None, profiled_extra=False):
     """keygen_pk + `repeat` proving sessions of one circuit; returns the result record (None on
     ranks that do not report).  Verified afterwards by the oracle's pairing verifier."""
     # halo2 hands create_proof the public inputs themselves, not an n-row column: keep the slice that
@@ -422,7 +431,10 @@ def proof_bench(ctx, k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=3,
     t_keygen = time.perf_counter() - t0
     times = []
     proof = b""
-    for _ in range(repeat):
+    for it in range(repeat + (1 if profiled_extra else 0)):
+        if it == repeat:            # one more proof with the per-scope HIP events on (not timed: the events cost host time)
+            ctx.prof_reset()
+            ctx.prof_enable(True)
         t0 = time.perf_counter()
         if barrier:
             barrier()
@@ -437,7 +449,10 @@ def proof_bench(ctx, k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=3,
         del keep
         if barrier:
             barrier()
-        times.append(time.perf_counter() - t0)
+        if it < repeat:
+            times.append(time.perf_counter() - t0)
+        else:
+            ctx.prof_enable(False)
     if not report:
         pk.destroy(); srs.destroy()
         return None
