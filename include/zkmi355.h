@@ -77,6 +77,9 @@ int zk_timer_stop_ms(zk_ctx* ctx, float* ms);   /* synchronises on the stop even
 int zk_prof_enable(zk_ctx* ctx, int on);
 int zk_prof_reset(zk_ctx* ctx);
 int zk_prof_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* count);
+/* algorithmic HBM bytes of the launches booked under `name` (scopes that state them: the expression evaluator
+ * counts 32 B per row for every distinct (column, rotation) operand, parked intermediate and result); 0 otherwise */
+int zk_prof_get_bytes(zk_ctx* ctx, const char* name, uint64_t* bytes);
 /* writes a ';'-separated list of the names seen so far into buf */
 int zk_prof_names(zk_ctx* ctx, char* buf, size_t len);
 
@@ -145,6 +148,13 @@ int zk_fr_prefix_sum(zk_ctx* ctx, const void* d_a, void* d_z, size_t n);
  * (t < 4096, 2^ext_k x 32 B each); reading one before it is written is ZK_ERR_INVALID_ARG.          */
 int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr, const void* const* h_col_ptrs, uint32_t num_cols,
                      const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out);
+/* Host only (no device): the instruction stream the evaluator's kernel runs for `program` -- memory operands fused
+ * into the operations (ADD_COL 16, SUB_COL 17, RSUB_COL 18, MUL_COL 19, FOLD_COL 20 | const << 12, NOP 21), bit 8 / 9
+ * of word 0 = "settle t0 / t1 first", parked intermediates as columns num_cols + slot.  fuse = 0 keeps the caller's
+ * sequence.  out_words may be NULL (sizes only).  For tests and for inspecting what a key's gates compile to. */
+int zk_host_quotient_lower(const uint32_t* program, uint32_t num_instr, uint32_t num_cols, int fuse, uint32_t* out_words, size_t cap_words,
+                           uint32_t* out_instr, int* out_depth);
+
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
 /* logUp multiplicities (halo2 Scroll fork, plonk/mv_lookup/prover.rs: m(X)): d_m[i] = number of rows

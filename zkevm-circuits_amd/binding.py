@@ -388,6 +388,11 @@ class Context:
         self._ck(lib().zk_prof_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def prof_get_bytes(self, name: str) -> int:
+        b = ctypes.c_uint64()
+        self._ck(lib().zk_prof_get_bytes(self.h, name.encode(), ctypes.byref(b)))
+        return b.value
+
     def prof_names(self):
         buf = ctypes.create_string_buffer(4096)
         self._ck(lib().zk_prof_names(self.h, buf, ctypes.c_size_t(4096)))

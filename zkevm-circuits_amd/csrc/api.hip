@@ -198,6 +198,15 @@ int zk_prof_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* count
     *count = it == ctx->prof.end() ? 0 : it->second.count;
     return ZK_OK;
 }
+int zk_prof_get_bytes(zk_ctx* ctx, const char* name, uint64_t* bytes) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, name && bytes, "null pointer");
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_resolve();
+    auto it = ctx->prof.find(name);
+    *bytes = it == ctx->prof.end() ? 0 : it->second.bytes;
+    return ZK_OK;
+}
 int zk_prof_names(zk_ctx* ctx, char* buf, size_t len) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, buf && len, "null pointer");

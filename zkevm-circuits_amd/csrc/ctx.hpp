@@ -85,9 +85,9 @@ struct zk_ctx {
     bool ntt_attr_set = false, quotient_attr_set = false;   // hipFuncSetAttribute (large dynamic LDS) is per device: remembered per context, not per process
     bool prof_on = false;
     const char* prof_tag = nullptr;      // when set, zk_quotient_eval books its launch under this name (the prover tags the big coset programs)
-    struct ProfEntry { double ms = 0; uint64_t count = 0; };
+    struct ProfEntry { double ms = 0; uint64_t count = 0; uint64_t bytes = 0; };   // bytes: algorithmic HBM bytes of the booked launches, where the scope states them
     std::map<std::string, ProfEntry> prof;
-    struct ProfPending { const char* name; hipEvent_t a, b; };
+    struct ProfPending { const char* name; hipEvent_t a, b; uint64_t bytes; };
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
@@ -103,6 +103,7 @@ struct zk_ctx {
                 auto& e = prof[p.name];
                 e.ms += ms;
                 e.count += 1;
+                e.bytes += p.bytes;
             }
             prof_pool.push_back(p.a);
             prof_pool.push_back(p.b);
@@ -135,12 +136,12 @@ struct zk_ctx {
 
 // RAII scope: records a HIP event pair around the enclosed launches on ctx->stream
 struct ZkProfScope {
-    zk_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t s;
+    zk_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t s; uint64_t bytes = 0;
     ZkProfScope(zk_ctx* ctx, const char* n, hipStream_t on = nullptr) : c(ctx), name(n), s(on ? on : ctx->stream) {
         if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, s); }
     }
     ~ZkProfScope() {
-        if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, s); c->prof_pending.push_back({name, a, b}); }
+        if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, s); c->prof_pending.push_back({name, a, b, bytes}); }
     }
 };
 

@@ -328,6 +328,80 @@ __global__ void __launch_bounds__(1024) k_msm_m_bin(const uint64_t* __restrict__
     }
 }
 
+// One-launch counting sort of a partition (the usual case: the partition's indices fit the LDS staging
+// buffer).  Workgroup `bin` counts its entries per bucket, scans the 2^range_bits counters in LDS --
+// partitions are contiguous in the index array, so offsets[b] = partition start + local prefix needs no
+// global scan --, then ranks the entries again (the second read comes from L2 / MALL), places the 4-byte
+// table indices in LDS and writes them out as ONE contiguous run: no partial-line writes (the four-slice
+// scatter above wrote 10x its payload through L2).  Also leaves counts[], the size histogram and the
+// closing offsets[nb] that the task split reads.  A partition larger than the staging buffer (skewed
+// scalars) scatters straight to global memory instead.
+constexpr uint32_t MSM_M_STAGE = 15u * 1024u;      // 60 KiB of indices + 8 KiB of counters: two workgroups per CU
+constexpr uint32_t MSM_SIZE_BINS = 256;            // == SIZE_BINS below
+__global__ void __launch_bounds__(1024) k_msm_m_binsort(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ hist_off, uint32_t nwg, int range_bits, uint32_t nb,
+                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_hist, uint32_t* __restrict__ idx) {
+    __shared__ uint32_t cnt[1 << MSM_RANGE_MAX_BITS];
+    __shared__ uint32_t stage[MSM_M_STAGE];
+    __shared__ uint32_t lh[MSM_SIZE_BINS];
+    __shared__ uint32_t wtot[16];
+    const uint32_t bin = blockIdx.x, range = 1u << range_bits;
+    const uint64_t gbase = (uint64_t)bin << range_bits;
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) cnt[t] = 0u;
+    if (threadIdx.x < MSM_SIZE_BINS) lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t lo = hist_off[(uint64_t)bin * nwg], hi = hist_off[(uint64_t)(bin + 1) * nwg];     // the scan's closing entry holds the total
+    for (uint32_t base = lo; base < hi; base += blockDim.x) {
+        const uint32_t e = base + threadIdx.x;
+        const bool live = e < hi;
+        const uint64_t ent = live ? entries[e] : 0ull;
+        (void)lds_take(cnt, (uint32_t)(ent >> 32), live);
+    }
+    __syncthreads();
+    {   // exclusive scan of the counters: thread t owns buckets 2t, 2t + 1 (range <= 2048)
+        const uint32_t t2 = 2 * threadIdx.x;
+        const uint32_t c0 = t2 < range ? cnt[t2] : 0u, c1 = t2 + 1 < range ? cnt[t2 + 1] : 0u;
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wtot[w];
+        const uint32_t ex = wbase + incl - (c0 + c1);
+        if (t2 < range) {
+            cnt[t2] = ex;
+            offsets[gbase + t2] = lo + ex;
+            counts[gbase + t2] = c0;
+            atomicAdd(&lh[min(c0, MSM_SIZE_BINS - 1)], 1u);
+        }
+        if (t2 + 1 < range) {
+            cnt[t2 + 1] = ex + c0;
+            offsets[gbase + t2 + 1] = lo + ex + c0;
+            counts[gbase + t2 + 1] = c1;
+            atomicAdd(&lh[min(c1, MSM_SIZE_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < MSM_SIZE_BINS && lh[threadIdx.x]) atomicAdd(&size_hist[threadIdx.x], lh[threadIdx.x]);
+    if (bin + 1 == gridDim.x && threadIdx.x == 0) offsets[nb] = hi;
+    const bool staged = hi - lo <= MSM_M_STAGE;
+    for (uint32_t base = lo; base < hi; base += blockDim.x) {
+        const uint32_t e = base + threadIdx.x;
+        const bool live = e < hi;
+        const uint64_t ent = live ? entries[e] : 0ull;
+        const uint32_t pos = lds_take(cnt, (uint32_t)(ent >> 32), live);
+        if (live) {
+            if (staged) stage[pos] = (uint32_t)ent;
+            else idx[lo + pos] = (uint32_t)ent;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < hi - lo; t += blockDim.x) idx[lo + t] = stage[t];
+    }
+}
+
 // ---- exclusive scan of the bucket counts, three small kernels (4096 counts per block) ----------
 constexpr int SCAN_T = 1024, SCAN_ITEMS = 4;
 __device__ __forceinline__ uint32_t block_scan_u32(uint32_t v, uint32_t* sh, uint32_t* total) {
@@ -396,6 +470,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restric
     __syncthreads();
     if (threadIdx.x < SIZE_BINS && lh[threadIdx.x]) atomicAdd(&size_hist[threadIdx.x], lh[threadIdx.x]);
 }
+static_assert(MSM_SIZE_BINS == SIZE_BINS, "k_msm_m_binsort bins bucket sizes like k_scan_u32_c");
 static_assert(SCAN_ITEMS == MSM_SLICES, "k_scan_u32_a scans MSM_SLICES entries per thread: one bucket");
 // size_hist (256 bins) -> start offset of each bin in the descending-size order
 // One wave.  Also picks this MSM's task size: TASK_CAP points when there is plenty of work, smaller
@@ -1060,6 +1135,8 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // launches (latency, not throughput), and with witness columns that fill few windows it can take
     // longer than the sort + accumulation of the next column.
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
+    const char* env_bs = getenv("ZK_MSM_BINSORT");
+    const bool binsort = !(env_bs && atoi(env_bs) == 0);
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
     for (size_t it = 0; it < count; ++it) {
         const int par = (int)(it & 1);
@@ -1149,19 +1226,25 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, hist_cnt, hist_off, (const uint32_t*)block_tot3);
             launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride);
             ZK_CHECK_LAUNCH(ctx);
-            // 2. counting sort inside every partition: counts, scans (bucket offsets, size bins, task split), scatter
-            hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-            ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
-            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
-            hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
+            // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
+            //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
+            if (binsort) {
+                hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, nb, offsets, counts, size_hist, idx);
+                ZK_CHECK_LAUNCH(ctx);
+            } else {
+                hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                ZK_CHECK_LAUNCH(ctx);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
+                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
+            }
             hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist, (const uint32_t*)(offsets + nb));
             hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
             hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
             ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
+            if (!binsort) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
             ZK_CHECK_LAUNCH(ctx);
         }
         {

@@ -25,11 +25,34 @@
 //
 // Arithmetic: the stack machine computes on nine 29-bit limbs (ff29.cuh) -- the carry-free
 // Montgomery product runs 1.6x faster than the 8 x 32 CIOS one.  Stack values stay in halo2curves'
-// R = 2^256 Montgomery form, normalised and below 2p.  mul29 divides by R' = 2^261, so a product of
-// two R-form values multiplies one operand by 32 first (a 5-bit limb shift: 64p still fits the
-// 261-bit container and 2p * 64p < 2^261 p); constants that only ever multiply (MUL_CONST, FOLD,
-// the vanishing inverses) are tabulated in R' form instead and need no shift.  Spilled stack
-// slots are packed to 8 words, so the LDS footprint is that of the 32-bit representation.
+// R = 2^256 Montgomery form.  mul29 divides by R' = 2^261, so a product of two R-form values
+// multiplies one operand by 32 first (a 5-bit limb shift, folded into the unpacking of a memory
+// operand); constants that only ever multiply (MUL_CONST, FOLD, the vanishing inverses) are
+// tabulated in R' form instead and need no shift.
+//
+// Lowering (host, `lower_program`): the caller's postfix program is rebuilt as expression trees and
+// re-emitted for the machine the kernel really implements --
+//   * every binary operation whose right (or, for ADD / MUL / SUB, left) operand is a column, a
+//     parked intermediate or a constant takes that operand from memory (ADD_COL, SUB_COL, RSUB_COL,
+//     MUL_COL, FOLD_COL, ADD_CONST, MUL_CONST): a gate like q * (a * b - c) runs as
+//     PUSH a, MUL_COL b, SUB_COL c, MUL_COL q, FOLD with no stack traffic at all;
+//   * the memory operand of instruction pc + 1 is loaded before instruction pc executes (its ~1000
+//     ALU cycles cover the load), instruction words are fetched two ahead;
+//   * sums are not reduced when they are produced: the lowering tracks, per stack entry, a bound on
+//     the value (in multiples of p) and on the limbs (in multiples of 2^29) and sets "settle this
+//     operand first" bits only where the consumer's precondition would fail (bounds below).
+// Results are bit-identical to the plain evaluation: every step is exact arithmetic mod p and the
+// value written is the canonical representative.
+//
+// Bounds (V = value bound in units of p, L = limb bound in units of 2^29; settled = (2, 1); a column,
+// constant or parked intermediate is canonical = (1, 1)):
+//   mul29(a, b)    needs b normalised, limbs of a < 2^31.2 (L <= 4), a * b < 2^261 p  (V_a V_b < 168);
+//                  result (2, 1).  b = 32 x (a canonical operand): V_a <= 5;  b = 32 x (settled): V_a V_b <= 5.
+//   add29          (V_a + V_b, L_a + L_b), kept <= (4, 4) so that the value can always be settled
+//   a - b          = a + K p (balanced limbs) - b with b normalised and below K p: (V_a + K, L_a + 2),
+//                  K = 1 for canonical b, 2 for settled b
+//   FOLD           acc = mul29(acc, y) + t: acc is only ever the first operand of a product by a
+//                  constant, so it is never settled: L_t <= 3
 #include "ctx.hpp"
 #include "ff29.cuh"
 
@@ -79,26 +102,52 @@ __device__ __forceinline__ Q29 q_shl5(const Q29& x) {
 }
 __device__ __forceinline__ Q29 q_mul(const Q29& a, const Q29& b) { return mul29(a, q_shl5(b)); }            // R-form x R-form -> R-form, < 2p
 
-enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
+enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13,
+                      // produced by the lowering only (never part of a caller's program): the second operand comes from memory
+                      K_ADD_COL = 16, K_SUB_COL = 17, K_RSUB_COL = 18, K_MUL_COL = 19, K_FOLD_COL = 20, K_NOP = 21 };
+constexpr uint32_t K_SETTLE0 = 0x100, K_SETTLE1 = 0x200;      // word 0 of a lowered instruction: settle t0 / t1 before executing
+constexpr int K_CONST_SHIFT = 12;                              // K_FOLD_COL keeps its constant index in the bits above
 
 constexpr int Q_THREADS = 256;
 constexpr int Q_MAX_STACK = 16;
 constexpr uint32_t Q_MAX_TMP = 4096;     // intermediates live in HBM, [slot][row]: 32 MiB per slot at 2^20 rows
 
 struct QStack {
-    uint32_t* base;   // [slot][limb][lane]
-    __device__ __forceinline__ Fr get(int slot) const {
-        Fr r;
+    uint32_t* base;   // [slot][limb][lane], nine raw limbs: a spilled value keeps its (possibly unsettled) form
+    __device__ __forceinline__ Q29 get(int slot) const {
+        Q29 r;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r.l[k] = base[(slot * 8 + k) * Q_THREADS + threadIdx.x];
+        for (int k = 0; k < 9; ++k) r.l[k] = base[(slot * 9 + k) * Q_THREADS + threadIdx.x];
         return r;
     }
-    __device__ __forceinline__ void put(int slot, const Fr& v) const {
+    __device__ __forceinline__ void put(int slot, const Q29& v) const {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) base[(slot * 8 + k) * Q_THREADS + threadIdx.x] = v.l[k];
+        for (int k = 0; k < 9; ++k) base[(slot * 9 + k) * Q_THREADS + threadIdx.x] = v.l[k];
     }
 };
+// limbs of 32 * a for a < 2^256 (the R -> R' step of a product, folded into the unpacking)
+__device__ __forceinline__ Q29 unpack29_x32(const Fr& a) {
+    Q29 r;
+    r.l[0] = (a.l[0] << 5) & MASK29;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int bit = 29 * i - 5, w = bit >> 5, sh = bit & 31;
+        uint32_t v = a.l[w] >> sh;
+        if (sh > 3 && w + 1 < 8) v |= a.l[w + 1] << (32 - sh);
+        r.l[i] = i == 8 ? v : (v & MASK29);
+    }
+    return r;
+}
+static inline bool k_has_mem_host(uint32_t w0) {
+    const uint32_t o = w0 & 0xffu;
+    return o == Q_PUSH_COL || (o >= K_ADD_COL && o <= K_FOLD_COL);
+}
+__device__ __forceinline__ bool k_has_mem(uint32_t w0) {
+    const uint32_t o = w0 & 0xffu;
+    return o == Q_PUSH_COL || (o >= K_ADD_COL && o <= K_FOLD_COL);
+}
 
+// Runs a LOWERED program (lower_program below): `prog` holds prog_len instructions followed by two END triples.
 __global__ void __launch_bounds__(Q_THREADS)
 k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const Fr* __restrict__ consts,
                 const Fr* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
@@ -112,12 +161,11 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     const Q29 zero29 = unpack29<Fr29P>(Fr::zero());
     Q29 acc = zero29;
     // The two topmost stack elements live in registers (t0 = top, t1 = second); element j < sp - 2
-    // lives in LDS slot j.  Runs like `a b MUL c SUB` never touch LDS, and the LDS footprint per
-    // lane (what bounds occupancy here) is max_depth - 2 slots.
+    // lives in LDS slot j.
     Q29 t0 = zero29, t1 = zero29;
     int sp = 0;
     auto push = [&](const Q29& v) {
-        if (sp >= 2) st.put(sp - 2, pack29_raw(t1));
+        if (sp >= 2) st.put(sp - 2, t1);
         t1 = t0;
         t0 = v;
         ++sp;
@@ -125,37 +173,216 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     auto drop_to = [&](const Q29& top) {      // two operands consumed, `top` is the new top of stack
         --sp;
         t0 = top;
-        if (sp >= 2) t1 = unpack29<Fr29P>(st.get(sp - 2));
+        if (sp >= 2) t1 = st.get(sp - 2);
     };
+    auto load = [&](uint32_t a, uint32_t b) -> Fr {
+        const int64_t rot = (int32_t)b;
+        const uint64_t row = (i + (uint64_t)(rot * (int64_t)rot_scale)) & (ne - 1);
+        return live ? ldg(cols[a] + row) : Fr::zero();
+    };
+    // instruction words are fetched two ahead, the memory operand one ahead: the load of instruction pc + 1 is
+    // in flight while instruction pc computes
+    uint32_t w0 = prog[0], w1 = prog[1], w2 = prog[2];
+    uint32_t n0 = prog[3], n1 = prog[4], n2 = prog[5];
+    Fr m_cur = Fr::zero();
+    if (k_has_mem(w0)) m_cur = load(w1, w2);
     for (uint32_t pc = 0; pc < prog_len; ++pc) {
+        const uint32_t f0 = prog[3 * pc + 6], f1 = prog[3 * pc + 7], f2 = prog[3 * pc + 8];
+        Fr m_next = Fr::zero();
+        if (k_has_mem(n0)) m_next = load(n1, n2);
+        const uint32_t op = w0 & 0xffu;
+        if (op == Q_END) break;
+        if (w0 & K_SETTLE0) t0 = q_settle(t0);
+        if (w0 & K_SETTLE1) t1 = q_settle(t1);
+        switch (op) {
+            case Q_PUSH_COL: push(unpack29<Fr29P>(m_cur)); break;
+            case Q_PUSH_CONST: push(unpack29<Fr29P>(ldg(consts + w1))); break;
+            case Q_ADD: drop_to(add29(t1, t0)); break;
+            case Q_SUB: { Q29 d = sub29k<2>(t1, t0); normalize29(d); drop_to(d); break; }     // the top limb of a settled subtrahend may borrow: carry it out before anyone multiplies
+            case Q_MUL: drop_to(mul29(t1, q_shl5(t0))); break;
+            case Q_NEG: t0 = sub29k<2>(zero29, t0); normalize29(t0); break;
+            case Q_SQUARE: t0 = mul29(t0, q_shl5(t0)); break;
+            case Q_DOUBLE: t0 = add29(t0, t0); break;
+            case Q_FOLD: acc = add29(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + w1))), t0); drop_to(t1); break;
+            case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + w1))); break;
+            case Q_ADD_CONST: t0 = add29(t0, unpack29<Fr29P>(ldg(consts + w1))); break;
+            case Q_TEE_TMP: if (live) stg(tmp + ((uint64_t)w1 * ne + i), pack29_lt2p(t0)); break;             // parked canonical: read back as a column
+            case K_ADD_COL: t0 = add29(t0, unpack29<Fr29P>(m_cur)); break;
+            case K_SUB_COL: t0 = sub29k<2>(t0, unpack29<Fr29P>(m_cur)); break;                                  // canonical subtrahend: its top limb is below that of 2p, no borrow
+            case K_RSUB_COL: t0 = sub29k<2>(unpack29<Fr29P>(m_cur), t0); normalize29(t0); break;
+            case K_MUL_COL: t0 = mul29(t0, unpack29_x32(m_cur)); break;
+            case K_FOLD_COL: acc = add29(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + (w0 >> K_CONST_SHIFT)))), unpack29<Fr29P>(m_cur)); break;
+            default: break;
+        }
+        w0 = n0; w1 = n1; w2 = n2;
+        n0 = f0; n1 = f1; n2 = f2;
+        m_cur = m_next;
+    }
+    if (live) {
+        if (t_evals) stg(out + i, pack29_lt2p(mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1)))))));
+        else { normalize29(acc); stg(out + i, reduce_lazy29(acc)); }       // acc < 6p, never settled on the way
+    }
+}
+
+// ---- lowering: caller's postfix program -> the kernel's instruction stream -------------------------------------
+struct LNode {
+    enum Kind : uint8_t { MEM, CONST, UN, BIN, CONSTOP, TEE, MAT } kind;
+    bool has_tee;           // the subtree parks an intermediate (evaluation order then matters for readers of that slot)
+    bool is_tmp;            // MEM: a parked intermediate read back
+    uint32_t op, a, b;      // UN / BIN / CONSTOP: opcode; MEM: column, rotation; CONST / CONSTOP: constant; TEE: slot
+    int32_t x, y;
+};
+struct LowInstr { uint32_t w0, a, b; };
+
+// expression trees of the program, re-emitted with memory operands (see the header comment)
+static void lower_fuse(const uint32_t* prog, uint32_t len, uint32_t num_cols, std::vector<LowInstr>* out) {
+    std::vector<LNode> nodes;
+    nodes.reserve(len);
+    std::vector<int32_t> st;
+    auto add = [&](LNode n) { nodes.push_back(n); return (int32_t)nodes.size() - 1; };
+    auto leafish = [&](int32_t n) { return nodes[n].kind == LNode::MEM || nodes[n].kind == LNode::CONST; };
+    struct Work { int32_t node; int plan; };
+    std::vector<Work> work;
+    // plans of a BIN node after its operands: 0 = stack op, 1 = y from memory, 2 = y constant, 3 = x from memory (operands swapped), 4 = x constant (swapped)
+    auto emit = [&](int32_t root) {
+        work.push_back({root, -1});
+        while (!work.empty()) {
+            const Work wk = work.back();
+            work.pop_back();
+            const LNode& n = nodes[wk.node];
+            switch (n.kind) {
+                case LNode::MAT: break;
+                case LNode::MEM: out->push_back({Q_PUSH_COL, n.a, n.b}); break;
+                case LNode::CONST: out->push_back({Q_PUSH_CONST, n.a, 0}); break;
+                case LNode::UN:
+                    if (wk.plan < 0) { work.push_back({wk.node, 0}); work.push_back({n.x, -1}); }
+                    else out->push_back({n.op, 0, 0});
+                    break;
+                case LNode::CONSTOP:
+                    if (wk.plan < 0) { work.push_back({wk.node, 0}); work.push_back({n.x, -1}); }
+                    else out->push_back({n.op, n.a, 0});
+                    break;
+                case LNode::TEE:
+                    if (wk.plan < 0) { work.push_back({wk.node, 0}); work.push_back({n.x, -1}); }
+                    else out->push_back({Q_TEE_TMP, n.a, 0});
+                    break;
+                case LNode::BIN: {
+                    const LNode &x = nodes[n.x], &y = nodes[n.y];
+                    if (wk.plan < 0) {
+                        int plan = 0;
+                        if (y.kind == LNode::MEM) plan = 1;
+                        else if (y.kind == LNode::CONST && (n.op == Q_ADD || n.op == Q_MUL)) plan = 2;
+                        else if (x.kind == LNode::MEM && !leafish(n.y) && !(x.is_tmp && y.has_tee)) plan = 3;
+                        else if (x.kind == LNode::CONST && !leafish(n.y) && (n.op == Q_ADD || n.op == Q_MUL)) plan = 4;
+                        work.push_back({wk.node, plan});
+                        if (plan == 0) { work.push_back({n.y, -1}); work.push_back({n.x, -1}); }
+                        else if (plan == 1 || plan == 2) work.push_back({n.x, -1});
+                        else work.push_back({n.y, -1});
+                    } else if (wk.plan == 0) out->push_back({n.op, 0, 0});
+                    else if (wk.plan == 1) out->push_back({n.op == Q_ADD ? K_ADD_COL : n.op == Q_SUB ? K_SUB_COL : K_MUL_COL, y.a, y.b});
+                    else if (wk.plan == 2) out->push_back({n.op == Q_ADD ? Q_ADD_CONST : Q_MUL_CONST, y.a, 0});
+                    else if (wk.plan == 3) out->push_back({n.op == Q_ADD ? K_ADD_COL : n.op == Q_SUB ? K_RSUB_COL : K_MUL_COL, x.a, x.b});
+                    else out->push_back({n.op == Q_ADD ? Q_ADD_CONST : Q_MUL_CONST, x.a, 0});
+                    break;
+                }
+            }
+        }
+    };
+    auto materialise_pending = [&]() {
+        for (int32_t& e : st)
+            if (nodes[e].kind != LNode::MAT) { emit(e); e = add({LNode::MAT, false, false, 0, 0, 0, -1, -1}); }
+    };
+    for (uint32_t pc = 0; pc < len; ++pc) {
         const uint32_t op = prog[3 * pc], a = prog[3 * pc + 1], b = prog[3 * pc + 2];
         if (op == Q_END) break;
         switch (op) {
-            case Q_PUSH_COL: {
-                const int64_t rot = (int32_t)b;
-                const uint64_t row = (i + (uint64_t)(rot * (int64_t)rot_scale)) & (ne - 1);
-                push(unpack29<Fr29P>(live ? ldg(cols[a] + row) : Fr::zero()));
+            case Q_PUSH_COL: st.push_back(add({LNode::MEM, false, false, 0, a, b, -1, -1})); break;
+            case Q_PUSH_TMP: st.push_back(add({LNode::MEM, false, true, 0, num_cols + a, 0, -1, -1})); break;     // parked intermediates are columns num_cols + slot
+            case Q_PUSH_CONST: st.push_back(add({LNode::CONST, false, false, 0, a, 0, -1, -1})); break;
+            case Q_ADD: case Q_SUB: case Q_MUL: {
+                const int32_t y = st.back(); st.pop_back();
+                const int32_t x = st.back(); st.pop_back();
+                st.push_back(add({LNode::BIN, nodes[x].has_tee || nodes[y].has_tee, false, op, 0, 0, x, y}));
                 break;
             }
-            case Q_PUSH_CONST: push(unpack29<Fr29P>(ldg(consts + a))); break;
-            case Q_ADD: drop_to(q_add(t1, t0)); break;
-            case Q_SUB: drop_to(q_sub(t1, t0)); break;
-            case Q_MUL: drop_to(q_mul(t1, t0)); break;
-            case Q_NEG: t0 = q_sub(zero29, t0); break;
-            case Q_SQUARE: t0 = q_mul(t0, t0); break;
-            case Q_DOUBLE: t0 = q_add(t0, t0); break;
-            case Q_FOLD: acc = q_add(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + a))), t0); drop_to(t1); break;
-            case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + a))); break;
-            case Q_ADD_CONST: t0 = q_add(t0, unpack29<Fr29P>(ldg(consts + a))); break;
-            case Q_TEE_TMP: if (live) tmp[(uint64_t)a * ne + i] = pack29_raw(t0); break;                       // normalised, < 2p < 2^256
-            case Q_PUSH_TMP: push(live ? unpack29<Fr29P>(tmp[(uint64_t)a * ne + i]) : zero29); break;
-            default: break;
+            case Q_NEG: case Q_SQUARE: case Q_DOUBLE: { const int32_t x = st.back(); st.back() = add({LNode::UN, nodes[x].has_tee, false, op, 0, 0, x, -1}); break; }
+            case Q_MUL_CONST: case Q_ADD_CONST: { const int32_t x = st.back(); st.back() = add({LNode::CONSTOP, nodes[x].has_tee, false, op, a, 0, x, -1}); break; }
+            case Q_TEE_TMP: { const int32_t x = st.back(); st.back() = add({LNode::TEE, true, false, 0, a, 0, x, -1}); break; }
+            case Q_FOLD: {
+                const int32_t r = st.back(); st.pop_back();
+                materialise_pending();
+                if (nodes[r].kind == LNode::MEM && a < (1u << (32 - K_CONST_SHIFT))) out->push_back({K_FOLD_COL | (a << K_CONST_SHIFT), nodes[r].a, nodes[r].b});
+                else { emit(r); out->push_back({Q_FOLD, a, 0}); }
+                break;
+            }
+            default: break;     // validate_program has refused everything else
         }
     }
-    if (live) {
-        if (t_evals) acc = mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1)))));
-        stg(out + i, pack29_lt2p(acc));
+    materialise_pending();
+}
+
+// Settle bits, prefetch hazards and stack depth of a fused program (bounds: header comment).  V in units of p, L in
+// units of 2^29; every stack entry stays within (4, 4), so q_settle (< 4p, limbs < 2^31) applies to any of them.
+static int lower_bounds(std::vector<LowInstr>* prog_io, uint32_t num_cols, int* max_depth) {
+    struct Bd { int V, L; };
+    std::vector<Bd> bs;
+    std::vector<LowInstr> out;
+    out.reserve(prog_io->size() + 8);
+    int mx = 0;
+    for (const LowInstr& in0 : *prog_io) {
+        LowInstr in = in0;
+        const uint32_t op = in.w0 & 0xffu;
+        auto settle0 = [&]() { in.w0 |= K_SETTLE0; bs.back() = {2, 1}; };
+        auto settle1 = [&]() { in.w0 |= K_SETTLE1; bs[bs.size() - 2] = {2, 1}; };
+        const size_t need = (op == Q_ADD || op == Q_SUB || op == Q_MUL) ? 2 : (op == Q_PUSH_COL || op == Q_PUSH_CONST || op == K_FOLD_COL || op == K_NOP) ? 0 : 1;
+        if (bs.size() < need) return -1;
+        switch (op) {
+            case Q_PUSH_COL: case Q_PUSH_CONST: bs.push_back({1, 1}); break;
+            case Q_ADD: {
+                if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) {
+                    if (bs.back().V > 2 || bs.back().L > 1) settle0();
+                    if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) settle1();
+                    if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) settle0();
+                }
+                const Bd r{bs[bs.size() - 2].V + bs.back().V, bs[bs.size() - 2].L + bs.back().L};
+                bs.pop_back(); bs.back() = r;
+                break;
+            }
+            case Q_SUB: {
+                if (bs.back().V > 2 || bs.back().L > 1) settle0();
+                if (bs[bs.size() - 2].V + 2 > 4 || bs[bs.size() - 2].L + 2 > 4) settle1();
+                const Bd r{bs[bs.size() - 2].V + 2, 1};
+                bs.pop_back(); bs.back() = r;
+                break;
+            }
+            case Q_MUL: {
+                if (bs.back().V > 2 || bs.back().L > 1) settle0();
+                if (bs[bs.size() - 2].V * bs.back().V > 5) settle1();
+                bs.pop_back(); bs.back() = {2, 1};
+                break;
+            }
+            case Q_NEG: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {3, 1}; break;       // 2p - t0 reaches 2p itself (t0 = 0): not below 2p
+            case Q_SQUARE: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {2, 1}; break;
+            case Q_DOUBLE: if (bs.back().V > 2 || bs.back().L > 2) settle0(); bs.back() = {2 * bs.back().V, 2 * bs.back().L}; break;
+            case Q_FOLD: if (bs.back().L > 3) settle0(); bs.pop_back(); break;
+            case Q_MUL_CONST: bs.back() = {2, 1}; break;
+            case Q_ADD_CONST: case K_ADD_COL: if (bs.back().V + 1 > 4 || bs.back().L + 1 > 4) settle0(); bs.back() = {bs.back().V + 1, bs.back().L + 1}; break;
+            case Q_TEE_TMP: if (bs.back().V > 2 || bs.back().L > 1) settle0(); break;
+            case K_SUB_COL: if (bs.back().V + 2 > 4 || bs.back().L + 2 > 4) settle0(); bs.back() = {bs.back().V + 2, bs.back().L + 2}; break;
+            case K_RSUB_COL: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {3, 1}; break;
+            case K_MUL_COL: bs.back() = {2, 1}; break;
+            case K_FOLD_COL: case K_NOP: break;
+            default: return -1;
+        }
+        // the memory operand of an instruction is loaded while its predecessor runs: a parked intermediate must not be
+        // read back by the instruction right behind the one that parks it
+        if (k_has_mem_host(in.w0) && in.a >= num_cols && !out.empty() && (out.back().w0 & 0xffu) == Q_TEE_TMP && out.back().a == in.a - num_cols) out.push_back({K_NOP, 0, 0});
+        out.push_back(in);
+        if ((int)bs.size() > mx) mx = (int)bs.size();
     }
+    *max_depth = mx;
+    prog_io->swap(out);
+    return 0;
 }
 
 // host-side validation of a program: stack discipline and operand ranges
@@ -211,6 +438,30 @@ static void vanishing_inverses(uint32_t k, uint32_t ext_k, std::vector<Fr>* out)
 
 using namespace zk;
 
+// The lowering as a host-only entry point (no device involved): what the kernel will run for a program.  Used by the
+// CPU tests, which execute the lowered stream limb by limb and check every bound the kernel relies on.
+extern "C" int zk_host_quotient_lower(const uint32_t* h_program, uint32_t num_instr, uint32_t num_cols, int fuse, uint32_t* out_words, size_t cap_words,
+                                      uint32_t* out_instr, int* out_depth) {
+    if (!h_program || !out_instr || !out_depth) return ZK_ERR_INVALID_ARG;
+    std::vector<LowInstr> low;
+    if (fuse) lower_fuse(h_program, num_instr, num_cols, &low);
+    else
+        for (uint32_t pc = 0; pc < num_instr && h_program[3 * pc] != Q_END; ++pc) {
+            const uint32_t op = h_program[3 * pc], a_ = h_program[3 * pc + 1], b_ = h_program[3 * pc + 2];
+            if (op == Q_PUSH_TMP) low.push_back({Q_PUSH_COL, num_cols + a_, 0});
+            else low.push_back({op, a_, b_});
+        }
+    int depth = 0;
+    if (lower_bounds(&low, num_cols, &depth)) return ZK_ERR_INVALID_ARG;
+    *out_instr = (uint32_t)low.size();
+    *out_depth = depth;
+    if (out_words) {
+        if (cap_words < low.size() * 3) return ZK_ERR_INVALID_ARG;
+        for (size_t i = 0; i < low.size(); ++i) { out_words[3 * i] = low[i].w0; out_words[3 * i + 1] = low[i].a; out_words[3 * i + 2] = low[i].b; }
+    }
+    return ZK_OK;
+}
+
 extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr, const void* const* h_col_ptrs, uint32_t num_cols,
                                 const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
@@ -225,7 +476,23 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         d_tmp = (Fr*)ctx->get_scratch(SC_QTMP, ((size_t)num_tmp << ext_k) * sizeof(Fr));
         if (!d_tmp) return ZK_ERR_OOM;
     }
+    // lower the program for the kernel (memory operands, settle bits, prefetch hazards); ZK_QUOTIENT_FUSE=0 keeps the
+    // caller's instruction sequence (measurement knob: only the bounds pass runs)
+    std::vector<LowInstr> low;
+    {
+        const char* env = getenv("ZK_QUOTIENT_FUSE");
+        if (env && atoi(env) == 0) {
+            for (uint32_t pc = 0; pc < num_instr && h_program[3 * pc] != Q_END; ++pc) {
+                const uint32_t op = h_program[3 * pc], a_ = h_program[3 * pc + 1], b_ = h_program[3 * pc + 2];
+                if (op == Q_PUSH_TMP) low.push_back({Q_PUSH_COL, num_cols + a_, 0});
+                else low.push_back({op, a_, b_});
+            }
+        } else lower_fuse(h_program, num_instr, num_cols, &low);
+        if (lower_bounds(&low, num_cols, &depth)) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: lowering failed");
+        if (depth > Q_MAX_STACK) return ctx->fail(ZK_ERR_UNSUPPORTED, "quotient program: stack deeper than %d", Q_MAX_STACK);
+    }
     if (depth < 1) depth = 1;
+    const uint32_t low_len = (uint32_t)low.size();
     std::vector<Fr> tev;
     if (divide_by_vanishing) vanishing_inverses(k, ext_k, &tev);
     // constants that multiply (MUL_CONST, FOLD) and the vanishing inverses go to the device in R' = 2^261 form too: x 32
@@ -233,7 +500,10 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     std::vector<Fr> consts_rp((const Fr*)h_consts, (const Fr*)h_consts + num_consts);
     for (Fr& c : consts_rp) c = times32(c);
     for (Fr& t : tev) t = times32(t);
-    const size_t prog_bytes = (size_t)num_instr * 12 + 12, col_bytes = (size_t)(num_cols ? num_cols : 1) * 8;
+    // column table = the caller's columns, then one pseudo-column per parked intermediate
+    std::vector<const void*> col_tab(h_col_ptrs, h_col_ptrs + num_cols);
+    for (uint32_t t = 0; t < num_tmp; ++t) col_tab.push_back(d_tmp + ((size_t)t << ext_k));
+    const size_t prog_bytes = (size_t)(low_len + 3) * 12, col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
     const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(Fr) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
@@ -242,23 +512,39 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     const Fr** d_cols = (const Fr**)(d + al(prog_bytes));
     Fr* d_consts = (Fr*)(d + al(prog_bytes) + al(col_bytes));
     Fr* d_tev = (Fr*)(d + al(prog_bytes) + al(col_bytes) + al(const_bytes));
-    std::vector<uint32_t> prog(h_program, h_program + (size_t)num_instr * 3);
-    prog.push_back(Q_END); prog.push_back(0); prog.push_back(0);
+    std::vector<uint32_t> prog;
+    prog.reserve((size_t)(low_len + 3) * 3);
+    for (const LowInstr& in : low) { prog.push_back(in.w0); prog.push_back(in.a); prog.push_back(in.b); }
+    for (int e = 0; e < 3; ++e) { prog.push_back(Q_END); prog.push_back(0); prog.push_back(0); }      // END + the two triples the kernel fetches ahead
     ZK_HIP(ctx, hipMemcpyAsync(d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (num_cols) ZK_HIP(ctx, hipMemcpyAsync(d_cols, h_col_ptrs, (size_t)num_cols * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!col_tab.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_cols, col_tab.data(), col_tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts, h_consts, (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts + num_consts, consts_rp.data(), (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     if (!tev.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_tev, tev.data(), tev_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
-    const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 8 * Q_THREADS * 4;    // the two topmost elements are in registers
+    const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
     if (!ctx->quotient_attr_set) {
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 8 * Q_THREADS * 4));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
         ctx->quotient_attr_set = true;
     }
     ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
+    if (ctx->prof_on) {
+        // algorithmic bytes of this launch: every distinct (column, rotation) operand is read once per row, parked
+        // intermediates are written and read back once each, one result per row is written
+        std::vector<uint64_t> ops;
+        uint64_t tmp_moves = 0;
+        for (uint32_t i = 0; i < num_instr; ++i) {
+            const uint32_t op = h_program[3 * i];
+            if (op == Q_PUSH_COL) ops.push_back(((uint64_t)h_program[3 * i + 1] << 32) | h_program[3 * i + 2]);
+            else if (op == Q_TEE_TMP || op == Q_PUSH_TMP) ++tmp_moves;
+        }
+        std::sort(ops.begin(), ops.end());
+        ops.erase(std::unique(ops.begin(), ops.end()), ops.end());
+        ps.bytes = (ops.size() + tmp_moves + 1) * ne * 32;
+    }
     hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                       num_instr + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+                       low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
