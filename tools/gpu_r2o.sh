@@ -1,0 +1,14 @@
+#!/bin/bash
+# pass O: full GPU suite + full bench line after the sort / evaluator changes
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+ROOT=$(pwd); O=$ROOT/gpurun_out/r2o; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+( time timeout 900 python bench.py ) > $O/bench_full.json 2> $O/bench_full.err
+python - <<PY
+import json
+d=json.load(open("$O/bench_full.json"))
+print(d["value"], "Mscalar/s", d["ms_per_step"], "ms/step", d["extra"]["kernel_avg_ms"], "lone", d["extra"]["msm_lone_ms"])
+for k,v in d.get("proof",{}).items(): print(k, {x:v.get(x) for x in ("value","create_proof_s","verified_by_oracle","error","chain_of_4_proofs_s")}, v.get("roofline_quotient"))
+PY
+tail -3 $O/bench_full.err

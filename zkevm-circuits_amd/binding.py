@@ -44,9 +44,10 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ZkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
-        _lib = ctypes.CDLL(LIB_PATH)
+        path = os.environ.get("ZKMI355_LIB", LIB_PATH)       # A/B measurements against another build of the library
+        if not os.path.exists(path):
+            raise ZkError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib = ctypes.CDLL(path)
         _lib.zk_last_error.restype = ctypes.c_char_p
         _lib.zk_version.restype = ctypes.c_char_p
         _lib.zk_srs_g.restype = ctypes.c_void_p

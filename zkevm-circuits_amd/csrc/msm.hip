@@ -41,6 +41,7 @@ struct MsmPlan {
     int c;          // window bits
     int W;          // windows
     uint32_t B;     // buckets per window = 2^(c-1)
+    int top_shift = 0;   // merged-window path: the top window's digit is scaled by 2^top_shift (its table entry is 2^(c (W-1) - top_shift) P)
 };
 
 static MsmPlan make_plan(size_t n) {
@@ -216,8 +217,12 @@ constexpr int MSM_M_MIN_C = 8, MSM_M_MAX_C = 22;
 constexpr uint32_t MSM_M_MAX_BINS = 1u << (MSM_M_MAX_C - 1 - MSM_RANGE_MAX_BITS);     // 1024 partitions of 2048 buckets
 constexpr uint32_t MSM_M_CHUNK = 2048;                                                   // scalars per workgroup of the partition passes
 constexpr uint32_t CODE_ZERO = 0xFFFFFFFFu;
+// The top window holds only the few leading bits of a scalar (14 of 20 at C = 20): its digits would all land in the
+// lowest buckets -- a handful of partitions with ten times the entries of the others.  Its digit is therefore scaled
+// by 2^top_shift (still at most 2^(C-1), so it never goes negative) against a table entry built with top_shift fewer
+// doublings: same product, buckets spread over the whole range.
 template <int C>
-__device__ __forceinline__ void recode_wide(const Fr& s, uint32_t (&code)[(256 + C - 1) / C]) {
+__device__ __forceinline__ void recode_wide(const Fr& s, uint32_t (&code)[(256 + C - 1) / C], int top_shift) {
     constexpr int W = (256 + C - 1) / C;
     constexpr uint32_t mask = (1u << C) - 1, half = 1u << (C - 1);
     uint32_t carry = 0;
@@ -227,6 +232,7 @@ __device__ __forceinline__ void recode_wide(const Fr& s, uint32_t (&code)[(256 +
         uint32_t d = limb < 8 ? (s.l[limb < 8 ? limb : 7] >> sh) : 0u;
         if (sh + C > 32 && limb + 1 < 8) d |= s.l[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
         d = (d & mask) + carry;
+        if (w == W - 1) d <<= top_shift;
         if (d > half) { carry = 1; const uint32_t mag = (1u << C) - d; code[w] = mag ? (NEG_BIT | (mag - 1)) : CODE_ZERO; }
         else { carry = 0; code[w] = d ? (d - 1) : CODE_ZERO; }
     }
@@ -256,19 +262,20 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* lds, uint32_t slot, bool 
 // and a read of W words per scalar).
 template <int C, bool SCATTER>
 __global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
-                                                          uint64_t* __restrict__ entries, uint64_t tab_stride) {
+                                                          uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift) {
     constexpr int W = (256 + C - 1) / C;
     __shared__ uint32_t lds[MSM_M_MAX_BINS];
     const uint32_t nbins = 1u << (C - 1 - range_bits), nwg = gridDim.x, g = blockIdx.x;
     for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = SCATTER ? hist_off[(uint64_t)t * nwg + g] : 0u;
     __syncthreads();
-    const uint64_t lo = (uint64_t)g * MSM_M_CHUNK, hi = min(n, lo + MSM_M_CHUNK);
+    const uint64_t chunk = (n + nwg - 1) / nwg;                    // scalars per workgroup (the host sizes the grid)
+    const uint64_t lo = min(n, (uint64_t)g * chunk), hi = min(n, lo + chunk);
     const uint32_t rmask = (1u << range_bits) - 1u;
     for (uint64_t base = lo; base < hi; base += blockDim.x) {          // uniform trip count: the ballots below see whole waves
         const uint64_t i = base + threadIdx.x;
         const bool live = i < hi;
         uint32_t code[W];
-        if (live) recode_wide<C>(from_mont(ldg(scalars + i)), code);
+        if (live) recode_wide<C>(from_mont(ldg(scalars + i)), code, top_shift);
         else {
 #pragma unroll
             for (int w = 0; w < W; ++w) code[w] = CODE_ZERO;
@@ -350,11 +357,30 @@ __global__ void __launch_bounds__(1024) k_msm_m_binsort(const uint64_t* __restri
     if (threadIdx.x < MSM_SIZE_BINS) lh[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t lo = hist_off[(uint64_t)bin * nwg], hi = hist_off[(uint64_t)(bin + 1) * nwg];     // the scan's closing entry holds the total
-    for (uint32_t base = lo; base < hi; base += blockDim.x) {
-        const uint32_t e = base + threadIdx.x;
-        const bool live = e < hi;
-        const uint64_t ent = live ? entries[e] : 0ull;
-        (void)lds_take(cnt, (uint32_t)(ent >> 32), live);
+    const bool staged = hi - lo <= MSM_M_STAGE;
+    // a staged partition is read ONCE: every thread keeps its <= 15 entries in registers between the counting and the
+    // ranking pass, all loads in flight together (one latency, not fifteen)
+    constexpr int PER = MSM_M_STAGE / 1024;
+    uint64_t ent_r[PER];
+    if (staged) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t e = lo + (uint32_t)j * 1024u + threadIdx.x;
+            ent_r[j] = e < hi ? entries[e] : ~0ull;                      // no real entry is all ones (its high word is a bucket index)
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (lo + (uint32_t)j * 1024u >= hi) break;                       // uniform
+            const bool live = ent_r[j] != ~0ull;
+            (void)lds_take(cnt, (uint32_t)(ent_r[j] >> 32), live);
+        }
+    } else {
+        for (uint32_t base = lo; base < hi; base += blockDim.x) {
+            const uint32_t e = base + threadIdx.x;
+            const bool live = e < hi;
+            const uint64_t ent = live ? entries[e] : 0ull;
+            (void)lds_take(cnt, (uint32_t)(ent >> 32), live);
+        }
     }
     __syncthreads();
     {   // exclusive scan of the counters: thread t owns buckets 2t, 2t + 1 (range <= 2048)
@@ -385,15 +411,21 @@ __global__ void __launch_bounds__(1024) k_msm_m_binsort(const uint64_t* __restri
     __syncthreads();
     if (threadIdx.x < MSM_SIZE_BINS && lh[threadIdx.x]) atomicAdd(&size_hist[threadIdx.x], lh[threadIdx.x]);
     if (bin + 1 == gridDim.x && threadIdx.x == 0) offsets[nb] = hi;
-    const bool staged = hi - lo <= MSM_M_STAGE;
-    for (uint32_t base = lo; base < hi; base += blockDim.x) {
-        const uint32_t e = base + threadIdx.x;
-        const bool live = e < hi;
-        const uint64_t ent = live ? entries[e] : 0ull;
-        const uint32_t pos = lds_take(cnt, (uint32_t)(ent >> 32), live);
-        if (live) {
-            if (staged) stage[pos] = (uint32_t)ent;
-            else idx[lo + pos] = (uint32_t)ent;
+    if (staged) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (lo + (uint32_t)j * 1024u >= hi) break;                       // uniform
+            const bool live = ent_r[j] != ~0ull;
+            const uint32_t pos = lds_take(cnt, (uint32_t)(ent_r[j] >> 32), live);
+            if (live) stage[pos] = (uint32_t)ent_r[j];
+        }
+    } else {
+        for (uint32_t base = lo; base < hi; base += blockDim.x) {
+            const uint32_t e = base + threadIdx.x;
+            const bool live = e < hi;
+            const uint64_t ent = live ? entries[e] : 0ull;
+            const uint32_t pos = lds_take(cnt, (uint32_t)(ent >> 32), live);
+            if (live) idx[lo + pos] = (uint32_t)ent;
         }
     }
     if (staged) {
@@ -562,7 +594,7 @@ __global__ void k_bases_to_rprime(const G1Affine* __restrict__ in, G1Affine* __r
 // them every window's bucket b carries the same weight (b+1): the W per-window bucket arrays are
 // first folded into one, the weighted reduction runs over 2^(c-1) buckets instead of W * 2^(c-1),
 // and the host Horner tail disappears.
-__global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __restrict__ bases_rp, uint64_t n, int c, int W, G1Affine* __restrict__ table) {
+__global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __restrict__ bases_rp, uint64_t n, int c, int W, G1Affine* __restrict__ table, int top_shift) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const G1Affine p0 = ldg(bases_rp + i);
@@ -570,8 +602,9 @@ __global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __r
     G1Xyzz29 cur = p0.is_identity() ? identity29() : G1Xyzz29{unpack29<Fq29P>(p0.x), unpack29<Fq29P>(p0.y), one29(), one29()};
 #pragma unroll 1
     for (int w = 1; w < W; ++w) {
+        const int steps = w == W - 1 ? c - top_shift : c;        // merged-window plans scale the top digit instead (MsmPlan::top_shift)
 #pragma unroll 1
-        for (int j = 0; j < c; ++j) cur = dbl29pt(cur);
+        for (int j = 0; j < steps; ++j) cur = dbl29pt(cur);
         const G1Affine a = to_affine_rp(cur);
         stg(table + (uint64_t)w * n + i, a);
         if (!a.is_identity()) cur = G1Xyzz29{unpack29<Fq29P>(a.x), unpack29<Fq29P>(a.y), one29(), one29()};   // keep Z = 1: cheaper doublings stay exact
@@ -1044,11 +1077,27 @@ static MsmPlan make_plan_merged(uint32_t k_srs) {
     p.c = c;
     p.W = (256 + c - 1) / c;
     p.B = 1u << (c - 1);
+    // largest shift that keeps the top digit (leading bits of a canonical scalar, plus the carry of the window below)
+    // at or below 2^(c-1)
+    const int low = c * (p.W - 1);
+    uint64_t top_max = 1;
+    if (low < 254) {
+        uint64_t v = 0;      // (modulus - 1) >> low, from the 8 x 32-bit limbs (the modulus is odd: -1 only clears bit 0)
+        for (int b = 0; b < 40 && low + b < 256; ++b) {
+            const int bit = low + b;
+            const uint32_t limb = bit < 32 ? FrP::M(0) - 1u : FrP::M(bit >> 5);
+            v |= (uint64_t)((limb >> (bit & 31)) & 1u) << b;
+        }
+        top_max = v + 1;
+    }
+    p.top_shift = 0;
+    while (p.top_shift + 1 <= c - 1 && (top_max << (p.top_shift + 1)) <= (1ull << (c - 1))) ++p.top_shift;
+    if (const char* e = getenv("ZK_MSM_TOP_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= p.top_shift) p.top_shift = v; }   // measurement knob
     return p;
 }
 template <bool SCATTER>
-static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride) {
-#define ZK_PART_CASE(C) case C: hipLaunchKernelGGL((k_msm_m_partition<C, SCATTER>), grid, dim3(256), 0, st, scalars, n, range_bits, hist, hist_off, entries, tab_stride); break;
+static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift) {
+#define ZK_PART_CASE(C) case C: hipLaunchKernelGGL((k_msm_m_partition<C, SCATTER>), grid, dim3(256), 0, st, scalars, n, range_bits, hist, hist_off, entries, tab_stride, top_shift); break;
     switch (c) {
         ZK_PART_CASE(8) ZK_PART_CASE(9) ZK_PART_CASE(10) ZK_PART_CASE(11) ZK_PART_CASE(12) ZK_PART_CASE(13) ZK_PART_CASE(14) ZK_PART_CASE(15)
         ZK_PART_CASE(16) ZK_PART_CASE(17) ZK_PART_CASE(18) ZK_PART_CASE(19) ZK_PART_CASE(20) ZK_PART_CASE(21) ZK_PART_CASE(22)
@@ -1087,8 +1136,21 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     if ((uint64_t)pl.W * tab_stride >= (1ull << 31) || max_entries >= (1ull << 32)) return ctx->fail(ZK_ERR_UNSUPPORTED, "MSM of %zu points x %d windows exceeds the 32-bit entry space: split it", n, pl.W);
     int range_bits = pl.c - 1;
     if (range_bits > MSM_RANGE_MAX_BITS) range_bits = MSM_RANGE_MAX_BITS;
+    // one-launch partition sort (k_msm_m_binsort) when 1024 partitions are small enough for its LDS staging buffer;
+    // ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
+    const char* env_bs = getenv("ZK_MSM_BINSORT");
+    bool binsort = !(env_bs && atoi(env_bs) == 0);
+    if (binsort) {
+        int rb = pl.c - 1 - 10;
+        if (rb < 0) rb = 0;
+        const uint64_t per_partition = max_entries / (nb >> rb);
+        if (per_partition + per_partition / 8 <= MSM_M_STAGE) range_bits = rb;
+        else binsort = false;
+    }
     const uint32_t nbins = nb >> range_bits;
-    const uint32_t nwg = (uint32_t)((n + MSM_M_CHUNK - 1) / MSM_M_CHUNK);
+    uint32_t chunk = MSM_M_CHUNK;
+    if (const char* e = getenv("ZK_MSM_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536) chunk = (uint32_t)v; }   // measurement knob
+    const uint32_t nwg = (uint32_t)((n + chunk - 1) / chunk);
     const uint32_t hist_cnt = nbins * nwg;
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
     const uint32_t scan_blocks_s = (nb + SCAN_T - 1) / SCAN_T;
@@ -1135,8 +1197,6 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // launches (latency, not throughput), and with witness columns that fill few windows it can take
     // longer than the sort + accumulation of the next column.
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
-    const char* env_bs = getenv("ZK_MSM_BINSORT");
-    const bool binsort = !(env_bs && atoi(env_bs) == 0);
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
     for (size_t it = 0; it < count; ++it) {
         const int par = (int)(it & 1);
@@ -1219,12 +1279,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZkProfScope ps(ctx, "msm_sort");
             ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
             // 1. partition by the high bucket bits while recoding: histogram, scan, scatter
-            launch_partition<false>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride);
+            launch_partition<false>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift);
             ZK_CHECK_LAUNCH(ctx);
             hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, hist_cnt, hist_off, (const uint32_t*)block_tot3);
-            launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride);
+            launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift);
             ZK_CHECK_LAUNCH(ctx);
             // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
             //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
@@ -1266,9 +1326,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
         {   // weighted bucket sum on a side stream: hides under the next MSMs
             ZkProfScope ps(ctx, "msm_reduce", side);
-            if (count == 1) {
-                // a lone MSM waits for its reduction: one launch with a scalar multiplication per lane has the shorter
-                // dependent chain (about 60 additions against 150 over the levels below), at twice the work
+            if (it + 2 >= count) {
+                // the caller waits for the reductions of the last two MSMs of a batch (and of a lone one): one launch with a
+                // scalar multiplication per lane has the shorter dependent chain (about 60 additions against 150 over the
+                // levels below), at twice the work
                 const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;      // <= nb / 2048 + 1 partials: fits red_pts
                 hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, nb, partial);
                 hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partial, rb, wsum_all + it);
@@ -1305,7 +1366,7 @@ static int srs_window_table_narrow(zk_ctx* ctx, const zk_srs* srs, int basis, si
         int rc = srs_bases_rp(ctx, srs, basis, &rp);
         if (rc) return rc;
         if (hipMalloc(&s->tabn[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tabn[basis] = nullptr; return ZK_OK; }
-        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tabn[basis]);
+        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tabn[basis], 0);
         ZK_CHECK_LAUNCH(ctx);
     }
     *out = s->tabn[basis];
@@ -1356,7 +1417,7 @@ int srs_window_table(zk_ctx* ctx, const zk_srs* srs, int basis, size_t n, const 
         if (rc) return rc;
         if (hipMalloc(&s->tab[basis], bytes) != hipSuccess) { (void)hipGetLastError(); s->tab[basis] = nullptr; return ZK_OK; }   // no memory: per-window path
         s->tab_c[basis] = pl.c;
-        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tab[basis]);
+        hipLaunchKernelGGL(k_build_window_tables, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rp, ns, pl.c, pl.W, s->tab[basis], pl.top_shift);
         ZK_CHECK_LAUNCH(ctx);
     }
     *out = s->tab[basis];

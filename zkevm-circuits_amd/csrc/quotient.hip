@@ -148,6 +148,8 @@ __device__ __forceinline__ bool k_has_mem(uint32_t w0) {
 }
 
 // Runs a LOWERED program (lower_program below): `prog` holds prog_len instructions followed by two END triples.
+// FULL: the grid covers the domain exactly (2^ext_k >= Q_THREADS), no lane needs masking.
+template <bool FULL>
 __global__ void __launch_bounds__(Q_THREADS)
 k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const Fr* __restrict__ consts,
                 const Fr* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
@@ -155,19 +157,18 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     QStack st{smem};
     const uint64_t ne = 1ull << ext_k;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < ne;
-    const uint32_t rot_scale = 1u << (ext_k - k);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;            // ext_k <= 28: row indices fit 32 bits
+    const bool live = FULL || i < (uint32_t)ne;
+    const uint32_t rot_scale = 1u << (ext_k - k), row_mask = (uint32_t)ne - 1u;
     const Q29 zero29 = unpack29<Fr29P>(Fr::zero());
     Q29 acc = zero29;
     // The two topmost stack elements live in registers (t0 = top, t1 = second); element j < sp - 2
     // lives in LDS slot j.
     Q29 t0 = zero29, t1 = zero29;
     int sp = 0;
-    auto push = [&](const Q29& v) {
+    auto push_shift = [&]() {                 // makes room on top: the caller writes t0 next
         if (sp >= 2) st.put(sp - 2, t1);
         t1 = t0;
-        t0 = v;
         ++sp;
     };
     auto drop_to = [&](const Q29& top) {      // two operands consumed, `top` is the new top of stack
@@ -176,27 +177,26 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         if (sp >= 2) t1 = st.get(sp - 2);
     };
     auto load = [&](uint32_t a, uint32_t b) -> Fr {
-        const int64_t rot = (int32_t)b;
-        const uint64_t row = (i + (uint64_t)(rot * (int64_t)rot_scale)) & (ne - 1);
+        const uint32_t row = (i + b * rot_scale) & row_mask;          // b = the rotation as a two's complement word: wraps like the domain
+        if (FULL) return ldg(cols[a] + row);
         return live ? ldg(cols[a] + row) : Fr::zero();
     };
     // instruction words are fetched two ahead, the memory operand one ahead: the load of instruction pc + 1 is
     // in flight while instruction pc computes
     uint32_t w0 = prog[0], w1 = prog[1], w2 = prog[2];
     uint32_t n0 = prog[3], n1 = prog[4], n2 = prog[5];
-    Fr m_cur = Fr::zero();
+    Fr m_cur, m_next;                          // only read by instructions that have a memory operand, which loaded them
     if (k_has_mem(w0)) m_cur = load(w1, w2);
     for (uint32_t pc = 0; pc < prog_len; ++pc) {
         const uint32_t f0 = prog[3 * pc + 6], f1 = prog[3 * pc + 7], f2 = prog[3 * pc + 8];
-        Fr m_next = Fr::zero();
         if (k_has_mem(n0)) m_next = load(n1, n2);
         const uint32_t op = w0 & 0xffu;
         if (op == Q_END) break;
         if (w0 & K_SETTLE0) t0 = q_settle(t0);
         if (w0 & K_SETTLE1) t1 = q_settle(t1);
         switch (op) {
-            case Q_PUSH_COL: push(unpack29<Fr29P>(m_cur)); break;
-            case Q_PUSH_CONST: push(unpack29<Fr29P>(ldg(consts + w1))); break;
+            case Q_PUSH_COL: push_shift(); t0 = unpack29<Fr29P>(m_cur); break;
+            case Q_PUSH_CONST: push_shift(); t0 = unpack29<Fr29P>(ldg(consts + w1)); break;
             case Q_ADD: drop_to(add29(t1, t0)); break;
             case Q_SUB: { Q29 d = sub29k<2>(t1, t0); normalize29(d); drop_to(d); break; }     // the top limb of a settled subtrahend may borrow: carry it out before anyone multiplies
             case Q_MUL: drop_to(mul29(t1, q_shl5(t0))); break;
@@ -206,7 +206,7 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
             case Q_FOLD: acc = add29(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + w1))), t0); drop_to(t1); break;
             case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + w1))); break;
             case Q_ADD_CONST: t0 = add29(t0, unpack29<Fr29P>(ldg(consts + w1))); break;
-            case Q_TEE_TMP: if (live) stg(tmp + ((uint64_t)w1 * ne + i), pack29_lt2p(t0)); break;             // parked canonical: read back as a column
+            case Q_TEE_TMP: if (live) stg(tmp + (((uint64_t)w1 << ext_k) + i), pack29_lt2p(t0)); break;             // parked canonical: read back as a column
             case K_ADD_COL: t0 = add29(t0, unpack29<Fr29P>(m_cur)); break;
             case K_SUB_COL: t0 = sub29k<2>(t0, unpack29<Fr29P>(m_cur)); break;                                  // canonical subtrahend: its top limb is below that of 2p, no borrow
             case K_RSUB_COL: t0 = sub29k<2>(unpack29<Fr29P>(m_cur), t0); normalize29(t0); break;
@@ -219,7 +219,7 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         m_cur = m_next;
     }
     if (live) {
-        if (t_evals) stg(out + i, pack29_lt2p(mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1)))))));
+        if (t_evals) stg(out + i, pack29_lt2p(mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1u)))))));
         else { normalize29(acc); stg(out + i, reduce_lazy29(acc)); }       // acc < 6p, never settled on the way
     }
 }
@@ -525,7 +525,8 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     const uint64_t ne = 1ull << ext_k;
     const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
     if (!ctx->quotient_attr_set) {
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
         ctx->quotient_attr_set = true;
     }
     ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
@@ -543,8 +544,13 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         ops.erase(std::unique(ops.begin(), ops.end()), ops.end());
         ps.bytes = (ops.size() + tmp_moves + 1) * ne * 32;
     }
-    hipLaunchKernelGGL(k_quotient_eval, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                       low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+    if (ne >= (uint64_t)Q_THREADS) {
+        hipLaunchKernelGGL(k_quotient_eval<true>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
+                           low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+    } else {
+        hipLaunchKernelGGL(k_quotient_eval<false>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
+                           low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+    }
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
