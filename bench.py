@@ -64,9 +64,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the full-proof section (N = 1 only)")
+    ap.add_argument("--proof-worker", default="", help=argparse.SUPPRESS)      # internal: run ONE proof shape in this process and print its record
     ap.add_argument("--batch", type=int, default=16, help="columns submitted per commit_batch call (pipelined on the device; a prover phase commits tens to a thousand)")
     args = ap.parse_args()
 
+    if args.proof_worker:
+        print(json.dumps(proof_worker(args.proof_worker)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_launcher(args))
 
@@ -144,19 +148,25 @@ def main():
                 dist.all_gather_into_tensor(gather, com_t)
             done += b
 
+    def device_sync():
+        # the library's streams belong to the HIP runtime it links (/opt/rocm), torch's to the one torch bundles:
+        # torch.cuda.synchronize() alone would not wait for the transforms the last batch left in flight
+        ctx.sync()
+        torch.cuda.synchronize()
+
     run_steps(args.warmup)
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     run_steps(args.steps)
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     if world > 1:
@@ -252,7 +262,7 @@ def main():
             b_.free()
         srs.destroy()
         if world == 1 and not args.no_proof:
-            out["proof"] = proof_section(ctx)
+            out["proof"] = proof_section()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -283,59 +293,87 @@ def cpu_baseline(srs, column):
     }
 
 
-def proof_section(ctx):
+PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20")
+
+
+def proof_section():
     """BASELINE's headline metric on one GPU: full-proof wall-clock of the SuperCircuit-shape circuit
-    (config 4 stand-in, k = 20: 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9)
-    and of the Keccak-shape circuit (config 3 stand-in, k = 18: 59 unusable rows, 13-rotation gates,
-    degree 9), SHPLONK + Blake2b as at [REF circuit-benchmarks/src/super_circuit.rs:117-132]; each proof
-    is checked by the oracle's pairing verifier.  The quotient evaluator's roofline comes from the
-    same run: bytes = 32 x n x (distinct (column, rotation) reads + 1 write) per coset launch."""
-    import bench_proof as bp
+    (config 4 stand-in, k = 20: 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9),
+    of the Keccak-shape circuit (config 3 stand-in, k = 18: 59 unusable rows, 13-rotation gates, degree 9)
+    and of the recursion shape (config 5 stand-in), SHPLONK as at [REF circuit-benchmarks/src/super_circuit.rs:117-132];
+    each proof is checked by the oracle's pairing verifier.  Every shape runs in a process of its own
+    (`bench.py --proof-worker <shape>`: a prover process holding the library and nothing else.  This process has
+    torch loaded for the launcher contract, i.e. torch's bundled HIP runtime next to the one the library links; with
+    both in one process the advice-phase uploads measured 30 % slower -- 0.88 against 0.66 ms per 32 MiB column,
+    tools/upload_order.py -- and a Rust / C prover has no torch in it)."""
+    import subprocess
 
     out = {}
-    # (name, builder, proofs per key, transcript): the recursion shape is BASELINE config 5's stand-in -- k = 22, 9 advice
-    # columns, FOUR sequential proofs sharing one proving key, Poseidon transcript as gen_snark_shplonk uses
-    # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
-    for name, build, repeat, tkind in (("keccak_shape_k18", lambda: bp.build_keccak_shape(ctx, 18), 2, None),
-                                       ("recursion_shape_k22", lambda: bp.build_large(ctx, 22, 3), 4, 1),
-                                       ("supercircuit_shape_k20", lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 2, None)):
+    only = os.environ.get("ZK_BENCH_PROOFS", "")          # measurement knob: comma-separated subset of the shapes
+    for name in PROOF_SHAPES:
+        if only and name not in only.split(","):
+            continue
         try:
-            t0 = time.perf_counter()
-            circ, blob, adv_m, inst_m, inst = build()
-            t_build = time.perf_counter() - t0
-            rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=True, t_build=t_build, transcript_kind=tkind,
-                                 profiled_extra=True)        # timed proofs run without the profiling events; one extra proof feeds the quotient roofline
-            if tkind == 1:
-                rec["transcript"] = "poseidon"
-                rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
-            prof = {nm: ctx.prof_get(nm) for nm in ctx.prof_names()}
-            n = 1 << circ.k
-            d, P, L = circ.degree(), len(circ.perm_cols), len(circ.lookups)
-            C = (P + d - 3) // (d - 2) if P else 0
-            # distinct (column, rotation) operands of the quotient program: the circuit's own queries, sigma, Z (x, wx, w^last x),
-            # phi (x, wx) and m per lookup, l_0 / l_last / l_active / X
-            reads = len(circ.advice_queries) + len(circ.fixed_queries) + len(circ.instance_queries) + P + (3 * C - 1 if C else 0) + 3 * L + 4
-            cosets = 1 << (circ.extended_k() - circ.k)
-            qbig = prof.get("quotient_coset", (0.0, 0))
-            if qbig[1]:
-                # The quotient is evaluated by degree class (DESIGN 4.3): a proof launches one program per (class, coset of that
-                # class) instead of one per coset.  `achieved` = the bytes those launches really stream (the library counts
-                # 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result) per launch) over their
-                # time.  `vs_full_domain` = what evaluating every constraint on every coset would stream (halo2's evaluate_h)
-                # over the same time: an EFFECTIVE rate, comparable across rounds, that may exceed the HBM peak.
-                per_proof_ms = qbig[0]                       # the profiled proof
-                streamed = ctx.prof_get_bytes("quotient_coset")
-                full = 32.0 * n * (reads + 1) * cosets
-                rec["roofline_quotient"] = {"kernel": "k_quotient_eval (all degree-class launches of one proof)", "bound": "hbm",
-                                            "achieved": round(streamed / (per_proof_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": round(streamed / (per_proof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_proof": round(per_proof_ms, 2),
-                                            "launches_per_proof": qbig[1], "algorithmic_bytes_per_proof": int(streamed),
-                                            "distinct_column_rotation_reads": reads, "cosets": cosets,
-                                            "vs_full_domain": {"bytes": int(full), "effective_GBps": round(full / (per_proof_ms * 1e-3) / 1e9, 1)}}
-            out[name] = rec
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", name], capture_output=True, text=True, timeout=900)
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode != 0 or not lines:
+                out[name] = {"error": f"worker exited with {res.returncode}: {res.stderr[-400:]}"}
+            else:
+                out[name] = json.loads(lines[-1])
+            if os.environ.get("ZK_PROVER_TRACE"):
+                sys.stderr.write(res.stderr)
         except Exception as e:           # the MSM / NTT line must survive a failure of the proof section
             out[name] = {"error": repr(e)}
     return out
+
+
+def proof_worker(name):
+    """One proof shape, measured in this (fresh) process.  The quotient evaluator's roofline comes from one extra,
+    profiled proof: bytes = what the launches really stream (counted by the library) over their time."""
+    import bench_proof as bp
+    import zkevm_circuits_amd as z
+
+    ctx = z.Context(0)
+    # (builder, proofs per key, transcript): the recursion shape is BASELINE config 5's stand-in -- k = 22, 9 advice
+    # columns, FOUR sequential proofs sharing one proving key, Poseidon transcript as gen_snark_shplonk uses
+    # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
+    build, repeat, tkind = {"keccak_shape_k18": (lambda: bp.build_keccak_shape(ctx, 18), 3, None),
+                            "recursion_shape_k22": (lambda: bp.build_large(ctx, 22, 3), 4, 1),
+                            "supercircuit_shape_k20": (lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 3, None)}[name]
+    t0 = time.perf_counter()
+    circ, blob, adv_m, inst_m, inst = build()
+    t_build = time.perf_counter() - t0
+    rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=True, t_build=t_build, transcript_kind=tkind,
+                         profiled_extra=True)        # timed proofs run without the profiling events; one extra proof feeds the quotient roofline
+    if tkind == 1:
+        rec["transcript"] = "poseidon"
+        rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
+    prof = {nm: ctx.prof_get(nm) for nm in ctx.prof_names()}
+    n = 1 << circ.k
+    d, P, L = circ.degree(), len(circ.perm_cols), len(circ.lookups)
+    C = (P + d - 3) // (d - 2) if P else 0
+    # distinct (column, rotation) operands of the quotient program: the circuit's own queries, sigma, Z (x, wx, w^last x),
+    # phi (x, wx) and m per lookup, l_0 / l_last / l_active / X
+    reads = len(circ.advice_queries) + len(circ.fixed_queries) + len(circ.instance_queries) + P + (3 * C - 1 if C else 0) + 3 * L + 4
+    cosets = 1 << (circ.extended_k() - circ.k)
+    qbig = prof.get("quotient_coset", (0.0, 0))
+    if qbig[1]:
+        # The quotient is evaluated by degree class (DESIGN 4.3): a proof launches one program per (class, coset of that
+        # class) instead of one per coset.  `achieved` = the bytes those launches really stream (the library counts
+        # 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result) per launch) over their
+        # time.  `vs_full_domain` = what evaluating every constraint on every coset would stream (halo2's evaluate_h)
+        # over the same time: an EFFECTIVE rate, comparable across rounds, that may exceed the HBM peak.
+        per_proof_ms = qbig[0]                       # the profiled proof
+        streamed = ctx.prof_get_bytes("quotient_coset")
+        full = 32.0 * n * (reads + 1) * cosets
+        rec["roofline_quotient"] = {"kernel": "k_quotient_eval (all degree-class launches of one proof)", "bound": "hbm",
+                                    "achieved": round(streamed / (per_proof_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(streamed / (per_proof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_proof": round(per_proof_ms, 2),
+                                    "launches_per_proof": qbig[1], "algorithmic_bytes_per_proof": int(streamed),
+                                    "distinct_column_rotation_reads": reads, "cosets": cosets,
+                                    "vs_full_domain": {"bytes": int(full), "effective_GBps": round(full / (per_proof_ms * 1e-3) / 1e9, 1)}}
+    ctx.close()
+    return rec
 
 
 if __name__ == "__main__":
