@@ -215,12 +215,15 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
 /* zk_commit_batch for columns still in host memory: column i+1 is uploaded (copy stream) while the
  * MSM of column i runs; d_cols[i] (n x 32 B device buffers) receive the columns.  This is the shape
  * of halo2's advice commitment loop (plonk/prover.rs: one commit_lagrange per witness column).     */
-/* zk_commit_batch with a hint per column (nullable array): narrow[i] != 0 = column i holds small
+/* zk_commit_batch with a hint per column (nullable array).  narrow[i] = 1: column i holds small
  * integers (below 2^64: selectors, bytes, counters, lookup multiplicities), whose digits leave most
  * Pippenger windows empty; such a column takes the per-window MSM path, which skips empty windows,
- * instead of the merged-window path, which always pays for its 2^(c-1) shared buckets.  The hint
- * affects speed only.  zk_commit_batch_h2d and zk_proof_advice_phase derive it themselves from a
- * sample of the host column.                                                                     */
+ * instead of the merged-window path, which always pays for its 2^(c-1) shared buckets.
+ * narrow[i] = 2: dense values in long runs of equal scalars (running products / sums that stay
+ * constant over stretches of rows): merged-window path with the sliced bucket sort, whose four
+ * workgroups per partition stream a run-filled partition faster than the one-launch sort does.
+ * 0: dense.  The hint affects speed only.  zk_commit_batch_h2d and zk_proof_advice_phase derive
+ * 0 / 1 themselves from a sample of the host column.                                              */
 int zk_commit_batch_hint(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, void* h_out_affine);
 int zk_commit_batch_h2d(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* h_cols, void* const* d_cols, size_t count, size_t n, void* h_out_affine);
 /* best_multiexp over HOST slices, exactly the reference signature (copies in, computes, copies

@@ -76,6 +76,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     zk::comm_release(ctx);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->stream2b) { (void)hipStreamSynchronize(ctx->stream2b); (void)hipStreamDestroy(ctx->stream2b); }
+    if (ctx->stream2c) { (void)hipStreamSynchronize(ctx->stream2c); (void)hipStreamDestroy(ctx->stream2c); }
     if (ctx->stream_aux) { (void)hipStreamSynchronize(ctx->stream_aux); (void)hipStreamDestroy(ctx->stream_aux); (void)hipEventDestroy(ctx->ev_aux); }
     if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); (void)hipEventDestroy(ctx->ev_copy); }
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
@@ -321,8 +322,8 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
     if (!ctx) return ZK_ERR_INVALID_ARG;
     return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr);
 }
-// The same with a hint per column (nullable): narrow[i] != 0 says column i holds small integers
-// (selectors, bytes, counters, lookup multiplicities) -- see zkmi355.h.
+// The same with a hint per column (nullable): 1 = small integers (selectors, bytes, counters, lookup
+// multiplicities), 2 = long runs of equal values (running products) -- see zkmi355.h.
 int zk_commit_batch_hint(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr, narrow);

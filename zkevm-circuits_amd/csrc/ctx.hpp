@@ -33,10 +33,10 @@ struct zk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
     // scratch arenas, grown on demand (never shrunk): index = purpose
-    zk::Scratch scratch[13];
+    zk::Scratch scratch[14];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
-    hipStream_t stream2 = nullptr, stream2b = nullptr;
-    hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
+    hipEvent_t ev_p1[3] = {nullptr, nullptr, nullptr}, ev_p2[3] = {nullptr, nullptr, nullptr};
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;
     hipEvent_t ev_copy = nullptr;
@@ -176,7 +176,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);

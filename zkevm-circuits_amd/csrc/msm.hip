@@ -979,7 +979,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
         }
@@ -1115,7 +1115,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     if (count == 0) return ZK_OK;
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
     bool any_narrow = false;
-    if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] != 0;
+    if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] == 1;
     // ---- per-window ("narrow") path: sizes and workspace, as in msm_batch_tab with a window table
     const MsmPlan pn = any_narrow ? *pl_n : MsmPlan{4, 64, 8};
     const uint32_t nbN = (uint32_t)pn.W * pn.B;
@@ -1180,33 +1180,42 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t red_pts = nb / 4 + 1024;       // scratch of the weighted bucket sum (group sums of every level, partials)
     const size_t max_tasks = (size_t)nb + std::max((size_t)(max_entries / TASK_CAP), (size_t)TASK_TARGET) + 1;
     const size_t npts29 = std::max((size_t)nb + red_pts + max_tasks, npts29_N);
-    char* bkbuf[2];
+    // three bucket buffers in rotation: the reduction of MSM it (a latency-bound chain on a side stream, about as long
+    // as a whole MSM) must only be finished when MSM it + 3 starts to accumulate
+    char* bkbuf[3];
     bkbuf[0] = (char*)ctx->get_scratch(SC_MSM_BUCKETS, sizeof(G1Xyzz29) * npts29);
     bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
+    bkbuf[2] = count > 2 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS3, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
     // one window sum per MSM, then one private copy of the window flags per MSM of the per-window path
     G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count + 256 * count);
-    if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
+    if (!bkbuf[0] || !bkbuf[1] || !bkbuf[2] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
         }
     }
-    // The reductions of consecutive MSMs alternate between two side streams: each is a chain of short
+    // The reductions of consecutive MSMs rotate over three side streams: each is a chain of short
     // launches (latency, not throughput), and with witness columns that fill few windows it can take
     // longer than the sort + accumulation of the next column.
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
+    if (!ctx->stream2c) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2c, hipStreamNonBlocking));
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
     for (size_t it = 0; it < count; ++it) {
-        const int par = (int)(it & 1);
-        hipStream_t side = par ? ctx->stream2b : ctx->stream2;
+        const int par = (int)(it % 3);
+        hipStream_t side = par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c;
         const Fr* d_scalars = d_scalar_ptrs[it];
         G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
         G1Xyzz29* partial = buckets + nb;
         G1Xyzz29* task_partial = partial + red_pts;
-        if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
-        if (any_narrow && narrow[it]) {
+        // reduce(it-3) must be done with this bucket buffer -- but only the accumulation writes it: the sort of this MSM
+        // (a third of its time) runs while that reduction finishes
+        auto wait_buffer = [&]() -> int {
+            if (it >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
+            return ZK_OK;
+        };
+        if (any_narrow && narrow[it] == 1) {
             // ---- per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with
             // empty windows skipped, bucket accumulation, fold of the occupied windows, one window reduced
             uint32_t* slice_countsN = ws;
@@ -1247,6 +1256,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            PK_TRY_MSM(wait_buffer());
             {
                 ZkProfScope ps(ctx, "msm_buckets_narrow");
                 hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)offsetsN, (const uint32_t*)idxN,
@@ -1288,7 +1298,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_CHECK_LAUNCH(ctx);
             // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
             //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
-            if (binsort) {
+            const bool bs_it = binsort && !(narrow && narrow[it] == 2);       // hint 2: long runs of equal scalars (running products) put whole runs into
+                                                                              // one partition; four slice-workgroups per partition stream them faster than one
+            if (bs_it) {
                 hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, nb, offsets, counts, size_hist, idx);
                 ZK_CHECK_LAUNCH(ctx);
             } else {
@@ -1304,9 +1316,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
             ZK_CHECK_LAUNCH(ctx);
-            if (!binsort) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
+            if (!bs_it) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
             ZK_CHECK_LAUNCH(ctx);
         }
+        PK_TRY_MSM(wait_buffer());
         {
             ZkProfScope ps(ctx, "msm_buckets");
             // idx already holds table indices: no window offset, no per-window skip (tab_stride = 0)
@@ -1343,6 +1356,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     }
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
     if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
+    if (count > 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[2], 0));
     std::vector<G1Xyzz> hw(count);
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1388,11 +1402,11 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
     std::vector<uint8_t> forced;
     if (const char* e = getenv("ZK_MSM_NARROW")) { forced.assign(count, (uint8_t)(atoi(e) != 0)); narrow = forced.data(); }
     bool any = false;
-    if (narrow) for (size_t i = 0; i < count; ++i) any |= narrow[i] != 0;
+    if (narrow) for (size_t i = 0; i < count; ++i) any |= narrow[i] == 1;
     const G1Affine* tabn = nullptr;
     MsmPlan pln{};
     if (any) { rc = srs_window_table_narrow(ctx, srs, basis, n, &tabn, &pln); if (rc) return rc; }
-    return msm_batch_merged(ctx, d_scalar_ptrs, count, tab, stride, make_plan_merged(srs->k), n, h_out, stage, stage_user, tabn, &pln, tabn ? narrow : nullptr);
+    return msm_batch_merged(ctx, d_scalar_ptrs, count, tab, stride, make_plan_merged(srs->k), n, h_out, stage, stage_user, tabn, &pln, narrow);
 }
 int msm_batch_rp(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out) {
     return msm_batch_tab(ctx, d_scalar_ptrs, count, d_bases, d_bases_rp, nullptr, 0, n, h_out);

@@ -375,8 +375,8 @@ void push_perm_col(PB& b, const std::pair<uint32_t, uint32_t>& c) { b.col(c.firs
 // `count` commitments over one basis, split over the ranks of a sharded session: rank r commits
 // columns i = r, r + world, ... (pipelined batch) and the 64-byte points are all-gathered, so every
 // rank ends up with all of them in order and the transcripts stay identical.
-int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out, bool narrow = false) {
-    const std::vector<uint8_t> hint(count, narrow ? 1 : 0);
+int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out, uint8_t kind = 0 /* zk_commit_batch_hint: 0 dense, 1 small values, 2 runs of equal values */) {
+    const std::vector<uint8_t> hint(count, kind);
     if (pr->world <= 1 || !pr->gather) return commit_batch_staged(ctx, srs, basis, ptrs, count, n, out, nullptr, nullptr, hint.data());
     if (count < pr->world && n >= ((size_t)pr->world << 10)) {
         // Fewer columns than ranks (aggregation layers: ~10 columns at k = 22..25, h pieces, the closing
@@ -928,7 +928,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (st[l] != 0xFFFFFFFFu) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: input at row %u is not in the table (witness does not satisfy the circuit)", l, st[l]);
         trace.mark("  lookup: m (all lookups)");
         std::vector<G1Affine> coms(pk->L);
-        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data(), true));      // multiplicities are small counts
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data(), 1));      // multiplicities are small counts
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup m");
@@ -980,7 +980,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         }
         trace.mark("  perm: chain + blind");
         std::vector<G1Affine> coms(pk->C);
-        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, zptrs.data(), pk->C, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, zptrs.data(), pk->C, n, coms.data(), 2));      // running products stay constant over every stretch of rows without copies
         trace.mark("  perm: commits");
         for (const G1Affine& com : coms) tr.write_point(com);
         if (pk->C && !host::fr_eq(start, one)) return ctx->fail(ZK_ERR_INVALID_ARG, "permutation argument does not close: copy constraints are not satisfied by the witness");
