@@ -73,7 +73,7 @@ def test_eval_polynomial_and_kate_division(ctx, cref, n):
             assert np.array_equal(dQ.download((n - 1, 4)), cref.kate_division(C, x))
 
 
-@pytest.mark.parametrize("n,count", [(1, 1), (100, 3), (4096, 7), (1 << 16, 20)])
+@pytest.mark.parametrize("n,count", [(1, 1), (100, 3), (512, 2), (513, 3), (4096, 7), (70001, 2), (1 << 16, 20)])
 def test_eval_polynomial_batch(ctx, cref, n, count):
     """zk_poly_eval_batch == eval_polynomial applied to each column (one launch, one sync)."""
     polys = [cref.rand_fr_stream(7000 + 13 * i + n, n) for i in range(count)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 output of tools/gpu_r2f.sh (gpurun_out/r2f/) into the committed summaries under
+"""Turns the rocprofv3 output of tools/gpu_r2z.sh (gpurun_out/r2z/) into the committed summaries under
 profiles/: kernel statistics of the bench line and of the SuperCircuit-shape proof, and the PMC
 traffic (FETCH_SIZE / WRITE_SIZE, separate passes) per launch of the MSM and NTT kernels."""
 import collections
@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r2f"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r2z"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 
@@ -39,7 +39,7 @@ def pmc(run, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-kern = ["k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_partition<20, true>", "k_msm_m_bin<false>", "k_msm_m_bin<true>", "k_ntt_pass", "k_ntt_last",
+kern = ["k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_partition<20, true>", "k_msm_m_binsort", "k_ntt_pass", "k_ntt_last",
         "k_wsum_level<false>", "k_msm_combine_wave"]
 traffic = {}
 lines = ["# PMC traffic per launch (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, `bench.py --no-proof --no-cpu-baseline`)", "",
@@ -52,7 +52,7 @@ for k in kern:
     lines.append(f"| `{k}` | {f_:.1f} | {2 * f_:.1f} | {w_:.1f} | {f_ + w_:.1f} | {2 * f_ + w_:.1f} |")
     traffic[k] = {"fetch_MiB": round(f_, 1), "write_MiB": round(w_, 1)}
 fb, wb = fetch.get("k_msm_buckets", 0.0) * 1024, write.get("k_msm_buckets", 0.0) * 1024
-traffic_json = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, see tools/gpu_r2f.sh",
+traffic_json = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, see tools/gpu_r2z.sh",
                 "msm_buckets_bytes_per_launch": int(fb + wb), "msm_buckets_fetch_bytes": int(fb), "msm_buckets_write_bytes": int(wb),
                 "msm_buckets_bytes_per_launch_fetch_doubled": int(2 * fb + wb),
                 "ntt_bytes_per_transform_fetch_doubled": int((2 * (fetch.get("k_ntt_pass", 0) + fetch.get("k_ntt_last", 0)) + write.get("k_ntt_pass", 0) + write.get("k_ntt_last", 0)) * 1024),

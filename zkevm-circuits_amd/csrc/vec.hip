@@ -194,6 +194,31 @@ __global__ void __launch_bounds__(256) k_eval_partial_multi(const Fr* const* __r
     Fr s = block_sum(acc, sh);
     if (threadIdx.x == 0) stg(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, s);
 }
+// Batched evaluation, one product per coefficient: block b owns the contiguous segment [b * seg, (b + 1) * seg) of
+// polynomial blockIdx.y; thread t runs Horner over its elements t, t + 256, ... of the segment in descending order with
+// the multiplier x^256 (coalesced: consecutive threads read consecutive coefficients), on 29-bit limbs with unsettled
+// sums, then lifts its value by x^t, the block sum by x^(segment start).  The two-level table is only read three times
+// per thread instead of once per coefficient (k_eval_partial_multi: two 8 x 32 products per coefficient).
+__global__ void __launch_bounds__(256) k_eval_horner_multi(const Fr* const* __restrict__ polys, uint64_t n, uint64_t seg, const Fr* __restrict__ lo, const Fr* __restrict__ hi, int h,
+                                                           Fr* __restrict__ partial) {
+    __shared__ Fr sh[256];
+    const Fr* c = polys[blockIdx.y];
+    const uint64_t start = (uint64_t)blockIdx.x * seg, end = min(n, start + seg);
+    auto rprime = [](Fr x) { for (int i = 0; i < 5; ++i) x = dbl(x); return x; };       // R -> R' = 2^261 form: x 32
+    const Fr29 xs = unpack29<Fr29P>(rprime(two_level_pow(lo, hi, h, 256)));
+    Fr29 acc = unpack29<Fr29P>(Fr::zero());
+    const int64_t iters = start < end ? (int64_t)((end - start + 255) / 256) : 0;
+    for (int64_t j = iters - 1; j >= 0; --j) {
+        const uint64_t i = start + (uint64_t)j * 256 + threadIdx.x;
+        // mul29 leaves a normalised value below 2p; adding a canonical coefficient keeps the limbs below 2^30 and the value
+        // below 3p: a valid first operand of the next product
+        acc = mul29(acc, xs);
+        if (i < end) acc = add29(acc, unpack29<Fr29P>(ldg(c + i)));
+    }
+    const Fr mine = pack29_lt2p(mul29(acc, unpack29<Fr29P>(rprime(two_level_pow(lo, hi, h, threadIdx.x)))));
+    Fr s = block_sum(mine, sh);
+    if (threadIdx.x == 0) stg(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, start < end ? s * two_level_pow(lo, hi, h, start) : Fr::zero());
+}
 __global__ void __launch_bounds__(256) k_sum_final_multi(const Fr* __restrict__ partial, uint32_t cnt, Fr* __restrict__ out) {
     __shared__ Fr sh[256];
     Fr acc = Fr::zero();
@@ -357,7 +382,12 @@ int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t coun
     Fr* results = partial + (size_t)blocks * count;
     const Fr** d_ptrs = (const Fr**)(results + count);
     ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_coeff_ptrs, 8 * count, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks, (unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)d_ptrs, (uint64_t)n, lo, hi, h, partial);
+    if (n >= 512) {
+        const uint64_t seg = (((uint64_t)n + blocks - 1) / blocks + 255) & ~(uint64_t)255;        // whole strides of 256 per segment
+        hipLaunchKernelGGL(k_eval_horner_multi, dim3(blocks, (unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)d_ptrs, (uint64_t)n, seg, lo, hi, h, partial);
+    } else {
+        hipLaunchKernelGGL(k_eval_partial_multi, dim3(blocks, (unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)d_ptrs, (uint64_t)n, lo, hi, h, partial);
+    }
     hipLaunchKernelGGL(k_sum_final_multi, dim3((unsigned)count), dim3(256), 0, ctx->stream, (const Fr*)partial, blocks, results);
     ZK_CHECK_LAUNCH(ctx);
     ZK_HIP(ctx, hipMemcpyAsync(h_out, results, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
