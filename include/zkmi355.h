@@ -73,7 +73,9 @@ int zk_timer_stop_ms(zk_ctx* ctx, float* ms);   /* synchronises on the stop even
 /* Per-kernel HIP-event profiling on the context stream.  While enabled, every named kernel group
  * ("msm_digits", "msm_sort", "msm_buckets", "msm_reduce", "msm_tail_host", "ntt_pass", "ntt_last",
  * ...) is bracketed by an event pair; zk_prof_get drains the stream and returns the accumulated
- * device milliseconds and launch count for one name.                                            */
+ * device milliseconds and launch count for one name.  on = 2 records only the groups of the roofline
+ * kernels ("msm_buckets", "ntt_*", "quotient*"): every event pair costs a little stream time, and a
+ * throughput measurement should carry as few as it needs.                                        */
 int zk_prof_enable(zk_ctx* ctx, int on);
 int zk_prof_reset(zk_ctx* ctx);
 int zk_prof_get(zk_ctx* ctx, const char* name, double* total_ms, uint64_t* count);

@@ -378,8 +378,9 @@ class Context:
         return ms.value
 
     # ---- profiling
-    def prof_enable(self, on: bool = True):
-        self._ck(lib().zk_prof_enable(self.h, ctypes.c_int(1 if on else 0)))
+    def prof_enable(self, on=True):
+        """True / 1: every kernel group; 2: only the roofline kernels' groups; False / 0: off"""
+        self._ck(lib().zk_prof_enable(self.h, ctypes.c_int(int(on))))
 
     def prof_reset(self):
         self._ck(lib().zk_prof_reset(self.h))

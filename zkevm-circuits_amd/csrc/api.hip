@@ -51,11 +51,6 @@ int zk_ctx_create(int device, zk_ctx** out) {
     c->pool_cap = (size_t)((double)c->prop.totalGlobalMem * 0.8);    // blocks of finished proofs stay pooled up to 80 % of the device
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }
     c->own_stream = true;
-    if (const char* e = getenv("ZK_EAGER_COPY_STREAM")) {
-        if (atoi(e)) {
-            if (hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return ZK_ERR_HIP; }
-        }
-    }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return ZK_ERR_HIP; }
     *out = c;
     return ZK_OK;
@@ -185,6 +180,7 @@ int zk_timer_stop_ms(zk_ctx* ctx, float* ms) {
 int zk_prof_enable(zk_ctx* ctx, int on) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ctx->prof_on = on != 0;
+    ctx->prof_main_only = on == 2;
     return ZK_OK;
 }
 int zk_prof_reset(zk_ctx* ctx) {

@@ -84,6 +84,7 @@ struct zk_ctx {
     // per-kernel HIP-event profiling (zk_prof_*): off by default
     bool ntt_attr_set = false, quotient_attr_set = false;   // hipFuncSetAttribute (large dynamic LDS) is per device: remembered per context, not per process
     bool prof_on = false;
+    bool prof_main_only = false;         // zk_prof_enable(ctx, 2): only the scopes of the roofline kernels (accumulation, transforms, evaluator) record events
     const char* prof_tag = nullptr;      // when set, zk_quotient_eval books its launch under this name (the prover tags the big coset programs)
     struct ProfEntry { double ms = 0; uint64_t count = 0; uint64_t bytes = 0; };   // bytes: algorithmic HBM bytes of the booked launches, where the scope states them
     std::map<std::string, ProfEntry> prof;
@@ -136,9 +137,10 @@ struct zk_ctx {
 
 // RAII scope: records a HIP event pair around the enclosed launches on ctx->stream
 struct ZkProfScope {
+    static bool is_main(const char* n) { return !strcmp(n, "msm_buckets") || !strncmp(n, "ntt_", 4) || !strncmp(n, "quotient", 8); }
     zk_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t s; uint64_t bytes = 0;
     ZkProfScope(zk_ctx* ctx, const char* n, hipStream_t on = nullptr) : c(ctx), name(n), s(on ? on : ctx->stream) {
-        if (c->prof_on) { a = c->prof_event(); (void)hipEventRecord(a, s); }
+        if (c->prof_on && (!c->prof_main_only || is_main(n))) { a = c->prof_event(); (void)hipEventRecord(a, s); }
     }
     ~ZkProfScope() {
         if (a) { hipEvent_t b = c->prof_event(); (void)hipEventRecord(b, s); c->prof_pending.push_back({name, a, b, bytes}); }
