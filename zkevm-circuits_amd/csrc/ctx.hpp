@@ -82,6 +82,7 @@ struct zk_ctx {
         pool_bytes = 0;
     }
     // per-kernel HIP-event profiling (zk_prof_*): off by default
+    uint32_t msm_attr_set = 0;            // bit C: k_msm_m_scatter_staged<C> has its dynamic-LDS attribute on this device
     bool ntt_attr_set = false, quotient_attr_set = false;   // hipFuncSetAttribute (large dynamic LDS) is per device: remembered per context, not per process
     bool prof_on = false;
     bool prof_main_only = false;         // zk_prof_enable(ctx, 2): only the scopes of the roofline kernels (accumulation, transforms, evaluator) record events

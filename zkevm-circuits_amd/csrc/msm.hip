@@ -294,6 +294,75 @@ __global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ 
         for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) hist[(uint64_t)t * nwg + g] = lds[t];
     }
 }
+// Scatter pass of the partition step with the runs staged in LDS.  k_msm_m_partition<C, true> lets every lane
+// write its 8-byte entry to the cursor of its own partition: 64 lanes, 64 partitions, 64 separate 32-byte
+// sectors -- 343 MiB written for 104 MiB of entries.  Here a workgroup (one scalar per thread) ranks its entries
+// per partition in LDS, lays them out partition by partition in a staging buffer and copies the buffer out
+// with consecutive lanes on consecutive entries: every (workgroup, partition) run leaves as one contiguous
+// burst.  Dynamic LDS: cnt[1024] | gdelta[1024] | wtot[16] | stage[1024 W] (u64) | pid[1024 W] (u16).
+constexpr uint32_t MSM_M_SCHUNK = 1024;                 // scalars per workgroup of the staged scatter (and of its histogram pass)
+template <int C>
+__global__ void __launch_bounds__(1024) k_msm_m_scatter_staged(const Fr* __restrict__ scalars, uint64_t n, int range_bits, const uint32_t* __restrict__ hist_off,
+                                                               uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift) {
+    constexpr int W = (256 + C - 1) / C;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    uint32_t* cnt = sm;                                  // counters, then local start of every partition
+    uint32_t* gdelta = sm + MSM_M_MAX_BINS;              // global cursor of (partition, this workgroup) minus the local start
+    uint32_t* wtot = gdelta + MSM_M_MAX_BINS;
+    uint64_t* stage = reinterpret_cast<uint64_t*>(wtot + 16);
+    uint16_t* pid = reinterpret_cast<uint16_t*>(stage + (size_t)MSM_M_SCHUNK * W);
+    const uint32_t nbins = 1u << (C - 1 - range_bits), nwg = gridDim.x, g = blockIdx.x;
+    const uint32_t rmask = (1u << range_bits) - 1u;
+    cnt[threadIdx.x] = 0u;                               // blockDim.x == MSM_M_MAX_BINS == 1024
+    __syncthreads();
+    const uint64_t chunk = (n + nwg - 1) / nwg;          // <= MSM_M_SCHUNK (the host sizes the grid)
+    const uint64_t i = min(n, (uint64_t)g * chunk) + threadIdx.x;
+    const bool live = threadIdx.x < chunk && i < min(n, ((uint64_t)g + 1) * chunk);
+    uint32_t code[W], rank[W];
+    if (live) recode_wide<C>(from_mont(ldg(scalars + i)), code, top_shift);
+    else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) code[w] = CODE_ZERO;
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const bool nz = code[w] != CODE_ZERO;
+        rank[w] = 0;
+        if (!__ballot(nz)) continue;
+        rank[w] = lds_take(cnt, (code[w] & 0x3FFFFFu) >> range_bits, nz);
+    }
+    __syncthreads();
+    {   // exclusive scan of the partition counters, one per thread
+        const uint32_t c0 = threadIdx.x < nbins ? cnt[threadIdx.x] : 0u;
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        uint32_t incl = c0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wtot[w];
+        const uint32_t ex = wbase + incl - c0;
+        if (threadIdx.x < nbins) {
+            cnt[threadIdx.x] = ex;
+            gdelta[threadIdx.x] = hist_off[(uint64_t)threadIdx.x * nwg + g] - ex;
+        }
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 16; ++w) total += wtot[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        if (code[w] == CODE_ZERO) continue;
+        const uint32_t bucket = code[w] & 0x3FFFFFu, part = bucket >> range_bits;
+        const uint32_t pos = cnt[part] + rank[w];
+        stage[pos] = ((uint64_t)(bucket & rmask) << 32) | (uint64_t)((uint32_t)((uint64_t)w * tab_stride + i) | (code[w] & NEG_BIT));
+        pid[pos] = (uint16_t)part;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) entries[gdelta[pid[e]] + e] = stage[e];
+}
+static size_t scatter_staged_lds(int W) { return (size_t)(2 * MSM_M_MAX_BINS + 16) * 4 + (size_t)MSM_M_SCHUNK * W * 10; }
 // Per-partition LDS counting sort: workgroup (bin, slice) streams its quarter of the partition's
 // entries; counters are laid out [bucket][slice] exactly as in the per-window path, so the same
 // scans produce every (bucket, slice) cursor.
@@ -1104,6 +1173,16 @@ static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars
     }
 #undef ZK_PART_CASE
 }
+static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift) {
+    const size_t lds = scatter_staged_lds(W);
+#define ZK_SS_CASE(C) case C: \
+        if (!(ctx->msm_attr_set & (1u << C))) { ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_msm_m_scatter_staged<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->msm_attr_set |= 1u << C; } \
+        hipLaunchKernelGGL((k_msm_m_scatter_staged<C>), grid, dim3(1024), lds, ctx->stream, scalars, n, range_bits, hist_off, entries, tab_stride, top_shift); break;
+    switch (c) { ZK_SS_CASE(19) ZK_SS_CASE(20) ZK_SS_CASE(21) ZK_SS_CASE(22) default: return ctx->fail(ZK_ERR_UNSUPPORTED, "staged scatter: window size %d", c); }
+#undef ZK_SS_CASE
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
 // d_table: [W][tab_stride] affine points, table[w][i] = 2^(c w) * P_i in R' form, built for plan `pl`.
 // Same pipelining as msm_batch_tab: the reduction of MSM i runs on the side stream under MSM i + 1.
 // narrow[it] != 0 (with d_table_n, the per-window table of plan pl_n): column `it` is expected to fill
@@ -1150,6 +1229,11 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t nbins = nb >> range_bits;
     uint32_t chunk = MSM_M_CHUNK;
     if (const char* e = getenv("ZK_MSM_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536) chunk = (uint32_t)v; }   // measurement knob
+    // scatter with LDS-staged runs (k_msm_m_scatter_staged): window sizes whose 1024 x W entries fit the LDS, and only next to the
+    // one-launch partition sort (same 1024-partition layout); ZK_MSM_STAGED=0 keeps the direct scatter (measurement knob)
+    const char* env_ss = getenv("ZK_MSM_STAGED");
+    const bool staged_scatter = binsort && pl.c >= 19 && scatter_staged_lds(pl.W) <= (size_t)150 * 1024 && !(env_ss && atoi(env_ss) == 0);
+    if (staged_scatter) chunk = MSM_M_SCHUNK;
     const uint32_t nwg = (uint32_t)((n + chunk - 1) / chunk);
     const uint32_t hist_cnt = nbins * nwg;
     const uint32_t scan_blocks = (nb + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
@@ -1294,7 +1378,8 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, hist_cnt, hist_off, (const uint32_t*)block_tot3);
-            launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift);
+            if (staged_scatter) PK_TRY_MSM(launch_scatter_staged(ctx, pl.c, pl.W, dim3(nwg), d_scalars, (uint64_t)n, range_bits, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift));
+            else launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift);
             ZK_CHECK_LAUNCH(ctx);
             // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
             //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
