@@ -229,12 +229,12 @@ def test_g_to_lagrange_2_16_timing(ctx, cref):
         s_.destroy()
 
 
-@pytest.mark.parametrize("k", [10, 14, 16])
+@pytest.mark.parametrize("k", [10, 14, 16, 19])      # 19: window size 19 -- one-launch partition sort + LDS-staged scatter
 def test_commit_paths_agree_with_the_oracle(ctx, cref, k):
     """Commitments over an SRS take the merged-window path (one bucket set for all windows, over the
     SRS's window table) or, for columns hinted as small-valued, the per-window path; both must give
     best_multiexp's point for every scalar distribution, alone and mixed inside one pipelined batch,
-    over both bases, also for n < 2^k."""
+    over both bases, also for n < 2^k.  Hint 2 (runs of equal scalars) keeps the sliced sort."""
     n = 1 << k
     rng = random.Random(k)
     srs = ctx.srs_setup_with_s(k, cref.fr_const(0xABCDE + k))
@@ -254,7 +254,7 @@ def test_commit_paths_agree_with_the_oracle(ctx, cref, k):
     for lagrange in (True, False):
         basis = srs.download_g_lagrange() if lagrange else srs.download_g()
         want = np.stack([cref.best_multiexp(kinds[nm], basis) for nm in names])
-        for hint in (None, [0] * len(names), [1] * len(names), [i % 2 for i in range(len(names))], [(i + 1) % 2 for i in range(len(names))]):
+        for hint in (None, [0] * len(names), [1] * len(names), [2] * len(names), [i % 3 for i in range(len(names))], [(i + 1) % 2 for i in range(len(names))]):
             got = ctx.commit_batch(srs, ptrs, n, lagrange=lagrange, narrow=hint)
             bad = [nm for nm, g_, w_ in zip(names, got, want) if not np.array_equal(g_, w_)]
             assert not bad, f"hint {hint}, lagrange {lagrange}: {bad} differ from best_multiexp"

@@ -587,7 +587,8 @@ class Context:
 
     def commit_batch(self, srs: Srs, scalar_ptrs: Sequence[int], n: int, lagrange: bool = False, narrow: Optional[Sequence[int]] = None) -> np.ndarray:
         """`len(scalar_ptrs)` commitments over one basis, pipelined on the device; returns (count, 8) u64.
-        narrow: optional per-column hint (1 = small integers: per-window MSM path), speed only."""
+        narrow: optional per-column hint (0 dense, 1 small integers: per-window MSM path, 2 long runs of equal
+        values: sliced sort), speed only."""
         count = len(scalar_ptrs)
         out = np.empty((max(count, 1), 8), dtype=np.uint64)
         ptrs = (ctypes.c_void_p * max(count, 1))(*[ctypes.c_void_p(p) for p in scalar_ptrs])
@@ -595,7 +596,7 @@ class Context:
             self._ck(lib().zk_commit_batch(self.h, srs.h, ctypes.c_int(1 if lagrange else 0), ptrs, ctypes.c_size_t(count), ctypes.c_size_t(n), _host_ptr(out)))
         else:
             assert len(narrow) == count
-            flags = (ctypes.c_uint8 * max(count, 1))(*[1 if f else 0 for f in narrow])
+            flags = (ctypes.c_uint8 * max(count, 1))(*[int(f) for f in narrow])
             self._ck(lib().zk_commit_batch_hint(self.h, srs.h, ctypes.c_int(1 if lagrange else 0), ptrs, ctypes.c_size_t(count), ctypes.c_size_t(n), flags, _host_ptr(out)))
         return out[:count]
 
