@@ -97,6 +97,8 @@ int zk_fr_batch_invert(zk_ctx* ctx, void* d_a, size_t n);
  *   out[i] = sum_j a[j] * omega^(i*j),   omega = ROOT_OF_UNITY^(2^(28-log_n))   (inverse = 0)
  *   inverse = 1: omega^-1 and the 1/n scale, i.e. EvaluationDomain::lagrange_to_coeff.          */
 int zk_ntt(zk_ctx* ctx, void* d_data, uint32_t log_n, int inverse);
+/* zk_ntt over `count` columns of the same size, in place, several columns per launch. */
+int zk_ntt_batch(zk_ctx* ctx, void* const* d_datas, size_t count, uint32_t log_n, int inverse);
 /* best_fft with an arbitrary primitive 2^log_n-th root (h_omega: one Fr), no scaling.            */
 int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega);
 /* ONE transform of size 2^log_n spread over `world` contexts, one per GPU (the
@@ -120,6 +122,9 @@ int zk_coeff_to_extended(zk_ctx* ctx, const void* d_coeffs, uint32_t k, uint32_t
  * halo2 is the union of the cosets g_r = zeta * omega_ext^r, r < 2^(ext_k-k): extended index
  * i * 2^(ext_k-k) + r  <->  element i of coset r.  d_out may alias d_coeffs.                       */
 int zk_coeff_to_coset(zk_ctx* ctx, const void* d_coeffs, uint32_t k, const void* h_g, void* d_out);
+/* The same for `count` polynomials on one coset, several columns per launch (the quotient reads hundreds of
+ * columns on every coset; below 2^20 rows one column does not fill the device). */
+int zk_coeff_to_coset_batch(zk_ctx* ctx, const void* const* d_coeffs, uint32_t k, const void* h_g, void* const* d_outs, size_t count);
 /* d_dst[i * stride + offset] = d_src[i] * scale, i < n: interleaves coset values into extended order */
 int zk_fr_scatter_scaled(zk_ctx* ctx, const void* d_src, size_t n, const void* h_scale, void* d_dst, size_t stride, size_t offset);
 /* EvaluationDomain::extended_to_coeff: inverse NTT over the extended domain, unscale by zeta^-i;

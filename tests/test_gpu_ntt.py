@@ -143,3 +143,30 @@ def test_extreme_inputs(ctx, cref, k, pattern):
     assert np.array_equal(d.download((n, 4)), want)
     ctx.ntt(d, k, inverse=True)
     assert np.array_equal(d.download((n, 4)), A)
+
+
+@pytest.mark.parametrize("k,count", [(0, 3), (1, 2), (5, 20), (10, 33), (13, 17), (18, 9), (20, 5)])
+def test_batched_transforms_equal_single_ones(ctx, cref, k, count):
+    """zk_ntt_batch / zk_coeff_to_coset_batch put several columns into one launch (blockIdx.y = column): every column must
+    come out exactly as from the single-column entry points, across group boundaries of the batch, forward and inverse."""
+    n = 1 << k
+    cols = [cref.rand_fr_stream(9100 + 31 * k + i, n) for i in range(count)]
+    want_f = [cref.best_fft(c, bn254.omega_for_k(k), k) for c in cols]
+    bufs = [ctx.to_device(c) for c in cols]
+    ctx.ntt_batch(bufs, k)
+    for b, w in zip(bufs, want_f):
+        assert np.array_equal(b.download((n, 4)), w)
+    ctx.ntt_batch(bufs, k, inverse=True)
+    for b, c in zip(bufs, cols):
+        assert np.array_equal(b.download((n, 4)), c)
+    g = cref.fr_const(0x5EED + k)
+    outs = [ctx.alloc(n * 32) for _ in range(count)]
+    ctx.coeff_to_coset_batch(bufs, k, g, outs)
+    single = ctx.alloc(n * 32)
+    for b, o in zip(bufs, outs):
+        ctx.coeff_to_coset(b, k, g, single)
+        assert np.array_equal(o.download((n, 4)), single.download((n, 4)))
+    # in place as well
+    ctx.coeff_to_coset_batch(bufs[:2], k, g, bufs[:2])
+    assert np.array_equal(bufs[0].download((n, 4)), outs[0].download((n, 4)))
+    ctx.ntt_batch([], k)

@@ -420,6 +420,16 @@ class Context:
     def ntt(self, data: DeviceBuffer, log_n: int, inverse: bool = False):
         self._ck(lib().zk_ntt(self.h, ctypes.c_void_p(data.ptr), ctypes.c_uint32(log_n), ctypes.c_int(1 if inverse else 0)))
 
+    def ntt_batch(self, datas: Sequence[DeviceBuffer], log_n: int, inverse: bool = False):
+        """zk_ntt over several columns of the same size, several columns per launch"""
+        ptrs = (ctypes.c_void_p * max(len(datas), 1))(*[ctypes.c_void_p(d.ptr) for d in datas])
+        self._ck(lib().zk_ntt_batch(self.h, ptrs, ctypes.c_size_t(len(datas)), ctypes.c_uint32(log_n), ctypes.c_int(1 if inverse else 0)))
+
+    def coeff_to_coset_batch(self, coeffs: Sequence[DeviceBuffer], k: int, g_mont: np.ndarray, outs: Sequence[DeviceBuffer]):
+        cp = (ctypes.c_void_p * max(len(coeffs), 1))(*[ctypes.c_void_p(d.ptr) for d in coeffs])
+        op = (ctypes.c_void_p * max(len(outs), 1))(*[ctypes.c_void_p(d.ptr) for d in outs])
+        self._ck(lib().zk_coeff_to_coset_batch(self.h, cp, ctypes.c_uint32(k), _host_ptr(np.ascontiguousarray(g_mont)), op, ctypes.c_size_t(len(coeffs))))
+
     def ntt_sharded(self, local: DeviceBuffer, log_n: int, rank: int, world: int, alltoall_cb, inverse: bool = False):
         """This rank's part of ONE 2^log_n transform spread over `world` GPUs (zk_ntt_sharded):
         in: x[rank + world * i]; out: [j1][c] = X[(rank * m / world + c) + m * j1], m = n / world.

@@ -238,6 +238,19 @@ int zk_ntt(zk_ctx* ctx, void* d_data, uint32_t log_n, int inverse) {
     Fr ninv = fr_inv_host(fr_from_u64(1ull << log_n));
     return ntt_run(ctx, (Fr*)d_data, log_n, omega_inv, &ninv, nullptr, nullptr);
 }
+// `count` columns of 2^log_n elements each, transformed in place; several columns share a launch (a 2^18 column alone
+// occupies a quarter of the CUs)
+int zk_ntt_batch(zk_ctx* ctx, void* const* d_datas, size_t count, uint32_t log_n, int inverse) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, d_datas || !count, "null pointer");
+    ZK_REQUIRE(ctx, log_n <= 28, "log_n exceeds the two-adicity of Fr (28)");
+    for (size_t i = 0; i < count; ++i) ZK_REQUIRE(ctx, d_datas[i], "null column pointer");
+    Fr omega = fr_root_of_unity(log_n);
+    if (!inverse) return ntt_run_many(ctx, (Fr* const*)d_datas, nullptr, count, log_n, omega, nullptr, nullptr, nullptr, false);
+    Fr omega_inv = fr_inv_host(omega);
+    Fr ninv = fr_inv_host(fr_from_u64(1ull << log_n));
+    return ntt_run_many(ctx, (Fr* const*)d_datas, nullptr, count, log_n, omega_inv, &ninv, nullptr, nullptr, false);
+}
 int zk_ntt_omega(zk_ctx* ctx, void* d_data, uint32_t log_n, const void* h_omega) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, d_data && h_omega, "null pointer");
@@ -264,6 +277,15 @@ int zk_coeff_to_coset(zk_ctx* ctx, const void* d_coeffs, uint32_t k, const void*
     ZK_REQUIRE(ctx, d_coeffs && d_out && h_g, "null pointer");
     ZK_REQUIRE(ctx, k <= 28, "k exceeds the two-adicity of Fr (28)");
     return ntt_run(ctx, (Fr*)d_out, k, fr_root_of_unity(k), nullptr, (const Fr*)h_g, nullptr, d_coeffs == d_out ? nullptr : (const Fr*)d_coeffs, /*fuse_pre=*/true);
+}
+// zk_coeff_to_coset for `count` polynomials on the same coset (the columns one coset of the quotient reads)
+int zk_coeff_to_coset_batch(zk_ctx* ctx, const void* const* d_coeffs, uint32_t k, const void* h_g, void* const* d_outs, size_t count) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_coeffs && d_outs) || !count, "null pointer");
+    ZK_REQUIRE(ctx, h_g, "null pointer");
+    ZK_REQUIRE(ctx, k <= 28, "k exceeds the two-adicity of Fr (28)");
+    for (size_t i = 0; i < count; ++i) ZK_REQUIRE(ctx, d_coeffs[i] && d_outs[i], "null column pointer");
+    return ntt_run_many(ctx, (Fr* const*)d_outs, (const Fr* const*)d_coeffs, count, k, fr_root_of_unity(k), nullptr, (const Fr*)h_g, nullptr, /*fuse_pre=*/true);
 }
 int zk_extended_to_coeff(zk_ctx* ctx, void* d_ext, uint32_t ext_k) {
     if (!ctx) return ZK_ERR_INVALID_ARG;

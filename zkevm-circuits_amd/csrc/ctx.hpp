@@ -192,6 +192,8 @@ Fr fr_zeta();
 int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale /*nullable*/, const Fr* coset_pre /*nullable: a[i] *= g^i before*/, const Fr* coset_post /*nullable: out[i] *= g^i after*/,
             const Fr* d_src = nullptr /*nullable: read the input from here, d_data receives the result*/,
             bool fuse_pre = false /*coset_pre from a cached full power table inside the first pass (no separate sweep)*/);
+// `count` transforms over one domain, NTT_BATCH columns per launch (d_srcs nullable: in place)
+int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_t count, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, bool fuse_pre);
 int fr_scale_run(zk_ctx* ctx, Fr* d_a, const Fr& s, uint64_t n);
 int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Affine* h_out);
 int msm_run_rp(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, const G1Affine* d_bases_rp, size_t n, G1Affine* h_out);

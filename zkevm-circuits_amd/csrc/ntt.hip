@@ -27,6 +27,11 @@ constexpr int NTT_LDS_BYTES_PER_ELT = 36;
 
 struct Tw29;        // one butterfly twiddle split into 29-bit limbs (48 B), defined with the kernels
 
+// One launch transforms up to NTT_BATCH columns over the same domain: blockIdx.y selects the column.  A 2^18 column
+// is 64 tiles -- a quarter of the CUs --, and a prover transforms hundreds of columns per stage.
+constexpr int NTT_BATCH = 16;
+struct NttIo { const Fr* src[NTT_BATCH]; Fr* dst[NTT_BATCH]; };
+
 struct NttPass {
     int log_np;     // digit size
     int log_m;      // stride of the digit (non-last)
@@ -198,10 +203,12 @@ __device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Tw29* __restr
 // memory: no staging copy on either side.  Steps are radix-4 (radix-2 first when log_np is odd).
 // LDS invariant: limbs 0..7 < 2^29 (normalised), value < 2^261.
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
+k_ntt_pass(NttIo io, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
            const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre,
            const Fr* __restrict__ out_tw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const Fr* __restrict__ src = io.src[blockIdx.y];
+    Fr* __restrict__ dst = io.dst[blockIdx.y];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
     const int T = 1 << log_t;
@@ -265,9 +272,11 @@ __host__ __device__ __forceinline__ int ntt_row_pad(int log_np) { return log_np 
 // output is multiplied by `fin` (1 or the inverse-transform scale, R' form), which also brings
 // the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_last(const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw, int log_np, int log_t,
+k_ntt_last(NttIo io, const Tw29* __restrict__ tw, int log_np, int log_t,
            int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre, int fin_folded) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const Fr* __restrict__ src = io.src[blockIdx.y];
+    Fr* __restrict__ dst = io.dst[blockIdx.y];
     const int tile = 1 << (log_np + log_t);
     const int T = 1 << log_t;
     // rows are padded by 8 words: the last step reads with c fastest (coalesced output), and with a row
@@ -429,7 +438,25 @@ static int pick_threads(int tile) { return tile >= 4096 ? 1024 : (tile >= 1024 ?
 // Generic driver.  `scale` (nullable) multiplies every output; coset_pre (nullable): a[i] *= g^i
 // before the transform; coset_post (nullable): out[i] *= g^i after it.  d_src (nullable): the input
 // is read from d_src and d_data only receives the result (out of place, no extra copy).
+// `count` transforms over the same domain, in place (d_src == nullptr) or from d_src[i] to d_data[i]; launched
+// NTT_BATCH columns at a time.  coset_post and the unfused coset shift are per-column passes and only taken by the
+// single-column entry point.
+int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_t count, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, bool fuse_pre);
 int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, const Fr* d_src, bool fuse_pre) {
+    return ntt_run_many(ctx, &d_data, d_src ? &d_src : nullptr, 1, log_n, omega, scale, coset_pre, coset_post, fuse_pre);
+}
+int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_t count, uint32_t log_n, const Fr& omega, const Fr* scale, const Fr* coset_pre, const Fr* coset_post, bool fuse_pre) {
+    if (count == 0) return ZK_OK;
+    if (count > 1 && (log_n == 0 || coset_post)) {          // rare shapes: one by one
+        for (size_t i = 0; i < count; ++i) {
+            const Fr* one_src = d_srcs ? d_srcs[i] : nullptr;
+            int r = ntt_run_many(ctx, d_datas + i, one_src ? &one_src : nullptr, 1, log_n, omega, scale, coset_pre, coset_post, fuse_pre);
+            if (r) return r;
+        }
+        return ZK_OK;
+    }
+    Fr* d_data = d_datas[0];
+    const Fr* d_src = d_srcs ? d_srcs[0] : nullptr;
     if (log_n == 0) {   // size-1 transform: identity (times the scale)
         if (d_src && d_src != d_data) ZK_HIP(ctx, hipMemcpyAsync(d_data, d_src, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
         if (scale) {
@@ -483,45 +510,78 @@ int ntt_run(zk_ctx* ctx, Fr* d_data, uint32_t log_n, const Fr& omega, const Fr* 
             }
         }
     }
-    if (coset_pre && !pre_table) { rc = run_distribute(*coset_pre, cur); if (rc) return rc; cur = d_data; }
+    if (coset_pre && !pre_table) {
+        if (count > 1) {                                     // no memory for the shift table: the columns go one by one through the separate pass
+            for (size_t i = 0; i < count; ++i) {
+                const Fr* one_src = d_srcs ? d_srcs[i] : nullptr;
+                int r = ntt_run_many(ctx, d_datas + i, one_src ? &one_src : nullptr, 1, log_n, omega, scale, coset_pre, coset_post, fuse_pre);
+                if (r) return r;
+            }
+            return ZK_OK;
+        }
+        rc = run_distribute(*coset_pre, cur); if (rc) return rc; cur = d_data;
+    }
 
     std::shared_ptr<NttDomain> dom;
     rc = get_domain(ctx, log_n, omega, scale, &dom);
     if (rc) return rc;
     const int P = dom->npass;
+    // columns per launch: enough tiles to give every CU a few workgroups, bounded by the scratch it takes
+    size_t per_launch = 1;
+    if (count > 1) {
+        const uint64_t tiles = std::max<uint64_t>(1, n >> 12);
+        per_launch = (size_t)std::min<uint64_t>(NTT_BATCH, std::max<uint64_t>(1, 1024 / tiles));
+    }
     Fr* scratch = nullptr;
     if (P > 1) {
-        scratch = (Fr*)ctx->get_scratch(SC_NTT, sizeof(Fr) * n);
+        scratch = (Fr*)ctx->get_scratch(SC_NTT, sizeof(Fr) * n * per_launch);
         if (!scratch) return ZK_ERR_OOM;
     }
-    // buffers: P=1: data->data (whole transform inside one workgroup, safe in place)
-    //          P=2: data->scratch, scratch->data;   P=3: data->data, data->scratch, scratch->data
-    for (int p = 0; p + 1 < P; ++p) {
-        const NttPass& ps = dom->pass[p];
-        int log_t = 12 - ps.log_np;
-        if (log_t > ps.log_m) log_t = ps.log_m;
-        const int tile = 1 << (ps.log_np + log_t);
-        Fr* out = (p == P - 2) ? scratch : d_data;
-        const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
-        const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
-        ZkProfScope pscope(ctx, "ntt_pass");
-        hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, out, ps.tw,
-                           dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw);
-        ZK_CHECK_LAUNCH(ctx);
-        cur = out;
-    }
-    {
-        const NttPass& ps = dom->pass[P - 1];
-        const int log_n1 = P == 1 ? 0 : dom->pass[0].log_np;
-        const int log_mid = P == 3 ? dom->pass[1].log_np : 0;
-        int log_t = 12 - ps.log_np;
-        if (log_t > log_n1) log_t = log_n1;
-        const int tile = 1 << (ps.log_np + log_t);
-        const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
-        ZkProfScope pscope(ctx, "ntt_last");
-        hipLaunchKernelGGL(k_ntt_last, dim3(blocks), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, cur, d_data, ps.tw,
-                           ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0);
-        ZK_CHECK_LAUNCH(ctx);
+    for (size_t first = 0; first < count; first += per_launch) {
+        const size_t nb = std::min(per_launch, count - first);
+        NttIo io_in{}, io_mid{}, io_last{};
+        // buffers: P=1: data->data (whole transform inside one workgroup, safe in place)
+        //          P=2: data->scratch, scratch->data;   P=3: data->data, data->scratch, scratch->data
+        for (size_t j = 0; j < nb; ++j) {
+            Fr* dd = d_datas[first + j];
+            const Fr* ss = (count == 1) ? cur : (d_srcs && d_srcs[first + j] ? d_srcs[first + j] : dd);
+            io_in.src[j] = ss;
+            io_in.dst[j] = dd;
+        }
+        NttIo cur_io = io_in;                                  // .src = where the next pass reads
+        for (int p = 0; p + 1 < P; ++p) {
+            const NttPass& ps = dom->pass[p];
+            int log_t = 12 - ps.log_np;
+            if (log_t > ps.log_m) log_t = ps.log_m;
+            const int tile = 1 << (ps.log_np + log_t);
+            NttIo io{};
+            for (size_t j = 0; j < nb; ++j) {
+                io.src[j] = cur_io.src[j];
+                io.dst[j] = (p == P - 2) ? scratch + j * n : d_datas[first + j];
+            }
+            const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
+            const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
+            ZkProfScope pscope(ctx, "ntt_pass");
+            hipLaunchKernelGGL(k_ntt_pass, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
+                               dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw);
+            ZK_CHECK_LAUNCH(ctx);
+            for (size_t j = 0; j < nb; ++j) cur_io.src[j] = io.dst[j];
+        }
+        {
+            const NttPass& ps = dom->pass[P - 1];
+            const int log_n1 = P == 1 ? 0 : dom->pass[0].log_np;
+            const int log_mid = P == 3 ? dom->pass[1].log_np : 0;
+            int log_t = 12 - ps.log_np;
+            if (log_t > log_n1) log_t = log_n1;
+            const int tile = 1 << (ps.log_np + log_t);
+            const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
+            NttIo io{};
+            for (size_t j = 0; j < nb; ++j) { io.src[j] = cur_io.src[j]; io.dst[j] = d_datas[first + j]; }
+            ZkProfScope pscope(ctx, "ntt_last");
+            hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
+                               ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0);
+            ZK_CHECK_LAUNCH(ctx);
+        }
     }
     if (coset_post) { rc = run_distribute(*coset_post, d_data); if (rc) return rc; }
     return ZK_OK;

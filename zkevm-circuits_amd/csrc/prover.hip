@@ -45,6 +45,7 @@ extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
 extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, size_t);
 extern "C" int zk_lookup_multiplicities(zk_ctx*, const void*, const void*, size_t, void*, size_t, uint64_t*);
 extern "C" int zk_coeff_to_coset(zk_ctx*, const void*, uint32_t, const void*, void*);
+extern "C" int zk_coeff_to_coset_batch(zk_ctx*, const void* const*, uint32_t, const void*, void* const*, size_t);
 extern "C" int zk_fr_scatter_scaled(zk_ctx*, const void*, size_t, const void*, void*, size_t, size_t);
 extern "C" int zk_msm_g1(zk_ctx*, const void*, const void*, size_t, void*);
 extern "C" int zk_g1_sum_host(const void*, size_t, void*);
@@ -1050,11 +1051,20 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
 
     // ---- coefficient forms of everything the quotient reads and the proof opens
     std::vector<DevBuf> pz_coeff(pk->C), m_coeff(pk->L), phi_coeff(pk->L);
-    for (uint32_t i = 0; i < pk->A; ++i) if (!adv_coeff[i].p) PK_TRY(to_coeff(ctx, pk, adv_lag[i], &adv_coeff[i]));
-    for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(to_coeff(ctx, pk, pz_lag[c], &pz_coeff[c]));
-    for (uint32_t l = 0; l < pk->L; ++l) {
-        PK_TRY(to_coeff(ctx, pk, lk_m[l], &m_coeff[l]));
-        PK_TRY(to_coeff(ctx, pk, lk_phi[l], &phi_coeff[l]));
+    {   // one batch: several columns share a launch (ntt_run_many)
+        std::vector<Fr*> dsts;
+        std::vector<const Fr*> srcs;
+        auto want = [&](const DevBuf& lagv, DevBuf* co) -> int {
+            if (!co->alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            dsts.push_back(co->fr());
+            srcs.push_back(lagv.fr());
+            return ZK_OK;
+        };
+        for (uint32_t i = 0; i < pk->A; ++i) if (!adv_coeff[i].p) PK_TRY(want(adv_lag[i], &adv_coeff[i]));
+        for (uint32_t c = 0; c < pk->C; ++c) PK_TRY(want(pz_lag[c], &pz_coeff[c]));
+        for (uint32_t l = 0; l < pk->L; ++l) { PK_TRY(want(lk_m[l], &m_coeff[l])); PK_TRY(want(lk_phi[l], &phi_coeff[l])); }
+        const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
+        PK_TRY(ntt_run_many(ctx, dsts.data(), srcs.data(), dsts.size(), pk->k, omega_inv, &ninv, nullptr, nullptr, false));
     }
     trace.mark("coefficient forms");
     // ---- the quotient's constraints in halo2's order: gates, permutation, lookups (folded with y below)
@@ -1225,6 +1235,9 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             std::vector<uint32_t> active;
             for (uint32_t e = 0; e <= E; ++e) if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0) active.push_back(e);
             part_of.clear();
+            std::vector<const void*> bat_src;                 // the coset transforms of this round go out as one batch
+            std::vector<void*> bat_dst;
+            std::vector<std::pair<uint32_t, DevBuf>> fresh_slots;      // cache slots being filled: published only once they hold their coset
             for (size_t i = 0; i < refs.size(); ++i) {
                 bool needed = false;
                 for (uint32_t e : active) needed |= std::find(qc[e].refs.begin(), qc[e].refs.end(), refs[i]) != qc[e].refs.end();
@@ -1243,10 +1256,13 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 else {
                     const Fr* cf = coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
                     if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
-                    PK_TRY(zk_coeff_to_coset(ctx, cf, k, &g, dst));
+                    bat_src.push_back(cf);
+                    bat_dst.push_back(dst);
                 }
-                if (cached) pk->part_cache[r_][refs[i]] = std::move(fresh);
+                if (cached) fresh_slots.emplace_back(refs[i], std::move(fresh));
             }
+            PK_TRY(zk_coeff_to_coset_batch(ctx, bat_src.data(), k, &g, bat_dst.data(), bat_src.size()));
+            for (auto& fs : fresh_slots) pk->part_cache[r_][fs.first] = std::move(fs.second);
             trace.mark("  quotient: cosets of the columns");
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
