@@ -20,7 +20,7 @@ def short(name):
 
 
 def kernel_table(run, title, note):
-    f = glob.glob(f"{src}/{run}/runc/*kernel_stats.csv")[0]
+    f = max(glob.glob(f"{src}/{run}/runc/*kernel_stats.csv"), key=os.path.getmtime)        # gpurun merges into gpurun_out/: an earlier pass may have left its files
     shutil.copy(f, f"profiles/{tag}_{run}_kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
     out = [f"# {title}", "", note, "", "| kernel | calls | total ms | avg us | share |", "|---|---|---|---|---|"]
@@ -30,7 +30,7 @@ def kernel_table(run, title, note):
 
 
 def pmc(run, counter):
-    f = glob.glob(f"{src}/{run}/runc/*counter_collection.csv")[0]
+    f = max(glob.glob(f"{src}/{run}/runc/*counter_collection.csv"), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -39,7 +39,7 @@ def pmc(run, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-kern = ["k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_partition<20, true>", "k_msm_m_binsort", "k_ntt_pass", "k_ntt_last",
+kern = ["k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_scatter_staged<20>", "k_msm_m_binsort", "k_ntt_pass", "k_ntt_last",
         "k_wsum_level<false>", "k_msm_combine_wave"]
 traffic = {}
 lines = ["# PMC traffic per launch (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, `bench.py --no-proof --no-cpu-baseline`)", "",
