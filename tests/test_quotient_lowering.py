@@ -318,3 +318,13 @@ def test_parked_intermediate_is_not_prefetched_behind_its_tee():
         assert ops[t + 1] == K_NOP
         cols = {(0, 0): P - 1, (1, 0): P - 1}
         assert run_lowered(words, cols, [R % P], 2) == run_plain(prog, cols, [R % P])
+
+
+def test_malformed_programs_are_refused_not_executed():
+    lib = binding.lib()
+    for prog in ([(Q_ADD, 0, 0)], [(Q_PUSH_COL, 0, 0), (Q_MUL, 0, 0)], [(Q_FOLD, 0, 0)], [(99, 0, 0)], [(K_MUL_COL, 0, 0)]):
+        words = np.array([w for ins in prog for w in ins], dtype=np.uint32)
+        n_out, depth = ctypes.c_uint32(), ctypes.c_int()
+        rc = lib.zk_host_quotient_lower(words.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(prog)), ctypes.c_uint32(4), ctypes.c_int(1),
+                                        None, ctypes.c_size_t(0), ctypes.byref(n_out), ctypes.byref(depth))
+        assert rc != 0, prog

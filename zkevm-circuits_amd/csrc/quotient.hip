@@ -443,6 +443,17 @@ using namespace zk;
 extern "C" int zk_host_quotient_lower(const uint32_t* h_program, uint32_t num_instr, uint32_t num_cols, int fuse, uint32_t* out_words, size_t cap_words,
                                       uint32_t* out_instr, int* out_depth) {
     if (!h_program || !out_instr || !out_depth) return ZK_ERR_INVALID_ARG;
+    {   // stack discipline of the caller's program (zk_quotient_eval checks the same, with messages, in validate_program)
+        int sp = 0;
+        for (uint32_t pc = 0; pc < num_instr && h_program[3 * pc] != Q_END; ++pc) {
+            const uint32_t op = h_program[3 * pc];
+            if (op == Q_PUSH_COL || op == Q_PUSH_CONST || op == Q_PUSH_TMP) ++sp;
+            else if (op == Q_ADD || op == Q_SUB || op == Q_MUL) { if (sp < 2) return ZK_ERR_INVALID_ARG; --sp; }
+            else if (op == Q_FOLD) { if (sp < 1) return ZK_ERR_INVALID_ARG; --sp; }
+            else if (op == Q_NEG || op == Q_SQUARE || op == Q_DOUBLE || op == Q_MUL_CONST || op == Q_ADD_CONST || op == Q_TEE_TMP) { if (sp < 1) return ZK_ERR_INVALID_ARG; }
+            else return ZK_ERR_INVALID_ARG;
+        }
+    }
     std::vector<LowInstr> low;
     if (fuse) lower_fuse(h_program, num_instr, num_cols, &low);
     else
