@@ -500,7 +500,12 @@ def main():
     # -> one rank per GPU, sharded proving session (zk_proof_set_sharding), rank 0 reports.
     world, rank, shard = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), None
     device = 0
-    if world > 1:
+    dist = None
+    if world > 1 and args.rccl:
+        # the library's own communicator, joined from the launcher's environment: no torch in a prover rank
+        from zkevm_circuits_amd import rendezvous
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    elif world > 1:
         import torch
         import torch.distributed as dist
         from zkevm_circuits_amd import sharding as shard
@@ -524,15 +529,18 @@ def main():
         inst_m = [plonk.column_to_mont(c) for c in inst]
     t_build = time.perf_counter() - t0
     hook = None
+    barrier = None
     if world > 1 and args.rccl:
-        shard.comm_init_from_torch(ctx)
+        rendezvous.comm_init_from_env(ctx)
         hook = lambda sess: sess.set_sharding_comm()
+        barrier = lambda: rendezvous.comm_barrier(ctx, rank, world)
     elif world > 1:    # device all-gather of the advice columns unless --host-upload asks every rank to upload everything
         hook = (lambda sess: shard.shard_session(sess)) if args.host_upload else (lambda sess: shard.shard_session_device(sess))
     out = proof_bench(ctx, args.k, circ, blob, adv_m, inst_m, inst, shplonk=args.shplonk, repeat=args.repeat, verify=not args.no_verify, pinned=args.pinned,
-                      t_build=t_build, session_hook=hook, barrier=(dist.barrier if world > 1 else None), report=(rank == 0), world=world)
+                      t_build=t_build, session_hook=hook, barrier=barrier or (dist.barrier if world > 1 else None), report=(rank == 0), world=world)
     if world > 1 and rank != 0:
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
         return
     d = circ.degree()
     if args.cpu_baseline:
@@ -563,7 +571,8 @@ def main():
         }
     if world > 1:
         out["metric"] = f"synthetic-shape full proof wall-clock (s), {world} ranks (sharded session)"
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 
 

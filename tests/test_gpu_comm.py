@@ -53,3 +53,18 @@ def test_single_rank_communicator(zk, ctx, cref):
     # a rank outside the world is refused before RCCL is touched
     with pytest.raises(zk.ZkError):
         ctx.comm_init(uid, 3, 2)
+
+
+def test_communicator_joined_from_the_launcher_environment(zk, ctx, monkeypatch, tmp_path):
+    """rendezvous.comm_init_from_env: what `bench_proof.py --rccl` does under a launcher, here with the one rank the box has"""
+    from zkevm_circuits_amd import rendezvous
+
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("ZK_COMM_ID_FILE", str(tmp_path / "uid"))
+    rank, world = rendezvous.comm_init_from_env(ctx)
+    try:
+        assert (rank, world) == (0, 1)
+        rendezvous.comm_barrier(ctx, rank, world)
+    finally:
+        ctx.comm_destroy()

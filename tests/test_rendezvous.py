@@ -1,0 +1,39 @@
+"""File rendezvous of the library's RCCL communicator id (zkevm-circuits_amd/rendezvous.py): CPU test of the channel
+itself -- rank 0 publishes atomically, the others wait for exactly 128 bytes, no torch gets imported."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+
+def _rank(rank, world, path, q):
+    from zkevm_circuits_amd import rendezvous
+
+    if rank == 0:
+        time.sleep(0.3)                      # the others must wait, not fail
+    uid = rendezvous.exchange_unique_id(lambda: bytes(range(128)), rank, world, path, timeout=20.0)
+    q.put((rank, uid, "torch" in sys.modules))
+
+
+def test_unique_id_reaches_every_rank_without_torch(tmp_path):
+    path = str(tmp_path / "uid")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 3, path, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert [g[0] for g in got] == [0, 1, 2]
+    assert all(g[1] == bytes(range(128)) for g in got)
+    assert not any(g[2] for g in got), "the rendezvous must not pull torch into a prover rank"
+    assert os.path.getsize(path) == 128
+
+
+def test_missing_id_times_out(tmp_path):
+    from zkevm_circuits_amd import rendezvous
+    import pytest
+
+    with pytest.raises(TimeoutError):
+        rendezvous.exchange_unique_id(lambda: b"", 1, 2, str(tmp_path / "never"), timeout=0.2)

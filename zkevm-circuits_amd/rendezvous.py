@@ -1,0 +1,56 @@
+"""Joining the library's RCCL communicator without torch in the process (csrc/comm.hip: zk_comm_unique_id / zk_comm_init).
+
+A prover rank started by any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT (torch.distributed.run,
+mpirun wrappers, a shell loop) needs one out-of-band step -- rank 0's 128-byte id must reach the other ranks -- and a
+file does it.  Keeping torch out matters for measurements: torch bundles its own HIP runtime, and with two runtimes in
+one process the witness uploads of a proving session ran 30 % slower (tools/upload_order.py)."""
+import os
+def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float = 120.0) -> bytes:
+    """Rank 0's 128-byte RCCL id to every rank through a file: the whole out-of-band channel a launcher needs to
+    provide (no torch, no MPI).  `make_id` is only called on rank 0.  The file appears atomically (write + rename)."""
+    import time
+
+    if rank == 0:
+        uid = make_id()
+        assert len(uid) == 128
+        if world > 1:
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
+def comm_init_from_env(ctx, timeout: float = 120.0):
+    """Joins the library's RCCL communicator from the launcher's environment alone (RANK, WORLD_SIZE, MASTER_PORT): rank 0
+    creates the unique id and publishes it in a file named after the launch (the launcher's pid is the parent of every
+    rank, so a file left behind by an earlier launch on the same port cannot be mistaken for this one's).  No torch in
+    the process: a prover rank holds the library and nothing else."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    path = os.environ.get("ZK_COMM_ID_FILE") or os.path.join(
+        os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}")
+    uid = exchange_unique_id(ctx.comm_unique_id, rank, world, path, timeout)
+    ctx.comm_init(uid, rank, world)
+    return rank, world
+
+
+def comm_barrier(ctx, rank: int, world: int):
+    """All ranks of the library's communicator meet here: a one-byte-per-rank all-gather, then the stream is drained."""
+    send, recv = ctx.alloc(256), ctx.alloc(256 * max(world, 1))
+    ctx.comm_allgather(send, 256, recv)
+    ctx.sync()
+    send.free()
+    recv.free()
+

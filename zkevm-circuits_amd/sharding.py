@@ -222,3 +222,4 @@ def comm_init_from_torch(ctx):
     dist.broadcast_object_list(box, src=0)
     ctx.comm_init(box[0], rank, world)
     return rank, world
+
