@@ -36,6 +36,7 @@ struct zk_ctx {
     zk::Scratch scratch[14];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
     hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
+    std::vector<hipStream_t> owned_streams;      // every stream zk_ctx_create made (roles may share one; 'd' entries of the layout have no role at all)
     hipEvent_t ev_p1[3] = {nullptr, nullptr, nullptr}, ev_p2[3] = {nullptr, nullptr, nullptr};
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;

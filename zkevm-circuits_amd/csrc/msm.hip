@@ -1046,13 +1046,12 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     // fold on the side stream reads them while the main stream already recodes the next column)
     G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count + 256 * count);
     if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
-    if (!ctx->stream2) {
-        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->stream2) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->ev_p1[0])
         for (int i = 0; i < 3; ++i) {
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
         }
-    }
 
     const dim3 gs((unsigned)((n + 255) / 256)), ts(256);
     if (!d_bases_rp) {
@@ -1273,13 +1272,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // one window sum per MSM, then one private copy of the window flags per MSM of the per-window path
     G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count + 256 * count);
     if (!bkbuf[0] || !bkbuf[1] || !bkbuf[2] || !wsum_all) return ZK_ERR_OOM;
-    if (!ctx->stream2) {
-        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->stream2) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->ev_p1[0])
         for (int i = 0; i < 3; ++i) {
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p1[i], hipEventDisableTiming));
             ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_p2[i], hipEventDisableTiming));
         }
-    }
     // The reductions of consecutive MSMs rotate over three side streams: each is a chain of short
     // launches (latency, not throughput), and with witness columns that fill few windows it can take
     // longer than the sort + accumulation of the next column.
