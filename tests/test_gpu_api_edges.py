@@ -136,3 +136,29 @@ def test_sharded_ntt_argument_checks_and_single_rank(zk, ctx, cref):
     ctx.ntt_sharded(buf, k, 0, 1, cb)                    # one rank: no exchange at all
     assert len(calls) == 1
     assert np.array_equal(buf.download((1 << k, 4)), cref.best_fft(x, bn254.omega_for_k(k), k))
+
+
+def test_profiling_levels_and_byte_accounting(zk, ctx, cref):
+    """zk_prof_enable(2) brackets only the roofline kernels' groups; the evaluator books the bytes its launches stream"""
+    k, n = 12, 1 << 12
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(5))
+    col = ctx.to_device(cref.rand_fr_stream(3, n))
+    ctx.prof_reset()
+    ctx.prof_enable(2)
+    ctx.commit(srs, col, n, lagrange=True)
+    ctx.ntt(col, k)
+    ctx.prof_enable(False)
+    names = set(ctx.prof_names())
+    assert names and all(nm == "msm_buckets" or nm.startswith(("ntt_", "quotient", "msm_buckets")) for nm in names), names
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    ctx.commit(srs, col, n, lagrange=True)
+    out = ctx.alloc(n * 32)
+    prog = np.array([(1, 0, 0), (1, 0, 1), (5, 0, 0), (9, 0, 0)], dtype=np.uint32)       # col * col(+1), folded
+    ctx.quotient_eval(prog, [col.ptr], cref.fr_const(1).reshape(1, 4), k, k, out)
+    ctx.prof_enable(False)
+    names = set(ctx.prof_names())
+    assert "msm_sort" in names and "quotient_eval" in names
+    assert ctx.prof_get_bytes("quotient_eval") == (2 + 1) * n * 32          # two distinct (column, rotation) operands + the result
+    assert ctx.prof_get_bytes("msm_sort") == 0
+    srs.destroy()

@@ -17,6 +17,8 @@
 // librccl is loaded on first use (dlopen): the library itself has no link-time dependency on it, and
 // a single-GPU deployment never touches it.
 #include <dlfcn.h>
+
+#include <string>
 #include <rccl/rccl.h>
 
 #include "ctx.hpp"
@@ -40,8 +42,19 @@ struct Rccl {
 static Rccl& rccl() {
     static Rccl r = [] {
         Rccl x;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that belongs to the HIP runtime this library links, by path: a bare "librccl.so.1" resolves to whatever copy
+        // the process already holds under that name -- torch's, when torch is imported, which talks to torch's own (possibly
+        // never initialised) HIP runtime instead of the one our streams and buffers live in.
+        std::string beside;
+        Dl_info info;
+        if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            beside = info.dli_fname;
+            const size_t slash = beside.rfind('/');
+            beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1) + "librccl.so.1";
+        }
+        for (const std::string& name : {beside, std::string("/opt/rocm/lib/librccl.so.1"), std::string("librccl.so.1"), std::string("librccl.so")}) {
+            if (name.empty()) continue;
+            x.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (x.lib) break;
         }
         if (!x.lib) return x;
@@ -50,6 +63,15 @@ static Rccl& rccl() {
         ZK_SYM(AllGather, "ncclAllGather") ZK_SYM(Send, "ncclSend") ZK_SYM(Recv, "ncclRecv") ZK_SYM(GroupStart, "ncclGroupStart")
         ZK_SYM(GroupEnd, "ncclGroupEnd") ZK_SYM(GetErrorString, "ncclGetErrorString")
 #undef ZK_SYM
+        // RCCL looks the HSA runtime up by name (dlopen("libhsa-runtime64.so")) for its capability queries.  A process that has
+        // imported torch holds torch's bundled copy under that name, and until torch touches the GPU that copy is not
+        // initialised: the queries fail with HSA_STATUS_ERROR_NOT_INITIALIZED and ncclCommInitRank reports "no ROCm-capable
+        // device".  hsa_init is reference-counted: initialise whichever copies are already loaded.
+        for (const char* name : {"libhsa-runtime64.so", "libhsa-runtime64.so.1"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) {
+                if (auto init = (int (*)())dlsym(h, "hsa_init")) (void)init();
+            }
+        }
         x.ok = true;
         return x;
     }();
