@@ -190,6 +190,16 @@ def main():
         ctx.commit(srs, d_cols[i % NCOL], N, lagrange=True)
         lone.append(time.perf_counter() - t1)
     lone_ms = sorted(lone)[len(lone) // 2] * 1e3
+    # N > 1 on real GPUs: the sharded proving session of the SuperCircuit shape (BASELINE config 4 is quoted on 8 GPUs) and of
+    # the recursion shape (config 5), every rank in a prover process of its own, exchanges through the library's RCCL
+    # communicator.  All ranks take part; only rank 0 gets the records.  Failures and time-outs stay inside the section.
+    sharded = None
+    if world > 1 and not shared_gpu and not args.no_proof:
+        for b_ in d_cols + d_work:
+            b_.free()
+        d_cols, d_work = [], []
+        sharded = sharded_proof_section(dist, rank, world, local_rank)
+        dist.barrier()
     if rank == 0:
         def avg_ms(name):
             ms, cnt = prof.get(name, (0.0, 0))
@@ -271,6 +281,8 @@ def main():
         srs.destroy()
         if world == 1 and not args.no_proof:
             out["proof"] = proof_section()
+        if sharded is not None:
+            out["proof_sharded"] = sharded
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -335,13 +347,83 @@ def proof_section():
     return out
 
 
+def sharded_proof_section(dist, rank, world, local_rank):
+    """One prover process per rank (`--proof-worker <shape>` with the launcher's RANK / WORLD_SIZE / LOCAL_RANK in its
+    environment): the ranks join the library's own RCCL communicator through a file (zkevm-circuits_amd/rendezvous.py) and
+    run the sharded session -- commitments split by column (by points when there are fewer columns than ranks), quotient
+    split by coset, witness columns uploaded by their owner and all-gathered device to device.  Returns the records on
+    rank 0, None elsewhere."""
+    import subprocess
+
+    def host_bytes_free():
+        """what this container may still take: the cgroup's limit if it has one, the machine's free memory otherwise"""
+        free = None
+        try:
+            import psutil
+            free = psutil.virtual_memory().available
+        except Exception:
+            pass
+        try:
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            if lim != "max":
+                cur = int(open("/sys/fs/cgroup/memory.current").read())
+                free = min(free, int(lim) - cur) if free is not None else int(lim) - cur
+        except Exception:
+            pass
+        return free
+
+    out = {}
+    need = {"supercircuit_shape_k20": 24 << 30, "recursion_shape_k22": 8 << 30}      # host bytes per rank (blob + witness + builder temporaries)
+    for name, limit in (("supercircuit_shape_k20", 150), ("recursion_shape_k22", 120)):      # expected: 20-30 s and 15 s
+        verdict = [None]
+        if rank == 0:
+            free = host_bytes_free()
+            if free is not None and free < world * need[name]:
+                verdict[0] = f"host memory: {free >> 30} GiB free, {world} ranks x {need[name] >> 30} GiB needed"
+        dist.broadcast_object_list(verdict, src=0)               # one verdict for all ranks
+        if verdict[0]:
+            if rank == 0:
+                out[name] = {"skipped": verdict[0]}
+            continue
+        env = dict(os.environ)
+        env["ZK_COMM_ID_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}_{name}")
+        env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+        failed = False
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", name], capture_output=True, text=True, timeout=limit, env=env)
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            failed = res.returncode != 0
+            if rank == 0:
+                out[name] = json.loads(lines[-1]) if not failed and lines else {"error": f"rank 0 worker exited with {res.returncode}: {res.stderr[-400:]}"}
+        except Exception as e:           # a time-out here usually means another rank failed and the collectives never completed
+            failed = True
+            if rank == 0:
+                out[name] = {"error": repr(e)}
+        if rank == 0:
+            try:
+                os.remove(env["ZK_COMM_ID_FILE"])
+            except OSError:
+                pass
+        if failed:                       # every rank sees the failure (its own exit code or the common time-out): none starts the next shape
+            break
+    return out if rank == 0 else None
+
+
 def proof_worker(name):
     """One proof shape, measured in this (fresh) process.  The quotient evaluator's roofline comes from one extra,
     profiled proof: bytes = what the launches really stream (counted by the library) over their time."""
     import bench_proof as bp
     import zkevm_circuits_amd as z
 
-    ctx = z.Context(0)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    ctx = z.Context(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
+    hook = barrier = None
+    if world > 1:
+        from zkevm_circuits_amd import rendezvous
+
+        rendezvous.comm_init_from_env(ctx)
+        hook = lambda sess: sess.set_sharding_comm()
+        barrier = lambda: rendezvous.comm_barrier(ctx, rank, world)
     # (builder, proofs per key, transcript): the recursion shape is BASELINE config 5's stand-in -- k = 22, 9 advice
     # columns, FOUR sequential proofs sharing one proving key, Poseidon transcript as gen_snark_shplonk uses
     # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
@@ -352,7 +434,16 @@ def proof_worker(name):
     circ, blob, adv_m, inst_m, inst = build()
     t_build = time.perf_counter() - t0
     rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=True, t_build=t_build, transcript_kind=tkind,
-                         profiled_extra=True)        # timed proofs run without the profiling events; one extra proof feeds the quotient roofline
+                         profiled_extra=world == 1,  # timed proofs run without the profiling events; one extra proof feeds the quotient roofline
+                         session_hook=hook, barrier=barrier, report=rank == 0, world=world)
+    if world > 1:
+        if rec is not None:
+            rec["metric"] = f"synthetic-shape full proof wall-clock (s), sharded session on {world} x MI355X (in-library RCCL)"
+            if tkind == 1:
+                rec["transcript"] = "poseidon"
+                rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
+        ctx.close()
+        return rec
     if tkind == 1:
         rec["transcript"] = "poseidon"
         rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
