@@ -198,7 +198,10 @@ def main():
         for b_ in d_cols + d_work:
             b_.free()
         d_cols, d_work = [], []
-        sharded = sharded_proof_section(dist, rank, world, local_rank)
+        try:
+            sharded = sharded_proof_section(dist, rank, world, local_rank)
+        except Exception as e:           # the MSM / NTT line must survive whatever happens in here
+            sharded = {"error": repr(e)} if rank == 0 else None
         dist.barrier()
     if rank == 0:
         def avg_ms(name):
