@@ -110,6 +110,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (hipStream_t st : streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->ev_pipe) (void)hipEventDestroy(ctx->ev_pipe);
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_p2) if (e) (void)hipEventDestroy(e);
     delete ctx;

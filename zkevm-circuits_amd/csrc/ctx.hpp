@@ -38,6 +38,7 @@ struct zk_ctx {
     hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
     std::vector<hipStream_t> owned_streams;      // every stream zk_ctx_create made (roles may share one; 'd' entries of the layout have no role at all)
     hipEvent_t ev_p1[3] = {nullptr, nullptr, nullptr}, ev_p2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_pipe = nullptr;        // joins the second MSM pipeline of small batches (msm_batch_merged)
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;
     hipEvent_t ev_copy = nullptr;

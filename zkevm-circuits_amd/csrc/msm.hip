@@ -1241,8 +1241,13 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] | counts[nb] | size_hist[256] nmulti[4] pad[64] | offsets[nb+1] | order[nb] |
     //                ntasks[nb] | toff[nb+1] | block_tot[...] | hist[hist_cnt] | hist_off[hist_cnt + 1] | idx[n W] | (8-B aligned) entries[n W] u64
     const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
-    const size_t words = std::max(head_words + 4 + 2 * max_entries, words_N);
-    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
+    const size_t words = (std::max(head_words + 4 + 2 * max_entries, words_N) + 63) & ~(size_t)63;
+    // Below 2^20 points an MSM does not fill the device: its sort / accumulation / combination is a chain of some twenty
+    // short launches.  Two such chains then run side by side -- even columns on the context's stream, odd columns on the
+    // third side stream, each with its own sort workspace -- and hide each other's latency.  ZK_MSM_PIPES overrides.
+    int npipe = (n <= ((size_t)1 << 19) && count >= 2) ? 2 : 1;
+    if (const char* e = getenv("ZK_MSM_PIPES")) { const int v = atoi(e); if (v == 1 || (v == 2 && count >= 2)) npipe = v; }
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * npipe);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* slice_counts = ws;
     uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
@@ -1283,10 +1288,36 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // longer than the sort + accumulation of the next column.
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
     if (!ctx->stream2c) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2c, hipStreamNonBlocking));
+    if (npipe == 2 && !ctx->ev_pipe) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe, hipEventDisableTiming));
+    hipStream_t mains[2] = {ctx->stream, npipe == 2 ? ctx->stream2c : ctx->stream};
+    struct StreamRestore { zk_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, ctx->stream};     // error returns included
+    if (npipe == 2) {           // the second pipeline starts behind everything already enqueued on the context's stream
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, mains[0]));
+        ZK_HIP(ctx, hipStreamWaitEvent(mains[1], ctx->ev_pipe, 0));
+    }
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
     for (size_t it = 0; it < count; ++it) {
-        const int par = (int)(it % 3);
-        hipStream_t side = par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c;
+        const int par = (int)(it % 3), pipe = (int)(it % (size_t)npipe);
+        hipStream_t side = npipe == 2 ? ((it & 1) ? ctx->stream2b : ctx->stream2) : (par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c);
+        ctx->stream = mains[pipe];
+        // this pipeline's copy of the sort workspace (same layout as above)
+        uint32_t* wsb = ws + (size_t)pipe * words;
+        uint32_t* slice_counts = wsb;
+        uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
+        uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
+        uint32_t* size_hist = counts + nb;
+        uint32_t* nmulti = size_hist + SIZE_BINS;
+        uint32_t* offsets = nmulti + 4 + 64;
+        uint32_t* order = offsets + nb + 1;
+        uint32_t* ntasks = order + nb;
+        uint32_t* toff = ntasks + nb;
+        uint32_t* block_tot = toff + nb + 1;
+        uint32_t* block_tot2 = block_tot + scan_blocks_s;
+        uint32_t* block_tot3 = block_tot2 + scan_blocks;
+        uint32_t* hist = block_tot3 + scan_blocks_h;
+        uint32_t* hist_off = hist + hist_cnt;
+        uint32_t* idx = hist_off + hist_cnt + 1;
+        uint64_t* entries = reinterpret_cast<uint64_t*>(wsb + ((head_words + 3) & ~(size_t)3));
         const Fr* d_scalars = d_scalar_ptrs[it];
         G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
         G1Xyzz29* partial = buckets + nb;
@@ -1300,7 +1331,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         if (any_narrow && narrow[it] == 1) {
             // ---- per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with
             // empty windows skipped, bucket accumulation, fold of the occupied windows, one window reduced
-            uint32_t* slice_countsN = ws;
+            uint32_t* slice_countsN = wsb;
             uint32_t* slice_offN = slice_countsN + (size_t)nbN * MSM_SLICES;
             uint32_t* countsN = slice_offN + (size_t)nbN * MSM_SLICES + 4;
             uint32_t* size_histN = countsN + nbN;
@@ -1313,7 +1344,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             uint32_t* block_totN = toffN + nbN + 1;
             uint32_t* block_tot2N = block_totN + scan_blocks_sN;
             uint32_t* idxN = block_tot2N + scan_blocks_N;
-            uint16_t* dig = reinterpret_cast<uint16_t*>(ws + ((head_words_N + 3) & ~(size_t)3));
+            uint16_t* dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
             G1Xyzz29* partialN = buckets + nbN;
             G1Xyzz29* task_partialN = partialN + red_blocks_N;
             G1Xyzz29* folded = task_partialN + max_tasks_N;
@@ -1364,7 +1395,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
-            if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+            if (stage && it + 1 < count) { ctx->stream = mains[(it + 1) % (size_t)npipe]; int rc = stage(stage_user, it + 1); if (rc) return rc; }
             continue;
         }
         {
@@ -1435,7 +1466,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             }
         }
         ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
-        if (stage && it + 1 < count) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+        if (stage && it + 1 < count) { ctx->stream = mains[(it + 1) % (size_t)npipe]; int rc = stage(stage_user, it + 1); if (rc) return rc; }
+    }
+    ctx->stream = mains[0];
+    if (npipe == 2) {
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, mains[1]));
+        ZK_HIP(ctx, hipStreamWaitEvent(mains[0], ctx->ev_pipe, 0));
     }
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
     if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
