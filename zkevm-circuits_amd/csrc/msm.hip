@@ -28,6 +28,9 @@
 //   5. tail      window sums go to the host: Horner over the windows (c doublings each; a
 //                dependent doubling chain is issue-bound on one GPU lane) and the affine
 //                normalisation; with window tables only the normalisation is left.
+#include <chrono>
+#include <cmath>
+
 #include "ctx.hpp"
 #include "ec29.cuh"
 #include "host_fq.hpp"
@@ -1192,6 +1195,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                      size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const G1Affine* d_table_n = nullptr, const MsmPlan* pl_n = nullptr, const uint8_t* narrow = nullptr) {
     if (count == 0) return ZK_OK;
     if (n == 0) { memset(h_out, 0, sizeof(G1Affine) * count); return ZK_OK; }
+    const auto t_batch0 = std::chrono::steady_clock::now();
     bool any_narrow = false;
     if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] == 1;
     // ---- per-window ("narrow") path: sizes and workspace, as in msm_batch_tab with a window table
@@ -1478,7 +1482,13 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     if (count > 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[2], 0));
     std::vector<G1Xyzz> hw(count);
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
+    const auto t_enq = std::chrono::steady_clock::now();
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("ZK_MSM_TRACE")) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zk msm] batch of %zu x 2^%.0f: host enqueue %.3f ms, device drained %.3f ms later\n", count, log2((double)n),
+                std::chrono::duration<double, std::milli>(t_enq - t_batch0).count(), std::chrono::duration<double, std::milli>(t_done - t_enq).count());
+    }
     for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
     return ZK_OK;
 }
