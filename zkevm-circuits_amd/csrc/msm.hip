@@ -47,6 +47,11 @@ struct MsmPlan {
     int top_shift = 0;   // merged-window path: the top window's digit is scaled by 2^top_shift (its table entry is 2^(c (W-1) - top_shift) P)
 };
 
+// Graph replay of small batches (msm_batch_merged, graph mode): what differs from column to column -- where the scalars are,
+// where the result goes -- is read from a device-side table, cols[*ctr], so that the launch sequence of a column can be
+// captured once and replayed with one API call; the last kernel of the sequence advances *ctr to the pipeline's next column.
+struct MsmCol { const Fr* scalars; G1Xyzz* out; };
+
 static MsmPlan make_plan(size_t n) {
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
@@ -94,8 +99,10 @@ __device__ __forceinline__ void recode_all(const Fr& s, uint32_t (&code)[(256 + 
 // a wave writes 256 contiguous bytes per row with dword stores (2-byte stores, one scalar per
 // lane, ran at a third of the rate).  n_pad is even.
 template <int C>
-__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, uint64_t n, uint64_t n_pad, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag) {
+__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars_arg, uint64_t n, uint64_t n_pad, uint16_t* __restrict__ dig, uint32_t* __restrict__ wflag,
+                                                    const MsmCol* __restrict__ cols = nullptr, const uint32_t* __restrict__ ctr = nullptr) {
     constexpr int W = (256 + C - 1) / C;
+    const Fr* __restrict__ scalars = cols ? cols[*ctr].scalars : scalars_arg;
     const uint64_t i = 2 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n_pad) return;
     uint32_t c0[W], c1[W];
@@ -118,8 +125,8 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
         if (any && (uint32_t)__builtin_ctzll(any) == (threadIdx.x & 63u) && wflag[w] == 0u) wflag[w] = 1u;
     }
 }
-static void launch_digits(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, uint64_t n_pad, uint16_t* dig, uint32_t* wflag) {
-#define ZK_DIG_CASE(C) case C: hipLaunchKernelGGL(k_msm_digits<C>, grid, dim3(256), 0, st, scalars, n, n_pad, dig, wflag); break;
+static void launch_digits(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, uint64_t n_pad, uint16_t* dig, uint32_t* wflag, const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr) {
+#define ZK_DIG_CASE(C) case C: hipLaunchKernelGGL(k_msm_digits<C>, grid, dim3(256), 0, st, scalars, n, n_pad, dig, wflag, cols, ctr); break;
     switch (c) {
         ZK_DIG_CASE(4) ZK_DIG_CASE(5) ZK_DIG_CASE(6) ZK_DIG_CASE(7) ZK_DIG_CASE(8) ZK_DIG_CASE(9) ZK_DIG_CASE(10)
         ZK_DIG_CASE(11) ZK_DIG_CASE(12) ZK_DIG_CASE(13) ZK_DIG_CASE(14) ZK_DIG_CASE(15) ZK_DIG_CASE(16)
@@ -264,9 +271,10 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* lds, uint32_t slot, bool 
 // (recoding again costs one Montgomery product per scalar; keeping the digits would cost a write
 // and a read of W words per scalar).
 template <int C, bool SCATTER>
-__global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
-                                                          uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift) {
+__global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars_arg, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
+                                                          uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift, const MsmCol* __restrict__ cols = nullptr, const uint32_t* __restrict__ ctr = nullptr) {
     constexpr int W = (256 + C - 1) / C;
+    const Fr* __restrict__ scalars = cols ? cols[*ctr].scalars : scalars_arg;
     __shared__ uint32_t lds[MSM_M_MAX_BINS];
     const uint32_t nbins = 1u << (C - 1 - range_bits), nwg = gridDim.x, g = blockIdx.x;
     for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = SCATTER ? hist_off[(uint64_t)t * nwg + g] : 0u;
@@ -305,9 +313,10 @@ __global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ 
 // burst.  Dynamic LDS: cnt[1024] | gdelta[1024] | wtot[16] | stage[1024 W] (u64) | pid[1024 W] (u16).
 constexpr uint32_t MSM_M_SCHUNK = 1024;                 // scalars per workgroup of the staged scatter (and of its histogram pass)
 template <int C>
-__global__ void __launch_bounds__(1024) k_msm_m_scatter_staged(const Fr* __restrict__ scalars, uint64_t n, int range_bits, const uint32_t* __restrict__ hist_off,
-                                                               uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift) {
+__global__ void __launch_bounds__(1024) k_msm_m_scatter_staged(const Fr* __restrict__ scalars_arg, uint64_t n, int range_bits, const uint32_t* __restrict__ hist_off,
+                                                               uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift, const MsmCol* __restrict__ cols = nullptr, const uint32_t* __restrict__ ctr = nullptr) {
     constexpr int W = (256 + C - 1) / C;
+    const Fr* __restrict__ scalars = cols ? cols[*ctr].scalars : scalars_arg;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     uint32_t* cnt = sm;                                  // counters, then local start of every partition
     uint32_t* gdelta = sm + MSM_M_MAX_BINS;              // global cursor of (partition, this workgroup) minus the local start
@@ -860,9 +869,11 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1Xyzz29* __re
     if (threadIdx.x == 0) partial[(uint64_t)w * gridDim.x + blockIdx.x] = sh[0];
 }
 // one block per window sums `cnt` partials; output in the canonical R-form XYZZ the host tail reads
-__global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* __restrict__ partial, uint32_t cnt, G1Xyzz* __restrict__ out) {
+__global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* __restrict__ partial, uint32_t cnt, G1Xyzz* __restrict__ out_arg,
+                                                                const MsmCol* __restrict__ cols = nullptr, uint32_t* ctr = nullptr, uint32_t ctr_step = 0) {
     __shared__ G1Xyzz29 sh[RED_THREADS];
     const uint32_t w = blockIdx.x;
+    G1Xyzz* out = cols ? cols[*ctr].out : out_arg;          // graph mode launches one block: every thread reads the counter before thread 0 advances it
     G1Xyzz29 acc = identity29();
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = add29pt(acc, ldg29(partial + (uint64_t)w * cnt + i));
     sh[threadIdx.x] = acc;
@@ -871,7 +882,10 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_window_sum(const G1Xyzz29* 
         if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) stg(out + w, to_std_xyzz(sh[0]));
+    if (threadIdx.x == 0) {
+        stg(out + w, to_std_xyzz(sh[0]));
+        if (cols) *ctr += ctr_step;                          // the tree sum above passed several barriers since the counter was read
+    }
 }
 
 // ---- weighted bucket sum of the merged path: sum_b (b + 1) * B_b over 2^19 .. 2^21 buckets -----------
@@ -1167,19 +1181,21 @@ static MsmPlan make_plan_merged(uint32_t k_srs) {
     return p;
 }
 template <bool SCATTER>
-static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift) {
-#define ZK_PART_CASE(C) case C: hipLaunchKernelGGL((k_msm_m_partition<C, SCATTER>), grid, dim3(256), 0, st, scalars, n, range_bits, hist, hist_off, entries, tab_stride, top_shift); break;
+static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift,
+                             const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr) {
+#define ZK_PART_CASE(C) case C: hipLaunchKernelGGL((k_msm_m_partition<C, SCATTER>), grid, dim3(256), 0, st, scalars, n, range_bits, hist, hist_off, entries, tab_stride, top_shift, cols, ctr); break;
     switch (c) {
         ZK_PART_CASE(8) ZK_PART_CASE(9) ZK_PART_CASE(10) ZK_PART_CASE(11) ZK_PART_CASE(12) ZK_PART_CASE(13) ZK_PART_CASE(14) ZK_PART_CASE(15)
         ZK_PART_CASE(16) ZK_PART_CASE(17) ZK_PART_CASE(18) ZK_PART_CASE(19) ZK_PART_CASE(20) ZK_PART_CASE(21) ZK_PART_CASE(22)
     }
 #undef ZK_PART_CASE
 }
-static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift) {
+static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift,
+                                 const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr) {
     const size_t lds = scatter_staged_lds(W);
 #define ZK_SS_CASE(C) case C: \
         if (!(ctx->msm_attr_set & (1u << C))) { ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_msm_m_scatter_staged<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->msm_attr_set |= 1u << C; } \
-        hipLaunchKernelGGL((k_msm_m_scatter_staged<C>), grid, dim3(1024), lds, ctx->stream, scalars, n, range_bits, hist_off, entries, tab_stride, top_shift); break;
+        hipLaunchKernelGGL((k_msm_m_scatter_staged<C>), grid, dim3(1024), lds, ctx->stream, scalars, n, range_bits, hist_off, entries, tab_stride, top_shift, cols, ctr); break;
     switch (c) { ZK_SS_CASE(19) ZK_SS_CASE(20) ZK_SS_CASE(21) ZK_SS_CASE(22) default: return ctx->fail(ZK_ERR_UNSUPPORTED, "staged scatter: window size %d", c); }
 #undef ZK_SS_CASE
     ZK_CHECK_LAUNCH(ctx);
@@ -1251,7 +1267,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // third side stream, each with its own sort workspace -- and hide each other's latency.  ZK_MSM_PIPES overrides.
     int npipe = (n <= ((size_t)1 << 19) && count >= 2) ? 2 : 1;
     if (const char* e = getenv("ZK_MSM_PIPES")) { const int v = atoi(e); if (v == 1 || (v == 2 && count >= 2)) npipe = v; }
-    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * npipe);
+    // Graph mode (below): the launch sequence of a column is captured once per pipeline and replayed -- at these sizes the
+    // host's launch rate, ~30 API calls per column, is what bounds a batch.  ZK_MSM_GRAPH=0 disables it.
+    const char* env_graph = getenv("ZK_MSM_GRAPH");
+    const bool want_graph = n <= ((size_t)1 << 19) && n >= 1024 && count >= 4 && !ctx->prof_on && !ctx->msm_graph_broken && !(env_graph && atoi(env_graph) == 0);
+    constexpr int GP = 4;                     // pipelines of the graph mode: the context's stream and the three side streams
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * (want_graph ? GP : npipe));
     if (!ws) return ZK_ERR_OOM;
     uint32_t* slice_counts = ws;
     uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
@@ -1292,7 +1313,181 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // longer than the sort + accumulation of the next column.
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
     if (!ctx->stream2c) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2c, hipStreamNonBlocking));
-    if (npipe == 2 && !ctx->ev_pipe) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe, hipEventDisableTiming));
+    if (!ctx->ev_pipe) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe, hipEventDisableTiming));
+    if (want_graph) {
+        // ---- graph mode: GP linear pipelines, column it on pipeline it % GP (stream, sort workspace and bucket buffer of its own;
+        // the reduction runs on the same stream: one launch, short chain), one hipGraphLaunch per column.
+        hipStream_t P[GP] = {ctx->stream, ctx->stream2, ctx->stream2b, ctx->stream2c};
+        char* bk[GP] = {bkbuf[0], bkbuf[1], bkbuf[2], (char*)ctx->get_scratch(SC_MSM_BUCKETS4, sizeof(G1Xyzz29) * npts29)};
+        char* desc = (char*)ctx->get_scratch(SC_MSM_DESC, sizeof(MsmCol) * count + 256);
+        if (!bk[3] || !desc) return ZK_ERR_OOM;
+        uint32_t* ctr_dev = (uint32_t*)desc;                                  // GP counters, then the table
+        MsmCol* cols_dev = (MsmCol*)(desc + 256);
+        {
+            std::vector<MsmCol> hcols(count);
+            for (size_t i = 0; i < count; ++i) hcols[i] = MsmCol{d_scalar_ptrs[i], wsum_all + i};
+            const uint32_t hctr[GP] = {0, 1, 2, 3};
+            ZK_HIP(ctx, hipMemcpyAsync(cols_dev, hcols.data(), sizeof(MsmCol) * count, hipMemcpyHostToDevice, P[0]));
+            ZK_HIP(ctx, hipMemcpyAsync(ctr_dev, hctr, sizeof(hctr), hipMemcpyHostToDevice, P[0]));
+            ZK_HIP(ctx, hipStreamSynchronize(P[0]));                          // the host copies live on this stack frame
+        }
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, P[0]));
+        for (int p = 1; p < GP; ++p) ZK_HIP(ctx, hipStreamWaitEvent(P[p], ctx->ev_pipe, 0));
+        struct StreamRestoreG { zk_ctx* c; hipStream_t s; ~StreamRestoreG() { c->stream = s; } } restore_g{ctx, ctx->stream};
+        // the launch sequence of one column of `kind` on pipeline p, enqueued on ctx->stream (being captured)
+        auto enqueue = [&](int kind, int p) -> int {
+            hipStream_t st = ctx->stream;
+            uint32_t* wsb = ws + (size_t)p * words;
+            G1Xyzz29* buckets = (G1Xyzz29*)bk[p];
+            const uint32_t* ctr = ctr_dev + p;
+            if (kind == 0) {           // per-window path over the narrow table
+                uint32_t* slice_countsN = wsb;
+                uint32_t* slice_offN = slice_countsN + (size_t)nbN * MSM_SLICES;
+                uint32_t* countsN = slice_offN + (size_t)nbN * MSM_SLICES + 4;
+                uint32_t* size_histN = countsN + nbN;
+                uint32_t* nmultiN = size_histN + SIZE_BINS;
+                uint32_t* wflag = nmultiN + 4;
+                uint32_t* offsetsN = wflag + 64;
+                uint32_t* orderN = offsetsN + nbN + 1;
+                uint32_t* ntasksN = orderN + nbN;
+                uint32_t* toffN = ntasksN + nbN;
+                uint32_t* block_totN = toffN + nbN + 1;
+                uint32_t* block_tot2N = block_totN + scan_blocks_sN;
+                uint32_t* idxN = block_tot2N + scan_blocks_N;
+                uint16_t* dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
+                G1Xyzz29* partialN = buckets + nbN;
+                G1Xyzz29* task_partialN = partialN + red_blocks_N;
+                G1Xyzz29* folded = task_partialN + max_tasks_N;
+                const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
+                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, st));
+                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, (const Fr*)nullptr, (uint64_t)n, n_pad, dig, wflag, cols_dev, ctr);
+                hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_totN, scan_blocks_sN, slice_offN, nbN * MSM_SLICES, offsetsN + nbN);
+                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)slice_countsN, nbN, slice_offN, (const uint32_t*)block_totN, offsetsN, countsN, size_histN);
+                hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, size_histN, (const uint32_t*)(offsetsN + nbN));
+                hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)countsN, nbN, size_histN, orderN, ntasksN);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)ntasksN, nbN, toffN, block_tot2N);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot2N, scan_blocks_N, toffN, nbN, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, nbN, toffN, (const uint32_t*)block_tot2N);
+                hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)slice_offN, idxN, (const uint32_t*)wflag, (uint32_t)pn.W);
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, st, d_table_n, (const uint32_t*)offsetsN, (const uint32_t*)idxN,
+                                   (const uint32_t*)orderN, (const uint32_t*)toffN, (const uint32_t*)nmultiN, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)toffN, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3((nbN + 255) / 256), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
+                hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
+                // the window flags are still this column's when the fold reads them: the next column of this pipeline comes behind it on the same stream
+                hipLaunchKernelGGL(k_msm_fold_windows, dim3((pn.B + 63) / 64), dim3(256), 0, st, (const G1Xyzz29*)buckets, pn.B, pn.W, folded, (const uint32_t*)wflag);
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, 1), dim3(RED_THREADS), 0, st, (const G1Xyzz29*)folded, pn.B, partialN);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, st, (const G1Xyzz29*)partialN, red_blocks_N, (G1Xyzz*)nullptr, cols_dev, ctr_dev + p, (uint32_t)GP);
+                ZK_CHECK_LAUNCH(ctx);
+                return ZK_OK;
+            }
+            // merged-window path (kind 1: one-launch partition sort, kind 2: sliced sort)
+            uint32_t* slice_counts = wsb;
+            uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
+            uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
+            uint32_t* size_hist = counts + nb;
+            uint32_t* nmulti = size_hist + SIZE_BINS;
+            uint32_t* offsets = nmulti + 4 + 64;
+            uint32_t* order = offsets + nb + 1;
+            uint32_t* ntasks = order + nb;
+            uint32_t* toff = ntasks + nb;
+            uint32_t* block_tot = toff + nb + 1;
+            uint32_t* block_tot2 = block_tot + scan_blocks_s;
+            uint32_t* block_tot3 = block_tot2 + scan_blocks;
+            uint32_t* hist = block_tot3 + scan_blocks_h;
+            uint32_t* hist_off = hist + hist_cnt;
+            uint32_t* idx = hist_off + hist_cnt + 1;
+            uint64_t* entries = reinterpret_cast<uint64_t*>(wsb + ((head_words + 3) & ~(size_t)3));
+            G1Xyzz29* partial = buckets + nb;
+            G1Xyzz29* task_partial = partial + red_pts;
+            const bool bs_it = kind == 1;
+            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, st));
+            launch_partition<false>(pl.c, dim3(nwg), st, (const Fr*)nullptr, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift, cols_dev, ctr);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, hist_cnt, hist_off, (const uint32_t*)block_tot3);
+            if (staged_scatter) PK_TRY_MSM(launch_scatter_staged(ctx, pl.c, pl.W, dim3(nwg), (const Fr*)nullptr, (uint64_t)n, range_bits, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift, cols_dev, ctr));
+            else launch_partition<true>(pl.c, dim3(nwg), st, (const Fr*)nullptr, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift, cols_dev, ctr);
+            if (bs_it) {
+                hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins), dim3(1024), 0, st, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, nb, offsets, counts, size_hist, idx);
+            } else {
+                hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, st, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, st, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
+                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
+                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, st, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
+            }
+            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, size_hist, (const uint32_t*)(offsets + nb));
+            hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, st, (const uint32_t*)counts, nb, size_hist, order, ntasks);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, st, (const uint32_t*)ntasks, nb, toff, block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, st, nb, toff, (const uint32_t*)block_tot2);
+            if (!bs_it) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, st, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
+            hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, d_table, (const uint32_t*)offsets, (const uint32_t*)idx,
+                               (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, 0, (uint64_t)0, (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
+            hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
+                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
+            hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
+                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
+            const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
+            hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, st, (const G1Xyzz29*)buckets, nb, partial);
+            hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, st, (const G1Xyzz29*)partial, rb, (G1Xyzz*)nullptr, cols_dev, ctr_dev + p, (uint32_t)GP);
+            ZK_CHECK_LAUNCH(ctx);
+            return ZK_OK;
+        };
+        if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
+        bool fallback = false;
+        for (size_t it = 0; it < count && !fallback; ++it) {
+            const int p = (int)(it % GP);
+            const int kind = (any_narrow && narrow[it] == 1) ? 0 : ((binsort && !(narrow && narrow[it] == 2)) ? 1 : 2);
+            ctx->stream = P[p];
+            // a graph is tied to every address baked into its kernel arguments
+            uint64_t key = 1469598103934665603ull;
+            for (uint64_t v : {(uint64_t)kind, (uint64_t)p, (uint64_t)n, (uint64_t)pl.c, (uint64_t)pn.c, (uint64_t)(uintptr_t)d_table, (uint64_t)(uintptr_t)d_table_n, (uint64_t)tab_stride,
+                               (uint64_t)(uintptr_t)ws, (uint64_t)words, (uint64_t)(uintptr_t)bk[p], (uint64_t)(uintptr_t)desc, (uint64_t)staged_scatter, (uint64_t)range_bits})
+                key = (key ^ v) * 1099511628211ull;
+            hipGraphExec_t exec = nullptr;
+            auto found = ctx->msm_graphs.find(key);
+            if (found != ctx->msm_graphs.end()) exec = (hipGraphExec_t)found->second;
+            else {
+                hipGraph_t graph = nullptr;
+                bool ok = hipStreamBeginCapture(P[p], hipStreamCaptureModeRelaxed) == hipSuccess;
+                int rc_e = ok ? enqueue(kind, p) : ZK_ERR_HIP;
+                if (ok) ok = hipStreamEndCapture(P[p], &graph) == hipSuccess && graph != nullptr;
+                ok = ok && rc_e == ZK_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (!ok) { (void)hipGetLastError(); ctx->msm_graph_broken = true; fallback = true; break; }
+                ctx->msm_graphs[key] = (void*)exec;
+            }
+            if (hipGraphLaunch(exec, P[p]) != hipSuccess) { (void)hipGetLastError(); ctx->msm_graph_broken = true; fallback = true; break; }
+            if (stage && it + 1 < count) { ctx->stream = P[(it + 1) % GP]; int rc = stage(stage_user, it + 1); if (rc) return rc; }
+        }
+        ctx->stream = P[0];
+        for (int p = 1; p < GP; ++p) {
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[p - 1], P[p]));
+            ZK_HIP(ctx, hipStreamWaitEvent(P[0], ctx->ev_p2[p - 1], 0));
+        }
+        if (!fallback) {
+            std::vector<G1Xyzz> hw(count);
+            ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
+            const auto t_enq = std::chrono::steady_clock::now();
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (getenv("ZK_MSM_TRACE")) {
+                const auto t_done = std::chrono::steady_clock::now();
+                fprintf(stderr, "[zk msm] batch of %zu x 2^%.0f (graph replay): host enqueue %.3f ms, device drained %.3f ms later\n", count, log2((double)n),
+                        std::chrono::duration<double, std::milli>(t_enq - t_batch0).count(), std::chrono::duration<double, std::milli>(t_done - t_enq).count());
+            }
+            for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+            return ZK_OK;
+        }
+        // capture or replay failed: drain what was launched and take the plain path below for the whole batch
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (stage) return ctx->fail(ZK_ERR_HIP, "MSM graph replay failed in a staged batch");       // uploads already consumed: cannot restart transparently
+    }
     hipStream_t mains[2] = {ctx->stream, npipe == 2 ? ctx->stream2c : ctx->stream};
     struct StreamRestore { zk_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, ctx->stream};     // error returns included
     if (npipe == 2) {           // the second pipeline starts behind everything already enqueued on the context's stream
