@@ -1484,9 +1484,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
             return ZK_OK;
         }
-        // capture or replay failed: drain what was launched and take the plain path below for the whole batch
+        // capture or replay failed: drain what was launched and take the plain path below for the whole batch (a staging
+        // callback is simply asked again: uploading a column twice and redoing its transform are idempotent)
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (stage) return ctx->fail(ZK_ERR_HIP, "MSM graph replay failed in a staged batch");       // uploads already consumed: cannot restart transparently
     }
     hipStream_t mains[2] = {ctx->stream, npipe == 2 ? ctx->stream2c : ctx->stream};
     struct StreamRestore { zk_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, ctx->stream};     // error returns included
