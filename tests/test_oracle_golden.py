@@ -63,7 +63,7 @@ def test_field_constants():
     assert b.FR_INV64 == 0xC2E1F593EFFFFFFF and b.FQ_INV64 == 0x87D20782E4866389
     assert b.FQ_MONT_R == 0x0E0A77C19A07DF2F666EA36F7879462C0A78EB28F5C70B3DD35D438DC58F0D9D
     assert (R * b.FR_INV64 + 1) % (1 << 64) == 0 and (P * b.FQ_INV64 + 1) % (1 << 64) == 0
-    # 29-bit radix constants used by ff29.cuh
+    # 29-bit radix constants used by ff29.hip.hpp
     assert (-pow(P, -1, 1 << 29)) % (1 << 29) == 0x4866389 and (-pow(R, -1, 1 << 29)) % (1 << 29) == 0xFFFFFFF
 
 

@@ -2,7 +2,7 @@
 
 `zk_host_quotient_lower` returns the instruction stream the kernel runs for a caller's postfix program.  This test
 executes that stream the way the kernel does -- nine 29-bit limbs in 32-bit words, 64-bit column sums, unsettled sums --
-with every precondition of ff29.cuh asserted (no 32-bit limb overflow, no 64-bit column overflow, no borrow out of a
+with every precondition of ff29.hip.hpp asserted (no 32-bit limb overflow, no 64-bit column overflow, no borrow out of a
 top limb that a product would read, settle only below 4p, ...), and compares the canonical result with plain big-int
 evaluation of the ORIGINAL program.  Columns hold adversarial values (0, 1, p - 1, random), so the static bounds the
 lowering derives are exercised at their edges.  No GPU involved: the kernel's arithmetic itself is covered by the
@@ -27,7 +27,7 @@ R = 1 << 256
 K_ADD_COL, K_SUB_COL, K_RSUB_COL, K_MUL_COL, K_FOLD_COL, K_NOP = 16, 17, 18, 19, 20, 21
 
 
-# ---- limb-level model of ff29.cuh ------------------------------------------------------------------
+# ---- limb-level model of ff29.hip.hpp ------------------------------------------------------------------
 def val(l):
     return sum(x << (29 * i) for i, x in enumerate(l))
 

@@ -7,8 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../zkevm-circuits_amd/csrc/ff.cuh"
-#include "../zkevm-circuits_amd/csrc/ff29.cuh"
+#include "../zkevm-circuits_amd/csrc/ff.hip.hpp"
+#include "../zkevm-circuits_amd/csrc/ff29.hip.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 

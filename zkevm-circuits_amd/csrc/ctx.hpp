@@ -11,8 +11,8 @@
 #include <vector>
 
 #include "../../include/zkmi355.h"
-#include "ec.cuh"
-#include "ff.cuh"
+#include "ec.hip.hpp"
+#include "ff.hip.hpp"
 
 namespace zk {
 

@@ -8,7 +8,7 @@
 // no inversion and the representation never needs a Z on its own.  Results leave the device as
 // XYZZ and are normalised to affine (the only form the transcript sees) on the host.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.hpp"
 
 namespace zk {
 

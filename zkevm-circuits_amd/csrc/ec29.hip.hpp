@@ -1,5 +1,5 @@
-// BN254 G1 group law on 9 x 29-bit limbs (ff29.cuh), used by the MSM inner loops.
-// Same formulas as ec.cuh (XYZZ: madd-2008-s / add-2008-s / dbl-2008-s-1, a = 0); coordinates are
+// BN254 G1 group law on 9 x 29-bit limbs (ff29.hip.hpp), used by the MSM inner loops.
+// Same formulas as ec.hip.hpp (XYZZ: madd-2008-s / add-2008-s / dbl-2008-s-1, a = 0); coordinates are
 // held in R' = 2^261 Montgomery form, lazily reduced:
 //
 //   stored invariant:  every limb 0..7 < 2^29 ("normalised"); x, y < 8p;  zz, zzz < 2p
@@ -9,8 +9,8 @@
 // Bound bookkeeping uses mul29's guarantee  out < a*b/2^261 + p  (p/2^261 < 0.006), so any
 // product of values below ~16p comes out below 2.6p, and sub29k<K> needs its subtrahend < K*p.
 #pragma once
-#include "ec.cuh"
-#include "ff29.cuh"
+#include "ec.hip.hpp"
+#include "ff29.hip.hpp"
 
 namespace zk {
 

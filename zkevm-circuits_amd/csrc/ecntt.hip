@@ -5,12 +5,12 @@
 //      g_lagrange[i] = (1/n) * sum_j omega^(-i j) * g[j]        (an inverse FFT over G1)
 //
 // so that commit_lagrange(evaluations) = commit(coefficients).  Radix-2 DIT over XYZZ points in
-// HBM (144 B each, ec29.cuh arithmetic): log2(n) stages of n/2 butterflies, each one scalar
+// HBM (144 B each, ec29.hip.hpp arithmetic): log2(n) stages of n/2 butterflies, each one scalar
 // multiplication by a 254-bit twiddle (double-and-add, ~4000 Montgomery products) and two point
 // additions.  A one-off per SRS size: 2^20 points take about half a second; the reference's CPU
 // version is the slow part of `downsize`.
 #include "ctx.hpp"
-#include "ec29.cuh"
+#include "ec29.hip.hpp"
 
 namespace zk {
 

@@ -19,7 +19,7 @@
 //     = X*W*2^256, so constants that multiply data (twiddles, SRS bases held by us) are stored
 //     in R' form and data needs no conversion.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.hpp"
 
 namespace zk {
 

@@ -6,7 +6,7 @@
 #include <cstdint>
 #include <cstring>
 
-#include "ec.cuh"
+#include "ec.hip.hpp"
 
 namespace zk {
 namespace host {

@@ -32,7 +32,7 @@
 #include <cmath>
 
 #include "ctx.hpp"
-#include "ec29.cuh"
+#include "ec29.hip.hpp"
 #include "host_fq.hpp"
 
 namespace zk {

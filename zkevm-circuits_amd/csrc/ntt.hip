@@ -10,13 +10,13 @@
 // back.  Input index is read big-endian in the digits, output little-endian; the last pass writes
 // to the digit-reversed position, so no separate transpose / bit-reversal kernel exists.
 //
-// Arithmetic: inside a pass elements live in LDS as nine 29-bit limbs (ff29.cuh; one u32 plane
+// Arithmetic: inside a pass elements live in LDS as nine 29-bit limbs (ff29.hip.hpp; one u32 plane
 // per limb, so a wave's accesses are 4-byte strided and bank-conflict-free on contiguous runs).
 // Butterflies use the carry-free 29-bit Montgomery product with twiddles held in R' = 2^261 form,
 // so data stays in halo2curves' R = 2^256 form with no conversion; sums are kept lazily reduced
 // and only the value written back to HBM is brought to the canonical representative.
 #include "ctx.hpp"
-#include "ff29.cuh"
+#include "ff29.hip.hpp"
 
 namespace zk {
 

@@ -23,7 +23,7 @@
 // HBM side: 32 B per (column, rotation) read + 32 B written per row -- the streaming-bound member
 // of the path.
 //
-// Arithmetic: the stack machine computes on nine 29-bit limbs (ff29.cuh) -- the carry-free
+// Arithmetic: the stack machine computes on nine 29-bit limbs (ff29.hip.hpp) -- the carry-free
 // Montgomery product runs 1.6x faster than the 8 x 32 CIOS one.  Stack values stay in halo2curves'
 // R = 2^256 Montgomery form.  mul29 divides by R' = 2^261, so a product of two R-form values
 // multiplies one operand by 32 first (a 5-bit limb shift, folded into the unpacking of a memory
@@ -54,7 +54,7 @@
 //   FOLD           acc = mul29(acc, y) + t: acc is only ever the first operand of a product by a
 //                  constant, so it is never settled: L_t <= 3
 #include "ctx.hpp"
-#include "ff29.cuh"
+#include "ff29.hip.hpp"
 
 namespace zk {
 

@@ -6,7 +6,7 @@
 // All kernels read/write 32-byte elements as two 16-byte transactions per lane, consecutive
 // lanes on consecutive elements (fully coalesced), grid-stride where a fixed grid is needed.
 #include "ctx.hpp"
-#include "ff29.cuh"
+#include "ff29.hip.hpp"
 
 namespace zk {
 
