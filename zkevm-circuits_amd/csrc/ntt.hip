@@ -551,7 +551,12 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
         NttIo cur_io = io_in;                                  // .src = where the next pass reads
         for (int p = 0; p + 1 < P; ++p) {
             const NttPass& ps = dom->pass[p];
-            int log_t = 12 - ps.log_np;
+            // tile of the strided passes: 4096 elements (T = 4: 128-byte runs) when there are two passes; with three passes
+            // 2048 elements measured 8-10 % faster (two workgroups per CU: one loads while the other computes)
+            int log_tile_pass = P == 3 ? 11 : 12;
+            if (const char* e = getenv("ZK_NTT_PASS_LOGTILE")) { const int v = atoi(e); if (v >= 10 && v <= 12) log_tile_pass = v; }    // measurement knob
+            int log_t = log_tile_pass - ps.log_np;
+            if (log_t < 0) log_t = 0;
             if (log_t > ps.log_m) log_t = ps.log_m;
             const int tile = 1 << (ps.log_np + log_t);
             NttIo io{};
@@ -571,7 +576,12 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             const NttPass& ps = dom->pass[P - 1];
             const int log_n1 = P == 1 ? 0 : dom->pass[0].log_np;
             const int log_mid = P == 3 ? dom->pass[1].log_np : 0;
-            int log_t = 12 - ps.log_np;
+            // the last pass reads whole rows: a 2048-element tile (two rows of 2^10, 72 KiB of LDS) lets two workgroups share a CU
+            // and overlap their load / compute / store phases: -4 % at 2^20, -5 % at 2^22
+            int log_tile_last = 11;
+            if (const char* e = getenv("ZK_NTT_LAST_LOGTILE")) { const int v = atoi(e); if (v >= 10 && v <= 12) log_tile_last = v; }    // measurement knob
+            int log_t = log_tile_last - ps.log_np;
+            if (log_t < 0) log_t = 0;
             if (log_t > log_n1) log_t = log_n1;
             const int tile = 1 << (ps.log_np + log_t);
             const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
