@@ -294,10 +294,11 @@ where
         drop(witness);
         let values: Vec<Vec<Fr>> = batch_invert_assigned_vecs(picked); // rational -> field, as upstream
         let ptrs: Vec<*const c_void> = values.iter().map(|c| c.as_ptr() as *const c_void).collect();
-        // Page-lock the witness for the upload (operational notes: 0.60 ms per 32 MiB column against 1.1 ms from
-        // pageable memory).  Registration pins pages and is not free either: ZKMI355_PIN_WITNESS=0 skips it, and a prover that
-        // synthesises into a `zk_host_alloc` arena needs neither.
-        let pin = std::env::var("ZKMI355_PIN_WITNESS").map(|v| v != "0").unwrap_or(true);
+        // Page-locked witness memory uploads at 0.60 ms per 32 MiB column, pageable memory at 0.80 ms (tools/h2d_rate.py) -- but
+        // registering a column costs 0.66 ms by itself, so pinning right here only pays when it happens off the critical path.
+        // Off by default (ZKMI355_PIN_WITNESS=1 turns it on); the real fix is a synthesis that writes into a `zk_host_alloc` arena
+        // kept across proofs.
+        let pin = std::env::var("ZKMI355_PIN_WITNESS").map(|v| v == "1").unwrap_or(false);
         let mut pinned: Vec<*mut c_void> = Vec::new();
         if pin {
             for c in &values {

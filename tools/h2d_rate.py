@@ -27,3 +27,27 @@ for name, tail, chunks in (("32 MiB copies", 0, 1), ("32 MiB + 192 B tail", 192,
     run(tail, chunks)
     gbs, ms = run(tail, chunks)
     print(f"{name:24s}: {gbs:6.1f} GB/s, {ms:.3f} ms per column")
+
+# a witness column that lives in ordinary (pageable) memory: upload as it is, or page-lock it first (hipHostRegister) and upload
+import numpy as np
+cols_np = [np.random.default_rng(i).integers(0, 1 << 62, size=N // 8, dtype=np.uint64) for i in range(8)]
+ck(hip.hipStreamSynchronize(s))
+t0 = time.perf_counter()
+for c, a in enumerate(cols_np):
+    ck(hip.hipMemcpyAsync(ctypes.c_void_p(d.value + c * N), ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(N), 1, s))
+ck(hip.hipStreamSynchronize(s))
+t_page = (time.perf_counter() - t0) / len(cols_np)
+t0 = time.perf_counter()
+for a in cols_np:
+    ck(hip.hipHostRegister(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(N), 0))
+t_reg = (time.perf_counter() - t0) / len(cols_np)
+t0 = time.perf_counter()
+for c, a in enumerate(cols_np):
+    ck(hip.hipMemcpyAsync(ctypes.c_void_p(d.value + c * N), ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(N), 1, s))
+ck(hip.hipStreamSynchronize(s))
+t_pin = (time.perf_counter() - t0) / len(cols_np)
+t0 = time.perf_counter()
+for a in cols_np:
+    ck(hip.hipHostUnregister(ctypes.c_void_p(a.ctypes.data)))
+t_unreg = (time.perf_counter() - t0) / len(cols_np)
+print(f"pageable column: {t_page * 1e3:.3f} ms upload; register {t_reg * 1e3:.3f} ms + upload {t_pin * 1e3:.3f} ms + unregister {t_unreg * 1e3:.3f} ms")
