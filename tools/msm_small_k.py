@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zkevm_circuits_amd as z
 from zkevm_circuits_amd import plonk
-from oracle import cref
+import bench_proof as bp
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 n = 1 << k
@@ -15,8 +15,7 @@ rng = np.random.default_rng(3)
 def dense_col():
     a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1); return a
 def small_col(bits, blind):
-    canon = np.zeros((n, 4), dtype=np.uint64); canon[:, 0] = rng.integers(0, 1 << bits, size=n, dtype=np.uint64)
-    m = cref.fe_binop("mul", 0, canon, np.broadcast_to(cref.to_mont([pow(2, 256, cref.R_MOD if hasattr(cref, "R_MOD") else 21888242871839275222246405745257275088548364400416034343698204186575808495617)])[0], (n, 4)).copy())
+    m = bp.to_mont_gpu(ctx, bp.small_to_limbs(rng.integers(0, 1 << bits, size=n, dtype=np.uint64)))     # Montgomery images, converted on the device
     if blind:
         m[n - blind:] = dense_col()[:blind]
     return m
