@@ -33,12 +33,14 @@ struct zk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
     // scratch arenas, grown on demand (never shrunk): index = purpose
-    zk::Scratch scratch[16];
+    zk::Scratch scratch[17];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
     hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
     std::vector<hipStream_t> owned_streams;      // every stream zk_ctx_create made (roles may share one; 'd' entries of the layout have no role at all)
     hipEvent_t ev_p1[3] = {nullptr, nullptr, nullptr}, ev_p2[3] = {nullptr, nullptr, nullptr};
     std::map<uint64_t, void*> msm_graphs;   // hipGraphExec_t per (column kind, pipeline, sizes, buffer addresses): msm_batch_merged's graph mode
+    uint32_t msm_blinded_tail = 0;          // set by the prover around a commit batch: this many rows at the end of the hint-1 (small-valued) columns
+                                            // hold field-sized blinding values; they are committed apart (k_msm_tails) so that the main MSM sees small values only
     bool msm_graph_broken = false;          // a capture or replay failed once: the plain launch path from then on
     hipEvent_t ev_pipe = nullptr;        // joins the second MSM pipeline of small batches (msm_batch_merged)
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
@@ -183,7 +185,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14, SC_MSM_TAILS = 15 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);

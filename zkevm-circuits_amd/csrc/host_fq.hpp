@@ -124,5 +124,11 @@ inline void msm_tail(const G1Xyzz* wsum, int W, int c, G1Affine* out) {
     pto_affine(acc, out);
 }
 
+// sum of two XYZZ points (canonical R form) as an affine point: the main part of a column's MSM and the part of its blinded tail
+inline void msm_tail2(const G1Xyzz* a, const G1Xyzz* b, G1Affine* out) {
+    PXyzz acc = padd(*reinterpret_cast<const PXyzz*>(a), *reinterpret_cast<const PXyzz*>(b));
+    pto_affine(acc, out);
+}
+
 }  // namespace host
 }  // namespace zk

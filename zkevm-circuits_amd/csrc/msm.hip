@@ -1152,6 +1152,46 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     return ZK_OK;
 }
 #define PK_TRY_MSM(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+// Blinded tails.  A witness column of small values ends in a few rows of field-sized blinding values (halo2: the last
+// blinding_factors + 1 rows); inside the main MSM they would put a handful of entries into EVERY window and undo what the
+// per-window path gains by skipping empty ones (2^18 bit columns: 0.34 instead of 0.21 ms).  They are committed here instead:
+// one workgroup per column, lane (r, w) lifts the unsigned c-bit digit w of tail scalar r over the merged plan's table entry
+// 2^(c w) P_{n_main + r} by double-and-add, the workgroup sums its lanes.  flags[col] != 1: identity.
+__global__ void __launch_bounds__(1024) k_msm_tails(const Fr* const* __restrict__ scalar_ptrs, const uint8_t* __restrict__ flags, uint64_t n_main, uint32_t tail,
+                                                    const G1Affine* __restrict__ table, uint64_t tab_stride, int c, int W, int top_shift, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz29 wsum[16];
+    const uint32_t col = blockIdx.x;
+    G1Xyzz29 acc = identity29();
+    if (flags[col] == 1) {
+        const Fr* scalars = scalar_ptrs[col];
+        for (uint32_t pair = threadIdx.x; pair < tail * (uint32_t)W; pair += blockDim.x) {
+            const uint32_t r = pair / (uint32_t)W, w = pair % (uint32_t)W;
+            const Fr sc = from_mont(ldg(scalars + n_main + r));
+            const int bit = (int)w * c, limb = bit >> 5, sh = bit & 31;
+            uint64_t d = limb < 8 ? ((uint64_t)sc.l[limb] >> sh) : 0ull;
+            if (limb + 1 < 8) d |= (uint64_t)sc.l[limb + 1] << (32 - sh);
+            d &= (1ull << c) - 1;
+            int bits = c;
+            if ((int)w == W - 1) { d <<= top_shift; bits = c + top_shift; }      // the table entry of the top window is 2^top_shift short (MsmPlan::top_shift)
+            if (d == 0) continue;
+            const G1Affine29 base = load_affine29(table + (uint64_t)w * tab_stride + n_main + r);
+            G1Xyzz29 t = identity29();
+            for (int b = bits - 1; b >= 0; --b) {
+                t = dbl29pt(t);
+                if ((d >> b) & 1) t = madd29(t, base);
+            }
+            acc = add29pt(acc, t);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc = add29pt(acc, shfl_down_pt(acc, off));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G1Xyzz29 s = wsum[0];
+        for (uint32_t i = 1; i < blockDim.x / 64; ++i) s = add29pt(s, wsum[i]);
+        stg(out + col, to_std_xyzz(s));
+    }
+}
 // ---- merged-window MSM over an SRS window table ----------------------------------------------------
 static MsmPlan make_plan_merged(uint32_t k_srs) {
     int c = (int)k_srs;
@@ -1214,6 +1254,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const auto t_batch0 = std::chrono::steady_clock::now();
     bool any_narrow = false;
     if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] == 1;
+    // blinded tails of the hint-1 columns (zk_ctx::msm_blinded_tail): committed by k_msm_tails, the main MSM stops in front of them
+    const uint32_t tail_rows = (any_narrow && ctx->msm_blinded_tail && (size_t)ctx->msm_blinded_tail + 1024 <= n && ctx->msm_blinded_tail <= 256) ? ctx->msm_blinded_tail : 0u;
+    const uint64_t n_narrow = (uint64_t)n - tail_rows;
     // ---- per-window ("narrow") path: sizes and workspace, as in msm_batch_tab with a window table
     const MsmPlan pn = any_narrow ? *pl_n : MsmPlan{4, 64, 8};
     const uint32_t nbN = (uint32_t)pn.W * pn.B;
@@ -1314,6 +1357,21 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     if (!ctx->stream2b) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2b, hipStreamNonBlocking));
     if (!ctx->stream2c) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2c, hipStreamNonBlocking));
     if (!ctx->ev_pipe) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe, hipEventDisableTiming));
+    // enqueues the tails kernel on the context's stream (all columns are on the device by then) and returns where its results land
+    G1Xyzz* tails_dev = nullptr;
+    auto enqueue_tails = [&]() -> int {
+        if (!tail_rows) return ZK_OK;
+        const size_t off_flags = (sizeof(void*) * count + 255) & ~(size_t)255, off_out = (off_flags + count + 255) & ~(size_t)255;
+        char* tb = (char*)ctx->get_scratch(SC_MSM_TAILS, off_out + sizeof(G1Xyzz) * count);
+        if (!tb) return ZK_ERR_OOM;
+        ZK_HIP(ctx, hipMemcpyAsync(tb, d_scalar_ptrs, sizeof(void*) * count, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(ctx, hipMemcpyAsync(tb + off_flags, narrow, count, hipMemcpyHostToDevice, ctx->stream));
+        tails_dev = (G1Xyzz*)(tb + off_out);
+        hipLaunchKernelGGL(k_msm_tails, dim3((unsigned)count), dim3(1024), 0, ctx->stream, (const Fr* const*)tb, (const uint8_t*)(tb + off_flags), n_narrow, tail_rows,
+                           d_table, (uint64_t)tab_stride, pl.c, pl.W, pl.top_shift, tails_dev);
+        ZK_CHECK_LAUNCH(ctx);
+        return ZK_OK;
+    };
     if (want_graph) {
         // ---- graph mode: GP linear pipelines, column it on pipeline it % GP (stream, sort workspace and bucket buffer of its own;
         // the reduction runs on the same stream: one launch, short chain), one hipGraphLaunch per column.
@@ -1360,7 +1418,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 G1Xyzz29* folded = task_partialN + max_tasks_N;
                 const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
                 ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, st));
-                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, (const Fr*)nullptr, (uint64_t)n, n_pad, dig, wflag, cols_dev, ctr);
+                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, (const Fr*)nullptr, n_narrow, n_pad, dig, wflag, cols_dev, ctr);
                 hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
                 hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
                 hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_totN, scan_blocks_sN, slice_offN, nbN * MSM_SLICES, offsetsN + nbN);
@@ -1448,7 +1506,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             // a graph is tied to every address baked into its kernel arguments
             uint64_t key = 1469598103934665603ull;
             for (uint64_t v : {(uint64_t)kind, (uint64_t)p, (uint64_t)n, (uint64_t)pl.c, (uint64_t)pn.c, (uint64_t)(uintptr_t)d_table, (uint64_t)(uintptr_t)d_table_n, (uint64_t)tab_stride,
-                               (uint64_t)(uintptr_t)ws, (uint64_t)words, (uint64_t)(uintptr_t)bk[p], (uint64_t)(uintptr_t)desc, (uint64_t)staged_scatter, (uint64_t)range_bits})
+                               (uint64_t)(uintptr_t)ws, (uint64_t)words, (uint64_t)(uintptr_t)bk[p], (uint64_t)(uintptr_t)desc, (uint64_t)staged_scatter, (uint64_t)range_bits, n_narrow})
                 key = (key ^ v) * 1099511628211ull;
             hipGraphExec_t exec = nullptr;
             auto found = ctx->msm_graphs.find(key);
@@ -1472,7 +1530,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_HIP(ctx, hipStreamWaitEvent(P[0], ctx->ev_p2[p - 1], 0));
         }
         if (!fallback) {
-            std::vector<G1Xyzz> hw(count);
+            PK_TRY_MSM(enqueue_tails());
+            std::vector<G1Xyzz> hw(count), ht(tail_rows ? count : 0);
+            if (tail_rows) ZK_HIP(ctx, hipMemcpyAsync(ht.data(), tails_dev, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
             ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
             const auto t_enq = std::chrono::steady_clock::now();
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1481,7 +1541,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 fprintf(stderr, "[zk msm] batch of %zu x 2^%.0f (graph replay): host enqueue %.3f ms, device drained %.3f ms later\n", count, log2((double)n),
                         std::chrono::duration<double, std::milli>(t_enq - t_batch0).count(), std::chrono::duration<double, std::milli>(t_done - t_enq).count());
             }
-            for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+            for (size_t it = 0; it < count; ++it) {
+                if (tail_rows && narrow[it] == 1) host::msm_tail2(hw.data() + it, ht.data() + it, h_out + it);
+                else host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+            }
             return ZK_OK;
         }
         // capture or replay failed: drain what was launched and take the plain path below for the whole batch (a staging
@@ -1552,7 +1615,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             {
                 ZkProfScope ps(ctx, "msm_sort");
                 ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
-                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
+                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, n_narrow, n_pad, dig, wflag);
                 hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
                 ZK_CHECK_LAUNCH(ctx);
                 hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
@@ -1675,7 +1738,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
     if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
     if (count > 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[2], 0));
-    std::vector<G1Xyzz> hw(count);
+    PK_TRY_MSM(enqueue_tails());
+    std::vector<G1Xyzz> hw(count), ht(tail_rows ? count : 0);
+    if (tail_rows) ZK_HIP(ctx, hipMemcpyAsync(ht.data(), tails_dev, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipMemcpyAsync(hw.data(), wsum_all, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
     const auto t_enq = std::chrono::steady_clock::now();
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1684,7 +1749,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         fprintf(stderr, "[zk msm] batch of %zu x 2^%.0f: host enqueue %.3f ms, device drained %.3f ms later\n", count, log2((double)n),
                 std::chrono::duration<double, std::milli>(t_enq - t_batch0).count(), std::chrono::duration<double, std::milli>(t_done - t_enq).count());
     }
-    for (size_t it = 0; it < count; ++it) host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+    for (size_t it = 0; it < count; ++it) {
+        if (tail_rows && narrow[it] == 1) host::msm_tail2(hw.data() + it, ht.data() + it, h_out + it);
+        else host::msm_tail(hw.data() + it, 1, pl.c, h_out + it);
+    }
     return ZK_OK;
 }
 // Per-window table of an SRS basis (plan make_plan(2^k): c = k - 4 <= 16), for the columns that fill

@@ -814,6 +814,9 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     std::vector<G1Affine> coms(sg.dst.size());
     std::vector<uint8_t> narrow(sg.src.size());
     sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of small values take the per-window MSM path
+    // ... and their blinding rows (the last blinding_factors + 1, field-sized) are committed apart, so that they do not occupy every window
+    struct TailGuard { zk_ctx* c; ~TailGuard() { c->msm_blinded_tail = 0; } } tail_guard{ctx};
+    ctx->msm_blinded_tail = pk->bf + 1;
     if (sg.world == 1) {
         PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg, narrow.data()));
     } else {
