@@ -241,6 +241,9 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_scalars, const void* h_bases, size
  * 13 windows at k = 20); without them (tables beyond ZK_MSM_TABLE_GB, default 32 GiB per basis)
  * one bucket set per window (c <= 16).                                                            */
 int zk_msm_plan(const zk_srs* srs, size_t n, int* window_bits, int* windows);
+/* Host only: the merged-window plan for an SRS of 2^k points, with the shift applied to the top window's digit (the top window
+ * holds only the leading bits of a scalar; its digit is scaled so that its entries spread over the bucket range). */
+int zk_host_msm_plan(uint32_t k, int* window_bits, int* windows, int* top_shift);
 
 /* Host-only: out = sum of n affine points (no context, no device).  Used to finish a point-sharded
  * MSM: each rank's 64-byte partial result is all-gathered as bytes (RCCL has no EC reduce op) and

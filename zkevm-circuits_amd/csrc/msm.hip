@@ -1855,6 +1855,18 @@ int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out
 
 }  // namespace zk
 
+// Host only: the merged-window plan of an SRS of 2^k points -- window bits, windows, and the shift the top window's digit is
+// scaled by (MsmPlan::top_shift).  For the CPU tests, which check the invariant the recoding relies on: the scaled top digit of
+// every canonical scalar, carry included, stays at or below 2^(c-1).
+extern "C" int zk_host_msm_plan(uint32_t k, int* window_bits, int* windows, int* top_shift) {
+    if (!window_bits || !windows || !top_shift || k > 28) return ZK_ERR_INVALID_ARG;
+    const zk::MsmPlan m = zk::make_plan_merged(k);
+    *window_bits = m.c;
+    *windows = m.W;
+    *top_shift = m.top_shift;
+    return ZK_OK;
+}
+
 // window size / window count the commitments over this SRS use for an MSM of n points (introspection for benches)
 extern "C" int zk_msm_plan(const zk_srs* srs, size_t n, int* window_bits, int* windows) {
     if (!srs || !window_bits || !windows) return ZK_ERR_INVALID_ARG;
