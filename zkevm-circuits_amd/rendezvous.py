@@ -39,6 +39,10 @@ def comm_init_from_env(ctx, timeout: float = 120.0):
     rank, so a file left behind by an earlier launch on the same port cannot be mistaken for this one's).  No torch in
     the process: a prover rank holds the library and nothing else."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+        # one node, rendezvous over loopback: RCCL's bootstrap must not go looking for another interface (the containers this runs
+        # in may have none, or one that does not route between the ranks)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     path = os.environ.get("ZK_COMM_ID_FILE") or os.path.join(
         os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}")
     uid = exchange_unique_id(ctx.comm_unique_id, rank, world, path, timeout)
