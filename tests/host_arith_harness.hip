@@ -1,0 +1,73 @@
+// Test harness: the device field / curve arithmetic of csrc/ff29.hip.hpp and csrc/ec29.hip.hpp compiled for the HOST
+// (hipcc --cuda-host-only; every function in those headers that the kernels' inner loops use is __host__ __device__),
+// so that tests/test_host_arith.py can check it limb by limb against big-int arithmetic without a GPU.  Not part of the
+// product library.
+#include <cstdint>
+#include <cstring>
+
+#include "../zkevm-circuits_amd/csrc/ec29.hip.hpp"
+
+using namespace zk;
+
+namespace {
+template <class P>
+F29<P> ld(const uint32_t* p) { F29<P> r; for (int i = 0; i < 9; ++i) r.l[i] = p[i]; return r; }
+template <class P>
+void st(uint32_t* p, const F29<P>& v) { for (int i = 0; i < 9; ++i) p[i] = v.l[i]; }
+G1Xyzz29 ldp(const uint32_t* p) { return G1Xyzz29{ld<Fq29P>(p), ld<Fq29P>(p + 9), ld<Fq29P>(p + 18), ld<Fq29P>(p + 27)}; }
+void stp(uint32_t* p, const G1Xyzz29& v) { st(p, v.x); st(p + 9, v.y); st(p + 18, v.zz); st(p + 27, v.zzz); }
+}  // namespace
+
+extern "C" {
+
+// field: which = 0 -> Fq, 1 -> Fr.  Limb arrays are 9 x u32, packed elements 8 x u32.
+void h_mul29(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    if (which) st(out, mul29(ld<Fr29P>(a), ld<Fr29P>(b))); else st(out, mul29(ld<Fq29P>(a), ld<Fq29P>(b)));
+}
+void h_sqr29(int which, const uint32_t* a, uint32_t* out) {
+    if (which) st(out, sqr29(ld<Fr29P>(a))); else st(out, sqr29(ld<Fq29P>(a)));
+}
+void h_unpack29(int which, const uint32_t* a8, uint32_t* out) {
+    if (which) { Fr v; memcpy(v.l, a8, 32); st(out, unpack29<Fr29P>(v)); } else { Fq v; memcpy(v.l, a8, 32); st(out, unpack29<Fq29P>(v)); }
+}
+void h_pack29(int which, const uint32_t* a, uint32_t* out8) {
+    if (which) { Fr v = pack29(ld<Fr29P>(a)); memcpy(out8, v.l, 32); } else { Fq v = pack29(ld<Fq29P>(a)); memcpy(out8, v.l, 32); }
+}
+void h_pack29_lt2p(int which, const uint32_t* a, uint32_t* out8) {
+    if (which) { Fr v = pack29_lt2p(ld<Fr29P>(a)); memcpy(out8, v.l, 32); } else { Fq v = pack29_lt2p(ld<Fq29P>(a)); memcpy(out8, v.l, 32); }
+}
+void h_reduce_lazy29(int which, const uint32_t* a, uint32_t* out8) {
+    if (which) { Fr v = reduce_lazy29(ld<Fr29P>(a)); memcpy(out8, v.l, 32); } else { Fq v = reduce_lazy29(ld<Fq29P>(a)); memcpy(out8, v.l, 32); }
+}
+void h_add_n(const uint32_t* a, const uint32_t* b, uint32_t* out) { st(out, add_n(ld<Fq29P>(a), ld<Fq29P>(b))); }
+// a - b + K p, normalised, for the K the group law uses
+int h_sub_n(int K, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    const Fq29 x = ld<Fq29P>(a), y = ld<Fq29P>(b);
+    switch (K) {
+        case 1: st(out, sub_n<1>(x, y)); return 0;
+        case 2: st(out, sub_n<2>(x, y)); return 0;
+        case 3: st(out, sub_n<3>(x, y)); return 0;
+        case 4: st(out, sub_n<4>(x, y)); return 0;
+        case 5: st(out, sub_n<5>(x, y)); return 0;
+        case 6: st(out, sub_n<6>(x, y)); return 0;
+        case 8: st(out, sub_n<8>(x, y)); return 0;
+        default: return -1;
+    }
+}
+int h_is_zero_mod_p(int maxk, const uint32_t* a) {
+    const Fq29 x = ld<Fq29P>(a);
+    return maxk == 3 ? (int)is_zero_mod_p29<3>(x) : maxk == 9 ? (int)is_zero_mod_p29<9>(x) : -1;
+}
+void h_inv_via29(int which, const uint32_t* a8, uint32_t* out8) {
+    if (which) { Fr v; memcpy(v.l, a8, 32); v = inv_via29<Fr29P>(v); memcpy(out8, v.l, 32); }
+    else { Fq v; memcpy(v.l, a8, 32); v = inv_via29<Fq29P>(v); memcpy(out8, v.l, 32); }
+}
+void h_one29(uint32_t* out) { st(out, one29()); }
+
+// group law: points are 36 x u32 (x, y, zz, zzz), affine points 18 x u32 (x, y)
+void h_madd29(const uint32_t* p, const uint32_t* q, uint32_t* out) { stp(out, madd29(ldp(p), G1Affine29{ld<Fq29P>(q), ld<Fq29P>(q + 9)})); }
+void h_add29pt(const uint32_t* p, const uint32_t* q, uint32_t* out) { stp(out, add29pt(ldp(p), ldp(q))); }
+void h_dbl29pt(const uint32_t* p, uint32_t* out) { stp(out, dbl29pt(ldp(p))); }
+void h_dbl_affine29(const uint32_t* q, uint32_t* out) { stp(out, dbl_affine29(G1Affine29{ld<Fq29P>(q), ld<Fq29P>(q + 9)})); }
+
+}  // extern "C"

@@ -97,22 +97,6 @@ __host__ __device__ __forceinline__ F29<P> add29(const F29<P>& a, const F29<P>& 
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
     return r;
 }
-// a - b + 4p with per-limb non-negativity (b normalised, b < 4p); result limbs < 2^31
-template <class P>
-__host__ __device__ __forceinline__ F29<P> sub29(const F29<P>& a, const F29<P>& b) {
-    // C = 4p written with limbs c[i] = 4*M[i] re-balanced so that every c[i] >= 2^29 (i < 8):
-    // borrow 2^29 from limb i+1 into limb i (c[i] += 2^29, c[i+1] -= 1).
-    F29<P> r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        uint32_t c = 4u * P::M(i);
-        if (i < 8) c += 1u << 29;
-        if (i > 0) c -= 1u;
-        r.l[i] = a.l[i] + c - b.l[i];
-    }
-    return r;
-}
-
 // limb i of K*p in "balanced" form: normalised limbs n[i] of K*p with 2^29 borrowed from the next
 // limb (c[i] = n[i] + 2^29 - [i > 0], c[8] = n[8] - 1), so c[i] >= 2^29 - 1 >= any normalised limb.
 template <class P>
