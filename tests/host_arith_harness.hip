@@ -39,6 +39,14 @@ void h_pack29_lt2p(int which, const uint32_t* a, uint32_t* out8) {
 void h_reduce_lazy29(int which, const uint32_t* a, uint32_t* out8) {
     if (which) { Fr v = reduce_lazy29(ld<Fr29P>(a)); memcpy(out8, v.l, 32); } else { Fq v = reduce_lazy29(ld<Fq29P>(a)); memcpy(out8, v.l, 32); }
 }
+void h_mul2add29(int which, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    if (which) st(out, mul2add29(ld<Fr29P>(a), ld<Fr29P>(b), ld<Fr29P>(c), ld<Fr29P>(d)));
+    else st(out, mul2add29(ld<Fq29P>(a), ld<Fq29P>(b), ld<Fq29P>(c), ld<Fq29P>(d)));
+}
+// K p - b limb by limb (K = 2: what the group law uses)
+void h_neg29k2(int which, const uint32_t* b, uint32_t* out) {
+    if (which) st(out, neg29k<2>(ld<Fr29P>(b))); else st(out, neg29k<2>(ld<Fq29P>(b)));
+}
 void h_add_n(const uint32_t* a, const uint32_t* b, uint32_t* out) { st(out, add_n(ld<Fq29P>(a), ld<Fq29P>(b))); }
 // a - b + K p, normalised, for the K the group law uses
 int h_sub_n(int K, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -53,6 +61,13 @@ int h_sub_n(int K, const uint32_t* a, const uint32_t* b, uint32_t* out) {
         case 8: st(out, sub_n<8>(x, y)); return 0;
         default: return -1;
     }
+}
+// a - b + K p with b the uncarried sum of S normalised values: (K, S) = (3, 2) and (4, 3) are what the group law uses
+int h_sub_nw(int K, int S, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    const Fq29 x = ld<Fq29P>(a), y = ld<Fq29P>(b);
+    if (K == 3 && S == 2) { st(out, sub_nw<3, 2>(x, y)); return 0; }
+    if (K == 4 && S == 3) { st(out, sub_nw<4, 3>(x, y)); return 0; }
+    return -1;
 }
 int h_is_zero_mod_p(int maxk, const uint32_t* a) {
     const Fq29 x = ld<Fq29P>(a);

@@ -116,6 +116,41 @@ def test_montgomery_product_and_square(h, which):
 
 
 @pytest.mark.parametrize("which", [0, 1])
+def test_two_product_pass(h, which):
+    """mul2add29(a, b, c, d) = (a b + c d) 2^-261 mod p with d = K p - x taken limb-wise (limbs up to 2^30), columns at their
+    maximum (all limbs 2^29 - 1 / 2^30 - 1) included: no 64-bit column may overflow."""
+    rng = random.Random(13 + which)
+    mod = MOD[which]
+    rinv = pow(RP, -1, mod)
+    for x in edge_values(mod, rng, 2) + [2 * mod - (1 << 232) - 1]:
+        if x >> 232 >= (2 * mod) >> 232:         # the top limb must stay below that of 2p
+            continue
+        out = U9()
+        h.h_neg29k2(which, U9(*limbs(x)), out)
+        assert val(out) == 2 * mod - x and all(int(v) < 1 << 30 for v in out)
+    full = [M29] * 8
+    worst = (U9(*(full + [M29])), U9(*(full + [0x30644e * 2])), U9(*(full + [M29])), U9(*([(1 << 30) - 1] * 8 + [0x30644e * 2])))
+    out = U9()
+    h.h_mul2add29(which, *worst, out)            # value far beyond the a b + c d < 2^261 p precondition: only the congruence is asked
+    a, b, c, d = (val(w) for w in worst)
+    assert val(out) % mod == (a * b + c * d) * rinv % mod
+    for _ in range(200):
+        a, b = rng.randrange(10 * mod), rng.randrange(8 * mod)
+        c, x = rng.randrange(8 * mod), rng.randrange(2 * mod)
+        if rng.random() < 0.2:
+            a, b, c, x = 10 * mod - 1, 8 * mod - 1, 8 * mod - 1, 0
+        dl = U9()
+        h.h_neg29k2(which, U9(*limbs(x)), dl)
+        d = 2 * mod - x
+        assert a * b + c * d < RP * mod
+        out = U9()
+        h.h_mul2add29(which, U9(*limbs(a)), U9(*limbs(b)), U9(*limbs(c)), dl, out)
+        v = val(out)
+        assert v % mod == (a * b + c * d) * rinv % mod
+        assert normalised(out) and v * RP < a * b + c * d + mod * RP
+
+
+@pytest.mark.parametrize("which", [0, 1])
 def test_lazy_reduction_and_inverse(h, which):
     rng = random.Random(11 + which)
     mod = MOD[which]
@@ -141,11 +176,28 @@ def test_subtractions_keep_limbs_non_negative(h):
                 out = U9()
                 assert h.h_sub_n(K, U9(*limbs(a)), U9(*limbs(b)), out) == 0
                 assert val(out) == a - b + K * P and normalised(out)
+    for K, S in ((3, 2), (4, 3)):                # subtrahend = uncarried sum of S normalised values, together below K p
+        for _ in range(60):
+            parts = [rng.randrange(K * P // S) for _ in range(S)]
+            if rng.random() < 0.3:
+                parts = [K * P // S - 1 - (1 << 232)] * S
+            bl = [sum(limbs(v)[i] for v in parts) for i in range(9)]
+            if rng.random() < 0.3:               # every limb at its maximum
+                bl = [S * M29] * 8 + [bl[8]]
+            b = val(bl)
+            a = rng.choice([0, 1, rng.randrange(8 * P)])
+            out = U9()
+            assert h.h_sub_nw(K, S, U9(*limbs(a)), U9(*bl), out) == 0
+            assert b < K * P and val(out) == a - b + K * P and normalised(out)
     for maxk in (3, 9):
         for k in range(0, maxk + 1):
             assert h.h_is_zero_mod_p(maxk, U9(*limbs(k * P))) == 1
             assert h.h_is_zero_mod_p(maxk, U9(*limbs(k * P + 1))) == 0
         assert h.h_is_zero_mod_p(maxk, U9(*limbs(rng.randrange(1, P)))) == 0
+        assert h.h_is_zero_mod_p(maxk, U9(*limbs((maxk + 1) * P))) == 0          # a multiple of p, but beyond the range asked for
+        for k in range(1, maxk + 1):             # same low limbs as k p, another top limb
+            assert h.h_is_zero_mod_p(maxk, U9(*(limbs(k * P)[:8] + [limbs(k * P)[8] + 1]))) == 0
+            assert h.h_is_zero_mod_p(maxk, U9(*(limbs(k * P)[:4] + [limbs(k * P)[4] ^ 1] + limbs(k * P)[5:]))) == 0
 
 
 # ---- group law ------------------------------------------------------------------------------------------------------

@@ -12,6 +12,12 @@
 #include "ec.hip.hpp"
 #include "ff29.hip.hpp"
 
+// 1: y3 of every addition / doubling as one two-product Montgomery pass (mul2add29) and the quick k*p filter in front of
+// is_zero_mod_p29; 0: the round-1 formulation (two reduced products and a subtraction), kept for A/B builds.
+#ifndef ZK_EC_FUSED
+#define ZK_EC_FUSED 1
+#endif
+
 namespace zk {
 
 struct G1Affine29 {
@@ -47,6 +53,23 @@ __host__ __device__ __forceinline__ bool is_identity29(const G1Xyzz29& p) { retu
 __host__ __device__ __forceinline__ bool is_identity29(const G1Affine29& p) { return all_zero29(p.x) && all_zero29(p.y); }
 
 // v normalised, 0 <= v < (MAXK + 1) * p :  v == 0 (mod p) ?
+#if ZK_EC_FUSED
+// v = k*p forces v.l[0] = k * p.l[0] (mod 2^29), so k = v.l[0] / p.l[0] (mod 2^29) = -(v.l[0] * INV) is the only candidate:
+// its multiple of p is rebuilt limb by limb and compared (9 multiply-adds, no branch, no table of multiples).
+template <int MAXK>
+__host__ __device__ __forceinline__ bool is_zero_mod_p29(const Fq29& v) {
+    const uint32_t k = (0u - v.l[0] * Fq29P::INV) & MASK29;
+    uint32_t diff = 0;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        acc += (uint64_t)k * Fq29P::M(i);
+        diff |= v.l[i] ^ (i < 8 ? (uint32_t)acc & MASK29 : (uint32_t)acc);
+        acc >>= 29;
+    }
+    return diff == 0 && k <= (uint32_t)MAXK;
+}
+#else
 template <int MAXK>
 __host__ __device__ __forceinline__ bool is_zero_mod_p29(const Fq29& v) {
     bool any = all_zero29(v);
@@ -65,10 +88,14 @@ __host__ __device__ __forceinline__ bool is_zero_mod_p29(const Fq29& v) {
     }
     return any;
 }
+#endif
 
 __host__ __device__ __forceinline__ Fq29 add_n(const Fq29& a, const Fq29& b) { Fq29 r = add29(a, b); normalize29(r); return r; }
 template <int K>
 __host__ __device__ __forceinline__ Fq29 sub_n(const Fq29& a, const Fq29& b) { Fq29 r = sub29k<K>(a, b); normalize29(r); return r; }
+// a - b + K p for a subtrahend that is the plain limb-wise sum of S normalised values (not carried): S borrows per limb
+template <int K, int S>
+__host__ __device__ __forceinline__ Fq29 sub_nw(const Fq29& a, const Fq29& b) { Fq29 r = sub29kw<K, S>(a, b); normalize29(r); return r; }
 
 // -y for a canonical affine y (y != 0 for points on the curve; y = 0 maps to p == 0 mod p)
 __host__ __device__ __forceinline__ Fq29 neg_canon29(const Fq29& y) { return sub_n<1>(zero29(), y); }
@@ -80,8 +107,16 @@ __host__ __device__ __forceinline__ G1Xyzz29 dbl_affine29(const G1Affine29& q) {
     Fq29 x2 = sqr29(q.x);
     Fq29 m = add_n(add29(x2, x2), x2);       // 3 x^2 < 3.1p
     G1Xyzz29 r;
+#if ZK_EC_FUSED
+    r.x = sub_nw<3, 2>(sqr29(m), add29(s, s));             // < 1.1p + 3p; the sum 2s is subtracted as it is, not carried first
+#else
     r.x = sub_n<3>(sqr29(m), add_n(s, s));                 // < 1.1p + 3p
+#endif
+#if ZK_EC_FUSED
+    r.y = mul2add29(m, sub_n<5>(s, r.x), q.y, neg29k<2>(w));    // m (s - x3) + y (2p - w) < (3.1 * 6.1 + 2) p^2: below 1.2p
+#else
     r.y = sub_n<2>(mul29(m, sub_n<5>(s, r.x)), mul29(w, q.y)); // s - x3 + 5p < 6.1p
+#endif
     r.zz = v;
     r.zzz = w;
     return r;
@@ -95,8 +130,16 @@ __host__ __device__ __forceinline__ G1Xyzz29 dbl29pt(const G1Xyzz29& p) {
     Fq29 x2 = sqr29(p.x);               // < 1.4p
     Fq29 m = add_n(add29(x2, x2), x2);       // < 4.2p
     G1Xyzz29 r;
+#if ZK_EC_FUSED
+    r.x = sub_nw<3, 2>(sqr29(m), add29(s, s));               // < 1.2p + 3p
+#else
     r.x = sub_n<3>(sqr29(m), add_n(s, s));                   // < 1.2p + 3p
+#endif
+#if ZK_EC_FUSED
+    r.y = mul2add29(m, sub_n<5>(s, r.x), p.y, neg29k<2>(w));    // (4.2 * 6.2 + 8 * 2) p^2 / 2^261 + p: below 1.3p
+#else
     r.y = sub_n<2>(mul29(m, sub_n<5>(s, r.x)), mul29(w, p.y));  // (s - x3 + 5p) < 6.2p
+#endif
     r.zz = mul29(v, p.zz);
     r.zzz = mul29(w, p.zzz);
     return r;
@@ -114,8 +157,16 @@ __host__ __device__ __forceinline__ G1Xyzz29 madd29(const G1Xyzz29& p, const G1A
     }
     Fq29 pp = sqr29(pd), ppp = mul29(pd, pp), qq = mul29(p.x, pp);   // < 1.5p, 1.1p, 1.1p
     G1Xyzz29 r;
+#if ZK_EC_FUSED
+    r.x = sub_nw<4, 3>(sqr29(rd), add29(add29(ppp, qq), qq));         // < 1.5p + 4p
+#else
     r.x = sub_n<4>(sqr29(rd), add_n(add29(ppp, qq), qq));            // < 1.5p + 4p
+#endif
+#if ZK_EC_FUSED
+    r.y = mul2add29(rd, sub_n<6>(qq, r.x), p.y, neg29k<2>(ppp));      // (9.1 * 7.2 + 8 * 2) p^2 / 2^261 + p: below 1.5p
+#else
     r.y = sub_n<2>(mul29(rd, sub_n<6>(qq, r.x)), mul29(p.y, ppp));       // < 1.4p + 2p
+#endif
     r.zz = mul29(p.zz, pp);
     r.zzz = mul29(p.zzz, ppp);
     return r;
@@ -133,8 +184,16 @@ __host__ __device__ __forceinline__ G1Xyzz29 add29pt(const G1Xyzz29& p, const G1
     }
     Fq29 pp = sqr29(pd), ppp = mul29(pd, pp), qq = mul29(u1, pp);
     G1Xyzz29 r;
+#if ZK_EC_FUSED
+    r.x = sub_nw<4, 3>(sqr29(rd), add29(add29(ppp, qq), qq));
+#else
     r.x = sub_n<4>(sqr29(rd), add_n(add29(ppp, qq), qq));
+#endif
+#if ZK_EC_FUSED
+    r.y = mul2add29(rd, sub_n<6>(qq, r.x), s1, neg29k<2>(ppp));
+#else
     r.y = sub_n<2>(mul29(rd, sub_n<6>(qq, r.x)), mul29(s1, ppp));
+#endif
     r.zz = mul29(mul29(p.zz, q.zz), pp);
     r.zzz = mul29(mul29(p.zzz, q.zzz), ppp);
     return r;

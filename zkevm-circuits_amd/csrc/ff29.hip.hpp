@@ -121,12 +121,221 @@ __host__ __device__ __forceinline__ F29<P> sub29k(const F29<P>& a, const F29<P>&
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + kp_balanced<P>(K, i) - b.l[i];
     return r;
 }
+// The same for a subtrahend whose limbs are plain sums of S normalised limbs (b.l[i] <= S * (2^29 - 1), b < K*p - S * 2^232):
+// S borrows of 2^29 per limb instead of one.  Result limbs < a.l[i] + (S + 1) * 2^29.
+template <int K, int S, class P>
+__host__ __device__ __forceinline__ F29<P> sub29kw(const F29<P>& a, const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t c = kp_balanced<P>(K, i);
+        if (i < 8) c += (uint32_t)(S - 1) << 29;
+        if (i > 0) c -= (uint32_t)(S - 1);
+        r.l[i] = a.l[i] + c - b.l[i];
+    }
+    return r;
+}
 // canonical representative of a normalised value < 2p
 template <class P>
 __host__ __device__ __forceinline__ Fp<typename P::P32> pack29_lt2p(const F29<P>& a) {
     Fp<typename P::P32> r = pack29_raw(a);
     cond_sub<typename P::P32>(r.l);
     return r;
+}
+
+// Column sums of the products below: acc + sum_j x[j]*y[j] (dotv: both factors in registers) and acc + sum_j x[j]*k[j]
+// (dotk: k[] compile-time constants, held in scalar registers).  Left to itself the compiler starts every column sum from
+// zero (so that the multiplications do not wait for the carry out of the previous column) and joins the carry with a 64-bit
+// add of its own: 16 instructions per product, bought for latency that four resident waves hide anyway.  ZK_MAD_CHAIN makes
+// the multiply-adds opaque so that the sums run as written, carry first: 1 = one asm statement per multiply-add, 2 = one
+// per column part (the hazard recogniser puts an s_nop behind every asm statement).  0 = plain C, the association is the
+// compiler's; host compilation always takes this form.
+#ifndef ZK_MAD_CHAIN
+#define ZK_MAD_CHAIN 0
+#endif
+#if ZK_MAD_CHAIN && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t dotv_asm(const uint32_t* x, const uint32_t* y, int n, uint64_t acc) {
+    switch (n) {
+        case 1:
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(y[0]) : "vcc");
+            break;
+        case 2:
+            asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %4, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]) : "vcc");
+            break;
+        case 3:
+            asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %5, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %6, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2]) : "vcc");
+            break;
+        case 4:
+            asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %6, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %8, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]) : "vcc");
+            break;
+        case 5:
+            asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %10, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]) : "vcc");
+            break;
+        case 6:
+            asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %12, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]) : "vcc");
+            break;
+        case 7:
+            asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %14, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]) : "vcc");
+            break;
+        case 8:
+            asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %14, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %15, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %8, %16, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]) : "vcc");
+            break;
+        case 9:
+            asm("v_mad_u64_u32 %0, vcc, %1, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %14, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %15, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %16, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %8, %17, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %9, %18, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]) : "vcc");
+            break;
+        default: break;
+    }
+    return acc;
+}
+__device__ __forceinline__ uint64_t dotk_asm(const uint32_t* x, const uint32_t* y, int n, uint64_t acc) {
+    switch (n) {
+        case 1:
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "s"(y[0]) : "vcc");
+            break;
+        case 2:
+            asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %4, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "s"(y[0]), "s"(y[1]) : "vcc");
+            break;
+        case 3:
+            asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %5, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %6, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "s"(y[0]), "s"(y[1]), "s"(y[2]) : "vcc");
+            break;
+        case 4:
+            asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %6, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %8, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]) : "vcc");
+            break;
+        case 5:
+            asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %10, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]), "s"(y[4]) : "vcc");
+            break;
+        case 6:
+            asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %12, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]), "s"(y[4]), "s"(y[5]) : "vcc");
+            break;
+        case 7:
+            asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %14, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]), "s"(y[4]), "s"(y[5]), "s"(y[6]) : "vcc");
+            break;
+        case 8:
+            asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %14, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %15, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %8, %16, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]), "s"(y[4]), "s"(y[5]), "s"(y[6]), "s"(y[7]) : "vcc");
+            break;
+        case 9:
+            asm("v_mad_u64_u32 %0, vcc, %1, %10, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %2, %11, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %3, %12, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %13, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %5, %14, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %6, %15, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %7, %16, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %8, %17, %0\n\t"
+                "v_mad_u64_u32 %0, vcc, %9, %18, %0\n\t"
+                : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "s"(y[0]), "s"(y[1]), "s"(y[2]), "s"(y[3]), "s"(y[4]), "s"(y[5]), "s"(y[6]), "s"(y[7]), "s"(y[8]) : "vcc");
+            break;
+        default: break;
+    }
+    return acc;
+}
+#endif
+__host__ __device__ __forceinline__ uint64_t dotv(const uint32_t* x, const uint32_t* y, int n, uint64_t acc) {
+#if ZK_MAD_CHAIN == 2 && defined(__HIP_DEVICE_COMPILE__)
+    return dotv_asm(x, y, n, acc);
+#elif ZK_MAD_CHAIN == 1 && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc = dotv_asm(x + j, y + j, 1, acc);
+    return acc;
+#else
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc += (uint64_t)x[j] * y[j];
+    return acc;
+#endif
+}
+__host__ __device__ __forceinline__ uint64_t dotk(const uint32_t* x, const uint32_t* k, int n, uint64_t acc) {
+#if ZK_MAD_CHAIN == 2 && defined(__HIP_DEVICE_COMPILE__)
+    return dotk_asm(x, k, n, acc);
+#elif ZK_MAD_CHAIN == 1 && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc = dotk_asm(x + j, k + j, 1, acc);
+    return acc;
+#else
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc += (uint64_t)x[j] * k[j];
+    return acc;
+#endif
 }
 
 // Montgomery product, product-scanning (FIPS) form, 64-bit column accumulator, no carries.
@@ -136,27 +345,63 @@ __host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& 
     F29<P> t;
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 17; ++k) {
+        // column k: a[i] * b[k - i] and m[i] * M[k - i] over lo <= i <= hi (the m[k] * M[0] term of k < 9 comes once m[k] is known)
+        const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8, nm = k < 9 ? k : 17 - k;
+        uint32_t ys[9], ks[9];
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M(k - i);
-        m[k] = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m[k] * P::M(0);
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; ++k) {
-#pragma unroll
-        for (int i = k - 8; i < 9; ++i) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)m[i] * P::M(k - i);
+        for (int i = lo; i <= hi; ++i) { ys[i - lo] = b.l[k - i]; ks[i - lo] = P::M(k - i); }
+        acc = dotv(a.l + lo, ys, hi - lo + 1, acc);
+        acc = dotk(m + lo, ks, nm, acc);
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * P::INV) & MASK29;
+            acc += (uint64_t)m[k] * P::M(0);
+        } else {
+            t.l[k - 9] = (uint32_t)acc & MASK29;
         }
-        t.l[k - 9] = (uint32_t)acc & MASK29;
         acc >>= 29;
     }
     t.l[8] = (uint32_t)acc;
     return t;
+}
+
+// (a*b + c*d) * 2^-261 mod p in one pass: the second product joins the column sums of the first, one reduction serves both
+// (243 v_mad_u64_u32 instead of 324 + the subtraction or addition that would have combined two reduced products).
+// a, b, c normalised (limbs < 2^29), d with limbs < 2^30 (e.g. K*p - x taken limb-wise, see neg29k), a*b + c*d < 2^261 * p:
+// a column holds at most 9*2^58 + 9*2^59 + 9*2^58 < 2^64.  Result normalised, < (a*b + c*d) / 2^261 + p.
+template <class P>
+__host__ __device__ __forceinline__ F29<P> mul2add29(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+    uint32_t m[9];
+    F29<P> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8, nm = k < 9 ? k : 17 - k;
+        uint32_t ys[9], ds[9], ks[9];
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) { ys[i - lo] = b.l[k - i]; ds[i - lo] = d.l[k - i]; ks[i - lo] = P::M(k - i); }
+        acc = dotv(a.l + lo, ys, hi - lo + 1, acc);
+        acc = dotv(c.l + lo, ds, hi - lo + 1, acc);
+        acc = dotk(m + lo, ks, nm, acc);
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * P::INV) & MASK29;
+            acc += (uint64_t)m[k] * P::M(0);
+        } else {
+            t.l[k - 9] = (uint32_t)acc & MASK29;
+        }
+        acc >>= 29;
+    }
+    t.l[8] = (uint32_t)acc;
+    return t;
+}
+// K*p - b taken limb by limb (b normalised, top limb of b below the top limb of K*p, i.e. b < K*p - 2^232): the value is
+// K*p - b, limbs are non-negative and below 2^30, not normalised -- what mul2add29 takes as its last operand.
+template <int K, class P>
+__host__ __device__ __forceinline__ F29<P> neg29k(const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = kp_balanced<P>(K, i) - b.l[i];
+    return r;
 }
 
 // canonical representative of a normalised lazy value < 64 m (sums of a few dozen reduced terms):
@@ -189,24 +434,24 @@ __host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) {
     F29<P> t;
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 17; ++k) {
+        const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8, nm = k < 9 ? k : 17 - k;
+        // cross terms lo <= i < k - i, then the square of the middle limb of an even column
+        uint32_t xs[9], ys[9], ks[9];
+        int n = 0;
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a2[i] * a.l[k - i];
-        if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = lo; 2 * i < k; ++i) { xs[n] = a2[i]; ys[n] = a.l[k - i]; ++n; }
+        if (!(k & 1)) { xs[n] = a.l[k / 2]; ys[n] = a.l[k / 2]; ++n; }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M(k - i);
-        m[k] = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m[k] * P::M(0);
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; ++k) {
-#pragma unroll
-        for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)a2[i] * a.l[k - i];
-        if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * P::M(k - i);
-        t.l[k - 9] = (uint32_t)acc & MASK29;
+        for (int i = lo; i <= hi; ++i) ks[i - lo] = P::M(k - i);
+        acc = dotv(xs, ys, n, acc);
+        acc = dotk(m + lo, ks, nm, acc);
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * P::INV) & MASK29;
+            acc += (uint64_t)m[k] * P::M(0);
+        } else {
+            t.l[k - 9] = (uint32_t)acc & MASK29;
+        }
         acc >>= 29;
     }
     t.l[8] = (uint32_t)acc;
