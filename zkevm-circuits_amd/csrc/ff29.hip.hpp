@@ -149,9 +149,11 @@ __host__ __device__ __forceinline__ Fp<typename P::P32> pack29_lt2p(const F29<P>
 // add of its own: 16 instructions per product, bought for latency that four resident waves hide anyway.  ZK_MAD_CHAIN makes
 // the multiply-adds opaque so that the sums run as written, carry first: 1 = one asm statement per multiply-add, 2 = one
 // per column part (the hazard recogniser puts an s_nop behind every asm statement).  0 = plain C, the association is the
-// compiler's; host compilation always takes this form.
+// compiler's; host compilation always takes this form.  Measured (tools/gpu_arith_ab.sh, one MI355X): mode 2 against mode 0
+// k_msm_buckets 0.998 -> 0.983 ms, the weighted bucket sum chain 2.01 -> 1.77 ms, NTT 2^20 124 -> 120 us, evaluator 3.43 ->
+// 3.34 ms; it also needs fewer registers (the evaluator 95 -> 77, the NTT passes lose their scratch spills).
 #ifndef ZK_MAD_CHAIN
-#define ZK_MAD_CHAIN 0
+#define ZK_MAD_CHAIN 2
 #endif
 #if ZK_MAD_CHAIN && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint64_t dotv_asm(const uint32_t* x, const uint32_t* y, int n, uint64_t acc) {
