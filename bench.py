@@ -39,7 +39,8 @@ NCOL = 16                  # rotating set: 16 x 32 MiB committed + 16 x 32 MiB t
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G) of the library's own product routine (tools/ubench.hip)
 MAD_PEAK_T = 30.4          # measured v_mad_u64_u32 lane-ops/s (T), tools/ubench.hip: the hardware-side bound
-MADS_PER_PRODUCT = 161     # v_mad_u64_u32 per 9 x 29-bit Montgomery product
+MADS_PER_PRODUCT = 162     # v_mad_u64_u32 per 9 x 29-bit Montgomery product (81 operand + 81 reduction, counted in the ISA)
+MADS_PER_MIXED_ADD = 1476  # per XYZZ mixed addition (csrc/ec29.hip.hpp madd29): 6 products x 162 + 2 squares x 126 + one two-product pass (243) + 9 (k p test)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
@@ -218,7 +219,7 @@ def main():
                    "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "note": note}
             if products:
                 gps = products / (ms * 1e-3) / 1e9
-                rec["alu"] = {"unit": "G Montgomery products/s", "achieved": round(gps, 1), "peak_own_routine": MULPEAK_G, "frac_own_routine": round(gps / MULPEAK_G, 3),
+                rec["alu"] = {"unit": "G Montgomery-product equivalents/s (162 multiply-adds each)", "achieved": round(gps, 1), "peak_own_routine": MULPEAK_G, "frac_own_routine": round(gps / MULPEAK_G, 3),
                               "peak_v_mad_u64_u32": round(MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT, 1), "frac_v_mad_u64_u32": round(gps / (MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT), 3)}
             return rec
 
@@ -238,7 +239,8 @@ def main():
                 traffic = None
         main_roof = hbm_roof("k_msm_buckets", 96.0 * N, bucket_ms,
                              "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 (SURVEY 8d); integer-ALU bound: one mixed XYZZ addition "
-                             f"(10 Montgomery products) per (scalar, window), {windows} windows", products=10.0 * N * windows)
+                             f"({MADS_PER_MIXED_ADD} multiply-adds = {MADS_PER_MIXED_ADD / MADS_PER_PRODUCT:.2f} Montgomery-product equivalents) per (scalar, window), {windows} windows",
+                             products=MADS_PER_MIXED_ADD / MADS_PER_PRODUCT * N * windows)
         if main_roof:
             main_roof["traffic"] = traffic            # PMC FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, from the committed rocprofv3 pass (profiles/); null until measured this round
             main_roof["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc pass of this command)" if traffic else None
