@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 output of tools/gpu_r2z.sh (gpurun_out/r2z/) into the committed summaries under
+"""Turns the rocprofv3 output of a record run (tools/gpu_r2_record.sh, earlier tools/gpu_r2z.sh; default gpurun_out/r2z/) into the committed summaries under
 profiles/: kernel statistics of the bench line and of the SuperCircuit-shape proof, and the PMC
 traffic (FETCH_SIZE / WRITE_SIZE, separate passes) per launch of the MSM and NTT kernels."""
 import collections
