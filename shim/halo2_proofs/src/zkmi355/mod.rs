@@ -25,16 +25,21 @@ use ff::Field;
 use halo2curves::bn256::{Bn256, Fr, G1Affine};
 use rand_core::RngCore;
 
-use crate::arithmetic::CurveAffine;
 use crate::circuit::Value;
 use crate::plonk::{
-    self, permutation, Advice, Any, Assigned, Assignment, Challenge, Circuit, Column, ConstraintSystem, Error, Fixed, FloorPlanner, Instance, Selector,
-    VerifyingKey,
+    self, Advice, Any, Assigned, Assignment, Challenge, Circuit, Column, ConstraintSystem, Error, Fixed, FloorPlanner, Instance, Selector, VerifyingKey,
 };
 use crate::poly::commitment::{CommitmentScheme, Params, Prover};
-use crate::poly::kzg::commitment::{KZGCommitmentScheme, ParamsKZG};
-use crate::poly::{batch_invert_assigned, EvaluationDomain};
+use crate::poly::kzg::commitment::ParamsKZG;
+use crate::poly::{batch_invert_assigned, LagrangeCoeff, Polynomial};
 use crate::transcript::{EncodedChallenge, TranscriptWrite};
+
+/// The upstream CPU implementations, for A/B runs next to the routed entry points (`plonk::create_proof` etc. resolve to
+/// this module's functions when the feature is on; `plonk::prover` / `plonk::keygen` are private modules).
+pub mod cpu {
+    pub use crate::plonk::keygen::{keygen_pk, keygen_pk2};
+    pub use crate::plonk::prover::create_proof;
+}
 
 /// One `zk_ctx` per process and device (the reference drives one proof at a time per `Prover`
 /// [REF prover/src/test/chunk.rs:19-25]); `ZKMI355_DEVICE` selects the GPU (default 0; under
@@ -67,8 +72,9 @@ fn check(g: &Gpu, rc: i32, what: &str) -> Result<(), Error> {
     log::error!("zkmi355 {what}: status {rc}: {msg}");
     // never unwind across the FFI; map to the closest halo2 error (SURVEY §8b "Errors")
     Err(match rc {
+        // plonk::Error has no variant for a failing backend: a rejected witness / blob is a constraint-system failure,
+        // everything else (device, memory) surfaces as Synthesis; the log line above carries the library's message
         ffi::ZK_ERR_INVALID_ARG => Error::ConstraintSystemFailure,
-        ffi::ZK_ERR_OOM | ffi::ZK_ERR_HIP | ffi::ZK_ERR_NO_DEVICE => Error::BackendError,
         _ => Error::Synthesis,
     })
 }
@@ -79,7 +85,7 @@ impl Gpu {
         if let Some(s) = self.srs.get(&k) {
             return Ok(*s);
         }
-        let (g, gl) = (params.get_g(), params.g_lagrange()); // &[G1Affine], n each, in-memory form = ABI form
+        let (g, gl) = (&params.g, &params.g_lagrange); // pub(crate) fields of ParamsKZG: Vec<G1Affine>, n each, in-memory form = ABI form
         let mut out = std::ptr::null_mut();
         let rc = unsafe { ffi::zk_srs_create(self.ctx, k, g.as_ptr() as *const c_void, gl.as_ptr() as *const c_void, &mut out) };
         check(self, rc, "zk_srs_create")?;
@@ -95,7 +101,7 @@ impl Gpu {
 /// under the vk's address.  `vk.transcript_repr()` — the value pinned at
 /// [REF zkevm-circuits/src/super_circuit/test.rs:70-85] — is installed so that proofs absorb exactly
 /// what upstream `verify_proof` absorbs.
-pub fn keygen_pk2<C, ConcreteCircuit>(params: &ParamsKZG<Bn256>, circuit: &ConcreteCircuit) -> Result<plonk::ProvingKey<G1Affine>, Error>
+pub fn keygen_pk2<ConcreteCircuit>(params: &ParamsKZG<Bn256>, circuit: &ConcreteCircuit) -> Result<plonk::ProvingKey<G1Affine>, Error>
 where
     ConcreteCircuit: Circuit<Fr>,
 {
@@ -116,7 +122,9 @@ fn register_key(params: &ParamsKZG<Bn256>, pk: &plonk::ProvingKey<G1Affine>) -> 
     let vk = pk.get_vk();
     let cs = vk.cs();
     // Lagrange forms kept by upstream's ProvingKey: `fixed_values` (after selector compression) and
-    // `permutation.permutations` (sigma columns) — crate-private fields, visible from inside the fork
+    // `permutation.permutations` (sigma columns).  Both are private to `plonk` / `plonk::permutation` upstream: the fork
+    // needs `pub(crate)` on `ProvingKey::{fixed_values, permutation}` and on `permutation::ProvingKey::permutations`
+    // (shim/README.md, "visibility patch")
     let fixed: Vec<Vec<Fr>> = pk.fixed_values.iter().map(|p| p.to_vec()).collect();
     let sigma: Vec<Vec<Fr>> = pk.permutation.permutations.iter().map(|p| p.to_vec()).collect();
     let blob = export::key_blob(cs, params.k(), &fixed, &sigma);
@@ -162,7 +170,7 @@ struct WitnessCollection<'a> {
     k: u32,
     current_phase: u8,
     advice_phase: &'a [u8],
-    advice: Vec<Vec<Assigned<Fr>>>,
+    advice: Vec<Polynomial<Assigned<Fr>, LagrangeCoeff>>,
     challenges: &'a HashMap<usize, Fr>,
     instances: &'a [&'a [Fr]],
     usable_rows: std::ops::RangeTo<usize>,
@@ -203,24 +211,30 @@ impl<'a> Assignment<Fr> for WitnessCollection<'a> {
 
 /// Drop-in for `halo2_proofs::plonk::create_proof` (KZG over Bn256; one circuit per call, which is
 /// what every reference call site passes: `&[circuit]`, `&[&instances]`).
-pub fn create_proof<'params, P, E, R, T, ConcreteCircuit>(
-    params: &'params ParamsKZG<Bn256>,
-    pk: &plonk::ProvingKey<G1Affine>,
+///
+/// Same generic parameter list as upstream, so the call sites' turbofish
+/// `create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, ChaChaRng, Blake2bWrite<..>, SuperCircuit<..>>`
+/// [REF circuit-benchmarks/src/super_circuit.rs:117-124] compiles unchanged; the associated-type equalities on `Scheme` pin it
+/// to KZG over Bn256 (the only scheme the reference instantiates), which makes `params`, `pk` and `instances` concrete types here.
+pub fn create_proof<'params, Scheme, P, E, R, T, ConcreteCircuit>(
+    params: &'params Scheme::ParamsProver,
+    pk: &plonk::ProvingKey<Scheme::Curve>,
     circuits: &[ConcreteCircuit],
-    instances: &[&[&[Fr]]],
+    instances: &[&[&[Scheme::Scalar]]],
     mut rng: R,
     transcript: &mut T,
 ) -> Result<(), Error>
 where
-    P: Prover<'params, KZGCommitmentScheme<Bn256>> + MultiOpenKind,
+    Scheme: CommitmentScheme<Scalar = Fr, Curve = G1Affine, ParamsProver = ParamsKZG<Bn256>>,
+    P: Prover<'params, Scheme> + MultiOpenKind,
     E: EncodedChallenge<G1Affine>,
-    R: RngCore,
+    R: RngCore + Send,
     T: TranscriptWrite<G1Affine, E>,
     ConcreteCircuit: Circuit<Fr>,
 {
     if circuits.len() != 1 || instances.len() != 1 {
         // halo2 batches several circuit instances into one transcript; no reference call site does.
-        return plonk::prover::create_proof::<KZGCommitmentScheme<Bn256>, P, E, R, T, ConcreteCircuit>(params, pk, circuits, instances, rng, transcript);
+        return plonk::prover::create_proof::<Scheme, P, E, R, T, ConcreteCircuit>(params, pk, circuits, instances, rng, transcript);
     }
     let (circuit, instance) = (&circuits[0], instances[0]);
     let vk = pk.get_vk();
@@ -233,7 +247,7 @@ where
     let mut g = gpu().lock().unwrap();
     let dpk = *g.keys.get(&(vk as *const _ as usize)).ok_or_else(|| {
         log::error!("zkmi355: this ProvingKey was not produced by zkmi355::keygen_pk / keygen_pk2");
-        Error::BackendError
+        Error::Synthesis
     })?;
 
     // ---- session: vk.transcript_repr and the instance values are absorbed by the library, in upstream's order
@@ -271,13 +285,15 @@ where
     let mut shape = [0u32; 16];
     unsafe { ffi::zk_pk_shape(g.ctx, dpk, shape.as_mut_ptr()) };
     let mut challenge_buf = vec![Fr::ZERO; (shape[10] as usize).max(1)];
-    for phase in cs.phases() {
-        let phase = phase.to_sealed().0; // u8
+    // `cs.phases()` yields sealed::Phase(0) ..= the highest advice phase, in order: the position IS the phase number
+    // (the inner u8 is private to plonk::circuit)
+    for (phase, _) in cs.phases().enumerate() {
+        let phase = phase as u8;
         let mut witness = WitnessCollection {
             k: params.k(),
             current_phase: phase,
             advice_phase: &advice_phase,
-            advice: vec![vec![Assigned::Zero; n]; cs.num_advice_columns()],
+            advice: vec![Polynomial { values: vec![Assigned::Zero; n], _marker: std::marker::PhantomData }; cs.num_advice_columns()],
             challenges: &challenges,
             instances: instance,
             usable_rows: ..usable,
@@ -287,12 +303,12 @@ where
             return Err(e);
         }
         let cols: Vec<u32> = (0..cs.num_advice_columns() as u32).filter(|i| advice_phase[*i as usize] == phase).collect();
-        let mut picked: Vec<Vec<Assigned<Fr>>> = Vec::with_capacity(cols.len());
+        let mut picked: Vec<Polynomial<Assigned<Fr>, LagrangeCoeff>> = Vec::with_capacity(cols.len());
         for i in &cols {
-            picked.push(std::mem::take(&mut witness.advice[*i as usize]));
+            picked.push(std::mem::replace(&mut witness.advice[*i as usize], Polynomial { values: Vec::new(), _marker: std::marker::PhantomData }));
         }
         drop(witness);
-        let values: Vec<Vec<Fr>> = batch_invert_assigned_vecs(picked); // rational -> field, as upstream
+        let values: Vec<Polynomial<Fr, LagrangeCoeff>> = batch_invert_assigned(picked); // rational -> field, as upstream
         let ptrs: Vec<*const c_void> = values.iter().map(|c| c.as_ptr() as *const c_void).collect();
         // Page-locked witness memory uploads at 0.60 ms per 32 MiB column, pageable memory at 0.80 ms (tools/h2d_rate.py) -- but
         // registering a column costs 0.66 ms by itself, so pinning right here only pays when it happens off the critical path.
@@ -331,17 +347,7 @@ where
     let rc = unsafe { ffi::zk_proof_finish(g.ctx, sess, dummy.as_mut_ptr() as *mut c_void, dummy.len(), &mut len) };
     check(&g, rc, "zk_proof_finish")?; // finish frees the session also on failure
     if hook.failed {
-        return Err(Error::TranscriptError(std::io::Error::new(std::io::ErrorKind::Other, "transcript write failed")));
+        return Err(Error::Transcript(std::io::Error::new(std::io::ErrorKind::Other, "transcript write failed")));
     }
     Ok(())
 }
-
-/// `batch_invert_assigned` over owned columns (upstream takes `Vec<Polynomial<Assigned<F>, LagrangeCoeff>>`).
-fn batch_invert_assigned_vecs(cols: Vec<Vec<Assigned<Fr>>>) -> Vec<Vec<Fr>> {
-    let domain_free: Vec<_> = cols.into_iter().map(crate::poly::Polynomial::from_assigned_vec).collect();
-    batch_invert_assigned(domain_free).into_iter().map(|p| p.to_vec()).collect()
-}
-
-// keep the unused-import lints quiet for items referenced only in cfg'd code
-#[allow(unused_imports)]
-use {permutation as _permutation, CommitmentScheme as _CommitmentScheme, CurveAffine as _CurveAffine, EvaluationDomain as _EvaluationDomain, Params as _Params};

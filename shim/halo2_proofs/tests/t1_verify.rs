@@ -86,7 +86,8 @@ impl Circuit<Fr> for TestCircuit {
             let (q, b) = (m.query_selector(q_lk), m.query_advice(b, Rotation::cur()));
             vec![(q * b, table)]
         });
-        *meta = std::mem::take(meta).chunk_lookups(); // as [REF zkevm-circuits/src/super_circuit/test.rs:59]
+        // keygen (in this fork) applies `chunk_lookups()` to the configured system, as for every circuit of the reference
+        // [REF zkevm-circuits/src/super_circuit/test.rs:59 does the same by hand to read the degree]
         TestConfig { a, b, c, rlc, q_mul, q_pow, q_lk, table, constant, instance, challenge }
     }
 
@@ -132,9 +133,9 @@ fn prove_and_verify(shplonk: bool) {
     let rng = XorShiftRng::from_seed([0u8; 16]); // the reference prover's gen_rng [REF prover/src/utils.rs:192-195]
     let mut transcript = Blake2bWrite::<_, G1Affine, Challenge255<_>>::init(vec![]);
     if shplonk {
-        zkmi355::create_proof::<ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).expect("proof");
+        zkmi355::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).expect("proof");
     } else {
-        zkmi355::create_proof::<ProverGWC<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).expect("proof");
+        zkmi355::create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).expect("proof");
     }
     let proof = transcript.finalize();
     // ---- the UPSTREAM verifier, unmodified [REF circuit-benchmarks/src/super_circuit.rs:141-154]
@@ -182,9 +183,9 @@ fn cpu_and_gpu_provers_are_interchangeable() {
         let rng = XorShiftRng::from_seed([7u8; 16]);
         let mut transcript = Blake2bWrite::<_, G1Affine, Challenge255<_>>::init(vec![]);
         if gpu {
-            zkmi355::create_proof::<ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).unwrap();
+            zkmi355::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).unwrap();
         } else {
-            plonk::prover::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).unwrap();
+            zkmi355::cpu::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, &pk, &[circuit.clone()], &[&[&[public]]], rng, &mut transcript).unwrap();
         }
         let proof = transcript.finalize();
         let mut read = Blake2bRead::<_, G1Affine, Challenge255<_>>::init(&proof[..]);
