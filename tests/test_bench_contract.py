@@ -63,3 +63,28 @@ def test_every_proof_in_the_line_was_verified(line):
     for name, rec in proofs.items():
         assert rec.get("verified_by_oracle") is True and not rec.get("error"), name
         assert rec["data"] == "synthetic-shape"
+
+
+def test_gpus_flag_without_a_launcher_starts_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run on 127.0.0.1 with N ranks and
+    hands its own flags through; under a launcher (WORLD_SIZE set) it must not."""
+    import argparse
+    import importlib
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd):
+        seen["cmd"] = cmd
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    args = argparse.Namespace(gpus=4, steps=7, warmup=3, batch=16, no_cpu_baseline=True, no_proof=False)
+    assert bench.relaunch_under_launcher(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail[:6] == ["--gpus", "4", "--steps", "7", "--warmup", "3"] and "--no-cpu-baseline" in tail and "--no-proof" not in tail
