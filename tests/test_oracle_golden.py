@@ -1,19 +1,26 @@
 """CPU: pins the Python oracle against every golden vector the reference holds for this path
  and re-derives the constants both the oracle and the HIP code hard-wire."""
 import hashlib
+import json
+import os
 
 from oracle import bn254 as b
 from oracle import pairing as pr
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = json.load(open(os.path.join(GOLDEN, "reference_vectors.json")))        # extracted from the reference's sources (golden/make_reference_vectors.py)
+PUB = json.load(open(os.path.join(GOLDEN, "published_vectors.json")))
+
 
 def test_g3_mockprover_third_challenge():
     # [REF zkevm-circuits/src/super_circuit.rs:729]
-    assert b.mock_prover_challenge(3) == 0x207A52BA34E1ED068BE1E33B0BC39C8EDE030835F549FE5C0DBE91DCE97D17D2
+    assert REF["G3_mockprover_third_challenge"]["ref"] == "zkevm-circuits/src/super_circuit.rs:729"
+    assert b.mock_prover_challenge(3) == int(REF["G3_mockprover_third_challenge"]["value"], 16) == 0x207A52BA34E1ED068BE1E33B0BC39C8EDE030835F549FE5C0DBE91DCE97D17D2
 
 
 def test_g4_fq_modulus_minus_two_word():
     # [REF zkevm-circuits/src/ecc_circuit/test.rs:208]  y = p - 2 is -2 mod p, i.e. -(G.y)
-    assert b.P_MOD - 2 == 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD45
+    assert b.P_MOD - 2 == int(REF["G4_fq_modulus_minus_two"]["value"], 16) == 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD45
     assert b.g1_add(b.G1_GEN, (1, b.P_MOD - 2)) is None
     assert not b.g1_is_on_curve((2, 3))
     assert not b.g1_is_on_curve((b.P_MOD + 1, b.P_MOD + 2))
@@ -23,6 +30,7 @@ def test_g5_ecadd_ecmul_precompile_vectors():
     # [REF bus-mapping/src/evm/opcodes/callop.rs:883-917]
     two_g = (0x030644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD3,
              0x15ED738C0E0A7C92E7845F96B2AE9C0A68A6A449E3538FC7FF3EBF7A5A18A2C4)
+    assert two_g == (int(REF["G5_two_G"]["x"], 16), int(REF["G5_two_G"]["y"], 16)) and REF["G5_two_G"]["occurrences"] == 2     # ecAdd and ecMul
     assert b.g1_add(b.G1_GEN, b.G1_GEN) == two_g
     assert b.g1_mul(b.G1_GEN, 2) == two_g
     assert b.g1_is_on_curve(two_g)
@@ -36,6 +44,7 @@ def test_g6_ecpairing_precompile_vector():
               "2fe02e47887507adf0ff1743cbac6ba291e66f59be6bd763950bb16041a0a85e", "2bd368e28381e8eccb5fa81fc26cf3f048eea9abfdd85d7ed3ab3698d63e4f90",
               "22606845ff186793914e03e21df544c34ffe2f2f3504de8a79d9159eca2d98d9", "1fb19bb476f6b9e44e2a32234da8212f61cd63919354bc06aef31e3cfaff3ebc",
               "2c0f001f52110ccfe69108924926e45f0b0c868df0e7bde1fe16d3242dc715f6", "2cf44499d5d27bb186308b7af7af02ac5bc9eeb6a3d147c186b21fb1b76e18da"]
+    assert pushed == REF["G6_ecpairing_pushed_words"]["words"]
     ws = [int(x, 16) for x in reversed(pushed)]
     pairs = []
     for i in range(2):
@@ -134,7 +143,7 @@ def test_chacha20_block_rfc7539_vector():
     """RFC 7539 section 2.3.2 known-answer test for the block function behind zk_fr_random."""
     key = bytes(range(32))
     blk = b.chacha20_block(key, 1 | (0x09000000 << 32), 0x4A000000)
-    assert blk.hex() == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
-                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert blk.hex() == PUB["chacha20_block_rfc7539_2_3_2"]["keystream_block"] == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                                                                                "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
     vals = b.fr_random_chacha(key, 7, 0, 4)
     assert len(set(vals)) == 4 and all(0 <= v < b.R_MOD for v in vals)
