@@ -336,6 +336,9 @@ size_t zk_transcript_proof(const zk_transcript* t, const void** data);
 /* host-only hashes behind them: Keccak-256 and the Poseidon permutation (5 x 32 B Montgomery Fr)   */
 int zk_host_keccak256(const void* data, size_t len, void* out32);
 int zk_host_poseidon_permute(void* state5_fr32);
+/* the same generator at width 3 (R_F = 8, R_P = 57): the permutation under the reference's Poseidon code hash; its value on
+ * (0, 0, 0) is POSEIDON_CODE_HASH_EMPTY (eth-types/src/lib.rs:278), which is what pins the constant generation          */
+int zk_host_poseidon_permute_width3(void* state3_fr32);
 typedef struct zk_transcript_vtable {
     int (*common_point)(void* user, const void* affine64);
     int (*common_scalar)(void* user, const void* fr32);

@@ -46,6 +46,10 @@ out["G6_ecpairing_pushed_words"] = {"words": words, "ref": f"{callop}:{text.coun
                                     "pins": "Fq2 / Fq12 tower, G2, the ate pairing: two pairs whose product is one (words are PUSHed last-first)"}
 m, ln = find("eth-types/src/lib.rs", r'Hash::from_str\("0x(c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470)"\)')
 out["keccak256_empty"] = {"value": m.group(1), "ref": f"eth-types/src/lib.rs:{ln}", "pins": "Keccak-256 (the EVM transcript's hash)"}
+m, ln = find("eth-types/src/lib.rs", r'Hash::from_str\("0x(2098f5fb9e239eab3ceac3f27b81e481dc3124d55ffed523a839ee8446b64864)"\)')
+out["G7_poseidon_code_hash_empty"] = {"value": m.group(1), "ref": f"eth-types/src/lib.rs:{ln}",
+                                      "pins": "the Poseidon constant generation (Grain LFSR, Cauchy MDS) and round schedule: the value is permute(0, 0, 0)[0] at T = 3, R_F = 8, "
+                                              "R_P = 57 -- the transcript's POSEIDON_SPEC is the same generator at T = 5, R_P = 60"}
 with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")

@@ -38,6 +38,20 @@ def test_keccak256():
         assert z.binding.host_keccak256(data) == hashes.keccak256(data)
 
 
+def test_poseidon_generator_is_pinned_by_the_reference():
+    """POSEIDON_CODE_HASH_EMPTY [REF eth-types/src/lib.rs:278] = first word of the width-3 permutation of (0, 0, 0): a vector the
+    reference itself holds, reproduced by the oracle's and by the product's constant generation."""
+    v = _golden("reference_vectors.json")["G7_poseidon_code_hash_empty"]
+    assert v["ref"] == "eth-types/src/lib.rs:278"
+    want = int(v["value"], 16)
+    assert hashes.poseidon_spec(3, 8, 57).permute([0, 0, 0])[0] == want
+    got = z.binding.host_poseidon_permute_width3(cref.to_mont([0, 0, 0]))
+    assert int(cref.from_mont(got)[0]) == want
+    rng = random.Random(17)
+    st = [rng.randrange(b.R_MOD) for _ in range(3)]
+    assert [int(x) for x in cref.from_mont(z.binding.host_poseidon_permute_width3(cref.to_mont(st)))] == hashes.poseidon_spec(3, 8, 57).permute(st)
+
+
 def test_poseidon_permutation():
     kat = _golden("published_vectors.json")["poseidonperm_x5_254_5"]
     assert kat["input"] == [0, 1, 2, 3, 4] and [int(v, 16) for v in kat["output"]] == POSEIDON_KAT

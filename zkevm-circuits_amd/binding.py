@@ -226,6 +226,15 @@ def host_poseidon_permute(state_mont: np.ndarray) -> np.ndarray:
     return st
 
 
+def host_poseidon_permute_width3(state_mont: np.ndarray) -> np.ndarray:
+    """(3, 4) u64 Montgomery Fr in and out: the same generator at T 3, R_F 8, R_P 57 (the reference's Poseidon code hash width)"""
+    st = np.ascontiguousarray(state_mont, dtype=np.uint64).reshape(3, 4).copy()
+    rc = lib().zk_host_poseidon_permute_width3(_host_ptr(st))
+    if rc != 0:
+        raise ZkError(f"zk_host_poseidon_permute_width3 failed with status {rc}")
+    return st
+
+
 _TR_IN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 _TR_OUT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 

@@ -61,8 +61,13 @@ inline void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
 }
 
 // ------------------------------------------------------------------------------------ Poseidon
-struct PoseidonSpec {
-    static constexpr int T = 5, RATE = 4, R_F = 8, R_P = 60;
+// One parameter set (x^5 over BN254 Fr): round constants and Cauchy MDS matrix from the Grain LFSR, the plain round schedule.
+// Two instances are in use: <5, 8, 60> = POSEIDON_SPEC, the transcript's permutation; <3, 8, 57> = the width of the reference's
+// Poseidon code hash, whose value for empty code (`POSEIDON_CODE_HASH_EMPTY`, eth-types/src/lib.rs:278) is permute(0, 0, 0)[0] --
+// a vector held by the reference that pins this generator.
+template <int T_, int R_F_, int R_P_>
+struct PoseidonPerm {
+    static constexpr int T = T_, RATE = T_ - 1, R_F = R_F_, R_P = R_P_;
     std::vector<F4> constants;      // [(R_F + R_P)][T]
     F4 mds[T][T];
 
@@ -99,7 +104,7 @@ struct PoseidonSpec {
         for (int i = 3; i >= 0; --i) { if (v.l[i] < M[i]) return true; if (v.l[i] > M[i]) return false; }
         return false;
     }
-    PoseidonSpec() {
+    PoseidonPerm() {
         Grain g;
         g.init(254, T, R_F, R_P);
         constants.resize((size_t)(R_F + R_P) * T);
@@ -114,7 +119,7 @@ struct PoseidonSpec {
         for (int i = 0; i < T; ++i)
             for (int j = 0; j < T; ++j) mds[i][j] = fr_inv(fr_add(xs[i], ys[j]));  // Cauchy matrix
     }
-    static const PoseidonSpec& get() { static const PoseidonSpec spec; return spec; }
+    static const PoseidonPerm& get() { static const PoseidonPerm spec; return spec; }
 
     static F4 pow5(const F4& v) { const F4 v2 = fr_mul(v, v); return fr_mul(fr_mul(v2, v2), v); }
     void permute(F4 s[T]) const {
@@ -133,6 +138,9 @@ struct PoseidonSpec {
         }
     }
 };
+
+using PoseidonSpec = PoseidonPerm<5, 8, 60>;
+using PoseidonWidth3 = PoseidonPerm<3, 8, 57>;
 
 // snark-verifier util::hash::Poseidon: `update` buffers; `squeeze` absorbs RATE elements per
 // permutation (a short chunk -- or an extra empty one after an exact multiple -- gets the padding

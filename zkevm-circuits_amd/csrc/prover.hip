@@ -1633,6 +1633,14 @@ int zk_host_poseidon_permute(void* state5_fr32) {
     memcpy(state5_fr32, st, sizeof st);
     return ZK_OK;
 }
+int zk_host_poseidon_permute_width3(void* state3_fr32) {
+    if (!state3_fr32) return ZK_ERR_INVALID_ARG;
+    F4 st[host::PoseidonWidth3::T];
+    memcpy(st, state3_fr32, sizeof st);
+    host::PoseidonWidth3::get().permute(st);
+    memcpy(state3_fr32, st, sizeof st);
+    return ZK_OK;
+}
 
 // One-shot create_proof: every advice column is known up front (no column depends on a challenge,
 // or the caller derived them already); runs the phases back to back.
