@@ -122,6 +122,10 @@ def test_pairing_golden_g6_and_bilinearity():
     assert _check([(Pa, Qb), (b.g1_neg(b.g1_mul(b.G1_GEN, a_ * b_ % R)), pr.G2_GEN), (None, pr.G2_GEN)])
     assert not _check([(Pa, Qb), (b.g1_neg(b.g1_mul(b.G1_GEN, (a_ * b_ + 1) % R)), pr.G2_GEN)])
     assert _check([])
+    # the reference's own valid case [REF zkevm-circuits/src/ecc_circuit/test.rs:239-266]: alpha = 0x102030, beta = 0x413121
+    alpha, beta = 0x102030, 0x413121
+    p_neg, q_b, s_ab = b.g1_neg(b.g1_mul(b.G1_GEN, alpha)), pr.ec_mul(pr.G2_GEN, beta), b.g1_mul(b.G1_GEN, alpha * beta)
+    assert _check([(p_neg, q_b), (s_ab, pr.G2_GEN)]) and not _check([(b.g1_neg(p_neg), q_b), (s_ab, pr.G2_GEN)])
 
 
 def test_accumulate_decide_and_limbs():

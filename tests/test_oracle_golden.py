@@ -147,3 +147,17 @@ def test_chacha20_block_rfc7539_vector():
                                                                                 "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
     vals = b.fr_random_chacha(key, 7, 0, 4)
     assert len(set(vals)) == 4 and all(0 <= v < b.R_MOD for v in vals)
+
+
+def test_reference_pairing_case_alpha_beta():
+    """The reference's own valid ecPairing case [REF zkevm-circuits/src/ecc_circuit/test.rs:239-266]: alpha = 0x102030, beta = 0x413121,
+    e(-alpha G1, beta G2) * e(alpha beta G1, G2) = 1 -- for the oracle's pairing and for the product's host pairing
+    (csrc/host_pairing.hpp behind zk_host_pairing_check)."""
+    import numpy as np
+
+    alpha, beta = 0x102030, 0x413121
+    p_neg = b.g1_neg(b.g1_mul(b.G1_GEN, alpha))
+    q = pr.ec_mul(pr.G2_GEN, beta)
+    s = b.g1_mul(b.G1_GEN, alpha * beta % b.R_MOD)
+    assert pr.pairing_check([(p_neg, q), (s, pr.G2_GEN)])
+    assert not pr.pairing_check([(b.g1_neg(p_neg), q), (s, pr.G2_GEN)])            # the reference's "invalid" variants break the relation
