@@ -297,3 +297,22 @@ def test_accumulation_chain_stays_within_bounds(h):
         assert same(from_xyzz(acc_l), acc)
         if acc is not None and i > 0:
             check_stored_invariant(acc_l)
+
+
+def test_exceptional_cases_inside_a_chain(h):
+    """doublings (q = the accumulated point) and cancellations (q = its inverse) met by lazily reduced accumulators in the middle of a
+    chain: the k p test of the mixed addition sees differences 8p + (u2 - x1) with every multiple of p that the bounds allow"""
+    for seed in range(6):
+        rng = random.Random(500 + seed)
+        pts = points(rng, 4)
+        acc_l, acc = xyzz_limbs(None, rng), None
+        for i in range(60):
+            r = rng.random()
+            q = acc if (acc is not None and r < 0.1) else o.g1_neg(acc) if (acc is not None and r < 0.2) else pts[rng.randrange(len(pts))]
+            out = U36()
+            h.h_madd29(U36(*acc_l), U18(*affine_limbs(q)), out)
+            acc_l, acc = list(out), o.g1_add(acc, q)
+            assert same(from_xyzz(acc_l), acc), (seed, i)
+            # a lazily reduced representation of the same point goes into the next step
+            if acc is not None and rng.random() < 0.5:
+                acc_l = xyzz_limbs(acc, rng)
