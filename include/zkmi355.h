@@ -52,7 +52,15 @@ void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_last_error(const zk_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream);
+/* Waits for EVERYTHING this context has enqueued: the library runs on six HIP streams (main, copy, auxiliary transforms,
+ * three MSM side streams) and zk_ctx_sync joins all of them, not only the main one -- entry points that return host data
+ * (commitments, proofs, downloads) are complete when they return; asynchronous ones (zk_ntt, zk_vec_*, zk_coeff_to_coset ...)
+ * are complete after zk_ctx_sync.  A caller-supplied main stream (zk_ctx_set_stream) is synchronised as well. */
 int zk_ctx_sync(zk_ctx* ctx);
+/* Diagnostics for the contract above: the number of library streams with work still in flight (0 after zk_ctx_sync), and
+ * a delay of about `usec` microseconds on one stream (role 0 main, 1 copy, 2 auxiliary, 3..5 MSM side streams). */
+int zk_ctx_streams_busy(zk_ctx* ctx, int* busy);
+int zk_ctx_debug_delay(zk_ctx* ctx, int role, uint32_t usec);
 int zk_buf_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr);
 int zk_buf_free(zk_ctx* ctx, void* d_ptr);
 /* Page-locked host memory for witness columns: uploads from it run at PCIe speed and overlap with

@@ -57,7 +57,9 @@ extern "C" {
     // ---- context
     pub fn zk_ctx_create(device: c_int, out: *mut *mut zk_ctx) -> c_int;
     pub fn zk_ctx_destroy(ctx: *mut zk_ctx);
+    /// joins every stream of the library (main, copy, auxiliary, MSM side streams)
     pub fn zk_ctx_sync(ctx: *mut zk_ctx) -> c_int;
+    pub fn zk_ctx_streams_busy(ctx: *mut zk_ctx, busy: *mut c_int) -> c_int;
     pub fn zk_last_error(ctx: *const zk_ctx) -> *const c_char;
 
     // ---- ParamsKZG

@@ -46,10 +46,14 @@ pub mod cpu {
 /// `torch.distributed`-style launchers set it from LOCAL_RANK).
 struct Gpu {
     ctx: *mut ffi::zk_ctx,
-    /// SRS handles by `k`: `ParamsKZG::downsize` yields a new `params` value, uploaded on first use
-    srs: HashMap<u32, *mut ffi::zk_srs>,
-    /// device-side keys by the address of the `VerifyingKey` they were generated with
-    keys: HashMap<usize, *mut ffi::zk_pk>,
+    /// SRS handles by (`k`, the raw bytes of `g[1] = s·G`): `ParamsKZG::downsize` yields a new `params` value, uploaded on
+    /// first use; two setups of the same size with different secrets (tests do that) are different entries
+    srs: HashMap<(u32, [u8; 64]), *mut ffi::zk_srs>,
+    /// device-side keys by `vk.transcript_repr()` — a hash of the pinned verifying key, so it survives every move of the
+    /// `ProvingKey` (upstream callers return it by value and park it in a map [REF prover/src/common/prover/utils.rs:55-59]);
+    /// the address of a `VerifyingKey` does not, and a freed address may be reused by another circuit's key.
+    /// Two `ProvingKey`s with the same repr (same circuit, same params) share one device key, which is what they describe.
+    keys: HashMap<[u8; 32], *mut ffi::zk_pk>,
 }
 unsafe impl Send for Gpu {}
 
@@ -82,14 +86,18 @@ fn check(g: &Gpu, rc: i32, what: &str) -> Result<(), Error> {
 impl Gpu {
     fn srs(&mut self, params: &ParamsKZG<Bn256>) -> Result<*mut ffi::zk_srs, Error> {
         let k = params.k();
-        if let Some(s) = self.srs.get(&k) {
+        let (g, gl) = (&params.g, &params.g_lagrange); // pub(crate) fields of ParamsKZG: Vec<G1Affine>, n each, in-memory form = ABI form
+        let mut tag = [0u8; 64];
+        // G1Affine is two 32-byte Montgomery-form coordinates in memory (the ABI's form): g[1] identifies the secret
+        tag.copy_from_slice(unsafe { std::slice::from_raw_parts(&g[1.min(g.len() - 1)] as *const G1Affine as *const u8, 64) });
+        let key = (k, tag);
+        if let Some(s) = self.srs.get(&key) {
             return Ok(*s);
         }
-        let (g, gl) = (&params.g, &params.g_lagrange); // pub(crate) fields of ParamsKZG: Vec<G1Affine>, n each, in-memory form = ABI form
         let mut out = std::ptr::null_mut();
         let rc = unsafe { ffi::zk_srs_create(self.ctx, k, g.as_ptr() as *const c_void, gl.as_ptr() as *const c_void, &mut out) };
         check(self, rc, "zk_srs_create")?;
-        self.srs.insert(k, out);
+        self.srs.insert(key, out);
         Ok(out)
     }
 }
@@ -98,7 +106,7 @@ impl Gpu {
 /// `keygen_pk2(params, circuit)` [REF prover/src/common/prover/utils.rs:55]: upstream keygen produces
 /// the `ProvingKey` the rest of the Rust world expects (vk, cs, fixed / permutation data); the same
 /// fixed and sigma columns go to the device as key blob v3, and the device-side key is remembered
-/// under the vk's address.  `vk.transcript_repr()` — the value pinned at
+/// under `vk.transcript_repr()` (move-stable: the `ProvingKey` is returned by value and moved again by the caller).  `vk.transcript_repr()` — the value pinned at
 /// [REF zkevm-circuits/src/super_circuit/test.rs:70-85] — is installed so that proofs absorb exactly
 /// what upstream `verify_proof` absorbs.
 pub fn keygen_pk2<ConcreteCircuit>(params: &ParamsKZG<Bn256>, circuit: &ConcreteCircuit) -> Result<plonk::ProvingKey<G1Affine>, Error>
@@ -146,10 +154,37 @@ fn register_key(params: &ParamsKZG<Bn256>, pk: &plonk::ProvingKey<G1Affine>) -> 
         let want: Vec<G1Affine> = vk.fixed_commitments().iter().chain(vk.permutation().commitments().iter()).cloned().collect();
         assert_eq!(coms, want, "zkmi355: device keygen disagrees with upstream keygen_vk");
     }
-    if let Some(old) = g.keys.insert(vk as *const _ as usize, dpk) {
-        unsafe { ffi::zk_pk_destroy(g.ctx, old) };
+    if let Some(old) = g.keys.insert(key_of(vk), dpk) {
+        unsafe { ffi::zk_pk_destroy(g.ctx, old) }; // the same circuit keyed again (e.g. after `clear_pks`): the newer device key wins
     }
     Ok(())
+}
+
+/// Registry key of a verifying key: the canonical bytes of `vk.transcript_repr()`.
+fn key_of(vk: &VerifyingKey<G1Affine>) -> [u8; 32] {
+    use ff::PrimeField;
+    let repr = vk.transcript_repr().to_repr();
+    let mut out = [0u8; 32];
+    out.copy_from_slice(repr.as_ref());
+    out
+}
+
+/// Releases the device-side key of `pk` (its fixed / sigma columns and coset cache — tens of GiB at k = 20).  Upstream's
+/// `ProvingKey` has no hook for this; callers that drop keys (`Prover::clear_pks` [REF prover/src/common/prover/utils.rs:49-60])
+/// call it next to the drop.  Dropping without it only leaks device memory until `release_all_keys`.
+pub fn release_key(pk: &plonk::ProvingKey<G1Affine>) {
+    let mut g = gpu().lock().unwrap();
+    if let Some(dpk) = g.keys.remove(&key_of(pk.get_vk())) {
+        unsafe { ffi::zk_pk_destroy(g.ctx, dpk) };
+    }
+}
+/// Releases every device-side key (what `clear_pks` means for the device).
+pub fn release_all_keys() {
+    let mut g = gpu().lock().unwrap();
+    let ctx = g.ctx;
+    for (_, dpk) in g.keys.drain() {
+        unsafe { ffi::zk_pk_destroy(ctx, dpk) };
+    }
 }
 
 // ---------------------------------------------------------------------------------------- prover
@@ -245,7 +280,7 @@ where
     let n = params.n() as usize;
     let usable = n - (cs.blinding_factors() + 1);
     let mut g = gpu().lock().unwrap();
-    let dpk = *g.keys.get(&(vk as *const _ as usize)).ok_or_else(|| {
+    let dpk = *g.keys.get(&key_of(vk)).ok_or_else(|| {
         log::error!("zkmi355: this ProvingKey was not produced by zkmi355::keygen_pk / keygen_pk2");
         Error::Synthesis
     })?;

@@ -193,3 +193,38 @@ fn cpu_and_gpu_provers_are_interchangeable() {
             .expect("accepted");
     }
 }
+
+/// The reference returns the `ProvingKey` by value and parks it in a map before proving
+/// [REF prover/src/common/prover/utils.rs:49-60]: the device-side key must be found after any number of moves
+/// (the registry is keyed by `vk.transcript_repr()`, not by an address), and two circuits must never see each other's key.
+#[test]
+fn proving_key_survives_moves_between_keygen_and_create_proof() {
+    use std::collections::BTreeMap;
+    let k = 10;
+    let params = ParamsKZG::<Bn256>::unsafe_setup_with_s(k, Fr::from(1234u64));
+    let mut pk_map: BTreeMap<String, halo2_proofs::plonk::ProvingKey<G1Affine>> = BTreeMap::new();
+    for rows in [100usize, 60] {
+        let circuit = TestCircuit { rows };
+        let pk = zkmi355::keygen_pk2(&params, &circuit).unwrap(); // returned by value ...
+        let boxed = Box::new(pk); // ... moved to the heap ...
+        pk_map.insert(format!("layer{rows}"), *boxed); // ... and into the map, as `Prover::pk_map` does
+    }
+    for rows in [60usize, 100] {
+        let circuit = TestCircuit { rows };
+        let public = {
+            let i = circuit.rows - 1;
+            Fr::from((i % 8) as u64).square() * Fr::from(((i + 3) % 8) as u64).square()
+        };
+        let pk = &pk_map[&format!("layer{rows}")];
+        let mut transcript = Blake2bWrite::<_, G1Affine, Challenge255<_>>::init(vec![]);
+        zkmi355::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _, _>(&params, pk, &[circuit.clone()], &[&[&[public]]], XorShiftRng::from_seed([1u8; 16]), &mut transcript)
+            .expect("the device key is found after the moves");
+        let proof = transcript.finalize();
+        let mut read = Blake2bRead::<_, G1Affine, Challenge255<_>>::init(&proof[..]);
+        verify_proof::<KZGCommitmentScheme<Bn256>, VerifierSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, _>(params.verifier_params(), pk.get_vk(), SingleStrategy::new(&params), &[&[&[public]]], &mut read)
+            .expect("accepted");
+    }
+    for (_, pk) in pk_map.iter() {
+        zkmi355::release_key(pk); // what `clear_pks` needs next to its `pk_map.clear()`
+    }
+}

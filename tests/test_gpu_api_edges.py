@@ -162,3 +162,19 @@ def test_profiling_levels_and_byte_accounting(zk, ctx, cref):
     assert ctx.prof_get_bytes("quotient_eval") == (2 + 1) * n * 32          # two distinct (column, rotation) operands + the result
     assert ctx.prof_get_bytes("msm_sort") == 0
     srs.destroy()
+
+
+def test_ctx_sync_joins_every_library_stream(ctx):
+    """zk_ctx_sync is the one fence a Rust / C caller has: it must drain the copy, auxiliary and MSM side
+    streams too, not only the main stream (a bench figure was once 3 % high because it did not)."""
+    ctx.sync()
+    assert ctx.streams_busy() == 0
+    for role in (1, 2, 3, 4, 5):            # copy, aux, three MSM side streams: 30 ms of work each, nothing on the main stream
+        ctx.debug_delay(role, 30000)
+    assert ctx.streams_busy() >= 1           # still in flight (the launches above returned immediately)
+    ctx.sync()
+    assert ctx.streams_busy() == 0
+    ctx.debug_delay(0, 2000)
+    ctx.debug_delay(4, 20000)
+    ctx.sync()
+    assert ctx.streams_busy() == 0

@@ -639,3 +639,24 @@ def test_degree_classes_leave_the_proof_unchanged(ctx, cref, srs8):
     assert proofs["1"] == proofs["0"]
     want = pp.create_proof(circ, pp.Srs(k, S_SECRET), adv, [], cref.from_mont(rep.reshape(1, 4))[0], bytes(range(16)), "shplonk")
     assert proofs["1"] == want
+
+
+def test_coset_cache_running_out_of_memory_falls_back_uncached(ctx, cref, srs8):
+    """the per-key coset cache must not fail a proof when the device has no room for another slot --
+    it freezes (slots that exist stay in use) and the remaining key columns are transformed per proof.  The
+    shortage is injected after 3 slots (ZK_PK_COSET_CACHE_FAIL_AFTER); two proofs on the same key, both equal
+    to the proof of an unconstrained key, and the shared budget is returned when the key goes."""
+    circ, adv, inst = build_circuit(7, seed=21, wide=True)
+    seed = bytes(range(16))
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    want = _session_proof(ctx, pk, adv, inst, seed, "shplonk")
+    assert _session_proof(ctx, pk, adv, inst, seed, "shplonk") == want          # second proof: every slot cached
+    pk.destroy()
+    os.environ["ZK_PK_COSET_CACHE_FAIL_AFTER"] = "3"
+    try:
+        pk = ctx.pk_create(srs8[circ.k], circ.blob())
+        assert _session_proof(ctx, pk, adv, inst, seed, "shplonk") == want
+        assert _session_proof(ctx, pk, adv, inst, seed, "shplonk") == want
+        pk.destroy()
+    finally:
+        os.environ.pop("ZK_PK_COSET_CACHE_FAIL_AFTER", None)

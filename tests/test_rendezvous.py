@@ -28,7 +28,7 @@ def test_unique_id_reaches_every_rank_without_torch(tmp_path):
     assert [g[0] for g in got] == [0, 1, 2]
     assert all(g[1] == bytes(range(128)) for g in got)
     assert not any(g[2] for g in got), "the rendezvous must not pull torch into a prover rank"
-    assert os.path.getsize(path) == 128
+    assert os.path.getsize(path) == 136          # the id + rank 0's pid (stale-file check)
 
 
 def test_missing_id_times_out(tmp_path):
@@ -37,3 +37,27 @@ def test_missing_id_times_out(tmp_path):
 
     with pytest.raises(TimeoutError):
         rendezvous.exchange_unique_id(lambda: b"", 1, 2, str(tmp_path / "never"), timeout=0.2)
+
+
+def test_stale_id_of_a_finished_launch_is_refused(tmp_path):
+    """a shell-loop launcher reuses port and parent pid, so the id file of the previous launch may still be
+    there when the ranks of the next one start.  A peer must not take it: its writer (rank 0 of the old launch) is gone."""
+    import struct
+    import subprocess
+    import pytest
+    from zkevm_circuits_amd import rendezvous
+
+    path = str(tmp_path / "uid")
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    with open(path, "wb") as f:
+        f.write(bytes(128) + struct.pack("<Q", dead.pid))           # left behind by a rank 0 that has exited
+    with pytest.raises(TimeoutError):
+        rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
+    with open(path, "wb") as f:
+        f.write(bytes(128))                                          # the old format (no pid) is not accepted either
+    with pytest.raises(TimeoutError):
+        rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
+    # rank 0 of the new launch replaces whatever is there
+    assert rendezvous.exchange_unique_id(lambda: bytes(range(128)), 0, 2, path) == bytes(range(128))
+    assert rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=5.0) == bytes(range(128))

@@ -361,7 +361,16 @@ class Context:
             self.h = None
 
     def sync(self):
+        """joins every stream of the library (main, copy, auxiliary, MSM side streams), not only the main one"""
         self._ck(lib().zk_ctx_sync(self.h))
+
+    def streams_busy(self) -> int:
+        n = ctypes.c_int()
+        self._ck(lib().zk_ctx_streams_busy(self.h, ctypes.byref(n)))
+        return n.value
+
+    def debug_delay(self, role: int, usec: int):
+        self._ck(lib().zk_ctx_debug_delay(self.h, ctypes.c_int(role), ctypes.c_uint32(usec)))
 
     def device_info(self):
         name = ctypes.create_string_buffer(256)

@@ -140,9 +140,52 @@ int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream) {
     }
     return ZK_OK;
 }
+// Joins EVERY stream the library runs on (main, copy, auxiliary transforms, the MSM side streams), the main stream last:
+// when it returns nothing this context enqueued is still in flight, whichever stream an entry point put it on.
 int zk_ctx_sync(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
+    std::set<hipStream_t> side(ctx->owned_streams.begin(), ctx->owned_streams.end());
+    for (hipStream_t st : {ctx->stream2, ctx->stream2b, ctx->stream2c, ctx->stream_aux, ctx->stream_copy}) if (st) side.insert(st);
+    side.erase(ctx->stream);
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // work the side streams wait for is behind events recorded here
+    for (hipStream_t st : side) ZK_HIP(ctx, hipStreamSynchronize(st));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+// How many of the library's streams still have work in flight (hipStreamQuery): 0 right after zk_ctx_sync.
+int zk_ctx_streams_busy(zk_ctx* ctx, int* busy) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, busy, "null pointer");
+    std::set<hipStream_t> all(ctx->owned_streams.begin(), ctx->owned_streams.end());
+    for (hipStream_t st : {ctx->stream, ctx->stream2, ctx->stream2b, ctx->stream2c, ctx->stream_aux, ctx->stream_copy}) if (st) all.insert(st);
+    int n = 0;
+    for (hipStream_t st : all) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); ++n; }
+        else if (e != hipSuccess) { (void)hipGetLastError(); return ctx->fail(ZK_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e)); }
+    }
+    *busy = n;
+    return ZK_OK;
+}
+// Diagnostic: keeps one of the library's streams busy for about `usec` microseconds (a one-wave kernel spinning on the
+// device clock).  role: 0 main, 1 copy, 2 auxiliary transforms, 3..5 the MSM side streams (created on demand).
+__global__ void k_debug_delay(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int zk_ctx_debug_delay(zk_ctx* ctx, int role, uint32_t usec) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, role >= 0 && role <= 5 && usec <= 2000000u, "role 0..5, at most two seconds");
+    hipStream_t* slot[6] = {&ctx->stream, &ctx->stream_copy, &ctx->stream_aux, &ctx->stream2, &ctx->stream2b, &ctx->stream2c};
+    if (!*slot[role]) {
+        ZK_HIP(ctx, hipStreamCreateWithFlags(slot[role], hipStreamNonBlocking));
+        ctx->owned_streams.push_back(*slot[role]);
+    }
+    int rate_khz = 100000;                    // wall_clock64 ticks at the constant 100 MHz reference clock on gfx9
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, ctx->device);
+    if (rate_khz <= 0) rate_khz = 100000;
+    hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, *slot[role], (uint64_t)usec * (uint64_t)rate_khz / 1000ull);
+    ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
 int zk_buf_alloc(zk_ctx* ctx, size_t bytes, void** d_ptr) {

@@ -108,11 +108,15 @@ int comm_allgather_host(zk_ctx* ctx, const void* h_send, size_t bytes, void* h_r
 int comm_alltoall_dev(zk_ctx* ctx, const void* d_send, size_t bytes_per_peer, void* d_recv) {
     if (!ctx->comm) return ctx->fail(ZK_ERR_INVALID_ARG, "no communicator: call zk_comm_init first");
     ZK_NCCL(ctx, rccl().GroupStart());
-    for (uint32_t p = 0; p < ctx->comm_world; ++p) {
-        ZK_NCCL(ctx, rccl().Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, (int)p, (ncclComm_t)ctx->comm, ctx->stream));
-        ZK_NCCL(ctx, rccl().Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, (int)p, (ncclComm_t)ctx->comm, ctx->stream));
+    // inside an open group nothing may return early: the first error is remembered, the group is always closed
+    ncclResult_t first = ncclSuccess;
+    for (uint32_t p = 0; p < ctx->comm_world && first == ncclSuccess; ++p) {
+        first = rccl().Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, (int)p, (ncclComm_t)ctx->comm, ctx->stream);
+        if (first == ncclSuccess) first = rccl().Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, (int)p, (ncclComm_t)ctx->comm, ctx->stream);
     }
-    ZK_NCCL(ctx, rccl().GroupEnd());
+    const ncclResult_t closed = rccl().GroupEnd();
+    ZK_NCCL(ctx, first);
+    ZK_NCCL(ctx, closed);
     return ZK_OK;
 }
 void comm_release(zk_ctx* ctx) {

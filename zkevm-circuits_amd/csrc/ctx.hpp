@@ -38,6 +38,7 @@ struct zk_ctx {
     hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
     std::vector<hipStream_t> owned_streams;      // every stream zk_ctx_create made (roles may share one; 'd' entries of the layout have no role at all)
     hipEvent_t ev_p1[3] = {nullptr, nullptr, nullptr}, ev_p2[3] = {nullptr, nullptr, nullptr};
+    std::map<uint64_t, std::vector<uint64_t>> msm_graph_keys;   // the full key behind every hash in msm_graphs (compared on a hit)
     std::map<uint64_t, void*> msm_graphs;   // hipGraphExec_t per (column kind, pipeline, sizes, buffer addresses): msm_batch_merged's graph mode
     uint32_t msm_blinded_tail = 0;          // set by the prover around a commit batch: this many rows at the end of the hint-1 (small-valued) columns
                                             // hold field-sized blinding values; they are committed apart (k_msm_tails) so that the main MSM sees small values only
@@ -60,6 +61,7 @@ struct zk_ctx {
     // recycled by exact size; every user is ordered on `stream`, so reuse needs no extra fence.
     std::map<size_t, std::vector<void*>> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)96 << 30;
+    size_t coset_cache_bytes = 0;        // device memory held by the coset caches of every proving key alive on this context (prover.hip)
     void* pool_get(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (!bytes) bytes = 256;

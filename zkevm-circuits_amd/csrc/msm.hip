@@ -1254,6 +1254,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const auto t_batch0 = std::chrono::steady_clock::now();
     bool any_narrow = false;
     if (d_table_n && pl_n && narrow) for (size_t i = 0; i < count; ++i) any_narrow |= narrow[i] == 1;
+    // the per-window path indexes n * W entries with 32 bits; decided BEFORE the blinded tails are split off: a column that
+    // takes the merged path over all n rows must not have its tail committed a second time by k_msm_tails
+    if (any_narrow && (uint64_t)n * pl_n->W >= (1ull << 32)) any_narrow = false;
     // blinded tails of the hint-1 columns (zk_ctx::msm_blinded_tail): committed by k_msm_tails, the main MSM stops in front of them
     const uint32_t tail_rows = (any_narrow && ctx->msm_blinded_tail && (size_t)ctx->msm_blinded_tail + 1024 <= n && ctx->msm_blinded_tail <= 256) ? ctx->msm_blinded_tail : 0u;
     const uint64_t n_narrow = (uint64_t)n - tail_rows;
@@ -1265,7 +1268,6 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const size_t dig_words = (size_t)(n_pad * pn.W + 1) / 2 + 4;
     const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * pn.W;
     const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
-    if (any_narrow && (uint64_t)n * pn.W >= (1ull << 32)) any_narrow = false;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
     const uint32_t red_blocks_N = ((pn.B + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
@@ -1509,9 +1511,25 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                                (uint64_t)(uintptr_t)ws, (uint64_t)words, (uint64_t)(uintptr_t)bk[p], (uint64_t)(uintptr_t)desc, (uint64_t)staged_scatter, (uint64_t)range_bits, n_narrow})
                 key = (key ^ v) * 1099511628211ull;
             hipGraphExec_t exec = nullptr;
+            const std::vector<uint64_t> key_tuple = {(uint64_t)kind, (uint64_t)p, (uint64_t)n, (uint64_t)pl.c, (uint64_t)pn.c, (uint64_t)(uintptr_t)d_table, (uint64_t)(uintptr_t)d_table_n, (uint64_t)tab_stride,
+                                                     (uint64_t)(uintptr_t)ws, (uint64_t)words, (uint64_t)(uintptr_t)bk[p], (uint64_t)(uintptr_t)desc, (uint64_t)staged_scatter, (uint64_t)range_bits, n_narrow};
             auto found = ctx->msm_graphs.find(key);
+            if (found != ctx->msm_graphs.end() && ctx->msm_graph_keys[key] != key_tuple) {       // a 64-bit hash collision: the stale graph goes
+                (void)hipGraphExecDestroy((hipGraphExec_t)found->second);
+                ctx->msm_graphs.erase(found);
+                found = ctx->msm_graphs.end();
+            }
             if (found != ctx->msm_graphs.end()) exec = (hipGraphExec_t)found->second;
             else {
+                // graphs bake scratch addresses in; when the scratch arenas were reallocated since, the old entries can never be
+                // hit again: the cache is emptied when it grows past what one key / size mix needs
+                if (ctx->msm_graphs.size() >= 48) {
+                    ZK_HIP(ctx, hipStreamSynchronize(P[0]));
+                    for (int q = 1; q < GP; ++q) ZK_HIP(ctx, hipStreamSynchronize(P[q]));
+                    for (auto& kv : ctx->msm_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
+                    ctx->msm_graphs.clear();
+                    ctx->msm_graph_keys.clear();
+                }
                 hipGraph_t graph = nullptr;
                 bool ok = hipStreamBeginCapture(P[p], hipStreamCaptureModeRelaxed) == hipSuccess;
                 int rc_e = ok ? enqueue(kind, p) : ZK_ERR_HIP;
@@ -1520,6 +1538,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 if (graph) (void)hipGraphDestroy(graph);
                 if (!ok) { (void)hipGetLastError(); ctx->msm_graph_broken = true; fallback = true; break; }
                 ctx->msm_graphs[key] = (void*)exec;
+                ctx->msm_graph_keys[key] = key_tuple;
             }
             if (hipGraphLaunch(exec, P[p]) != hipSuccess) { (void)hipGetLastError(); ctx->msm_graph_broken = true; fallback = true; break; }
             if (stage && it + 1 < count) { ctx->stream = P[(it + 1) % GP]; int rc = stage(stage_user, it + 1); if (rc) return rc; }

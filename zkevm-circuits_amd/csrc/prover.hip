@@ -153,7 +153,8 @@ struct zk_pk {
     // part_cache[r][column reference].  Plain device allocations owned by the key (a slot appears
     // only once it is filled).  A key serves one proving thread at a time, as its context does.
     mutable std::vector<std::unordered_map<uint32_t, DevBuf>> part_cache;
-    mutable int part_cache_state = -1;       // -1 undecided, 0 off, 1 on
+    mutable int part_cache_state = -1;       // -1 undecided, 0 off, 1 on, 2 frozen (slots that exist are used, no new ones: an allocation failed)
+    mutable size_t part_cache_bytes = 0;     // what this key's slots hold of the context's shared budget (zk_ctx::coset_cache_bytes)
     std::vector<G1Affine> fixed_com, sigma_com;
     F4 vk_repr;                              // vk.transcript_repr: the default, or what zk_pk_set_transcript_repr installed
     std::vector<Query> inst_q;               // instance queries (verifier side; carried for the vk)
@@ -420,6 +421,7 @@ extern "C" {
 
 void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk) {
     if (ctx) (void)zk_ctx_sync(ctx);
+    if (ctx && pk) ctx->coset_cache_bytes -= std::min(ctx->coset_cache_bytes, pk->part_cache_bytes);     // its slots go back to the shared budget
     delete pk;
 }
 
@@ -1206,12 +1208,21 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         if (pk->part_cache_state < 0) {       // decide once: do the key's own cosets fit the budget?
             size_t key_cols = 0;
             for (uint32_t ref : refs) key_cols += of_key(ref);
+            // The budget is shared by every key alive on this context (a Prover keeps the chunk, compression and aggregation
+            // keys resident together): the cap (ZK_PK_COSET_CACHE_GB, default 96) or a third of the device, whichever is
+            // smaller, less what other keys already hold -- and it must fit what the device has free right now, counting
+            // the session pool's parked blocks as free (pool_trim gives them back).
             const char* env = getenv("ZK_PK_COSET_CACHE_GB");
-            const double budget = (env ? atof(env) : 96.0) * (double)(1ull << 30);
-            pk->part_cache_state = (double)key_cols * nparts * n * 32.0 <= budget ? 1 : 0;
+            double budget = (env ? atof(env) : 96.0) * (double)(1ull << 30);
+            budget = std::min(budget, (double)ctx->prop.totalGlobalMem / 3.0) - (double)ctx->coset_cache_bytes;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            const double need = (double)key_cols * nparts * n * 32.0;
+            const double session = (double)refs.size() * n * 32.0 + (double)((size_t)n << E) * 32.0 * 2.0;       // this proof's own coset buffers and h
+            pk->part_cache_state = (need <= budget && need + session <= (double)free_b + (double)ctx->pool_bytes) ? 1 : 0;
             if (pk->part_cache_state) pk->part_cache.resize(nparts);
         }
-        const bool cache_on = pk->part_cache_state == 1;
+        const bool cache_on = pk->part_cache_state >= 1;
         std::vector<DevBuf> part_buf(refs.size());
         for (size_t i = 0; i < refs.size(); ++i)
             if (!(cache_on && of_key(refs[i])) && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
@@ -1251,8 +1262,23 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 if (cached) {
                     auto it = pk->part_cache[r_].find(refs[i]);
                     if (it != pk->part_cache[r_].end()) { part_of[refs[i]] = it->second.p; continue; }   // computed by an earlier proof
-                    if (!fresh.alloc_unpooled(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");   // lives as long as the key, not the session's pool
-                    dst = fresh.p;
+                    // a slot lives as long as the key, not the session's pool.  When the device has no room for it: give the
+                    // pool's parked blocks back and retry; if that fails too, freeze the cache (existing slots stay in use) and
+                    // compute this coset into a session buffer like any witness column's -- the proof goes on, uncached.
+                    const char* env_fail = getenv("ZK_PK_COSET_CACHE_FAIL_AFTER");        // test knob: the device "runs out" after this many slots
+                    const bool inject = env_fail && pk->part_cache_bytes / (n * 32) + fresh_slots.size() >= (size_t)atoll(env_fail);
+                    bool got = pk->part_cache_state == 1 && !inject && fresh.alloc_unpooled(n * 32);
+                    if (!got && pk->part_cache_state == 1) {
+                        (void)hipGetLastError();
+                        ctx->pool_trim();
+                        got = !inject && fresh.alloc_unpooled(n * 32);
+                        if (!got) { (void)hipGetLastError(); pk->part_cache_state = 2; }
+                    }
+                    if (got) dst = fresh.p;
+                    else {
+                        if (!part_buf[i].p && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                        dst = part_buf[i].p;
+                    }
                 }
                 part_of[refs[i]] = dst;
                 if (refs[i] == colref(CT_SPECIAL, SP_X)) PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n));   // X on the coset: g * omega^i
@@ -1262,10 +1288,14 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                     bat_src.push_back(cf);
                     bat_dst.push_back(dst);
                 }
-                if (cached) fresh_slots.emplace_back(refs[i], std::move(fresh));
+                if (cached && fresh.p) fresh_slots.emplace_back(refs[i], std::move(fresh));
             }
             PK_TRY(zk_coeff_to_coset_batch(ctx, bat_src.data(), k, &g, bat_dst.data(), bat_src.size()));
-            for (auto& fs : fresh_slots) pk->part_cache[r_][fs.first] = std::move(fs.second);
+            for (auto& fs : fresh_slots) {
+                pk->part_cache_bytes += n * 32;
+                ctx->coset_cache_bytes += n * 32;
+                pk->part_cache[r_][fs.first] = std::move(fs.second);
+            }
             trace.mark("  quotient: cosets of the columns");
             Fr gn = g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);

@@ -5,27 +5,45 @@ mpirun wrappers, a shell loop) needs one out-of-band step -- rank 0's 128-byte i
 file does it.  Keeping torch out matters for measurements: torch bundles its own HIP runtime, and with two runtimes in
 one process the witness uploads of a proving session ran 30 % slower (tools/upload_order.py)."""
 import os
+def _alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    return True
+
+
 def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float = 120.0) -> bytes:
     """Rank 0's 128-byte RCCL id to every rank through a file: the whole out-of-band channel a launcher needs to
-    provide (no torch, no MPI).  `make_id` is only called on rank 0.  The file appears atomically (write + rename)."""
+    provide (no torch, no MPI).  `make_id` is only called on rank 0.  The file appears atomically (write + rename)
+    and carries the id followed by rank 0's pid: a file whose writer is gone is a leftover of an earlier launch
+    (same shell, same port, or a fixed ZK_COMM_ID_FILE) and is never accepted -- rank 0 also removes whatever is
+    at `path` before it even creates its id, and `retire_unique_id` removes the file once every rank has joined."""
+    import struct
     import time
 
     if rank == 0:
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
         uid = make_id()
         assert len(uid) == 128
         if world > 1:
             tmp = f"{path}.{os.getpid()}.tmp"
             with open(tmp, "wb") as f:
-                f.write(uid)
+                f.write(uid + struct.pack("<Q", os.getpid()))
             os.replace(tmp, path)
         return uid
     deadline = time.monotonic() + timeout
     while True:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+                blob = f.read()
+            if len(blob) == 136 and _alive(struct.unpack("<Q", blob[128:])[0]):
+                return blob[:128]
         except FileNotFoundError:
             pass
         if time.monotonic() > deadline:
@@ -33,11 +51,25 @@ def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float
         time.sleep(0.01)
 
 
+def retire_unique_id(ctx, rank: int, world: int, path: str):
+    """After zk_comm_init: every rank has read the id (first barrier), rank 0 removes the file, and nobody leaves
+    before it is gone (second barrier) -- a second rendezvous in the same launch cannot pick up this one's id."""
+    if world <= 1:
+        return
+    comm_barrier(ctx, rank, world)
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
+    comm_barrier(ctx, rank, world)
+
+
 def comm_init_from_env(ctx, timeout: float = 120.0):
     """Joins the library's RCCL communicator from the launcher's environment alone (RANK, WORLD_SIZE, MASTER_PORT): rank 0
-    creates the unique id and publishes it in a file named after the launch (the launcher's pid is the parent of every
-    rank, so a file left behind by an earlier launch on the same port cannot be mistaken for this one's).  No torch in
-    the process: a prover rank holds the library and nothing else."""
+    creates the unique id and publishes it in a file named after the launch (port + the launcher's pid, the parent of
+    every rank); stale files are refused (see exchange_unique_id) and the file is removed once all ranks have joined.
+    No torch in the process: a prover rank holds the library and nothing else."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
         # one node, rendezvous over loopback: RCCL's bootstrap must not go looking for another interface (the containers this runs
@@ -47,6 +79,7 @@ def comm_init_from_env(ctx, timeout: float = 120.0):
         os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}")
     uid = exchange_unique_id(ctx.comm_unique_id, rank, world, path, timeout)
     ctx.comm_init(uid, rank, world)
+    retire_unique_id(ctx, rank, world, path)
     return rank, world
 
 
