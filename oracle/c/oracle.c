@@ -300,6 +300,36 @@ API void orc_srs_powers(const fe *s, aff *g, size_t n) {
     free(pw);
 }
 
+/* SURVEY 8(d) config 2, second base set: n pseudo-random affine points with no known discrete logarithms --
+ * x_i = splitmix64 stream (seed, index) reduced below p, incremented until x^3 + 3 is a square; y = the root
+ * (x^3 + 3)^((p + 1) / 4) (p = 3 mod 4), negated when the stream's next bit says so.  Montgomery form, as every
+ * base at the ABI.  Each point depends only on (seed, i): the loop is parallel and reproducible. */
+API void orc_hash_to_curve_points(uint64_t seed, aff *o, size_t n) {
+    fe three_c = {{3, 0, 0, 0}}, one_c = {{1, 0, 0, 0}}, three, one;
+    fe_mul(&three, &three_c, &FQ.r2, &FQ); fe_mul(&one, &one_c, &FQ.r2, &FQ);
+    uint64_t e[4];                              /* (p + 1) / 4 */
+    { unsigned __int128 c = 1; uint64_t t[4]; for (int i = 0; i < 4; ++i) { c += FQ.m[i]; t[i] = (uint64_t)c; c >>= 64; }
+      for (int i = 0; i < 4; ++i) e[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : 0); }
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t st = seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(i + 1));
+        fe x, rhs, y, chk;
+        for (int w = 0; w < 4; ++w) x.l[w] = splitmix64(&st);
+        x.l[3] &= 0x3fffffffffffffffULL;
+        while (ge_mod(x.l, FQ.m)) sub_mod_raw(x.l, FQ.m);       /* raw limbs taken as the Montgomery image: still uniform */
+        const int flip = (int)(splitmix64(&st) & 1);
+        for (;;) {
+            fe_sqr(&rhs, &x, &FQ); fe_mul(&rhs, &rhs, &x, &FQ); fe_add(&rhs, &rhs, &three, &FQ);
+            fe_pow(&y, &rhs, e, &FQ);
+            fe_sqr(&chk, &y, &FQ);
+            if (fe_eq(&chk, &rhs) && !fe_is_zero(&y)) break;
+            fe_add(&x, &x, &one, &FQ);
+        }
+        if (flip) fe_neg(&y, &y, &FQ);
+        o[i].x = x; o[i].y = y;
+    }
+}
+
 /* arithmetic::multiexp_serial restated: unsigned c-bit windows, (256/c)+1 segments from the
  * top with c doublings between, buckets folded by running sum.  Scalars in Montgomery form are
  * first taken to canonical bytes (to_repr) exactly as the reference does. */

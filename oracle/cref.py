@@ -233,6 +233,13 @@ def srs_powers(s: int, n: int) -> np.ndarray:
     return g
 
 
+def hash_to_curve_points(seed: int, n: int) -> np.ndarray:
+    """n pseudo-random affine G1 points (unknown discrete logs): SURVEY 8(d) config 2's second base set"""
+    g = np.empty((n, 8), dtype=np.uint64)
+    lib().orc_hash_to_curve_points(ctypes.c_uint64(seed), _p(g), ctypes.c_size_t(n))
+    return g
+
+
 def best_multiexp(scalars: np.ndarray, bases: np.ndarray, threads: int = 0) -> np.ndarray:
     """halo2 best_multiexp restated; returns (8,) affine Montgomery."""
     if threads <= 0:

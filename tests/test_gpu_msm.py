@@ -292,3 +292,52 @@ def test_skewed_columns_stay_fast_on_both_paths(ctx, cref):
             assert all(np.array_equal(g_, want) for g_ in got), (name, hint)
             assert dt < 4 * t_dense + 2e-3, f"{name} on path {hint}: {dt * 1e3:.2f} ms per MSM against {t_dense * 1e3:.2f} ms for dense scalars"
     srs.destroy()
+
+
+def _config2_scalar_sets(cref, n):
+    """SURVEY 8(d) config 2 verbatim: (a) uniform in [0, r), (b) witness-like 60 % zero / 30 % below 2^16 / 10 % uniform,
+    (c) all-ones, (d) all-(r - 1)."""
+    uni = cref.rand_fr_stream(0xA11CE, n)
+    rng = np.random.default_rng(0xC0FFEE)
+    kind = rng.random(n)
+    small = cref.to_mont([int(v) for v in rng.integers(0, 1 << 16, size=n)])
+    wit = cref.rand_fr_stream(0xB0B, n)
+    wit[kind < 0.9] = small[kind < 0.9]
+    wit[kind < 0.6] = 0
+    return {"uniform": uni, "witness_like": wit, "all_ones": np.tile(cref.fr_const(1)[0], (n, 1)), "all_r_minus_1": np.tile(cref.fr_const(R - 1)[0], (n, 1))}
+
+
+def test_msm_2_20_random_bases_all_config2_scalar_sets(ctx, cref):
+    """BASELINE configs[1] at full size against the oracle's best_multiexp, on bases with NO structure
+    (hash-to-curve, seed 0xC0FFEE -- the closed forms over s^i G cannot see a wrong table entry or a
+    mis-sorted bucket that happens to cancel): zk_msm_g1 over raw device bases, and zk_commit_batch over an
+    SRS made of the same points (plan c = 20, 13 windows, scaled top window; the witness-like set also takes
+    the per-window path through the hint) -- every result bit-exact."""
+    k, n = 20, 1 << 20
+    P = cref.hash_to_curve_points(0xC0FFEE, n)
+    P2 = cref.hash_to_curve_points(0xC0FFEE + 1, n)
+    sets = _config2_scalar_sets(cref, n)
+    want = {name: cref.best_multiexp(S, P) for name, S in sets.items()}
+    want2 = {name: cref.best_multiexp(S, P2) for name, S in sets.items()}
+    srs = ctx.srs_create(k, P, P2)            # g = P, g_lagrange = P2: an SRS container over arbitrary points
+    dP = ctx.to_device(P)
+    dev = {name: ctx.to_device(S) for name, S in sets.items()}
+    names = list(sets)
+    for name in names:                        # the table-free path over raw bases
+        assert np.array_equal(ctx.msm(dev[name].ptr, dP.ptr, n), want[name]), f"zk_msm_g1 {name}"
+    got = ctx.commit_batch(srs, [dev[nm].ptr for nm in names], n)
+    for i, nm in enumerate(names):
+        assert np.array_equal(got[i], want[nm]), f"zk_commit_batch (coefficient basis) {nm}"
+    got = ctx.commit_batch(srs, [dev[nm].ptr for nm in names], n, lagrange=True)
+    for i, nm in enumerate(names):
+        assert np.array_equal(got[i], want2[nm]), f"zk_commit_batch (Lagrange basis) {nm}"
+    # hinted: the small-valued sets on the per-window path, the runs of equal scalars on the sliced sort
+    hints = [0, 1, 2, 2]
+    got = ctx.commit_batch(srs, [dev[nm].ptr for nm in names], n, lagrange=True, narrow=hints)
+    for i, nm in enumerate(names):
+        assert np.array_equal(got[i], want2[nm]), f"zk_commit_batch_hint({hints[i]}) {nm}"
+    # a lone commitment (the short-latency reduction) agrees with the pipelined one
+    assert np.array_equal(ctx.commit(srs, dev["uniform"], n), want["uniform"])
+    for b in list(dev.values()) + [dP]:
+        b.free()
+    srs.destroy()

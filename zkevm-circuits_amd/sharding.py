@@ -15,8 +15,25 @@ import ctypes
 from typing import Dict, List, Sequence
 
 import numpy as np
-import torch
-import torch.distributed as dist
+
+
+class _LazyModule:
+    """torch is plumbing for the callback-based exchanges only; the pure index helpers below (ntt_shard_input ...) and
+    the in-library RCCL path must work in a prover rank that never loads torch (its bundled HIP runtime next to the
+    library's slows the witness uploads, tools/upload_order.py) -- so it is imported on first use, not at import."""
+
+    def __init__(self, name):
+        self._name, self._mod = name, None
+
+    def __getattr__(self, attr):
+        if self._mod is None:
+            import importlib
+            self._mod = importlib.import_module(self._name)
+        return getattr(self._mod, attr)
+
+
+torch = _LazyModule("torch")
+dist = _LazyModule("torch.distributed")
 
 from . import binding
 
