@@ -111,6 +111,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_pipe) (void)hipEventDestroy(ctx->ev_pipe);
+    for (auto e : ctx->ev_sorted) if (e) (void)hipEventDestroy(e);
     for (auto& kv : ctx->msm_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
     for (auto e : ctx->ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_p2) if (e) (void)hipEventDestroy(e);

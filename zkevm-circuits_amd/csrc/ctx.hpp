@@ -43,6 +43,7 @@ struct zk_ctx {
     uint32_t msm_blinded_tail = 0;          // set by the prover around a commit batch: this many rows at the end of the hint-1 (small-valued) columns
                                             // hold field-sized blinding values; they are committed apart (k_msm_tails) so that the main MSM sees small values only
     bool msm_graph_broken = false;          // a capture or replay failed once: the plain launch path from then on
+    hipEvent_t ev_sorted[2] = {nullptr, nullptr};   // sort-ahead of msm_batch_merged: workspace copy i holds a finished sort
     hipEvent_t ev_pipe = nullptr;        // joins the second MSM pipeline of small batches (msm_batch_merged)
     // copy stream: host -> device staging of the next column under the current MSM (api.hip)
     hipStream_t stream_copy = nullptr;
@@ -50,6 +51,21 @@ struct zk_ctx {
     // auxiliary compute stream: transforms of freshly uploaded columns run beside the commitment pipeline
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_aux = nullptr;
+    // The auxiliary stream is created with the highest stream priority (ZK_AUX_PRIORITY=0: default priority): what runs on it
+    // -- transforms of freshly uploaded columns, the sort-ahead of the next MSM -- is short, memory- or latency-bound work that
+    // must find workgroup slots WHILE a chip-filling accumulation kernel of the main stream is in flight; at equal priority the
+    // dispatcher hands every freed slot to the kernel with thousands of workgroups pending and the side work starves.
+    bool ensure_aux() {
+        if (stream_aux) return true;
+        int least = 0, greatest = 0;
+        const char* e = getenv("ZK_AUX_PRIORITY");
+        const bool prio = !(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+        hipError_t rc = prio ? hipStreamCreateWithPriority(&stream_aux, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&stream_aux, hipStreamNonBlocking);
+        if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamCreateWithFlags(&stream_aux, hipStreamNonBlocking); }
+        if (rc != hipSuccess) { stream_aux = nullptr; return false; }
+        if (!ev_aux && hipEventCreateWithFlags(&ev_aux, hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
     // RCCL communicator of this rank (comm.hip; opaque here so that rccl.h stays out of the other translation units)
     void* comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;

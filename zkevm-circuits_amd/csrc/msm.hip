@@ -562,6 +562,8 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint
 // counts[b] = sum of its slices) and bins every bucket by size (descending order of size -> a wave
 // works on buckets of equal length; big ones start first).
 constexpr uint32_t SIZE_BINS = 256;
+constexpr uint32_t TASK_DONE_MAX = 16384;  // multi-task buckets at positions below this are combined inside k_msm_buckets (done-counters behind nmulti + 68)
+constexpr uint32_t TASK_INLINE_MAX = 8;    // ... when they were split into at most this many tasks
 constexpr uint32_t TASK_CAP = 48;       // points per task, see "skew-proof work split" below
 __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ slice_counts, uint32_t nbuckets, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_hist) {
@@ -609,6 +611,9 @@ __global__ void __launch_bounds__(64) k_size_bins_scan(uint32_t* size_hist, cons
     for (int k = 0; k < 4; ++k) {
         const uint32_t bin = SIZE_BINS - 1 - (4 * lane + k);
         if (bin == cap) size_hist[SIZE_BINS] = run;          // M: buckets with more than `cap` points come first
+        // H: the "heavy" ones among them, split into more than TASK_INLINE_MAX tasks (or of unknown size: the last bin); they
+        // come first of all.  Buckets at positions [H, M) below TASK_DONE_MAX are put together inside k_msm_buckets.
+        if (bin == min(TASK_INLINE_MAX * cap, SIZE_BINS - 2)) size_hist[SIZE_BINS + 2] = run;
         size_hist[bin] = run;
         run += c[k];
     }
@@ -704,6 +709,17 @@ __global__ void __launch_bounds__(256) k_msm_fold_windows(const G1Xyzz29* __rest
     if (q == 0 && b < B) stg29(folded + b, add29pt(sh[threadIdx.x], sh[threadIdx.x + 1]));
 }
 
+__device__ __forceinline__ G1Xyzz29 shfl_down_pt(const G1Xyzz29& p, int off) {
+    G1Xyzz29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = __shfl_down(p.x.l[i], off);
+        r.y.l[i] = __shfl_down(p.y.l[i], off);
+        r.zz.l[i] = __shfl_down(p.zz.l[i], off);
+        r.zzz.l[i] = __shfl_down(p.zzz.l[i], off);
+    }
+    return r;
+}
 __device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ idx, uint32_t lo, uint32_t hi) {
     G1Xyzz29 acc = identity29();
     for (uint32_t j = lo; j < hi; ++j) {
@@ -726,23 +742,76 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
                                                      int log_b, uint64_t tab_stride, const uint32_t* __restrict__ wflag) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
     const uint32_t M = *nmulti;
     const uint32_t Tm = M ? toff[M] : 0u;
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < Tm) {
-        uint32_t lo_p = 0, hi_p = M;             // toff[lo_p] <= v < toff[hi_p]
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    // what this lane accumulates: points idx[lo, hi) into bucket b -- ONE call site of the accumulation loop for every kind of
+    // lane (2100 instructions of mixed addition: a second inlined copy competes for the instruction cache two CUs share)
+    enum : uint32_t { NONE, ORDINARY, HEAVY, IN_WAVE, STRADDLE };
+    // the task behind virtual index v: position of its bucket, first task of the bucket, task count -- recomputed after the loop
+    // instead of kept alive across it (four registers that would push the kernel past 128 VGPRs = from four waves per SIMD to three)
+    auto task_of = [&](uint32_t& lo_p, uint32_t& t0, uint32_t& nt) {
+        uint32_t hi_p = M;                       // toff[lo_p] <= v < toff[hi_p]
+        lo_p = 0;
         while (hi_p - lo_p > 1) {
             const uint32_t mid = (lo_p + hi_p) >> 1;
             if (toff[mid] <= v) lo_p = mid; else hi_p = mid;
         }
-        const uint32_t b = order[lo_p], chunk = v - toff[lo_p], cap = nmulti[1];
-        const uint32_t lo = offsets[b] + chunk * cap, hi = min(lo + cap, offsets[b + 1]);
-        stg29(partial + v, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi));
-        return;
+        t0 = toff[lo_p];
+        nt = toff[lo_p + 1] - t0;
+    };
+    uint32_t b = 0, lo = 0, hi = 0;
+    bool ordinary = false;
+    if (v < Tm) {
+        uint32_t lo_p, t0, nt;
+        task_of(lo_p, t0, nt);
+        const uint32_t cap = nmulti[1];
+        b = order[lo_p];
+        lo = offsets[b] + (v - t0) * cap;
+        hi = min(lo + cap, offsets[b + 1]);
+    } else {
+        const uint32_t p = M + (v - Tm);
+        if (p < nbuckets) {
+            b = order[p];
+            if (!(tab_stride && wflag[b >> log_b] == 0u)) { ordinary = true; lo = offsets[b]; hi = offsets[b + 1]; }      // empty window: the fold skips it, nothing to write
+        }
     }
-    const uint32_t p = M + (v - Tm);
-    if (p >= nbuckets) return;
-    const uint32_t b = order[p];
-    if (tab_stride && wflag[b >> log_b] == 0u) return;      // empty window: the fold skips it, nothing to write
-    stg29(buckets + b, accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, offsets[b], offsets[b + 1]));
+    G1Xyzz29 acc = accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi);
+    if (ordinary) stg29(buckets + b, acc);
+    if ((v & ~63u) >= Tm) return;                // a wave of ordinary buckets only: done
+    // ---- a wave that holds tasks of split buckets (they come first).  A bucket that was split into a handful of tasks -- the
+    // 12 000 buckets of the scaled top window of a uniform column (three tasks each), the tail of the size distribution -- is put
+    // together HERE: its tasks are consecutive lanes, so a segmented shuffle reduction at the end of the wave (two or three
+    // additions) finishes it without touching memory.  Only a bucket whose tasks straddle a wave boundary (~3 %) goes through
+    // memory: partials published with a device-scope fence, a counter, and the last arriver adds them up (the fence writes the
+    // XCD's dirty L2 lines back: 37 000 of them per launch cost 40 us, profiles/r03_combine.md; a thousand do not).  The
+    // combination kernels behind this one keep the "heavy" buckets -- more than TASK_INLINE_MAX tasks: selector / boolean
+    // columns -- and exit at once when there are none.
+    uint32_t mode = NONE, lo_p = 0, t0 = 0, nt = 0, chunk = 0;
+    if (v < Tm) {
+        task_of(lo_p, t0, nt);
+        chunk = v - t0;
+        mode = (lo_p < nmulti[2] || lo_p >= TASK_DONE_MAX) ? HEAVY : ((lane >= chunk && lane - chunk + nt <= 64u) ? IN_WAVE : STRADDLE);
+    }
+    if (mode == HEAVY) stg29(partial + v, acc);
+    if (mode == STRADDLE) {
+        uint32_t* done = const_cast<uint32_t*>(nmulti) + 4 + 64;            // zeroed with the size histogram before every MSM
+        stg29(partial + v, acc);
+        __threadfence();
+        if (atomicAdd(done + lo_p, 1u) + 1u == nt) {
+            __threadfence();                     // acquire at device scope: the other tasks may have run behind another XCD's L2
+            for (uint32_t i = 0; i < nt; ++i)
+                if (i != chunk) acc = add29pt(acc, ldg29(partial + t0 + i));
+            stg29(buckets + b, acc);
+        }
+    }
+    const uint32_t key = mode == IN_WAVE ? lo_p : 0xFFFFFF00u + lane;      // other lanes: unique keys, never merged
+    for (int off = 1; off < (int)TASK_INLINE_MAX; off <<= 1) {
+        const uint32_t okey = __shfl_down(key, off);
+        const bool take = lane + off < 64u && okey == key;
+        if (!__ballot(take)) break;              // segments are contiguous: no pair at this distance, none further
+        const G1Xyzz29 other = shfl_down_pt(acc, off);
+        if (take) acc = add29pt(acc, other);
+    }
+    if (mode == IN_WAVE && chunk == 0) stg29(buckets + b, acc);
 }
 // ---- combining the task partials of multi-task buckets ---------------------------------------------
 // 1. k_msm_combine_wave: one lane per task partial; lanes of a wave that belong to the same bucket
@@ -759,60 +828,65 @@ __device__ __forceinline__ uint32_t bucket_of_task(const uint32_t* __restrict__ 
     }
     return lo_p;
 }
-__device__ __forceinline__ G1Xyzz29 shfl_down_pt(const G1Xyzz29& p, int off) {
-    G1Xyzz29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        r.x.l[i] = __shfl_down(p.x.l[i], off);
-        r.y.l[i] = __shfl_down(p.y.l[i], off);
-        r.zz.l[i] = __shfl_down(p.zz.l[i], off);
-        r.zzz.l[i] = __shfl_down(p.zzz.l[i], off);
-    }
-    return r;
-}
 __global__ void __launch_bounds__(256) k_msm_combine_wave(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ toff, G1Xyzz29* __restrict__ partial) {
-    const uint32_t M = *nmulti;
+    // A fixed, small grid walks the tasks with a grid stride: a workgroup that finds nothing to do still costs the
+    // dispatcher ~15 ns, and a grid sized for the worst case (one lane per possible task: 3000+ workgroups) took 48 us per
+    // MSM to establish that a uniform column has NO multi-task bucket at all (profiles/r03_combine_grid.md).
+    const uint32_t M = nmulti[0], H = nmulti[2];
+    if (H == 0 && M <= TASK_DONE_MAX) return;          // every split bucket was put together inside k_msm_buckets: the common case costs one load
     const uint32_t Tm = M ? toff[M] : 0u;
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
-    if ((v & ~63u) >= Tm) return;                // whole wave past the last task
-    const bool live = v < Tm;
-    uint32_t key = 0xFFFFFF00u + lane;           // dead lanes: unique keys, never merged
-    G1Xyzz29 acc = identity29();
-    if (live) { key = bucket_of_task(toff, M, v); acc = ldg29(partial + v); }
-    const uint32_t prev = __shfl_up(key, 1);
-    bool merged = false;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t okey = __shfl_down(key, off);
-        const bool take = lane + off < 64u && okey == key;
-        if (!__ballot(take)) break;              // segments are contiguous: no pair at this distance, none further
-        const G1Xyzz29 other = shfl_down_pt(acc, off);
-        if (take) { acc = add29pt(acc, other); merged = true; }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; (v & ~63u) < Tm; v += gridDim.x * blockDim.x) {      // whole waves stay together
+        const bool live = v < Tm;
+        uint32_t key = 0xFFFFFF00u + lane;           // dead lanes: unique keys, never merged
+        G1Xyzz29 acc = identity29();
+        if (live) {
+            const uint32_t pos = bucket_of_task(toff, M, v);
+            if (pos < H || pos >= TASK_DONE_MAX) { key = pos; acc = ldg29(partial + v); }     // else: combined inside k_msm_buckets
+        }
+        const uint32_t prev = __shfl_up(key, 1);
+        bool merged = false;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t okey = __shfl_down(key, off);
+            const bool take = lane + off < 64u && okey == key;
+            if (!__ballot(take)) break;              // segments are contiguous: no pair at this distance, none further
+            const G1Xyzz29 other = shfl_down_pt(acc, off);
+            if (take) { acc = add29pt(acc, other); merged = true; }
+        }
+        if (live && merged && (lane == 0 || prev != key)) stg29(partial + v, acc);
     }
-    if (live && merged && (lane == 0 || prev != key)) stg29(partial + v, acc);
 }
 // leader slots of a bucket whose tasks are [base, base + cnt): base, then the multiples of 64 inside
 __device__ __forceinline__ uint32_t leader_count(uint32_t base, uint32_t cnt) { return ((base + cnt - 1) >> 6) - (base >> 6) + 1; }
 __device__ __forceinline__ uint32_t leader_slot(uint32_t base, uint32_t i) { return i ? (((base >> 6) + i) << 6) : base; }
 
 constexpr uint32_t COMBINE_SMALL = 32;
+// grid of the two grid-stride combination kernels: enough workgroups to fill the chip when there IS work (a selector column:
+// thousands of task partials), few enough that the no-work case costs a couple of microseconds
+static inline unsigned combine_grid(size_t worst_case_blocks) { return (unsigned)std::min<size_t>(std::max<size_t>(worst_case_blocks, 1), 512); }
 // multi-task buckets with few leaders: one lane each, sequential sum
 __global__ void __launch_bounds__(256) k_msm_combine_small(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks,
                                                            const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial, G1Xyzz29* __restrict__ buckets) {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= *nmulti) return;
-    const uint32_t base = toff[m], cnt = leader_count(base, ntasks[m]);
-    if (cnt > COMBINE_SMALL) return;
-    G1Xyzz29 acc = ldg29(partial + base);
-    for (uint32_t i = 1; i < cnt; ++i) acc = add29pt(acc, ldg29(partial + leader_slot(base, i)));
-    stg29(buckets + order[m], acc);
+    const uint32_t M = nmulti[0], H = nmulti[2];
+    if (H == 0 && M <= TASK_DONE_MAX) return;
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {      // small fixed grid, see k_msm_combine_wave
+        if (m >= H && m < TASK_DONE_MAX) continue;                                                       // combined inside k_msm_buckets
+        const uint32_t base = toff[m], cnt = leader_count(base, ntasks[m]);
+        if (cnt > COMBINE_SMALL) continue;
+        G1Xyzz29 acc = ldg29(partial + base);
+        for (uint32_t i = 1; i < cnt; ++i) acc = add29pt(acc, ldg29(partial + leader_slot(base, i)));
+        stg29(buckets + order[m], acc);
+    }
 }
 // one workgroup per multi-task bucket with many leaders: strided sums + LDS tree
 __global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial,
                                                      G1Xyzz29* __restrict__ buckets) {
     __shared__ G1Xyzz29 sh[256];
-    const uint32_t total = *nmulti;
+    const uint32_t total = nmulti[0], H = nmulti[2];
+    if (H == 0 && total <= TASK_DONE_MAX) return;
     for (uint32_t m = blockIdx.x; m < total; m += gridDim.x) {
+        if (m >= H && m < TASK_DONE_MAX) continue;                                                       // combined inside k_msm_buckets
         const uint32_t p = m, base = toff[p], cnt = leader_count(base, ntasks[p]);
         if (cnt <= COMBINE_SMALL) continue;      // handled by k_msm_combine_small (uniform across the workgroup)
         G1Xyzz29 acc = identity29();
@@ -1025,7 +1099,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     const uint32_t scan_blocks_s = (nb + SCAN_T - 1) / SCAN_T;                    // scan over the [bucket][slice] counters: one bucket per thread
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
-    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + (size_t)n * pl.W;
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + (size_t)n * pl.W;
     const size_t words = head_words + 4 + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
@@ -1035,7 +1109,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
     uint32_t* wflag = nmulti + 4;          // 64 words: W <= 64 windows (c >= 4)
-    uint32_t* offsets = wflag + 64;
+    uint32_t* offsets = wflag + 64 + TASK_DONE_MAX;
     uint32_t* order = offsets + nb + 1;
     uint32_t* ntasks = order + nb;
     uint32_t* toff = ntasks + nb;
@@ -1092,7 +1166,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));   // size_hist + nmulti + wflag
+        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, ctx->stream));   // size_hist + nmulti + wflag
         launch_digits(pl.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
         hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
@@ -1117,10 +1191,10 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     }
     {
         ZkProfScope ps(ctx, "msm_combine");
-        hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
-        hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
+        hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
+        hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nb + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
-        hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
+        hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
                            (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
         ZK_CHECK_LAUNCH(ctx);
     }
@@ -1231,11 +1305,12 @@ static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars
 #undef ZK_PART_CASE
 }
 static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift,
-                                 const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr) {
+                                 const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr, hipStream_t st = nullptr) {
     const size_t lds = scatter_staged_lds(W);
+    if (!st) st = ctx->stream;
 #define ZK_SS_CASE(C) case C: \
         if (!(ctx->msm_attr_set & (1u << C))) { ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_msm_m_scatter_staged<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->msm_attr_set |= 1u << C; } \
-        hipLaunchKernelGGL((k_msm_m_scatter_staged<C>), grid, dim3(1024), lds, ctx->stream, scalars, n, range_bits, hist_off, entries, tab_stride, top_shift, cols, ctr); break;
+        hipLaunchKernelGGL((k_msm_m_scatter_staged<C>), grid, dim3(1024), lds, st, scalars, n, range_bits, hist_off, entries, tab_stride, top_shift, cols, ctr); break;
     switch (c) { ZK_SS_CASE(19) ZK_SS_CASE(20) ZK_SS_CASE(21) ZK_SS_CASE(22) default: return ctx->fail(ZK_ERR_UNSUPPORTED, "staged scatter: window size %d", c); }
 #undef ZK_SS_CASE
     ZK_CHECK_LAUNCH(ctx);
@@ -1266,7 +1341,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t scan_blocks_N = (nbN + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), scan_blocks_sN = (nbN + SCAN_T - 1) / SCAN_T;
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * pn.W + 1) / 2 + 4;
-    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * pn.W;
+    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * pn.W;
     const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
@@ -1305,7 +1380,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t scan_blocks_h = (hist_cnt + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
     // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] | counts[nb] | size_hist[256] nmulti[4] pad[64] | offsets[nb+1] | order[nb] |
     //                ntasks[nb] | toff[nb+1] | block_tot[...] | hist[hist_cnt] | hist_off[hist_cnt + 1] | idx[n W] | (8-B aligned) entries[n W] u64
-    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
     const size_t words = (std::max(head_words + 4 + 2 * max_entries, words_N) + 63) & ~(size_t)63;
     // Below 2^20 points an MSM does not fill the device: its sort / accumulation / combination is a chain of some twenty
     // short launches.  Two such chains then run side by side -- even columns on the context's stream, odd columns on the
@@ -1317,14 +1392,16 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const char* env_graph = getenv("ZK_MSM_GRAPH");
     const bool want_graph = n <= ((size_t)1 << 19) && n >= 1024 && count >= 4 && !ctx->prof_on && !ctx->msm_graph_broken && !(env_graph && atoi(env_graph) == 0);
     constexpr int GP = 4;                     // pipelines of the graph mode: the context's stream and the three side streams
-    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * (want_graph ? GP : npipe));
+    const char* env_sa = getenv("ZK_MSM_SORT_AHEAD");
+    const int ws_copies = want_graph ? GP : ((npipe == 2 || (count >= 2 && env_sa && atoi(env_sa) == 1)) ? 2 : 1);
+    uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * ws_copies);
     if (!ws) return ZK_ERR_OOM;
     uint32_t* slice_counts = ws;
     uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
     uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
-    uint32_t* offsets = nmulti + 4 + 64;
+    uint32_t* offsets = nmulti + 4 + 64 + TASK_DONE_MAX;
     uint32_t* order = offsets + nb + 1;
     uint32_t* ntasks = order + nb;
     uint32_t* toff = ntasks + nb;
@@ -1407,7 +1484,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 uint32_t* size_histN = countsN + nbN;
                 uint32_t* nmultiN = size_histN + SIZE_BINS;
                 uint32_t* wflag = nmultiN + 4;
-                uint32_t* offsetsN = wflag + 64;
+                uint32_t* offsetsN = wflag + 64 + TASK_DONE_MAX;
                 uint32_t* orderN = offsetsN + nbN + 1;
                 uint32_t* ntasksN = orderN + nbN;
                 uint32_t* toffN = ntasksN + nbN;
@@ -1419,7 +1496,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 G1Xyzz29* task_partialN = partialN + red_blocks_N;
                 G1Xyzz29* folded = task_partialN + max_tasks_N;
                 const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
-                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, st));
+                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
                 launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, (const Fr*)nullptr, n_narrow, n_pad, dig, wflag, cols_dev, ctr);
                 hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
                 hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
@@ -1433,10 +1510,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)slice_offN, idxN, (const uint32_t*)wflag, (uint32_t)pn.W);
                 hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, st, d_table_n, (const uint32_t*)offsetsN, (const uint32_t*)idxN,
                                    (const uint32_t*)orderN, (const uint32_t*)toffN, (const uint32_t*)nmultiN, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
-                hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)toffN, task_partialN);
-                hipLaunchKernelGGL(k_msm_combine_small, dim3((nbN + 255) / 256), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks_N + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)toffN, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nbN + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
                                    (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
-                hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
+                hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, st, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
                                    (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
                 // the window flags are still this column's when the fold reads them: the next column of this pipeline comes behind it on the same stream
                 hipLaunchKernelGGL(k_msm_fold_windows, dim3((pn.B + 63) / 64), dim3(256), 0, st, (const G1Xyzz29*)buckets, pn.B, pn.W, folded, (const uint32_t*)wflag);
@@ -1451,7 +1528,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
             uint32_t* size_hist = counts + nb;
             uint32_t* nmulti = size_hist + SIZE_BINS;
-            uint32_t* offsets = nmulti + 4 + 64;
+            uint32_t* offsets = nmulti + 4 + 64 + TASK_DONE_MAX;
             uint32_t* order = offsets + nb + 1;
             uint32_t* ntasks = order + nb;
             uint32_t* toff = ntasks + nb;
@@ -1465,7 +1542,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             G1Xyzz29* partial = buckets + nb;
             G1Xyzz29* task_partial = partial + red_pts;
             const bool bs_it = kind == 1;
-            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, st));
+            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
             launch_partition<false>(pl.c, dim3(nwg), st, (const Fr*)nullptr, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift, cols_dev, ctr);
             hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
@@ -1488,10 +1565,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             if (!bs_it) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, st, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
             hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, d_table, (const uint32_t*)offsets, (const uint32_t*)idx,
                                (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, 0, (uint64_t)0, (const uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
-            hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
+            hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
+            hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nb + 255) / 256)), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
                                (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
-            hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
+            hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, st, (const uint32_t*)nmulti, (const uint32_t*)order,
                                (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
             const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
             hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, st, (const G1Xyzz29*)buckets, nb, partial);
@@ -1576,93 +1653,167 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, mains[0]));
         ZK_HIP(ctx, hipStreamWaitEvent(mains[1], ctx->ev_pipe, 0));
     }
+    // Sort-ahead (one pipeline, >= 2 columns): the sort of MSM it + 1 (recoding, partition, counting sort, task split: a third
+    // of an MSM's time on the main stream, bound by memory and launch latency) runs on the auxiliary stream UNDER the bucket
+    // accumulation of MSM it (bound by integer issue), on the second copy of the sort workspace.  OFF by default
+    // (ZK_MSM_SORT_AHEAD=1 enables): measured in round 3 (profiles/r03_sort_ahead.md) it LOSES 11-15 % -- beside a kernel with
+    // thousands of workgroups pending, the sort's 1024-thread / 104 KiB-LDS workgroups rarely find a CU with room, its dozen
+    // dependent launches stretch from 0.29 to 0.8-1.3 ms, and the accumulation slows by the slots they do get; a
+    // high-priority stream changes nothing.  Kept as a knob because the refactoring it needed (sort / accumulate as separate
+    // steps over workspace slots) is what a future partition-level pipeline would start from.
+    const bool sort_ahead = npipe == 1 && ws_copies == 2;
+    hipStream_t sort_st = nullptr;
+    if (sort_ahead) {
+        if (!ctx->ensure_aux()) return ctx->fail(ZK_ERR_HIP, "could not create the auxiliary stream");
+        sort_st = ctx->stream_aux;
+        for (int i = 0; i < 2; ++i) if (!ctx->ev_sorted[i]) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, mains[0]));          // the sorts start behind everything already enqueued on the context's stream
+        ZK_HIP(ctx, hipStreamWaitEvent(sort_st, ctx->ev_pipe, 0));
+    }
+    // the sort workspace of a slot, merged-window layout (see above) and per-window layout
+    struct WsM { uint32_t *slice_counts, *slice_off, *counts, *size_hist, *nmulti, *offsets, *order, *ntasks, *toff, *block_tot, *block_tot2, *block_tot3, *hist, *hist_off, *idx; uint64_t* entries; };
+    struct WsN { uint32_t *slice_counts, *slice_off, *counts, *size_hist, *nmulti, *wflag, *offsets, *order, *ntasks, *toff, *block_tot, *block_tot2, *idx; uint16_t* dig; };
+    auto ws_merged = [&](int slot) {
+        WsM w;
+        uint32_t* wsb = ws + (size_t)slot * words;
+        w.slice_counts = wsb;
+        w.slice_off = w.slice_counts + (size_t)nb * MSM_SLICES;
+        w.counts = w.slice_off + (size_t)nb * MSM_SLICES + 4;
+        w.size_hist = w.counts + nb;
+        w.nmulti = w.size_hist + SIZE_BINS;
+        w.offsets = w.nmulti + 4 + 64 + TASK_DONE_MAX;
+        w.order = w.offsets + nb + 1;
+        w.ntasks = w.order + nb;
+        w.toff = w.ntasks + nb;
+        w.block_tot = w.toff + nb + 1;
+        w.block_tot2 = w.block_tot + scan_blocks_s;
+        w.block_tot3 = w.block_tot2 + scan_blocks;
+        w.hist = w.block_tot3 + scan_blocks_h;
+        w.hist_off = w.hist + hist_cnt;
+        w.idx = w.hist_off + hist_cnt + 1;
+        w.entries = reinterpret_cast<uint64_t*>(wsb + ((head_words + 3) & ~(size_t)3));
+        return w;
+    };
+    auto ws_narrow = [&](int slot) {
+        WsN w;
+        uint32_t* wsb = ws + (size_t)slot * words;
+        w.slice_counts = wsb;
+        w.slice_off = w.slice_counts + (size_t)nbN * MSM_SLICES;
+        w.counts = w.slice_off + (size_t)nbN * MSM_SLICES + 4;
+        w.size_hist = w.counts + nbN;
+        w.nmulti = w.size_hist + SIZE_BINS;
+        w.wflag = w.nmulti + 4;
+        w.offsets = w.wflag + 64 + TASK_DONE_MAX;
+        w.order = w.offsets + nbN + 1;
+        w.ntasks = w.order + nbN;
+        w.toff = w.ntasks + nbN;
+        w.block_tot = w.toff + nbN + 1;
+        w.block_tot2 = w.block_tot + scan_blocks_sN;
+        w.idx = w.block_tot2 + scan_blocks_N;
+        w.dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
+        return w;
+    };
+    const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
+    auto is_narrow = [&](size_t it) { return any_narrow && narrow[it] == 1; };
+    // ---- the sort of MSM `it` into workspace `slot`, enqueued on `st`
+    auto enqueue_sort = [&](size_t it, int slot, hipStream_t st) -> int {
+        const Fr* d_scalars = d_scalar_ptrs[it];
+        ZkProfScope ps(ctx, "msm_sort", st);
+        if (is_narrow(it)) {
+            // per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with empty windows skipped
+            const WsN w = ws_narrow(slot);
+            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
+            ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+            launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, d_scalars, n_narrow, n_pad, w.dig, w.wflag);
+            hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, w.slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)w.wflag, (uint32_t)pn.W);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbN * MSM_SLICES, w.slice_off, w.block_tot);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot, scan_blocks_sN, w.slice_off, nbN * MSM_SLICES, w.offsets + nbN);
+            hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbN, w.slice_off, (const uint32_t*)w.block_tot, w.offsets, w.counts, w.size_hist);
+            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, w.size_hist, (const uint32_t*)(w.offsets + nbN));
+            hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)w.counts, nbN, w.size_hist, w.order, w.ntasks);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)w.ntasks, nbN, w.toff, w.block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot2, scan_blocks_N, w.toff, nbN, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, nbN, w.toff, (const uint32_t*)w.block_tot2);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)w.slice_off, w.idx, (const uint32_t*)w.wflag, (uint32_t)pn.W);
+            ZK_CHECK_LAUNCH(ctx);
+            ZK_HIP(ctx, hipMemcpyAsync(wflag_it, w.wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            return ZK_OK;
+        }
+        const WsM w = ws_merged(slot);
+        ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+        // 1. partition by the high bucket bits while recoding: histogram, scan, scatter
+        launch_partition<false>(pl.c, dim3(nwg), st, d_scalars, (uint64_t)n, range_bits, w.hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift);
+        ZK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, (const uint32_t*)w.hist, hist_cnt, w.hist_off, w.block_tot3);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot3, scan_blocks_h, w.hist_off, hist_cnt, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, hist_cnt, w.hist_off, (const uint32_t*)w.block_tot3);
+        if (staged_scatter) PK_TRY_MSM(launch_scatter_staged(ctx, pl.c, pl.W, dim3(nwg), d_scalars, (uint64_t)n, range_bits, (const uint32_t*)w.hist_off, w.entries, (uint64_t)tab_stride, pl.top_shift, nullptr, nullptr, st));
+        else launch_partition<true>(pl.c, dim3(nwg), st, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)w.hist_off, w.entries, (uint64_t)tab_stride, pl.top_shift);
+        ZK_CHECK_LAUNCH(ctx);
+        // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
+        //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
+        const bool bs_it = binsort && !(narrow && narrow[it] == 2);       // hint 2: long runs of equal scalars (running products) put whole runs into
+                                                                          // one partition; four slice-workgroups per partition stream them faster than one
+        if (bs_it) {
+            hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins), dim3(1024), 0, st, (const uint64_t*)w.entries, (const uint32_t*)w.hist_off, nwg, range_bits, nb, w.offsets, w.counts, w.size_hist, w.idx);
+            ZK_CHECK_LAUNCH(ctx);
+        } else {
+            hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, st, (const uint64_t*)w.entries, (const uint32_t*)w.hist_off, nwg, range_bits, w.slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nb * MSM_SLICES, w.slice_off, w.block_tot);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot, scan_blocks_s, w.slice_off, nb * MSM_SLICES, w.offsets + nb);
+            hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nb, w.slice_off, (const uint32_t*)w.block_tot, w.offsets, w.counts, w.size_hist);
+        }
+        hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, w.size_hist, (const uint32_t*)(w.offsets + nb));
+        hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, st, (const uint32_t*)w.counts, nb, w.size_hist, w.order, w.ntasks);
+        hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, st, (const uint32_t*)w.ntasks, nb, w.toff, w.block_tot2);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot2, scan_blocks, w.toff, nb, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, st, nb, w.toff, (const uint32_t*)w.block_tot2);
+        ZK_CHECK_LAUNCH(ctx);
+        if (!bs_it) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, st, (const uint64_t*)w.entries, (const uint32_t*)w.hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)w.slice_off, w.idx);
+        ZK_CHECK_LAUNCH(ctx);
+        return ZK_OK;
+    };
     if (stage) { int rc = stage(stage_user, 0); if (rc) return rc; }
+    if (sort_ahead) {
+        // whatever the staging callback made the context's stream wait for (the upload of column 0) the sort stream must see too
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_pipe, mains[0]));
+        ZK_HIP(ctx, hipStreamWaitEvent(sort_st, ctx->ev_pipe, 0));
+        PK_TRY_MSM(enqueue_sort(0, 0, sort_st));
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_sorted[0], sort_st));
+    }
     for (size_t it = 0; it < count; ++it) {
         const int par = (int)(it % 3), pipe = (int)(it % (size_t)npipe);
+        const int slot = sort_ahead ? (int)(it & 1) : pipe;
         hipStream_t side = npipe == 2 ? ((it & 1) ? ctx->stream2b : ctx->stream2) : (par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c);
         ctx->stream = mains[pipe];
-        // this pipeline's copy of the sort workspace (same layout as above)
-        uint32_t* wsb = ws + (size_t)pipe * words;
-        uint32_t* slice_counts = wsb;
-        uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
-        uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
-        uint32_t* size_hist = counts + nb;
-        uint32_t* nmulti = size_hist + SIZE_BINS;
-        uint32_t* offsets = nmulti + 4 + 64;
-        uint32_t* order = offsets + nb + 1;
-        uint32_t* ntasks = order + nb;
-        uint32_t* toff = ntasks + nb;
-        uint32_t* block_tot = toff + nb + 1;
-        uint32_t* block_tot2 = block_tot + scan_blocks_s;
-        uint32_t* block_tot3 = block_tot2 + scan_blocks;
-        uint32_t* hist = block_tot3 + scan_blocks_h;
-        uint32_t* hist_off = hist + hist_cnt;
-        uint32_t* idx = hist_off + hist_cnt + 1;
-        uint64_t* entries = reinterpret_cast<uint64_t*>(wsb + ((head_words + 3) & ~(size_t)3));
-        const Fr* d_scalars = d_scalar_ptrs[it];
         G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
-        G1Xyzz29* partial = buckets + nb;
-        G1Xyzz29* task_partial = partial + red_pts;
+        if (sort_ahead) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[slot], 0));
+        else PK_TRY_MSM(enqueue_sort(it, slot, ctx->stream));
         // reduce(it-3) must be done with this bucket buffer -- but only the accumulation writes it: the sort of this MSM
-        // (a third of its time) runs while that reduction finishes
-        auto wait_buffer = [&]() -> int {
-            if (it >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
-            return ZK_OK;
-        };
-        if (any_narrow && narrow[it] == 1) {
-            // ---- per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with
-            // empty windows skipped, bucket accumulation, fold of the occupied windows, one window reduced
-            uint32_t* slice_countsN = wsb;
-            uint32_t* slice_offN = slice_countsN + (size_t)nbN * MSM_SLICES;
-            uint32_t* countsN = slice_offN + (size_t)nbN * MSM_SLICES + 4;
-            uint32_t* size_histN = countsN + nbN;
-            uint32_t* nmultiN = size_histN + SIZE_BINS;
-            uint32_t* wflag = nmultiN + 4;
-            uint32_t* offsetsN = wflag + 64;
-            uint32_t* orderN = offsetsN + nbN + 1;
-            uint32_t* ntasksN = orderN + nbN;
-            uint32_t* toffN = ntasksN + nbN;
-            uint32_t* block_totN = toffN + nbN + 1;
-            uint32_t* block_tot2N = block_totN + scan_blocks_sN;
-            uint32_t* idxN = block_tot2N + scan_blocks_N;
-            uint16_t* dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
+        // runs while that reduction finishes
+        if (it >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
+        if (is_narrow(it)) {
+            // ---- per-window path: bucket accumulation, fold of the occupied windows, one window reduced
+            const WsN w = ws_narrow(slot);
             G1Xyzz29* partialN = buckets + nbN;
             G1Xyzz29* task_partialN = partialN + red_blocks_N;
             G1Xyzz29* folded = task_partialN + max_tasks_N;
             uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
-            const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
-            {
-                ZkProfScope ps(ctx, "msm_sort");
-                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
-                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, n_narrow, n_pad, dig, wflag);
-                hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
-                ZK_CHECK_LAUNCH(ctx);
-                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
-                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_totN, scan_blocks_sN, slice_offN, nbN * MSM_SLICES, offsetsN + nbN);
-                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_sN), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_countsN, nbN, slice_offN, (const uint32_t*)block_totN, offsetsN, countsN, size_histN);
-                hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_histN, (const uint32_t*)(offsetsN + nbN));
-                hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)countsN, nbN, size_histN, orderN, ntasksN);
-                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasksN, nbN, toffN, block_tot2N);
-                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2N, scan_blocks_N, toffN, nbN, (uint32_t*)nullptr);
-                hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_N), dim3(SCAN_T), 0, ctx->stream, nbN, toffN, (const uint32_t*)block_tot2N);
-                ZK_CHECK_LAUNCH(ctx);
-                hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)slice_offN, idxN, (const uint32_t*)wflag, (uint32_t)pn.W);
-                ZK_CHECK_LAUNCH(ctx);
-            }
-            ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            PK_TRY_MSM(wait_buffer());
             {
                 ZkProfScope ps(ctx, "msm_buckets_narrow");
-                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)offsetsN, (const uint32_t*)idxN,
-                                   (const uint32_t*)orderN, (const uint32_t*)toffN, (const uint32_t*)nmultiN, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag);
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
+                                   (const uint32_t*)w.order, (const uint32_t*)w.toff, (const uint32_t*)w.nmulti, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag_it);
             }
             {
                 ZkProfScope ps(ctx, "msm_combine");
-                hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)toffN, task_partialN);
-                hipLaunchKernelGGL(k_msm_combine_small, dim3((nbN + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
-                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
-                hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmultiN, (const uint32_t*)orderN,
-                                   (const uint32_t*)ntasksN, (const uint32_t*)toffN, (const G1Xyzz29*)task_partialN, buckets);
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.toff, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nbN + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
+                hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
@@ -1676,78 +1827,58 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
-            if (stage && it + 1 < count) { ctx->stream = mains[(it + 1) % (size_t)npipe]; int rc = stage(stage_user, it + 1); if (rc) return rc; }
-            continue;
-        }
-        {
-            ZkProfScope ps(ctx, "msm_sort");
-            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68) * 4, ctx->stream));
-            // 1. partition by the high bucket bits while recoding: histogram, scan, scatter
-            launch_partition<false>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift);
-            ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
-            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_h), dim3(SCAN_T), 0, ctx->stream, hist_cnt, hist_off, (const uint32_t*)block_tot3);
-            if (staged_scatter) PK_TRY_MSM(launch_scatter_staged(ctx, pl.c, pl.W, dim3(nwg), d_scalars, (uint64_t)n, range_bits, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift));
-            else launch_partition<true>(pl.c, dim3(nwg), ctx->stream, d_scalars, (uint64_t)n, range_bits, (uint32_t*)nullptr, (const uint32_t*)hist_off, entries, (uint64_t)tab_stride, pl.top_shift);
-            ZK_CHECK_LAUNCH(ctx);
-            // 2. counting sort inside every partition, one launch (bucket offsets, counts, size histogram, sorted table indices);
-            //    ZK_MSM_BINSORT=0 keeps the sliced count / scan / scatter sequence (measurement knob)
-            const bool bs_it = binsort && !(narrow && narrow[it] == 2);       // hint 2: long runs of equal scalars (running products) put whole runs into
-                                                                              // one partition; four slice-workgroups per partition stream them faster than one
-            if (bs_it) {
-                hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, nb, offsets, counts, size_hist, idx);
-                ZK_CHECK_LAUNCH(ctx);
-            } else {
-                hipLaunchKernelGGL((k_msm_m_bin<false>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-                ZK_CHECK_LAUNCH(ctx);
-                hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb * MSM_SLICES, slice_off, block_tot);
-                hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot, scan_blocks_s, slice_off, nb * MSM_SLICES, offsets + nb);
-                hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_s), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)slice_counts, nb, slice_off, (const uint32_t*)block_tot, offsets, counts, size_hist);
+        } else {
+            const WsM w = ws_merged(slot);
+            G1Xyzz29* partial = buckets + nb;
+            G1Xyzz29* task_partial = partial + red_pts;
+            {
+                ZkProfScope ps(ctx, "msm_buckets");
+                // idx already holds table indices: no window offset, no per-window skip (tab_stride = 0)
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_table, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
+                                   (const uint32_t*)w.order, (const uint32_t*)w.toff, (const uint32_t*)w.nmulti, nb, buckets, task_partial, 0, (uint64_t)0, (const uint32_t*)nullptr);
             }
-            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, ctx->stream, size_hist, (const uint32_t*)(offsets + nb));
-            hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)counts, nb, size_hist, order, ntasks);
-            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, (const uint32_t*)ntasks, nb, toff, block_tot2);
-            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, ctx->stream, block_tot2, scan_blocks, toff, nb, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks), dim3(SCAN_T), 0, ctx->stream, nb, toff, (const uint32_t*)block_tot2);
-            ZK_CHECK_LAUNCH(ctx);
-            if (!bs_it) hipLaunchKernelGGL((k_msm_m_bin<true>), dim3(nbins * MSM_SLICES), dim3(1024), 0, ctx->stream, (const uint64_t*)entries, (const uint32_t*)hist_off, nwg, range_bits, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx);
-            ZK_CHECK_LAUNCH(ctx);
-        }
-        PK_TRY_MSM(wait_buffer());
-        {
-            ZkProfScope ps(ctx, "msm_buckets");
-            // idx already holds table indices: no window offset, no per-window skip (tab_stride = 0)
-            hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, d_table, (const uint32_t*)offsets, (const uint32_t*)idx,
-                               (const uint32_t*)order, (const uint32_t*)toff, (const uint32_t*)nmulti, nb, buckets, task_partial, 0, (uint64_t)0, (const uint32_t*)nullptr);
-        }
-        {
-            ZkProfScope ps(ctx, "msm_combine");
-            hipLaunchKernelGGL(k_msm_combine_wave, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)toff, task_partial);
-            hipLaunchKernelGGL(k_msm_combine_small, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
-                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
-            hipLaunchKernelGGL(k_msm_combine, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)nmulti, (const uint32_t*)order,
-                               (const uint32_t*)ntasks, (const uint32_t*)toff, (const G1Xyzz29*)task_partial, buckets);
-            ZK_CHECK_LAUNCH(ctx);
-        }
-        ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
-        ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
-        {   // weighted bucket sum on a side stream: hides under the next MSMs
-            ZkProfScope ps(ctx, "msm_reduce", side);
-            if (it + 2 >= count) {
-                // the caller waits for the reductions of the last two MSMs of a batch (and of a lone one): one launch with a
-                // scalar multiplication per lane has the shorter dependent chain (about 60 additions against 150 over the
-                // levels below), at twice the work
-                const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;      // <= nb / 2048 + 1 partials: fits red_pts
-                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, nb, partial);
-                hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partial, rb, wsum_all + it);
+            {
+                ZkProfScope ps(ctx, "msm_combine");
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.toff, task_partial);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nb + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partial, buckets);
+                hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partial, buckets);
                 ZK_CHECK_LAUNCH(ctx);
-            } else {
-                PK_TRY_MSM(wsum_enqueue(ctx, side, buckets, nb, partial, wsum_all + it));
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
+            ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
+            {   // weighted bucket sum on a side stream: hides under the next MSMs
+                ZkProfScope ps(ctx, "msm_reduce", side);
+                if (it + 2 >= count) {
+                    // the caller waits for the reductions of the last two MSMs of a batch (and of a lone one): one launch with a
+                    // scalar multiplication per lane has the shorter dependent chain (about 60 additions against 150 over the
+                    // levels below), at twice the work
+                    const uint32_t rb = ((nb + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;      // <= nb / 2048 + 1 partials: fits red_pts
+                    hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rb, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, nb, partial);
+                    hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partial, rb, wsum_all + it);
+                    ZK_CHECK_LAUNCH(ctx);
+                } else {
+                    PK_TRY_MSM(wsum_enqueue(ctx, side, buckets, nb, partial, wsum_all + it));
+                }
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
+        }
+        if (it + 1 < count) {
+            if (sort_ahead) {
+                // the next column: its staging (upload) is fenced into the sort stream, its sort goes into the other workspace copy,
+                // free once the accumulation + combination of MSM it - 1 (recorded as ev_p1 of that iteration) are through
+                ctx->stream = sort_st;
+                if (stage) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+                if (it >= 1) ZK_HIP(ctx, hipStreamWaitEvent(sort_st, ctx->ev_p1[(it - 1) % 3], 0));
+                PK_TRY_MSM(enqueue_sort(it + 1, (int)((it + 1) & 1), sort_st));
+                ZK_HIP(ctx, hipEventRecord(ctx->ev_sorted[(it + 1) & 1], sort_st));
+            } else if (stage) {
+                ctx->stream = mains[(it + 1) % (size_t)npipe];
+                int rc = stage(stage_user, it + 1);
+                if (rc) return rc;
             }
         }
-        ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
-        if (stage && it + 1 < count) { ctx->stream = mains[(it + 1) % (size_t)npipe]; int rc = stage(stage_user, it + 1); if (rc) return rc; }
     }
     ctx->stream = mains[0];
     if (npipe == 2) {

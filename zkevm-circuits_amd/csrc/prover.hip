@@ -779,10 +779,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     memcpy(blind_pinned.p, sg.blind_v.data(), sg.blind_v.size() * sizeof(F4));
     sg.blind = (const F4*)blind_pinned.p;
     PK_TRY(copy_stream_open(ctx));
-    if (!ctx->stream_aux) {
-        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking));
-        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
-    }
+    if (!ctx->ensure_aux()) return ctx->fail(ZK_ERR_HIP, "could not create the auxiliary stream");
     ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));                 // pooled blocks: everything enqueued so far comes first
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
     // Sharded session: every rank uploads every column (each GPU has its own PCIe link; all of them
