@@ -89,7 +89,9 @@ def vk_commitments(circ, srs: Srs):
 
 # ------------------------------------------------------------------------------------ the prover
 def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]], vk_repr: int,
-                 seed16: bytes = bytes(16), multiopen: str = "gwc", transcript: str = "blake2b") -> bytes:
+                 seed16: bytes = bytes(16), multiopen: str = "gwc", transcript: str = "blake2b", phase_witness=None) -> bytes:
+    """phase_witness(phase, challenges so far) -> {advice column: values}: the columns of a later phase, synthesised once
+    the challenges they depend on exist (what halo2 does by calling Circuit::synthesize once per phase)."""
     n, k, u, bf, d = circ.n, circ.k, circ.u, circ.bf, circ.degree()
     A, Pn, L = circ.A, len(circ.perm_cols), len(circ.lookups)
     chunk = d - 2
@@ -119,6 +121,10 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     challenges = [0] * len(chal_phase)
     for ph in range(max([0] + list(adv_phase) + list(chal_phase)) + 1):
         cols = [i for i in range(A) if adv_phase[i] == ph]
+        if phase_witness is not None:
+            for i, col in phase_witness(ph, list(challenges)).items():
+                assert adv_phase[i] == ph
+                adv[i] = list(col)
         for i in cols:
             for row in range(u, n):          # halo2: advice_values[n - (blinding_factors + 1)..], row u included
                 adv[i][row] = rng.next_fr()

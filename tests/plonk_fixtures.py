@@ -87,9 +87,6 @@ def build_circuit(k: int, seed: int = 1, wide: bool = False):
         if wide:
             adv[3][r1 + 1] = adv[3][r1] * adv[4][r1] % R * x % R
         c.copy((plonk.ADVICE, 2, r0), (plonk.ADVICE, 0, r1))
-    for j, r0 in enumerate(adds[:8]):                  # public inputs
-        inst[0][j] = adv[1][r0]
-        c.copy((plonk.ADVICE, 1, r0), (plonk.INSTANCE, 0, j))
     if adds:                                           # a constant from a fixed column
         r0 = adds[-1]
         c.fixed[6][0] = 12345
@@ -103,6 +100,11 @@ def build_circuit(k: int, seed: int = 1, wide: bool = False):
             adv[4][muls[1]] = adv[4][muls[0]]
             adv[3][muls[1] + 1] = adv[3][muls[1]] * adv[4][muls[1]] % R * adv[0][muls[1]] % R
             c.copy((plonk.ADVICE, 4, muls[0]), (plonk.ADVICE, 4, muls[1]))
+    # public inputs last: a Rust circuit can only issue `constrain_instance` after its region (the order of the copy calls
+    # decides the cycles of the permutation, so the T1 kit's Rust replay must be able to follow it -- shim/t1_standalone)
+    for j, r0 in enumerate(adds[:8]):
+        inst[0][j] = adv[1][r0]
+        c.copy((plonk.ADVICE, 1, r0), (plonk.INSTANCE, 0, j))
     return c, adv, inst
 
 

@@ -51,15 +51,16 @@ struct zk_ctx {
     // auxiliary compute stream: transforms of freshly uploaded columns run beside the commitment pipeline
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_aux = nullptr;
-    // The auxiliary stream is created with the highest stream priority (ZK_AUX_PRIORITY=0: default priority): what runs on it
-    // -- transforms of freshly uploaded columns, the sort-ahead of the next MSM -- is short, memory- or latency-bound work that
-    // must find workgroup slots WHILE a chip-filling accumulation kernel of the main stream is in flight; at equal priority the
-    // dispatcher hands every freed slot to the kernel with thousands of workgroups pending and the side work starves.
+    // The auxiliary stream (transforms of freshly uploaded columns beside the commitment pipeline).  ZK_AUX_PRIORITY=1 creates it
+    // with the highest stream priority -- a measurement knob, OFF by default: it did not help the sort-ahead experiment
+    // (profiles/r03_sort_ahead.md) and it slows the witness uploads of the advice phase from 0.64 to 0.94 ms per 32 MiB column
+    // (643 -> 940 ms for the SuperCircuit shape, tools/gpu_r3i.sh): a priority stream takes a hardware queue of its own, and which
+    // streams share queues decides the upload rate (DESIGN "stream topology").
     bool ensure_aux() {
         if (stream_aux) return true;
         int least = 0, greatest = 0;
         const char* e = getenv("ZK_AUX_PRIORITY");
-        const bool prio = !(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+        const bool prio = e && atoi(e) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
         hipError_t rc = prio ? hipStreamCreateWithPriority(&stream_aux, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&stream_aux, hipStreamNonBlocking);
         if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamCreateWithFlags(&stream_aux, hipStreamNonBlocking); }
         if (rc != hipSuccess) { stream_aux = nullptr; return false; }

@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint
 // counts[b] = sum of its slices) and bins every bucket by size (descending order of size -> a wave
 // works on buckets of equal length; big ones start first).
 constexpr uint32_t SIZE_BINS = 256;
-constexpr uint32_t TASK_DONE_MAX = 16384;  // multi-task buckets at positions below this are combined inside k_msm_buckets (done-counters behind nmulti + 68)
+constexpr uint32_t TASK_DONE_MAX = 1u << 17;   // done-counters (behind nmulti + 68) of the split buckets that straddle a wave boundary inside k_msm_buckets: positions below this
 constexpr uint32_t TASK_INLINE_MAX = 8;    // ... when they were split into at most this many tasks
 constexpr uint32_t TASK_CAP = 48;       // points per task, see "skew-proof work split" below
 __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ slice_counts, uint32_t nbuckets, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     // what this lane accumulates: points idx[lo, hi) into bucket b -- ONE call site of the accumulation loop for every kind of
     // lane (2100 instructions of mixed addition: a second inlined copy competes for the instruction cache two CUs share)
-    enum : uint32_t { NONE, ORDINARY, HEAVY, IN_WAVE, STRADDLE };
+    enum : uint32_t { NONE, ORDINARY, HEAVY, IN_WAVE, STRADDLE, LEFT };
     // the task behind virtual index v: position of its bucket, first task of the bucket, task count -- recomputed after the loop
     // instead of kept alive across it (four registers that would push the kernel past 128 VGPRs = from four waves per SIMD to three)
     auto task_of = [&](uint32_t& lo_p, uint32_t& t0, uint32_t& nt) {
@@ -789,9 +789,10 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     if (v < Tm) {
         task_of(lo_p, t0, nt);
         chunk = v - t0;
-        mode = (lo_p < nmulti[2] || lo_p >= TASK_DONE_MAX) ? HEAVY : ((lane >= chunk && lane - chunk + nt <= 64u) ? IN_WAVE : STRADDLE);
+        mode = lo_p < nmulti[2] ? HEAVY : ((lane >= chunk && lane - chunk + nt <= 64u) ? IN_WAVE : (lo_p < TASK_DONE_MAX ? STRADDLE : LEFT));
     }
-    if (mode == HEAVY) stg29(partial + v, acc);
+    if (mode == HEAVY || mode == LEFT) stg29(partial + v, acc);
+    if (mode == LEFT && chunk == 0) atomicAdd(const_cast<uint32_t*>(nmulti) + 3, 1u);       // a straddling bucket beyond the done-counters: the combination kernels take it (and must run)
     if (mode == STRADDLE) {
         uint32_t* done = const_cast<uint32_t*>(nmulti) + 4 + 64;            // zeroed with the size histogram before every MSM
         stg29(partial + v, acc);
@@ -828,12 +829,20 @@ __device__ __forceinline__ uint32_t bucket_of_task(const uint32_t* __restrict__ 
     }
     return lo_p;
 }
+// which split buckets k_msm_buckets left to the combination kernels: the heavy ones (positions below H) and, beyond its
+// done-counters, those whose tasks straddle a wave boundary
+__device__ __forceinline__ bool left_to_kernels(const uint32_t* __restrict__ toff, uint32_t pos, uint32_t H) {
+    if (pos < H) return true;
+    if (pos < TASK_DONE_MAX) return false;
+    const uint32_t t0 = toff[pos], nt = toff[pos + 1] - t0;
+    return (t0 & 63u) + nt > 64u;
+}
 __global__ void __launch_bounds__(256) k_msm_combine_wave(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ toff, G1Xyzz29* __restrict__ partial) {
     // A fixed, small grid walks the tasks with a grid stride: a workgroup that finds nothing to do still costs the
     // dispatcher ~15 ns, and a grid sized for the worst case (one lane per possible task: 3000+ workgroups) took 48 us per
     // MSM to establish that a uniform column has NO multi-task bucket at all (profiles/r03_combine_grid.md).
     const uint32_t M = nmulti[0], H = nmulti[2];
-    if (H == 0 && M <= TASK_DONE_MAX) return;          // every split bucket was put together inside k_msm_buckets: the common case costs one load
+    if (H == 0 && nmulti[3] == 0) return;              // every split bucket was put together inside k_msm_buckets: the common case costs one load
     const uint32_t Tm = M ? toff[M] : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; (v & ~63u) < Tm; v += gridDim.x * blockDim.x) {      // whole waves stay together
@@ -842,7 +851,7 @@ __global__ void __launch_bounds__(256) k_msm_combine_wave(const uint32_t* __rest
         G1Xyzz29 acc = identity29();
         if (live) {
             const uint32_t pos = bucket_of_task(toff, M, v);
-            if (pos < H || pos >= TASK_DONE_MAX) { key = pos; acc = ldg29(partial + v); }     // else: combined inside k_msm_buckets
+            if (left_to_kernels(toff, pos, H)) { key = pos; acc = ldg29(partial + v); }     // else: combined inside k_msm_buckets
         }
         const uint32_t prev = __shfl_up(key, 1);
         bool merged = false;
@@ -868,9 +877,9 @@ static inline unsigned combine_grid(size_t worst_case_blocks) { return (unsigned
 __global__ void __launch_bounds__(256) k_msm_combine_small(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks,
                                                            const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial, G1Xyzz29* __restrict__ buckets) {
     const uint32_t M = nmulti[0], H = nmulti[2];
-    if (H == 0 && M <= TASK_DONE_MAX) return;
+    if (H == 0 && nmulti[3] == 0) return;
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {      // small fixed grid, see k_msm_combine_wave
-        if (m >= H && m < TASK_DONE_MAX) continue;                                                       // combined inside k_msm_buckets
+        if (!left_to_kernels(toff, m, H)) continue;                                                      // combined inside k_msm_buckets
         const uint32_t base = toff[m], cnt = leader_count(base, ntasks[m]);
         if (cnt > COMBINE_SMALL) continue;
         G1Xyzz29 acc = ldg29(partial + base);
@@ -884,9 +893,9 @@ __global__ void __launch_bounds__(256) k_msm_combine(const uint32_t* __restrict_
                                                      G1Xyzz29* __restrict__ buckets) {
     __shared__ G1Xyzz29 sh[256];
     const uint32_t total = nmulti[0], H = nmulti[2];
-    if (H == 0 && total <= TASK_DONE_MAX) return;
+    if (H == 0 && nmulti[3] == 0) return;
     for (uint32_t m = blockIdx.x; m < total; m += gridDim.x) {
-        if (m >= H && m < TASK_DONE_MAX) continue;                                                       // combined inside k_msm_buckets
+        if (!left_to_kernels(toff, m, H)) continue;                                                      // combined inside k_msm_buckets
         const uint32_t p = m, base = toff[p], cnt = leader_count(base, ntasks[p]);
         if (cnt <= COMBINE_SMALL) continue;      // handled by k_msm_combine_small (uniform across the workgroup)
         G1Xyzz29 acc = identity29();

@@ -166,6 +166,12 @@ struct zk_proof {
     host::XorShiftRng rng;
     host::Transcript tr;
     std::vector<DevBuf> inst_lag, inst_coeff, adv_lag, adv_coeff;
+    // Cosets of advice columns computed AHEAD, during the advice phases (the uploads are PCIe-bound and leave the device idle for
+    // part of every column; which coset reads which column is a property of the key, advice_coset_plan): adv_coset[r][column],
+    // empty where nothing was precomputed.  pre_mask[column] = cosets to precompute (bit r), chosen once per session.
+    std::vector<std::vector<DevBuf>> adv_coset;
+    std::vector<uint32_t> pre_mask;
+    bool pre_planned = false;
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
@@ -735,6 +741,7 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
 // values) and squeezes the challenges that become available after it into h_challenges (Fr each,
 // in challenge-index order).  When h_challenges is given, *num_challenges holds its capacity (in
 // challenges) on entry; on return it holds how many the phase produced.
+static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr);
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
@@ -763,8 +770,46 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         uint32_t world = 1;
         std::vector<size_t> own;                                         // device-gather mode: only these columns are uploaded by this rank
         const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
+        // plain (unsharded) sessions: coefficient forms AND the planned cosets of the columns, several columns per launch, on the
+        // auxiliary stream behind their uploads
+        zk_proof* pr = nullptr; std::vector<uint32_t> col; std::vector<size_t> pending; std::vector<Fr> g_of_r;
+        int flush() {
+            if (pending.empty()) return ZK_OK;
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->stream_aux;
+            struct Back { zk_ctx* c; hipStream_t s; ~Back() { c->stream = s; } } back{ctx, main_stream};
+            const size_t n_ = (size_t)1 << pk->k;
+            std::vector<Fr*> dsts;
+            std::vector<const Fr*> srcs;
+            for (size_t c_ : pending) {
+                if (!coeff[c_]->alloc(n_ * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                dsts.push_back(coeff[c_]->fr());
+                srcs.push_back(lag[c_]->fr());
+            }
+            const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
+            PK_TRY(ntt_run_many(ctx, dsts.data(), srcs.data(), dsts.size(), pk->k, omega_inv, &ninv, nullptr, nullptr, false));
+            for (size_t r = 0; r < g_of_r.size(); ++r) {
+                std::vector<const void*> csrc;
+                std::vector<void*> cdst;
+                for (size_t c_ : pending) {
+                    const uint32_t gc = col[c_];
+                    if (!(pr->pre_mask[gc] >> r & 1u)) continue;
+                    DevBuf& slot = pr->adv_coset[r][gc];
+                    if (!slot.alloc(n_ * 32)) {          // the estimate was too generous: stop computing ahead, the quotient transforms the rest itself
+                        for (uint32_t& m_ : pr->pre_mask) m_ = 0;
+                        break;
+                    }
+                    csrc.push_back(coeff[c_]->p);
+                    cdst.push_back(slot.p);
+                }
+                if (!csrc.empty()) PK_TRY(zk_coeff_to_coset_batch(ctx, csrc.data(), pk->k, &g_of_r[r], cdst.data(), csrc.size()));
+            }
+            pending.clear();
+            return ZK_OK;
+        }
     } sg{ctx, (size_t)pk->u * 32, (size_t)(pk->bf + 1) * 32, {}, {}, {}};   // halo2: advice_values[n - (blinding_factors + 1)..] are random, row u included
     sg.pk = pk;
+    sg.pr = pr;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
         if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
@@ -772,6 +817,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         sg.dst.push_back(pr->adv_lag[c].p);
         sg.lag.push_back(&pr->adv_lag[c]);
         sg.coeff.push_back(&pr->adv_coeff[c]);
+        sg.col.push_back(c);
         for (uint32_t r = 0; r <= pk->bf; ++r) sg.blind_v.push_back(pr->rng.next_fr());
     }
     PinnedBuf blind_pinned;
@@ -786,6 +832,12 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     // are needed for the quotient) but commits only columns rank, rank + world, ...: the upload of
     // `world` columns hides one MSM.
     sg.world = pr->world > 1 && pr->gather ? pr->world : 1;
+    if (!pr->pre_planned) PK_TRY(plan_advice_cosets(ctx, pr));
+    if (sg.world == 1 && !pr->adv_coset.empty()) {
+        const Fr w_ext = fr_root_of_unity(pk->ext_k);
+        Fr g = fr_zeta();
+        for (size_t r = 0; r < pr->adv_coset.size(); ++r) { sg.g_of_r.push_back(g); g = g * w_ext; }
+    }
     auto stage = [](void* user, size_t it) -> int {
         Stage* s_ = (Stage*)user;
         if (!s_->own.empty()) {      // device-gather mode: one own column per call
@@ -799,10 +851,15 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         }
         // the group uploaded by the previous call is on the device (the main stream has waited for it):
         // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
-        if (it > 0)
+        if (it > 0 && s_->world == 1) {
+            s_->pending.push_back(it - 1);
+            if (s_->pending.size() >= 4) PK_TRY(s_->flush());        // four columns share a launch of each transform (zk_ntt_batch granularity at k = 20)
+        } else if (it > 0)
             for (size_t c_ = (it - 1) * s_->world; c_ < std::min(it * (size_t)s_->world, s_->dst.size()); ++c_)
                 PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
+        static const bool skip_upload = getenv("ZK_DEBUG_SKIP_UPLOAD") != nullptr;       // measurement only (the proof is garbage): is the phase bound by PCIe or by the device?
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
+            if (skip_upload) continue;
             ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
         }
@@ -818,6 +875,10 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     ctx->msm_blinded_tail = pk->bf + 1;
     if (sg.world == 1) {
         PK_TRY(commit_batch_staged(ctx, pk->srs, 1, (const void* const*)sg.dst.data(), sg.dst.size(), n, coms.data(), stage, &sg, narrow.data()));
+        if (!sg.dst.empty()) {                    // the last column (its upload was fenced into the auxiliary stream by the last staging call) and what is pending
+            sg.pending.push_back(sg.dst.size() - 1);
+            PK_TRY(sg.flush());
+        }
     } else {
         const size_t total = sg.dst.size(), per = (total + sg.world - 1) / sg.world;
         std::vector<const void*> mine;
@@ -872,6 +933,187 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     pr->absorbed.clear();
     pr->absorbed.shrink_to_fit();
     ++pr->phase;
+    return ZK_OK;
+}
+
+// The quotient's constraints in halo2's order: gates, permutation, lookups (folded with y by the caller).  A pure function of
+// the key: challenges enter as constant indices, so the programs -- and with them which column is read on which coset -- are
+// known before any witness exists (the advice phase uses that to transform columns ahead of time, advice_coset_plan).
+static void build_constraints(const zk_pk* pk, std::vector<Prog>& cons, bool& gates_share_tmps_out) {
+    PB q;
+    auto end_c = [&] { cons.push_back(std::move(q.g)); q.g.clear(); };
+    for (const Prog& g : pk->gates) cons.push_back(g);
+    const int32_t rot_last = -(int32_t)(pk->bf + 1);
+    if (pk->C) {
+        q.col(CT_SPECIAL, SP_L0).cst(C_ONE).col(CT_PERM_Z, 0).op(Q_SUB).op(Q_MUL); end_c();                                   // l0 (1 - Z_0)
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_PERM_Z, pk->C - 1).op(Q_SQUARE).col(CT_PERM_Z, pk->C - 1).op(Q_SUB).op(Q_MUL); end_c();   // l_last (Z^2 - Z)
+        for (uint32_t c = 1; c < pk->C; ++c) {
+            q.col(CT_SPECIAL, SP_L0).col(CT_PERM_Z, c).col(CT_PERM_Z, c - 1, rot_last).op(Q_SUB).op(Q_MUL);          // l0 (Z_c - Z_{c-1}(w^last X))
+            end_c();
+        }
+        for (uint32_t c = 0; c < pk->C; ++c) {
+            const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
+            q.col(CT_SPECIAL, SP_LACTIVE);
+            q.col(CT_PERM_Z, c, 1);
+            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SIGMA, j).mulc(C_BETA).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
+            q.col(CT_PERM_Z, c, 0);
+            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SPECIAL, SP_X).mulc(C_DELTA0 + j).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
+            q.op(Q_SUB).op(Q_MUL); end_c();
+        }
+    }
+    // lookup identities (plonk::evaluation, mv-lookup): with phi_a = f_a + beta and tau = t + beta,
+    //   l_active * ( tau * prod_a phi_a * (phi(wX) - phi(X))  -  prod_a phi_a * (tau * sum_a 1/phi_a - m) )
+    // An argument with several input tuples parks tau and the phi_a of a row in intermediates (slots
+    // above the ones the gate programs use) and forms sum_a prod_{b != a} phi_b from them.
+    uint32_t tmp_base = 0;
+    for (const Prog& g : pk->gates) for (const Instr& in : g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
+    const bool gates_share_tmps = tmp_base != 0;
+    for (uint32_t l = 0; l < pk->L; ++l) {
+        const auto& lk = pk->lookups[l];
+        const uint32_t N = (uint32_t)lk.inputs.size();
+        q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL); end_c();
+        q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL); end_c();
+        q.col(CT_SPECIAL, SP_LACTIVE);
+        if (N == 1) {
+            // (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta))
+            q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
+            push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
+            push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
+            push_compressed(q, lk.tables); q.addc(C_BETA);
+            q.col(CT_LK_M, l); push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
+            q.op(Q_SUB).op(Q_SUB).op(Q_MUL); end_c();
+            continue;
+        }
+        const uint32_t t_tau = tmp_base, t_phi = tmp_base + 1;          // reused by every multi-input lookup: a row's values are consumed right away
+        auto tmp = [&](uint32_t op, uint32_t slot) { q.g.push_back({op, slot, 0}); };
+        // prod = phi_0 * ... * phi_{N-1}, each factor parked on the way
+        for (uint32_t a = 0; a < N; ++a) {
+            push_compressed(q, lk.inputs[a]); q.addc(C_BETA);
+            tmp(Q_TEE_TMP, t_phi + a);
+            if (a) q.op(Q_MUL);
+        }
+        tmp(Q_TEE_TMP, t_phi + N);                                       // prod
+        // lhs = tau * prod * (phi(wX) - phi(X))
+        push_compressed(q, lk.tables); q.addc(C_BETA);
+        tmp(Q_TEE_TMP, t_tau);
+        q.op(Q_MUL);
+        q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB).op(Q_MUL);
+        // rhs = tau * sum_a prod_{b != a} phi_b - prod * m
+        for (uint32_t a = 0; a < N; ++a) {
+            bool first = true;
+            for (uint32_t b2 = 0; b2 < N; ++b2) {
+                if (b2 == a) continue;
+                tmp(Q_PUSH_TMP, t_phi + b2);
+                if (!first) q.op(Q_MUL);
+                first = false;
+            }
+            if (a) q.op(Q_ADD);
+        }
+        tmp(Q_PUSH_TMP, t_tau); q.op(Q_MUL);
+        tmp(Q_PUSH_TMP, t_phi + N); q.col(CT_LK_M, l).op(Q_MUL);
+        q.op(Q_SUB);
+        q.op(Q_SUB).op(Q_MUL); end_c();
+    }
+    gates_share_tmps_out = gates_share_tmps;
+}
+// e = ceil(log2(degree - 1)) of every constraint (its degree class, see zk_proof_finish), or E for all when classes are off
+static int classify_constraints(zk_ctx* ctx, const zk_pk* pk, const std::vector<Prog>& cons, bool split, uint32_t E, std::vector<uint32_t>& cls) {
+    cls.assign(cons.size(), E);
+    std::vector<int> tmp_deg;
+    for (uint32_t i = 0; i < cons.size(); ++i) {
+        const int dg = program_degree(cons[i], &tmp_deg);
+        if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: malformed constraint program %u", i);
+        if ((uint32_t)dg > pk->d) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: constraint %u has degree %d above the circuit degree %u", i, dg, pk->d);
+        uint32_t e = 0;
+        while (e < E && ((uint32_t)1 << e) < (uint32_t)std::max(dg - 1, 1)) ++e;
+        cls[i] = split ? e : E;
+    }
+    return ZK_OK;
+}
+static bool quotient_split_enabled(bool sharded, bool gates_share_tmps) {
+    const char* split_env = getenv("ZK_QUOTIENT_SPLIT");
+    return !(split_env && atoi(split_env) == 0) && !sharded && !gates_share_tmps;     // intermediates shared between gates tie their rows together
+}
+// For every advice column: the set of cosets r (bit r) of the extended domain on which some constraint class active there reads it.
+static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::vector<uint32_t>& mask) {
+    std::vector<Prog> cons;
+    bool share = false;
+    build_constraints(pk, cons, share);
+    const uint32_t E = pk->ext_k - pk->k;
+    std::vector<uint32_t> cls;
+    PK_TRY(classify_constraints(ctx, pk, cons, quotient_split_enabled(sharded, share), E, cls));
+    mask.assign(pk->A, 0u);
+    if (E > 5) return ZK_OK;           // more than 32 cosets: no plan (the quotient transforms everything itself)
+    for (uint32_t i = 0; i < cons.size(); ++i) {
+        uint32_t cosets = 0;
+        for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - cls[i])) - 1u)) == 0) cosets |= 1u << r;
+        for (const Instr& in : cons[i])
+            if (in.op == Q_PUSH_COL && (in.a >> 24) == CT_ADVICE && (in.a & 0xFFFFFFu) < pk->A) mask[in.a & 0xFFFFFFu] |= cosets;
+    }
+    return ZK_OK;
+}
+
+// Which cosets of which advice columns this session computes ahead, during its advice phases (zk_proof::pre_mask, adv_coset).
+// Cosets are taken in the order of how many advice columns they serve, as long as the buffers fit what the device can spare:
+// free memory (the pool's parked blocks count as free) less everything the session still has to allocate -- Lagrange and
+// coefficient forms of the advice columns, of m / phi / Z, one coset buffer per column the quotient reads, h -- less the
+// key's own coset cache if it is still to be filled, capped by ZK_ADVICE_COSET_GB (default 64; 0 turns the feature off).
+// Sharded sessions do not precompute (their quotient is split by coset over the ranks).
+static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
+    pr->pre_planned = true;
+    const zk_pk* pk = pr->pk;
+    const bool sharded = pr->world > 1 && pr->gather;
+    const char* env = getenv("ZK_ADVICE_COSET_GB");
+    const double cap = (env ? atof(env) : 64.0) * (double)(1ull << 30);
+    if (sharded || cap <= 0 || pk->A == 0) return ZK_OK;
+    std::vector<uint32_t> mask;
+    PK_TRY(advice_coset_plan(ctx, pk, sharded, mask));
+    const uint32_t E = pk->ext_k - pk->k, R = 1u << E;
+    if (E > 5) return ZK_OK;
+    const double col_bytes = (double)((size_t)1 << pk->k) * 32.0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ZK_OK; }
+    // columns' worth of buffers still to come, the advice columns' own coset buffers aside (counted below, per choice of cosets):
+    // Lagrange + coefficient forms of the advice columns, of m / phi / Z with their temporaries, their coset buffers, h, slack
+    const double cols_ahead = 2.0 * pk->A + 3.0 * (2.0 * pk->L + pk->C) + (2.0 * pk->L + pk->C + pk->I + 8.0) + 2.0 * R + 32.0;
+    double avail = (double)free_b + (double)ctx->pool_bytes - cols_ahead * col_bytes - 16.0 * (double)(1ull << 30);
+    if (pk->part_cache_state < 0 || (pk->part_cache_state == 1 && pk->part_cache_bytes == 0)) {
+        // the key's own cosets (fixed, sigma, l_0 ...) are still to be cached by this proof's quotient: reserved in full (every
+        // column on every coset -- an upper bound; once a proof has filled the cache, what it holds is what it needs)
+        const double key_need = (double)(pk->F + pk->P + 4) * R * col_bytes;
+        const char* kenv = getenv("ZK_PK_COSET_CACHE_GB");
+        const double kcap = std::min((kenv ? atof(kenv) : 96.0) * (double)(1ull << 30), (double)ctx->prop.totalGlobalMem / 3.0);
+        if (key_need <= kcap) avail -= std::max(0.0, key_need - (double)pk->part_cache_bytes);
+    }
+    const double budget = std::min(cap, avail);
+    std::vector<std::pair<uint32_t, uint32_t>> by_count;          // (columns served, coset)
+    for (uint32_t r = 0; r < R; ++r) {
+        uint32_t cnt = 0;
+        for (uint32_t m_ : mask) cnt += m_ >> r & 1u;
+        if (cnt) by_count.push_back({cnt, r});
+    }
+    std::sort(by_count.begin(), by_count.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    uint32_t chosen = 0;
+    double used = 0;
+    for (const auto& cr : by_count) {
+        uint32_t rest = 0;                       // advice columns the quotient still has to transform itself (one coset buffer each)
+        for (uint32_t m_ : mask) rest += (m_ & ~(chosen | 1u << cr.second)) != 0;
+        if (used + cr.first * col_bytes > cap || used + (cr.first + rest) * col_bytes > avail) break;
+        used += cr.first * col_bytes;
+        chosen |= 1u << cr.second;
+    }
+    if (getenv("ZK_PROVER_TRACE")) {
+        fprintf(stderr, "[zk prover] advice coset plan: free %.1f + pooled %.1f GiB, reserve %.1f GiB, budget %.1f GiB, cosets by columns served:", free_b / 1073741824.0, ctx->pool_bytes / 1073741824.0,
+                (cols_ahead * col_bytes) / 1073741824.0 + 16.0, budget / 1073741824.0);
+        for (const auto& cr : by_count) fprintf(stderr, " r%u:%u", cr.second, cr.first);
+        fprintf(stderr, " -> chosen 0x%x\n", chosen);
+    }
+    if (!chosen) return ZK_OK;
+    pr->pre_mask.assign(pk->A, 0u);
+    for (uint32_t c = 0; c < pk->A; ++c) pr->pre_mask[c] = mask[c] & chosen;
+    pr->adv_coset.resize(R);
+    for (auto& v : pr->adv_coset) v.resize(pk->A);
+    if (getenv("ZK_PROVER_TRACE")) fprintf(stderr, "[zk prover] advice cosets computed ahead: cosets 0x%x, %.1f GiB\n", chosen, used / (double)(1ull << 30));
     return ZK_OK;
 }
 
@@ -1071,80 +1313,9 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     trace.mark("coefficient forms");
     // ---- the quotient's constraints in halo2's order: gates, permutation, lookups (folded with y below)
     std::vector<Prog> cons;
-    PB q;
-    auto end_c = [&] { cons.push_back(std::move(q.g)); q.g.clear(); };
-    for (const Prog& g : pk->gates) cons.push_back(g);
+    bool gates_share_tmps = false;
+    build_constraints(pk, cons, gates_share_tmps);
     const int32_t rot_last = -(int32_t)(pk->bf + 1);
-    if (pk->C) {
-        q.col(CT_SPECIAL, SP_L0).cst(C_ONE).col(CT_PERM_Z, 0).op(Q_SUB).op(Q_MUL); end_c();                                   // l0 (1 - Z_0)
-        q.col(CT_SPECIAL, SP_LLAST).col(CT_PERM_Z, pk->C - 1).op(Q_SQUARE).col(CT_PERM_Z, pk->C - 1).op(Q_SUB).op(Q_MUL); end_c();   // l_last (Z^2 - Z)
-        for (uint32_t c = 1; c < pk->C; ++c) {
-            q.col(CT_SPECIAL, SP_L0).col(CT_PERM_Z, c).col(CT_PERM_Z, c - 1, rot_last).op(Q_SUB).op(Q_MUL);          // l0 (Z_c - Z_{c-1}(w^last X))
-            end_c();
-        }
-        for (uint32_t c = 0; c < pk->C; ++c) {
-            const uint32_t j0 = c * pk->chunk, j1 = std::min(pk->P, j0 + pk->chunk);
-            q.col(CT_SPECIAL, SP_LACTIVE);
-            q.col(CT_PERM_Z, c, 1);
-            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SIGMA, j).mulc(C_BETA).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
-            q.col(CT_PERM_Z, c, 0);
-            for (uint32_t j = j0; j < j1; ++j) { push_perm_col(q, pk->perm_cols[j]); q.col(CT_SPECIAL, SP_X).mulc(C_DELTA0 + j).op(Q_ADD).addc(C_GAMMA).op(Q_MUL); }
-            q.op(Q_SUB).op(Q_MUL); end_c();
-        }
-    }
-    // lookup identities (plonk::evaluation, mv-lookup): with phi_a = f_a + beta and tau = t + beta,
-    //   l_active * ( tau * prod_a phi_a * (phi(wX) - phi(X))  -  prod_a phi_a * (tau * sum_a 1/phi_a - m) )
-    // An argument with several input tuples parks tau and the phi_a of a row in intermediates (slots
-    // above the ones the gate programs use) and forms sum_a prod_{b != a} phi_b from them.
-    uint32_t tmp_base = 0;
-    for (const Prog& g : pk->gates) for (const Instr& in : g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
-    const bool gates_share_tmps = tmp_base != 0;
-    for (uint32_t l = 0; l < pk->L; ++l) {
-        const auto& lk = pk->lookups[l];
-        const uint32_t N = (uint32_t)lk.inputs.size();
-        q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL); end_c();
-        q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL); end_c();
-        q.col(CT_SPECIAL, SP_LACTIVE);
-        if (N == 1) {
-            // (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta))
-            q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
-            push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
-            push_compressed(q, lk.tables); q.addc(C_BETA).op(Q_MUL);
-            push_compressed(q, lk.tables); q.addc(C_BETA);
-            q.col(CT_LK_M, l); push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
-            q.op(Q_SUB).op(Q_SUB).op(Q_MUL); end_c();
-            continue;
-        }
-        const uint32_t t_tau = tmp_base, t_phi = tmp_base + 1;          // reused by every multi-input lookup: a row's values are consumed right away
-        auto tmp = [&](uint32_t op, uint32_t slot) { q.g.push_back({op, slot, 0}); };
-        // prod = phi_0 * ... * phi_{N-1}, each factor parked on the way
-        for (uint32_t a = 0; a < N; ++a) {
-            push_compressed(q, lk.inputs[a]); q.addc(C_BETA);
-            tmp(Q_TEE_TMP, t_phi + a);
-            if (a) q.op(Q_MUL);
-        }
-        tmp(Q_TEE_TMP, t_phi + N);                                       // prod
-        // lhs = tau * prod * (phi(wX) - phi(X))
-        push_compressed(q, lk.tables); q.addc(C_BETA);
-        tmp(Q_TEE_TMP, t_tau);
-        q.op(Q_MUL);
-        q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB).op(Q_MUL);
-        // rhs = tau * sum_a prod_{b != a} phi_b - prod * m
-        for (uint32_t a = 0; a < N; ++a) {
-            bool first = true;
-            for (uint32_t b2 = 0; b2 < N; ++b2) {
-                if (b2 == a) continue;
-                tmp(Q_PUSH_TMP, t_phi + b2);
-                if (!first) q.op(Q_MUL);
-                first = false;
-            }
-            if (a) q.op(Q_ADD);
-        }
-        tmp(Q_PUSH_TMP, t_tau); q.op(Q_MUL);
-        tmp(Q_PUSH_TMP, t_phi + N); q.col(CT_LK_M, l).op(Q_MUL);
-        q.op(Q_SUB);
-        q.op(Q_SUB).op(Q_MUL); end_c();
-    }
     // The extended domain is evaluated one coset at a time (g_r = zeta * omega_ext^r, r < 2^(ext_k-k)):
     // every column the program reads is taken to that coset with a size-n transform of its
     // coefficients, the program runs over n rows (rotations are index shifts inside a coset), and
@@ -1163,20 +1334,9 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // (what halo2's evaluate_h does); how much is saved depends on the circuit's degree profile.
     const uint32_t E = ext_k - k, K = (uint32_t)cons.size();
     const bool sharded = pr->world > 1 && pr->gather;
-    const char* split_env = getenv("ZK_QUOTIENT_SPLIT");
-    const bool split = !(split_env && atoi(split_env) == 0) && !sharded && !gates_share_tmps;     // intermediates shared between gates tie their rows together
-    std::vector<uint32_t> cls(K, E);
-    {
-        std::vector<int> tmp_deg;
-        for (uint32_t i = 0; i < K; ++i) {
-            const int dg = program_degree(cons[i], &tmp_deg);
-            if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: malformed constraint program %u", i);
-            if ((uint32_t)dg > pk->d) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: constraint %u has degree %d above the circuit degree %u", i, dg, pk->d);
-            uint32_t e = 0;
-            while (e < E && ((uint32_t)1 << e) < (uint32_t)std::max(dg - 1, 1)) ++e;
-            cls[i] = split ? e : E;
-        }
-    }
+    const bool split = quotient_split_enabled(sharded, gates_share_tmps);
+    std::vector<uint32_t> cls;
+    PK_TRY(classify_constraints(ctx, pk, cons, split, E, cls));
     struct QClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; DevBuf h; };
     std::vector<QClass> qc(E + 1);
     for (uint32_t i = 0; i < K; ++i) {
@@ -1220,9 +1380,12 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (pk->part_cache_state) pk->part_cache.resize(nparts);
         }
         const bool cache_on = pk->part_cache_state >= 1;
-        std::vector<DevBuf> part_buf(refs.size());
-        for (size_t i = 0; i < refs.size(); ++i)
-            if (!(cache_on && of_key(refs[i])) && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        std::vector<DevBuf> part_buf(refs.size());       // one coset buffer per column that is transformed here: allocated on first use
+        auto pre_coset = [&](uint32_t ref, uint32_t r) -> const void* {      // an advice column's coset r computed during the advice phases, if any
+            if ((ref >> 24) != CT_ADVICE || r >= pr->adv_coset.size()) return nullptr;
+            const uint32_t c_ = ref & 0xFFFFFFu;
+            return c_ < pr->adv_coset[r].size() ? pr->adv_coset[r][c_].p : nullptr;
+        };
         DevBuf hpart;
         if (!hpart.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         std::unordered_map<uint32_t, const void*> part_of;
@@ -1253,6 +1416,8 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 bool needed = false;
                 for (uint32_t e : active) needed |= std::find(qc[e].refs.begin(), qc[e].refs.end(), refs[i]) != qc[e].refs.end();
                 if (!needed) continue;
+                if (const void* pre = pre_coset(refs[i], r_)) { part_of[refs[i]] = pre; continue; }
+                if (!(cache_on && of_key(refs[i])) && !part_buf[i].p && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
                 void* dst = part_buf[i].p;
                 DevBuf fresh;                             // a cache slot being filled: published only once it holds the coset
                 const bool cached = cache_on && of_key(refs[i]);

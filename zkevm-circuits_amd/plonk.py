@@ -98,6 +98,57 @@ def colref(ctype: int, index: int) -> int:
     return (ctype << 24) | index
 
 
+def expr_identifier(e: Expr) -> str:
+    """halo2 `Expression::identifier()` [EXT-RECALL plonk/circuit.rs]: the string the mv-lookup fork keys its `lookups_map`
+    (a BTreeMap, so arguments come out in the order of these strings) with -- tables that differ get different keys,
+    and for the column-only tables of the fixtures the order is the order of `fixed[i][rot]` strings."""
+    if isinstance(e, Col):
+        return f"{ {FIXED: 'fixed', ADVICE: 'advice', INSTANCE: 'instance'}[e.ctype]}[{e.index}][{e.rotation}]"
+    if isinstance(e, Const):
+        return f"0x{e.value:064x}"
+    if isinstance(e, Challenge):
+        return f"challenge[{e.index}]"
+    if isinstance(e, Neg):
+        return "(-" + expr_identifier(e.a) + ")"
+    return "(" + expr_identifier(e.a) + {Q_ADD: "+", Q_SUB: "-", Q_MUL: "*"}[e.op] + expr_identifier(e.b) + ")"
+
+
+def expr_tokens(e: Expr) -> List[str]:
+    """postfix tokens of an expression, leaves in the order halo2's closures would query them (depth first, left to right):
+    a:<col>:<rot> f:<col>:<rot> i:<col>:<rot> k:<hex constant> c:<challenge> + - * n(egate)"""
+    if isinstance(e, Col):
+        return [f"{ {FIXED: 'f', ADVICE: 'a', INSTANCE: 'i'}[e.ctype]}:{e.index}:{e.rotation}"]
+    if isinstance(e, Const):
+        return [f"k:{e.value:x}"]
+    if isinstance(e, Challenge):
+        return [f"c:{e.index}"]
+    if isinstance(e, Neg):
+        return expr_tokens(e.a) + ["n"]
+    return expr_tokens(e.a) + expr_tokens(e.b) + [{Q_ADD: "+", Q_SUB: "-", Q_MUL: "*"}[e.op]]
+
+
+def expr_from_tokens(tokens: Sequence[str]) -> Expr:
+    st: List[Expr] = []
+    for t in tokens:
+        if t in "+-*":
+            b_, a_ = st.pop(), st.pop()
+            st.append(Bin({"+": Q_ADD, "-": Q_SUB, "*": Q_MUL}[t], a_, b_))
+        elif t == "n":
+            st.append(Neg(st.pop()))
+        else:
+            kind, *rest = t.split(":")
+            if kind in "afi":
+                st.append(Col({"f": FIXED, "a": ADVICE, "i": INSTANCE}[kind], int(rest[0]), int(rest[1])))
+            elif kind == "k":
+                st.append(Const(int(rest[0], 16)))
+            elif kind == "c":
+                st.append(Challenge(int(rest[0])))
+            else:
+                raise ValueError(f"bad token {t!r}")
+    assert len(st) == 1
+    return st[0]
+
+
 class Lookup:
     """halo2 `mv_lookup::Argument`: one table tuple and one or more input tuples looked up in it
     (`inputs_expressions: Vec<Vec<Expression>>`; `chunk_lookups()` merges the inputs that share a
@@ -140,6 +191,9 @@ class Circuit:
         self.advice_queries: List[Tuple[int, int]] = []      # (column, rotation), registration order
         self.fixed_queries: List[Tuple[int, int]] = []
         self.instance_queries: List[Tuple[int, int]] = []
+        # configure-time calls in call order (what `Circuit::configure` of a Rust circuit must replay to arrive at the same
+        # ConstraintSystem: query registration order = evaluation order, enable_equality order = permutation column order)
+        self.ops: List[tuple] = []
 
     # -- columns
     def fixed_col(self, i, rot=0): return Col(FIXED, i, rot)
@@ -162,6 +216,7 @@ class Circuit:
     def add_gate(self, e: Expr):
         self._register(e)
         self.gates.append(e)
+        self.ops.append(("gate", e))
 
     def add_lookup(self, inputs: Sequence[Expr], tables: Sequence[Expr], name: str = "lookup"):
         """one lookup argument with one input tuple (what `lookup_any` yields when nothing is merged)"""
@@ -169,6 +224,7 @@ class Circuit:
         for e in list(inputs) + list(tables):
             self._register(e)
         self.lookups.append(Lookup(name, tables, [inputs]))
+        self.ops.append(("lookup", name, list(inputs), list(tables)))
 
     def lookup_any(self, name: str, inputs: Sequence[Expr], tables: Sequence[Expr]):
         """halo2 `ConstraintSystem::lookup_any` of the mv-lookup fork: lookups into the same table
@@ -177,7 +233,8 @@ class Circuit:
         assert len(inputs) == len(tables)
         for e in list(inputs) + list(tables):
             self._register(e)
-        ident = repr([self.compile(t) for t in tables])
+        self.ops.append(("lookup", name, list(inputs), list(tables)))
+        ident = "".join(expr_identifier(t) for t in tables)      # upstream: table_expressions_identifier, the BTreeMap key
         if ident in self.lookups_map:
             self.lookups_map[ident].inputs.append(list(inputs))
         else:
@@ -224,6 +281,7 @@ class Circuit:
         if (ctype, index) not in self.perm_cols:
             self.perm_cols.append((ctype, index))
             self._register(Col(ctype, index, 0))       # halo2: enable_equality queries the column at Rotation::cur()
+            self.ops.append(("enable_equality", ctype, index))
 
     def copy(self, a: Tuple[int, int, int], b: Tuple[int, int, int]):
         """(ctype, index, row) == (ctype, index, row)"""
@@ -346,6 +404,87 @@ class Circuit:
             go(g)
             progs.append(out)
         return progs
+
+    def halo2_blinding_factors(self) -> int:
+        """halo2 `ConstraintSystem::blinding_factors` [EXT-RECALL plonk/circuit.rs]: max(3, most distinct rotations any advice
+        column is queried at) + 1 (multi-open) + 1 (h evaluation).  Upstream DERIVES this number; a circuit meant for upstream's
+        verifier must be built with it (the fixtures of the GPU suite are free to use more blinding rows)."""
+        per_col = [0] * max(self.A, 1)
+        for col, _rot in self.advice_queries:
+            per_col[col] += 1
+        return max(3, max(per_col)) + 2
+
+    # -- T1 kit: the circuit as a text file a stand-alone Rust program replays against UPSTREAM halo2 (shim/t1_standalone)
+    def kit_desc(self) -> str:
+        """Everything `Circuit::configure` + keygen's `synthesize` of an equivalent Rust circuit need, one item per line:
+        shape, phases, the configure-time calls in call order, non-zero fixed cells, copy constraints in call order
+        (advice / fixed pairs first, pairs with an instance cell last: a Rust region can only express them in that order)."""
+        tname = {FIXED: "fixed", ADVICE: "advice", INSTANCE: "instance"}
+        assert not self.lookups_map, "call chunk_lookups() first"
+        assert self.bf == self.halo2_blinding_factors(), f"upstream derives blinding_factors = {self.halo2_blinding_factors()} for this circuit, it was built with {self.bf}"
+        region = [c for c in self.copies if INSTANCE not in (c[0][0], c[1][0])]
+        inst = [c for c in self.copies if INSTANCE in (c[0][0], c[1][0])]
+        assert self.copies == region + inst, "copy constraints with instance cells must come last (constrain_instance runs after the region)"
+        out = ["zkmi355-t1-kit 1", f"k {self.k}", f"blinding_factors {self.bf}", f"degree {self.degree()}",
+               f"fixed {self.F}", "advice " + " ".join(str(p) for p in self.advice_phase) if self.A else "advice",
+               f"instance {self.I}", "challenges " + " ".join(str(p) for p in self.challenge_phase)]
+        for op in self.ops:
+            if op[0] == "gate":
+                out.append("gate " + " ".join(expr_tokens(op[1])))
+            elif op[0] == "lookup":
+                _, name, inputs, tables = op
+                out.append(f"lookup {name.replace(' ', '_')} {len(inputs)} " + " | ".join(" ".join(expr_tokens(e)) for e in list(inputs) + list(tables)))
+            else:
+                out.append(f"enable_equality {tname[op[1]]} {op[2]}")
+        for col in range(self.F):
+            for row, v in enumerate(self.fixed[col]):
+                if v % R_MOD:
+                    out.append(f"fixed_cell {col} {row} {v % R_MOD:x}")
+        for a, b in self.copies:
+            out.append(f"copy {tname[a[0]]} {a[1]} {a[2]} {tname[b[0]]} {b[1]} {b[2]}")
+        out.append("end")
+        return "\n".join(out) + "\n"
+
+    @classmethod
+    def from_kit_desc(cls, text: str) -> "Circuit":
+        """Rebuilds the circuit from the file alone (what the Rust side does, restated: the kit's self-check proves that
+        the file carries everything)."""
+        tnum = {"fixed": FIXED, "advice": ADVICE, "instance": INSTANCE}
+        lines = [ln.split() for ln in text.splitlines() if ln.strip()]
+        assert lines[0] == ["zkmi355-t1-kit", "1"] and lines[-1] == ["end"]
+        head = {ln[0]: ln[1:] for ln in lines[1:8]}
+        circ = cls(int(head["k"][0]), int(head["fixed"][0]), len(head["advice"]), int(head["instance"][0]), int(head["blinding_factors"][0]))
+        circ.advice_phase = [int(p) for p in head["advice"]]
+        circ.challenge_phase = [int(p) for p in head["challenges"]]
+        any_lookup = False
+        for ln in lines[8:-1]:
+            if ln[0] == "gate":
+                circ.add_gate(expr_from_tokens(ln[1:]))
+            elif ln[0] == "lookup":
+                n_in = int(ln[2])
+                groups, cur = [], []
+                for tok in ln[3:]:
+                    if tok == "|":
+                        groups.append(cur)
+                        cur = []
+                    else:
+                        cur.append(tok)
+                groups.append(cur)
+                exprs = [expr_from_tokens(g) for g in groups]
+                circ.lookup_any(ln[1], exprs[:n_in], exprs[n_in:])
+                any_lookup = True
+            elif ln[0] == "enable_equality":
+                circ.enable_equality(tnum[ln[1]], int(ln[2]))
+            elif ln[0] == "fixed_cell":
+                circ.fixed[int(ln[1])][int(ln[2])] = int(ln[3], 16)
+            elif ln[0] == "copy":
+                circ.copy((tnum[ln[1]], int(ln[2]), int(ln[3])), (tnum[ln[4]], int(ln[5]), int(ln[6])))
+            else:
+                raise ValueError(f"bad line {ln}")
+        if any_lookup:
+            circ.chunk_lookups()           # upstream keygen does this itself after configure [EXT-RECALL plonk/keygen.rs create_domain]
+        assert circ.degree() == int(head["degree"][0]) and circ.bf == int(head["blinding_factors"][0])
+        return circ
 
     def sigma_columns(self) -> List[List[int]]:
         """halo2 ``permutation::keygen::Assembly``: cycles of equal cells -> sigma_j(omega^i) =
