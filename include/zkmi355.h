@@ -170,6 +170,14 @@ int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr,
 int zk_host_quotient_lower(const uint32_t* program, uint32_t num_instr, uint32_t num_cols, int fuse, uint32_t* out_words, size_t cap_words,
                            uint32_t* out_instr, int* out_depth);
 
+/* Host only, for tests: how the prover distributes constraint programs over its degree classes when the programs share
+ * intermediates (TEE_TMP in one constraint, PUSH_TMP in a later one -- halo2's GraphEvaluator intermediates as exported): a
+ * class that reads an intermediate it has not computed re-materialises the defining sub-expression.  words: 3 per instruction,
+ * `count` programs back to back; cls[i] < classes.  Output: the class programs back to back, each constraint followed by the
+ * marker {FOLD (9), i, 0}.  *conflict = 1 for slot reuse across constraints (the prover then evaluates a single class). */
+int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const uint32_t* cls, uint32_t count, uint32_t classes,
+                           uint32_t* out_words, size_t out_cap_words, uint32_t* out_lens, int* conflict);
+
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
 /* logUp multiplicities (halo2 Scroll fork, plonk/mv_lookup/prover.rs: m(X)): d_m[i] = number of rows

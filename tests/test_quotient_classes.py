@@ -1,0 +1,124 @@
+"""CPU: the degree-class assembly of constraint programs that share intermediates (csrc/prover.hip TmpSplit, through the
+host-only hook zk_host_split_programs).  halo2's GraphEvaluator shares intermediates between gates; the exported programs
+carry them as TEE_TMP / PUSH_TMP.  A degree class evaluates only its own constraints, so an intermediate parked by another
+class's constraint has to be re-materialised -- every constraint must keep its value whichever class it lands in."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+PUSH_COL, PUSH_CONST, ADD, SUB, MUL, NEG, SQUARE, DOUBLE, FOLD, MUL_CONST, ADD_CONST, TEE, PUSH_TMP = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+
+
+def evaluate(prog, cols, consts, tmp, out):
+    st = []
+    for op, a, b in prog:
+        if op == PUSH_COL: st.append(cols[a])
+        elif op == PUSH_CONST: st.append(consts[a])
+        elif op == ADD: y, x = st.pop(), st.pop(); st.append((x + y) % R)
+        elif op == SUB: y, x = st.pop(), st.pop(); st.append((x - y) % R)
+        elif op == MUL: y, x = st.pop(), st.pop(); st.append(x * y % R)
+        elif op == NEG: st.append(-st.pop() % R)
+        elif op == SQUARE: x = st.pop(); st.append(x * x % R)
+        elif op == DOUBLE: st.append(2 * st.pop() % R)
+        elif op == TEE: tmp[a] = st[-1]
+        elif op == PUSH_TMP: st.append(tmp[a])          # KeyError = read before this evaluation defined it
+        elif op == FOLD: out[a] = st.pop()
+        else: raise AssertionError(op)
+    return st
+
+
+def random_constraints(rng, count, ncols, nconsts, reuse_slots=False):
+    """postfix programs; products are parked with TEE_TMP now and then, later constraints pick parked values up"""
+    slots = []           # slots defined so far (any constraint)
+    progs = []
+
+    def expr(depth, prog):
+        pick = rng.random()
+        if depth <= 0 or pick < 0.25:
+            if slots and rng.random() < 0.4:
+                prog.append((PUSH_TMP, rng.choice(slots), 0))
+            elif rng.random() < 0.8:
+                prog.append((PUSH_COL, rng.randrange(ncols), 0))
+            else:
+                prog.append((PUSH_CONST, rng.randrange(nconsts), 0))
+            return
+        if pick < 0.35:
+            expr(depth - 1, prog)
+            prog.append((rng.choice([NEG, SQUARE, DOUBLE]), 0, 0))
+        else:
+            expr(depth - 1, prog)
+            expr(depth - 1, prog)
+            prog.append((rng.choice([ADD, SUB, MUL, MUL]), 0, 0))
+        if rng.random() < 0.3:
+            s = rng.choice(slots) if (reuse_slots and slots and rng.random() < 0.5) else (max(slots) + 1 if slots else 0)
+            prog.append((TEE, s, 0))
+            if s not in slots:
+                slots.append(s)
+    for _ in range(count):
+        p = []
+        expr(rng.randrange(2, 5), p)
+        progs.append(p)
+    return progs
+
+
+def split(zk, progs, cls, classes):
+    lib = zk.lib()
+    words = np.array([w for p in progs for ins in p for w in ins], dtype=np.uint32)
+    lens = np.array([len(p) for p in progs], dtype=np.uint32)
+    cls_a = np.array(cls, dtype=np.uint32)
+    out_lens = np.zeros(classes, dtype=np.uint32)
+    conflict = ctypes.c_int()
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.zk_host_split_programs(ptr(words), ptr(lens), ptr(cls_a), ctypes.c_uint32(len(progs)), ctypes.c_uint32(classes), None, ctypes.c_size_t(0), ptr(out_lens), ctypes.byref(conflict)) == 0
+    out = np.zeros(3 * int(out_lens.sum()), dtype=np.uint32)
+    assert lib.zk_host_split_programs(ptr(words), ptr(lens), ptr(cls_a), ctypes.c_uint32(len(progs)), ctypes.c_uint32(classes), ptr(out), ctypes.c_size_t(out.size), ptr(out_lens), ctypes.byref(conflict)) == 0
+    res, at = [], 0
+    for e in range(classes):
+        n = int(out_lens[e])
+        res.append([tuple(int(x) for x in out[3 * (at + j):3 * (at + j) + 3]) for j in range(n)])
+        at += n
+    return res, conflict.value
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_every_constraint_keeps_its_value_in_its_class(zk, seed):
+    rng = random.Random(seed)
+    ncols, nconsts, count, classes = 6, 3, rng.randrange(4, 14), rng.randrange(1, 5)
+    progs = random_constraints(rng, count, ncols, nconsts)
+    cls = [rng.randrange(classes) for _ in range(count)]
+    class_progs, conflict = split(zk, progs, cls, classes)
+    assert conflict == 0
+    for _ in range(4):
+        cols = [rng.randrange(R) for _ in range(ncols)]
+        consts = [rng.randrange(R) for _ in range(nconsts)]
+        want, tmp = {}, {}
+        for i, p in enumerate(progs):                     # the whole list in order, one shared parking area: what a single class does
+            st = evaluate(p, cols, consts, tmp, want)
+            assert len(st) == 1
+            want[i] = st[0]
+        got = {}
+        for e in range(classes):                          # every class on its own, starting from an EMPTY parking area
+            assert evaluate(class_progs[e], cols, consts, {}, got) == []
+        assert got == want
+    # a class that holds everything is the original sequence (nothing re-materialised)
+    one, _ = split(zk, progs, [0] * count, 1)
+    assert [ins for ins in one[0] if ins[0] != FOLD] == [ins for p in progs for ins in p]
+
+
+def test_slot_reuse_across_constraints_is_reported(zk):
+    # slot 0 defined twice, read by a third constraint: which definition a re-materialisation would take is ambiguous -> single class
+    progs = [[(PUSH_COL, 0, 0), (PUSH_COL, 1, 0), (MUL, 0, 0), (TEE, 0, 0)],
+             [(PUSH_COL, 2, 0), (SQUARE, 0, 0), (TEE, 0, 0)],
+             [(PUSH_TMP, 0, 0), (PUSH_COL, 3, 0), (ADD, 0, 0)]]
+    _, conflict = split(zk, progs, [0, 1, 0], 2)
+    assert conflict == 1
+    # the same slot reused but only ever read inside the constraint that wrote it (the prover's lookup identities): fine
+    progs = [[(PUSH_COL, 0, 0), (TEE, 5, 0), (PUSH_TMP, 5, 0), (MUL, 0, 0)], [(PUSH_COL, 1, 0), (TEE, 5, 0), (PUSH_TMP, 5, 0), (ADD, 0, 0)]]
+    _, conflict = split(zk, progs, [0, 1], 2)
+    assert conflict == 0
+    # a read before any definition is malformed
+    _, conflict = split(zk, [[(PUSH_TMP, 3, 0)]], [0], 1)
+    assert conflict == 1

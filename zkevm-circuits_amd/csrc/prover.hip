@@ -1030,9 +1030,85 @@ static int classify_constraints(zk_ctx* ctx, const zk_pk* pk, const std::vector<
     }
     return ZK_OK;
 }
+// Intermediates shared between constraints (TEE_TMP in one gate, PUSH_TMP in a later one: the common-subexpression
+// elimination of halo2's GraphEvaluator as it survives the export) and degree classes: a class evaluates only ITS constraints,
+// so a class that reads an intermediate another class parked must compute it itself.  `TmpSplit` re-materialises: walking the
+// constraints in order, a PUSH_TMP whose definition this class has not emitted yet is replaced by the defining sub-expression
+// (its own PUSH_TMPs resolved the same way) followed by the TEE_TMP; afterwards the class reads the slot like any other.
+// Classes run as separate launches over the same parking area, each defining what it reads before reading it.
+// Not handled (ok() == false, the caller evaluates everything as one class, as before): a slot that is defined more than once
+// AND read by a constraint other than the one that defined it (slot reuse with cross-constraint lifetime).
+struct TmpSplit {
+    std::vector<Prog> defs;                       // slot -> defining sub-expression (postfix, without the TEE)
+    std::vector<uint32_t> ver;                    // slot -> number of definitions seen so far
+    std::vector<std::vector<uint32_t>> have;      // class -> slot -> version this class has emitted (0 = none)
+    bool conflict = false;
+    static int arity(uint32_t op) {
+        switch (op) {
+            case Q_PUSH_COL: case Q_PUSH_CONST: case Q_PUSH_TMP: return 0;
+            case Q_ADD: case Q_SUB: case Q_MUL: return 2;
+            default: return 1;                    // NEG, DOUBLE, SQUARE, ADD_CONST, MUL_CONST, TEE_TMP (peeks: one in, one out)
+        }
+    }
+    // the sub-expression whose value is on top of the stack after instruction t - 1 of g
+    static Prog sub_expression(const Prog& g, size_t t) {
+        int need = 1;
+        size_t start = t;
+        while (start > 0 && need > 0) { --start; need += arity(g[start].op) - 1; }
+        return Prog(g.begin() + start, g.begin() + t);
+    }
+    explicit TmpSplit(size_t classes) : have(classes) {}
+    void grow(uint32_t s) {
+        if (s >= ver.size()) { ver.resize(s + 1, 0); defs.resize(s + 1); }
+        for (auto& h : have) if (s >= h.size()) h.resize(s + 1, 0);
+    }
+    void emit_push(uint32_t s, uint32_t e, Prog& out, int depth = 0) {
+        grow(s);
+        if (have[e][s] == ver[s] && ver[s]) { out.push_back({Q_PUSH_TMP, s, 0}); return; }
+        if (!ver[s] || depth > 64) { conflict = true; out.push_back({Q_PUSH_TMP, s, 0}); return; }     // read before any definition: malformed
+        for (const Instr& in : defs[s]) {
+            if (in.op == Q_PUSH_TMP) emit_push(in.a, e, out, depth + 1);
+            else {
+                if (in.op == Q_TEE_TMP) { grow(in.a); have[e][in.a] = ver[in.a]; }
+                out.push_back(in);
+            }
+        }
+        out.push_back({Q_TEE_TMP, s, 0});
+        have[e][s] = ver[s];
+    }
+    // appends constraint g (class e) to out with its intermediates resolved for that class
+    void append(const Prog& g, uint32_t e, Prog& out) {
+        for (size_t t = 0; t < g.size(); ++t) {
+            const Instr& in = g[t];
+            if (in.op == Q_TEE_TMP) {
+                grow(in.a);
+                defs[in.a] = sub_expression(g, t);
+                ++ver[in.a];
+                have[e][in.a] = ver[in.a];
+                out.push_back(in);
+            } else if (in.op == Q_PUSH_TMP) emit_push(in.a, e, out);
+            else out.push_back(in);
+        }
+    }
+};
+// slot reuse with cross-constraint lifetime (see TmpSplit): such keys keep the single-class evaluation
+static bool tmp_slots_conflict(const std::vector<Prog>& cons) {
+    std::vector<uint32_t> ndef, def_at;
+    std::vector<uint8_t> cross;
+    auto grow = [&](uint32_t s) { if (s >= ndef.size()) { ndef.resize(s + 1, 0); def_at.resize(s + 1, 0); cross.resize(s + 1, 0); } };
+    for (uint32_t i = 0; i < cons.size(); ++i)
+        for (const Instr& in : cons[i]) {
+            if (in.op == Q_TEE_TMP) { grow(in.a); ++ndef[in.a]; def_at[in.a] = i; }
+            else if (in.op == Q_PUSH_TMP) { grow(in.a); if (!ndef[in.a]) return true; if (def_at[in.a] != i) cross[in.a] = 1; }
+        }
+    for (size_t s_ = 0; s_ < ndef.size(); ++s_) if (ndef[s_] > 1 && cross[s_]) return true;
+    return false;
+}
 static bool quotient_split_enabled(bool sharded, bool gates_share_tmps) {
     const char* split_env = getenv("ZK_QUOTIENT_SPLIT");
-    return !(split_env && atoi(split_env) == 0) && !sharded && !gates_share_tmps;     // intermediates shared between gates tie their rows together
+    (void)gates_share_tmps;                   // shared intermediates are re-materialised per class (TmpSplit); slot-reuse conflicts are checked by the caller
+    (void)sharded;                            // sharded sessions distribute (class, coset) pairs over the ranks (zk_proof_finish)
+    return !(split_env && atoi(split_env) == 0);
 }
 // For every advice column: the set of cosets r (bit r) of the extended domain on which some constraint class active there reads it.
 static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::vector<uint32_t>& mask) {
@@ -1041,13 +1117,18 @@ static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::ve
     build_constraints(pk, cons, share);
     const uint32_t E = pk->ext_k - pk->k;
     std::vector<uint32_t> cls;
-    PK_TRY(classify_constraints(ctx, pk, cons, quotient_split_enabled(sharded, share), E, cls));
+    PK_TRY(classify_constraints(ctx, pk, cons, quotient_split_enabled(sharded, share) && !tmp_slots_conflict(cons), E, cls));
     mask.assign(pk->A, 0u);
     if (E > 5) return ZK_OK;           // more than 32 cosets: no plan (the quotient transforms everything itself)
-    for (uint32_t i = 0; i < cons.size(); ++i) {
+    // the class programs as zk_proof_finish assembles them (shared intermediates re-materialised per class: a class may read
+    // columns through an intermediate that another class's constraint defined)
+    std::vector<Prog> progs(E + 1);
+    TmpSplit tmps(E + 1);
+    for (uint32_t i = 0; i < cons.size(); ++i) tmps.append(cons[i], cls[i], progs[cls[i]]);
+    for (uint32_t e = 0; e <= E; ++e) {
         uint32_t cosets = 0;
-        for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - cls[i])) - 1u)) == 0) cosets |= 1u << r;
-        for (const Instr& in : cons[i])
+        for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - e)) - 1u)) == 0) cosets |= 1u << r;
+        for (const Instr& in : progs[e])
             if (in.op == Q_PUSH_COL && (in.a >> 24) == CT_ADVICE && (in.a & 0xFFFFFFu) < pk->A) mask[in.a & 0xFFFFFFu] |= cosets;
     }
     return ZK_OK;
@@ -1114,6 +1195,37 @@ static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
     pr->adv_coset.resize(R);
     for (auto& v : pr->adv_coset) v.resize(pk->A);
     if (getenv("ZK_PROVER_TRACE")) fprintf(stderr, "[zk prover] advice cosets computed ahead: cosets 0x%x, %.1f GiB\n", chosen, used / (double)(1ull << 30));
+    return ZK_OK;
+}
+
+// Host only (no device), for tests: the degree-class assembly of constraint programs with shared intermediates, exactly as
+// zk_proof_finish performs it (TmpSplit).  words: 3 per instruction, the `count` programs back to back (lens[i] instructions
+// each); cls[i] < classes.  Output: the class programs back to back (out_lens[e] instructions each), every constraint followed
+// by the marker {Q_FOLD, i, 0} so that a test can tell the constraints' values apart.  *conflict = 1 when the programs reuse a
+// slot across constraints (the prover then keeps a single class).
+int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const uint32_t* cls, uint32_t count, uint32_t classes,
+                           uint32_t* out_words, size_t out_cap_words, uint32_t* out_lens, int* conflict) {
+    if (!words || !lens || !cls || !out_lens || !conflict || classes == 0) return ZK_ERR_INVALID_ARG;
+    std::vector<Prog> cons(count);
+    size_t at = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (cls[i] >= classes) return ZK_ERR_INVALID_ARG;
+        for (uint32_t j = 0; j < lens[i]; ++j, ++at) cons[i].push_back({words[3 * at], words[3 * at + 1], words[3 * at + 2]});
+    }
+    *conflict = tmp_slots_conflict(cons) ? 1 : 0;
+    std::vector<Prog> progs(classes);
+    TmpSplit tmps(classes);
+    for (uint32_t i = 0; i < count; ++i) {
+        tmps.append(cons[i], cls[i], progs[cls[i]]);
+        progs[cls[i]].push_back({Q_FOLD, i, 0});
+    }
+    if (tmps.conflict) *conflict = 1;
+    size_t total = 0;
+    for (uint32_t e = 0; e < classes; ++e) { out_lens[e] = (uint32_t)progs[e].size(); total += progs[e].size(); }
+    if (!out_words) return ZK_OK;
+    if (3 * total > out_cap_words) return ZK_ERR_INVALID_ARG;
+    size_t w = 0;
+    for (const Prog& pg : progs) for (const Instr& in : pg) { out_words[w++] = in.op; out_words[w++] = in.a; out_words[w++] = in.b; }
     return ZK_OK;
 }
 
@@ -1334,14 +1446,15 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // (what halo2's evaluate_h does); how much is saved depends on the circuit's degree profile.
     const uint32_t E = ext_k - k, K = (uint32_t)cons.size();
     const bool sharded = pr->world > 1 && pr->gather;
-    const bool split = quotient_split_enabled(sharded, gates_share_tmps);
+    const bool split = quotient_split_enabled(sharded, gates_share_tmps) && !tmp_slots_conflict(cons);
     std::vector<uint32_t> cls;
     PK_TRY(classify_constraints(ctx, pk, cons, split, E, cls));
     struct QClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; DevBuf h; };
     std::vector<QClass> qc(E + 1);
+    TmpSplit tmps(E + 1);
     for (uint32_t i = 0; i < K; ++i) {
         QClass& c = qc[cls[i]];
-        c.prog.insert(c.prog.end(), cons[i].begin(), cons[i].end());
+        tmps.append(cons[i], cls[i], c.prog);                                        // the constraint, its shared intermediates resolved for this class
         c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
         c.last = i;
         c.used = true;
@@ -1393,21 +1506,44 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         part.part = &part_of;
         const Fr w_n = fr_root_of_unity(k), w_ext = fr_root_of_unity(ext_k);
         Fr g = fr_zeta();
-        // sharded session: rank q evaluates cosets q, q + world, ...; after every round of `world`
-        // cosets the (already divided) results are all-gathered and interleaved into h on every rank
+        // Sharded session: the unit of work is a (class, coset) pair -- class e on coset r costs the transforms of the columns
+        // that class reads plus its program -- and the pairs are dealt to the ranks longest first (every rank computes the same
+        // deal).  A rank keeps the finished, already divided n-row results of its pairs; afterwards they are all-gathered round
+        // by round (round t = every rank's t-th pair) and interleaved into the classes' buffers on every rank.
         const Fr one_fr = Fr::one();
         std::vector<uint8_t> send, recv;
         DevBuf rtmp, gbuf;
+        struct Pair { uint32_t e, r; double cost; };
+        std::vector<std::vector<Pair>> deal(sharded ? pr->world : 1);       // per rank, in the order of evaluation (by coset, then class)
+        std::vector<DevBuf> mine;                                           // this rank's finished pairs, in that order
+        auto owner = [&](uint32_t e, uint32_t r) -> uint32_t {
+            for (uint32_t q_ = 0; q_ < deal.size(); ++q_) for (const Pair& pp_ : deal[q_]) if (pp_.e == e && pp_.r == r) return q_;
+            return 0;
+        };
         if (sharded) {
             send.assign(n * 32, 0);
             recv.resize((size_t)pr->world * n * 32);
             if (!rtmp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            std::vector<Pair> all;
+            for (uint32_t e = 0; e <= E; ++e)
+                if (qc[e].used)
+                    for (uint32_t r = 0; r < nparts; r += 1u << (E - e)) all.push_back({e, r, (double)qc[e].refs.size() + (double)qc[e].prog.size() / 64.0});
+            std::stable_sort(all.begin(), all.end(), [](const Pair& a, const Pair& b) { return a.cost > b.cost; });
+            std::vector<double> load(pr->world, 0.0);
+            for (const Pair& pp_ : all) {
+                uint32_t best = 0;
+                for (uint32_t q_ = 1; q_ < pr->world; ++q_) if (load[q_] < load[best]) best = q_;
+                load[best] += pp_.cost;
+                deal[best].push_back(pp_);
+            }
+            for (auto& d_ : deal) std::sort(d_.begin(), d_.end(), [](const Pair& a, const Pair& b) { return a.r != b.r ? a.r < b.r : a.e < b.e; });
         }
         for (uint32_t r_ = 0; r_ < nparts; ++r_) {
-          if (!sharded || r_ % pr->world == pr->rank) {
-            // classes whose extended domain contains this coset, and the columns they read
-            std::vector<uint32_t> active;
-            for (uint32_t e = 0; e <= E; ++e) if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0) active.push_back(e);
+          // classes whose extended domain contains this coset (sharded: those of them this rank was dealt), and the columns they read
+          std::vector<uint32_t> active;
+          for (uint32_t e = 0; e <= E; ++e)
+              if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0 && (!sharded || owner(e, r_) == pr->rank)) active.push_back(e);
+          if (!active.empty()) {
             part_of.clear();
             std::vector<const void*> bat_src;                 // the coset transforms of this round go out as one batch
             std::vector<void*> bat_dst;
@@ -1472,29 +1608,41 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 Fr scale;
                 memcpy((void*)&scale, yp.l, 32);
                 scale = scale * vinv;
-                if (sharded) PK_TRY(zk_fr_scale(ctx, hpart.p, &scale, n));            // peers receive the finished values (one class in sharded sessions)
+                if (sharded) {                 // peers receive the finished values: keep them until the exchange
+                    PK_TRY(zk_fr_scale(ctx, hpart.p, &scale, n));
+                    DevBuf keep;
+                    if (!keep.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                    ZK_HIP(ctx, hipMemcpyAsync(keep.p, hpart.p, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                    mine.push_back(std::move(keep));
+                }
                 PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &scale, qc[e].h.p, (size_t)1 << e, r_ >> (E - e)));
             }
             trace.mark("  quotient: program");
           }
             g = g * w_ext;
-            if (sharded && pr->use_comm && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
-                // in-library RCCL: the finished cosets go device to device, stream-ordered (no host copy, no synchronisation)
-                const uint32_t round0 = r_ - r_ % pr->world;
-                if (!gbuf.p && !gbuf.alloc((size_t)pr->world * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-                PK_TRY(comm_allgather_dev(ctx, hpart.p, n * 32, gbuf.p));
-                for (uint32_t q_ = 0; q_ < pr->world; ++q_) {
-                    if (q_ == pr->rank || round0 + q_ >= nparts) continue;
-                    PK_TRY(zk_fr_scatter_scaled(ctx, (char*)gbuf.p + (size_t)q_ * n * 32, n, &one_fr, h.p, nparts, round0 + q_));
+        }
+        if (sharded) {
+            if (mine.size() != deal[pr->rank].size()) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: %zu pairs evaluated, %zu dealt", mine.size(), deal[pr->rank].size());
+            size_t rounds = 0;
+            for (const auto& d_ : deal) rounds = std::max(rounds, d_.size());
+            for (size_t t = 0; t < rounds; ++t) {
+                const void* mine_t = t < mine.size() ? mine[t].p : hpart.p;           // a rank without a t-th pair sends filler nobody reads
+                const char* got = nullptr;
+                if (pr->use_comm) {
+                    // in-library RCCL: the finished pairs go device to device, stream-ordered (no host copy, no synchronisation)
+                    if (!gbuf.p && !gbuf.alloc((size_t)pr->world * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                    PK_TRY(comm_allgather_dev(ctx, mine_t, n * 32, gbuf.p));
+                    got = (const char*)gbuf.p;
+                } else {
+                    if (t < mine.size()) PK_TRY(zk_d2h(ctx, send.data(), mine_t, n * 32));
+                    if (pr->gather(pr->gather_user, send.data(), n * 32, recv.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
                 }
-            } else if (sharded && (r_ % pr->world == pr->world - 1 || r_ + 1 == nparts)) {
-                const uint32_t round0 = r_ - r_ % pr->world;                        // first coset of this round
-                if (round0 + pr->rank < nparts) PK_TRY(zk_d2h(ctx, send.data(), hpart.p, n * 32));
-                if (pr->gather(pr->gather_user, send.data(), n * 32, recv.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
                 for (uint32_t q_ = 0; q_ < pr->world; ++q_) {
-                    if (q_ == pr->rank || round0 + q_ >= nparts) continue;
-                    PK_TRY(zk_h2d(ctx, rtmp.p, recv.data() + (size_t)q_ * n * 32, n * 32));
-                    PK_TRY(zk_fr_scatter_scaled(ctx, rtmp.p, n, &one_fr, h.p, nparts, round0 + q_));
+                    if (q_ == pr->rank || t >= deal[q_].size()) continue;
+                    const Pair& pp_ = deal[q_][t];
+                    const void* src = got ? (const void*)(got + (size_t)q_ * n * 32) : nullptr;
+                    if (!src) { PK_TRY(zk_h2d(ctx, rtmp.p, recv.data() + (size_t)q_ * n * 32, n * 32)); src = rtmp.p; }
+                    PK_TRY(zk_fr_scatter_scaled(ctx, src, n, &one_fr, qc[pp_.e].h.p, (size_t)1 << pp_.e, pp_.r >> (E - pp_.e)));
                 }
             }
         }
