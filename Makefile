@@ -2,6 +2,10 @@
 PYTHON ?= python
 GPU ?=
 
+all:
+	$(MAKE) -C zkevm-circuits_amd -s
+	$(MAKE) -C oracle -s
+
 # T1 kit (shim/t1_standalone/README.md): kit inputs + self-check proofs, verified from the files alone, packed with the Rust
 # program that puts them in front of upstream verify_proof.  `make t1-kit GPU=--gpu` proves through libzkmi355.so.
 t1-kit:
@@ -12,4 +16,4 @@ t1-kit:
 	tar czf t1_kit.tar.gz t1_kit shim/t1_standalone tools/t1_kit.py tests/plonk_fixtures.py
 	@echo "t1_kit.tar.gz ready: follow shim/t1_standalone/README.md (4 commands)"
 
-.PHONY: t1-kit
+.PHONY: all t1-kit

@@ -432,7 +432,7 @@ def proof_worker(name):
     # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
     build, repeat, tkind = {"keccak_shape_k18": (lambda: bp.build_keccak_shape(ctx, 18), 3, None),
                             "recursion_shape_k22": (lambda: bp.build_large(ctx, 22, 3), 4, 1),
-                            "supercircuit_shape_k20": (lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 3, None)}[name]
+                            "supercircuit_shape_k20": (lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 4, None)}[name]
     t0 = time.perf_counter()
     circ, blob, adv_m, inst_m, inst = build()
     t_build = time.perf_counter() - t0

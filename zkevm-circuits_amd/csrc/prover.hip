@@ -1111,7 +1111,7 @@ static bool quotient_split_enabled(bool sharded, bool gates_share_tmps) {
     return !(split_env && atoi(split_env) == 0);
 }
 // For every advice column: the set of cosets r (bit r) of the extended domain on which some constraint class active there reads it.
-static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::vector<uint32_t>& mask) {
+static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::vector<uint32_t>& mask, size_t* key_slots = nullptr) {
     std::vector<Prog> cons;
     bool share = false;
     build_constraints(pk, cons, share);
@@ -1131,6 +1131,20 @@ static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::ve
         for (const Instr& in : progs[e])
             if (in.op == Q_PUSH_COL && (in.a >> 24) == CT_ADVICE && (in.a & 0xFFFFFFu) < pk->A) mask[in.a & 0xFFFFFFu] |= cosets;
     }
+    if (key_slots) {          // (column of the key, coset) pairs the quotient reads: what the key's coset cache will hold
+        std::unordered_map<uint32_t, uint32_t> key_mask;
+        for (uint32_t e = 0; e <= E; ++e) {
+            uint32_t cosets = 0;
+            for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - e)) - 1u)) == 0) cosets |= 1u << r;
+            for (const Instr& in : progs[e]) {
+                const uint32_t t = in.a >> 24;
+                if (in.op == Q_PUSH_COL && (t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL)) key_mask[in.a] |= cosets;
+            }
+        }
+        size_t cnt = 0;
+        for (const auto& kv : key_mask) cnt += (size_t)__builtin_popcount(kv.second);
+        *key_slots = cnt;
+    }
     return ZK_OK;
 }
 
@@ -1148,7 +1162,8 @@ static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
     const double cap = (env ? atof(env) : 64.0) * (double)(1ull << 30);
     if (sharded || cap <= 0 || pk->A == 0) return ZK_OK;
     std::vector<uint32_t> mask;
-    PK_TRY(advice_coset_plan(ctx, pk, sharded, mask));
+    size_t key_slots = 0;
+    PK_TRY(advice_coset_plan(ctx, pk, sharded, mask, &key_slots));
     const uint32_t E = pk->ext_k - pk->k, R = 1u << E;
     if (E > 5) return ZK_OK;
     const double col_bytes = (double)((size_t)1 << pk->k) * 32.0;
@@ -1159,9 +1174,9 @@ static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
     const double cols_ahead = 2.0 * pk->A + 3.0 * (2.0 * pk->L + pk->C) + (2.0 * pk->L + pk->C + pk->I + 8.0) + 2.0 * R + 32.0;
     double avail = (double)free_b + (double)ctx->pool_bytes - cols_ahead * col_bytes - 16.0 * (double)(1ull << 30);
     if (pk->part_cache_state < 0 || (pk->part_cache_state == 1 && pk->part_cache_bytes == 0)) {
-        // the key's own cosets (fixed, sigma, l_0 ...) are still to be cached by this proof's quotient: reserved in full (every
-        // column on every coset -- an upper bound; once a proof has filled the cache, what it holds is what it needs)
-        const double key_need = (double)(pk->F + pk->P + 4) * R * col_bytes;
+        // the key's own cosets (fixed, sigma, l_0 ...) are still to be cached by this proof's quotient: reserved, counted from the
+        // class programs (a fixed column read only by low-degree gates is cached on two cosets, not on all)
+        const double key_need = (double)key_slots * col_bytes;
         const char* kenv = getenv("ZK_PK_COSET_CACHE_GB");
         const double kcap = std::min((kenv ? atof(kenv) : 96.0) * (double)(1ull << 30), (double)ctx->prop.totalGlobalMem / 3.0);
         if (key_need <= kcap) avail -= std::max(0.0, key_need - (double)pk->part_cache_bytes);
@@ -1476,8 +1491,16 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         const uint32_t nparts = 1u << E;
         auto of_key = [](uint32_t ref) { const uint32_t t = ref >> 24; return t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL; };
         if (pk->part_cache_state < 0) {       // decide once: do the key's own cosets fit the budget?
-            size_t key_cols = 0;
-            for (uint32_t ref : refs) key_cols += of_key(ref);
+            size_t key_slots = 0;             // (column of the key, coset) pairs some class reads: what the cache will hold
+            for (uint32_t ref : refs) {
+                if (!of_key(ref)) continue;
+                for (uint32_t r = 0; r < nparts; ++r) {
+                    bool read = false;
+                    for (uint32_t e = 0; e <= E && !read; ++e)
+                        read = qc[e].used && (r & ((1u << (E - e)) - 1u)) == 0 && std::find(qc[e].refs.begin(), qc[e].refs.end(), ref) != qc[e].refs.end();
+                    key_slots += read;
+                }
+            }
             // The budget is shared by every key alive on this context (a Prover keeps the chunk, compression and aggregation
             // keys resident together): the cap (ZK_PK_COSET_CACHE_GB, default 96) or a third of the device, whichever is
             // smaller, less what other keys already hold -- and it must fit what the device has free right now, counting
@@ -1487,7 +1510,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             budget = std::min(budget, (double)ctx->prop.totalGlobalMem / 3.0) - (double)ctx->coset_cache_bytes;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-            const double need = (double)key_cols * nparts * n * 32.0;
+            const double need = (double)key_slots * n * 32.0;
             const double session = (double)refs.size() * n * 32.0 + (double)((size_t)n << E) * 32.0 * 2.0;       // this proof's own coset buffers and h
             pk->part_cache_state = (need <= budget && need + session <= (double)free_b + (double)ctx->pool_bytes) ? 1 : 0;
             if (pk->part_cache_state) pk->part_cache.resize(nparts);
