@@ -316,7 +316,7 @@ def cpu_baseline(srs, column):
     }
 
 
-PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20")
+PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20", "keccak_shape_k16_cpu_vs_gpu")
 
 
 def proof_section():
@@ -412,11 +412,73 @@ def sharded_proof_section(dist, rank, world, local_rank):
     return out if rank == 0 else None
 
 
+def cpu_vs_gpu_worker(k=16):
+    """The proof-level CPU baseline, MEASURED (SURVEY 8d last row; the reference's `[Proof generation]` timer
+    [REF circuit-benchmarks/src/super_circuit.rs:115-134] needs Rust): halo2's create_proof restated over arrays with the
+    oracle's C primitives and OpenMP (oracle/cpu_prover.py: whole-extended-domain evaluate_h, as upstream's CPU prover), on the
+    Keccak shape at k = 16 -- a quarter of the rows of BASELINE config 3, so that the run stays around ten to thirty seconds of
+    host time -- beside the GPU session on the SAME circuit, witness, seed and vk.transcript_repr: the two proofs must be the
+    same bytes.  Key generation (fixed / sigma forms, halo2's keygen_pk) and the SRS are outside both timings."""
+    import numpy as np
+
+    import bench_proof as bp
+    import zkevm_circuits_amd as z
+    from oracle import cpu_prover as cp, cref
+
+    S = 0x5EC2E7
+    ctx = z.Context(0)
+    circ, blob, adv_m, inst_m, inst = bp.build_keccak_shape(ctx, k)
+    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
+    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
+    pinned = []
+    for a in adv_m:
+        h = ctx.host_alloc(a.shape)
+        h[:] = a
+        pinned.append(h)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(S))
+    pk = ctx.pk_create(srs, blob)
+    _, rep = pk.vk(circ.F + len(circ.perm_cols))
+    repr_int = cref.from_mont(rep.reshape(1, 4))[0]
+    gpu_times, gpu_proof = [], b""
+    for _ in range(4):
+        t0 = time.perf_counter()
+        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+        sess.set_multiopen(1)
+        sess.advice_phase({i: c for i, c in enumerate(pinned)})
+        gpu_proof = sess.finish()
+        gpu_times.append(time.perf_counter() - t0)
+    pk.destroy()
+    srs.destroy()
+    ctx.close()
+    circ_h, adv_h, inst_h = bp.build_keccak_shape(None, k)          # same seed: the same circuit and witness, host side only
+    key = cp.keygen(circ_h)
+    srs_h = cp.Srs(k, S)
+    stages = {}
+    t0 = time.perf_counter()
+    cpu_proof = cp.create_proof(circ_h, srs_h, adv_h, inst_h, repr_int, bytes(16), "shplonk", timings=stages, key=key)
+    cpu_s = time.perf_counter() - t0
+    threads = cref.num_threads()
+    return {
+        "metric": "synthetic-shape full proof wall-clock (s): restated CPU prover vs 1x MI355X, same circuit / witness / seed",
+        "shape": f"Keccak shape at k = {k} ({circ.A} advice, {circ.F} fixed, {len(circ.perm_cols)} permutation columns, {len(circ.lookups)} lookups, degree {circ.degree()}, {circ.bf} blinding factors)",
+        "cpu_baseline": {"value": round(cpu_s, 3), "unit": "s", "cores": threads, "kind": "port",
+                         "sample": f"ONE full proof of the k = {k} Keccak shape: halo2 create_proof restated over arrays (oracle/cpu_prover.py), C primitives, OpenMP {threads} threads; "
+                                   "keygen and SRS outside the timing; not the reference's Rust prover (no toolchain here)",
+                         "stages_s": {name: round(v, 3) for name, v in stages.items()}},
+        "gpu_s": round(min(gpu_times), 4), "gpu_create_proof_s": [round(t, 4) for t in gpu_times],
+        "speedup_vs_restated_cpu": round(cpu_s / min(gpu_times), 1),
+        "same_proof_bytes": cpu_proof == gpu_proof, "proof_bytes": len(gpu_proof), "data": "synthetic-shape",
+    }
+
+
 def proof_worker(name):
     """One proof shape, measured in this (fresh) process.  The quotient evaluator's roofline comes from one extra,
     profiled proof: bytes = what the launches really stream (counted by the library) over their time."""
     import bench_proof as bp
     import zkevm_circuits_amd as z
+
+    if name == "keccak_shape_k16_cpu_vs_gpu":
+        return cpu_vs_gpu_worker(16)
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     ctx = z.Context(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)

@@ -285,6 +285,29 @@ def build_keccak_shape(ctx, k: int, pairs: int = 48, window: int = 12, lookups: 
             b_v[j, r0 - 3] += a_v[j, r0 + i]
         b_v[j, r2] = a_v[j, r2 - 5] * a_v[j, r2 + window - 5]
     c.copies = copies
+    if ctx is None:
+        # host-only variant (the restated CPU prover's input, bench.py cpu_baseline leg): fixed and advice columns as
+        # Montgomery arrays made by the oracle's C conversion, nothing touches a device
+        from oracle import cref
+        import ctypes
+
+        def host_mont(v):
+            canon = np.ascontiguousarray(small_to_limbs(v))
+            out = np.empty_like(canon)
+            cref.lib().orc_fe_to_mont_vec(0, canon.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(canon.shape[0]))
+            return out
+
+        def sel_h(rows_):
+            v = np.zeros(n, dtype=np.uint64)
+            v[rows_] = 1
+            return host_mont(v)
+        ta_h = np.zeros(n, dtype=np.uint64)
+        ta_h[:tab_n] = np.arange(tab_n, dtype=np.uint64)
+        c.fixed = [sel_h(r0), sel_h(r2), sel_h(np.arange(u)), host_mont(ta_h), sel_h(r3)]
+        adv_h = []
+        for j in range(pairs):
+            adv_h += [host_mont(a_v[j]), host_mont(b_v[j])]
+        return c, adv_h, [[int(v) for v in inst[0, :pub.size]]]
     adv_m = []
     for j in range(pairs):
         adv_m.append(to_mont_gpu(ctx, small_to_limbs(a_v[j])))

@@ -209,6 +209,66 @@ API void orc_prefix_sum(const fe *a, fe *z, size_t n) {
     for (size_t i = 0; i < n; ++i) { z[i] = acc; fe_add(&acc, &acc, &a[i], &FR); }
 }
 
+/* ------------------------------------------------------------------ vector helpers of the restated CPU prover (oracle/cpu_prover.py)
+ * Row-parallel (OpenMP) like halo2's `parallelize` chunks.  All values Montgomery form. */
+API void orc_fe_mul_vec_mt(const fe *a, const fe *b, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) fe_mul(&o[i], &a[i], &b[i], &FR);
+}
+API void orc_fe_add_vec_mt(const fe *a, const fe *b, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) fe_add(&o[i], &a[i], &b[i], &FR);
+}
+API void orc_fe_sub_vec_mt(const fe *a, const fe *b, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) fe_sub(&o[i], &a[i], &b[i], &FR);
+}
+/* o = a * s + b   (b may be NULL: o = a * s) */
+API void orc_fe_scale_add(const fe *a, const fe *s, const fe *b, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) { fe t; fe_mul(&t, &a[i], s, &FR); if (b) fe_add(&o[i], &t, &b[i], &FR); else o[i] = t; }
+}
+API void orc_fe_add_scalar(const fe *a, const fe *s, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) fe_add(&o[i], &a[i], s, &FR);
+}
+/* o[i] = a[(i + shift) mod n]  (a rotation of a column on a cyclic domain) */
+API void orc_fe_rotate(const fe *a, long long shift, fe *o, size_t n) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) { long long j = ((long long)i + shift) % (long long)n; if (j < 0) j += (long long)n; o[i] = a[j]; }
+}
+/* Postfix expression over columns, every row (plonk::evaluation restated as a stack machine; the same instruction set as the
+ * key blob: 1 PUSH_COL (a = index into cols, b = rotation), 2 PUSH_CONST (a = index into consts), 3 ADD, 4 SUB, 5 MUL, 6 NEG).
+ * Row i reads cols[a][(i + rot * stride) mod n].  Returns 0, or -1 on a malformed program. */
+API int orc_eval_program(const uint32_t *prog, size_t n_instr, const fe *const *cols, const fe *consts, size_t n, long long stride, fe *out) {
+    int depth = 0, maxd = 0;
+    for (size_t p = 0; p < n_instr; ++p) {
+        uint32_t op = prog[3 * p];
+        if (op == 1 || op == 2) { if (++depth > maxd) maxd = depth; }
+        else if (op >= 3 && op <= 5) { if (depth < 2) return -1; --depth; }
+        else if (op == 6) { if (depth < 1) return -1; }
+        else return -1;
+    }
+    if (depth != 1 || maxd > 64) return -1;
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        fe st[64]; int sp = 0;
+        for (size_t p = 0; p < n_instr; ++p) {
+            const uint32_t op = prog[3 * p], a = prog[3 * p + 1]; const int32_t rot = (int32_t)prog[3 * p + 2];
+            switch (op) {
+                case 1: { long long j = ((long long)i + (long long)rot * stride) % (long long)n; if (j < 0) j += (long long)n; st[sp++] = cols[a][j]; break; }
+                case 2: st[sp++] = consts[a]; break;
+                case 3: fe_add(&st[sp - 2], &st[sp - 2], &st[sp - 1], &FR); --sp; break;
+                case 4: fe_sub(&st[sp - 2], &st[sp - 2], &st[sp - 1], &FR); --sp; break;
+                case 5: fe_mul(&st[sp - 2], &st[sp - 2], &st[sp - 1], &FR); --sp; break;
+                default: fe_neg(&st[sp - 1], &st[sp - 1], &FR); break;
+            }
+        }
+        out[i] = st[0];
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ G1 */
 typedef struct { fe x, y; } aff;
 typedef struct { fe x, y, z; } jac;

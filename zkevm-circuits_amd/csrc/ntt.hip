@@ -262,6 +262,7 @@ k_ntt_pass(NttIo io, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
     }
 }
 
+static bool ntt_xcd_remap() { static const bool on = getenv("ZK_NTT_XCD") && atoi(getenv("ZK_NTT_XCD")) == 1; return on; }      // measurement knob, off: neutral at every size (profiles/r03_ntt_xcd.md)
 __host__ __device__ __forceinline__ int ntt_row_pad(int log_np) { return log_np >= 8 ? 8 : 0; }     // <= 16 rows per tile then: at most 128 extra elements
 // ----------------------------------------------------------------------------------- last pass
 // Rows of n_P contiguous elements; tile = T rows i1 = blk*T + c (row stride = midN * n_P) at a
@@ -273,7 +274,7 @@ __host__ __device__ __forceinline__ int ntt_row_pad(int log_np) { return log_np 
 // the lazy sums back below 2p.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_last(NttIo io, const Tw29* __restrict__ tw, int log_np, int log_t,
-           int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre, int fin_folded) {
+           int log_n1, int log_mid, Fr fin, const Fr* __restrict__ pre, int fin_folded, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const Fr* __restrict__ src = io.src[blockIdx.y];
     Fr* __restrict__ dst = io.dst[blockIdx.y];
@@ -283,7 +284,13 @@ k_ntt_last(NttIo io, const Tw29* __restrict__ tw, int log_np, int log_t,
     // stride that is a multiple of the 32 banks the T rows of a wave would collide on every bank
     const int row = (1 << log_np) + ntt_row_pad(log_np);
     Lds29 L{smem, T * row};
-    const uint32_t mid = blockIdx.x & ((1u << log_mid) - 1), blk = blockIdx.x >> log_mid;
+    // Workgroups go to the eight XCDs round-robin and each XCD has its own L2.  A tile of T rows writes T * 32-byte runs
+    // (64 B at T = 2), i.e. HALF of every 128-byte line it touches; the other half belongs to the tile next to it.  With the
+    // plain numbering those two tiles run on different XCDs and each L2 writes its half back on its own (masked partial
+    // writes); renumbered so that neighbouring tiles are consecutive workgroups of ONE XCD, the halves meet in that L2.
+    uint32_t bx = blockIdx.x;
+    if (xcd_remap) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const uint32_t mid = bx & ((1u << log_mid) - 1), blk = bx >> log_mid;
     const Fr29 fin29 = unpack29<Fr29P>(fin);
 
     for (int s = 0; s < log_np;) {
@@ -589,7 +596,8 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             for (size_t j = 0; j < nb; ++j) { io.src[j] = cur_io.src[j]; io.dst[j] = d_datas[first + j]; }
             ZkProfScope pscope(ctx, "ntt_last");
             hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
-                               ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0);
+                               ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0,
+                               (log_mid == 0 && blocks % 8 == 0 && blocks >= 16 && ntt_xcd_remap()) ? 1 : 0);
             ZK_CHECK_LAUNCH(ctx);
         }
     }
