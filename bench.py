@@ -4,8 +4,10 @@
 A "step" is one pass of the hot path over one column: KZG-commit a 2^20-row column
 (`commit_lagrange` = one 2^20 MSM over g_lagrange) and transform it (`lagrange_to_coeff` = one 2^20
 NTT).  Inputs are resident in HBM before the timed region starts.  The steps walk a ROTATING set of
-16 distinct columns to commit and 16 distinct columns to transform (1 GiB, beyond the 256 MiB
-Infinity Cache), so no step finds its input in a cache the previous step filled.
+32 distinct columns to commit and 32 distinct columns to transform (2 GiB, eight times the 256 MiB
+Infinity Cache), so no step finds its input in a cache the previous step filled.  Columns are
+submitted the way a prover phase submits them: a batch of commitments (pipelined on the device),
+then the batch of transforms (zk_ntt_batch).
 
 `python bench.py --gpus N` launches itself as N ranks (torch.distributed.run, one rank per GPU,
 backend nccl = RCCL) when it was not started under a launcher already.  Multi-GPU: the
@@ -35,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 K = 20
 N = 1 << K
-NCOL = 16                  # rotating set: 16 x 32 MiB committed + 16 x 32 MiB transformed
+NCOL = 32                  # rotating set: 32 x 32 MiB committed + 32 x 32 MiB transformed (2 GiB, eight times the Infinity Cache)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G) of the library's own product routine (tools/ubench.hip)
 MAD_PEAK_T = 30.4          # measured v_mad_u64_u32 lane-ops/s (T), tools/ubench.hip: the hardware-side bound
@@ -66,7 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the full-proof section (N = 1 only)")
     ap.add_argument("--proof-worker", default="", help=argparse.SUPPRESS)      # internal: run ONE proof shape in this process and print its record
-    ap.add_argument("--batch", type=int, default=16, help="columns submitted per commit_batch call (pipelined on the device; a prover phase commits tens to a thousand)")
+    ap.add_argument("--batch", type=int, default=32, help="columns submitted per commit_batch call (pipelined on the device; a prover phase commits tens to a thousand)")
     args = ap.parse_args()
 
     if args.proof_worker:
@@ -138,8 +140,8 @@ def main():
             ids = [(cursor[0] + j) % NCOL for j in range(b)]
             cursor[0] += b
             coms = ctx.commit_batch(srs, [d_cols[i].ptr for i in ids], N, lagrange=True)    # b x MSM 2^20, b distinct columns
-            for i in ids:
-                ctx.ntt(d_work[i], K, inverse=True)                                           # b x NTT 2^20 (lagrange_to_coeff), b distinct buffers
+            ctx.ntt_batch([d_work[i] for i in ids], K, inverse=True)                       # b x NTT 2^20 (lagrange_to_coeff), b distinct buffers, as the prover
+                                                                                          # transforms the columns of a round (zk_ntt_batch: four columns share a launch)
             if world > 1:
                 # one exchange per commitment round, as in the prover: every rank needs every
                 # commitment of the batch (64 B each) before the next transcript challenge
@@ -228,20 +230,23 @@ def main():
         msm_pipelined_ms = sort_ms + (bucket_ms or 0.0) + comb_ms            # the reduction runs on the side stream under the next MSM
         msm_lone_ms = lone_ms                                                # what one MSM alone costs (measured above): nothing hides its reduction
         ntt_ms = (prof.get("ntt_pass", (0, 0))[0] + prof.get("ntt_last", (0, 0))[0]) / max(args.steps, 1)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("msm_buckets_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, tsrc = None, None
+        for tname in ("traffic_r03.json", "traffic_r02.json"):           # the newest committed rocprofv3 --pmc pass of this command
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                try:
+                    traffic, tsrc = json.load(open(tpath)).get("msm_buckets_bytes_per_launch"), tname
+                except Exception:
+                    traffic = None
+                if traffic:
+                    break
         main_roof = hbm_roof("k_msm_buckets", 96.0 * N, bucket_ms,
                              "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 (SURVEY 8d); integer-ALU bound: one mixed XYZZ addition "
                              f"({MADS_PER_MIXED_ADD} multiply-adds = {MADS_PER_MIXED_ADD / MADS_PER_PRODUCT:.2f} Montgomery-product equivalents) per (scalar, window), {windows} windows",
                              products=MADS_PER_MIXED_ADD / MADS_PER_PRODUCT * N * windows)
         if main_roof:
             main_roof["traffic"] = traffic            # PMC FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, from the committed rocprofv3 pass (profiles/); null until measured this round
-            main_roof["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc pass of this command)" if traffic else None
+            main_roof["traffic_source"] = f"profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, per launch, as reported: the guide's x2 FETCH correction is for coalesced streaming reads and these are 64-byte gathers -- profiles/r03_pmc_traffic.md gives both)" if traffic else None
         rooflines = [r for r in (
             main_roof,
             hbm_roof("k_ntt_pass + k_ntt_last (one 2^20 transform)", 64.0 * N, ntt_ms,
@@ -262,7 +267,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, 1 column per step per GPU", "k": K,
                        "parallelism": f"column-sharded x{world}, all_gather(64 B commitment per column) once per commit batch, backend {'gloo (ranks share a GPU)' if shared_gpu else 'nccl (RCCL)'}" if world > 1 else "single GPU",
-                       "columns_per_commit_batch": args.batch, "rotating_columns": f"{NCOL} committed + {NCOL} transformed, 32 MiB each (1 GiB working set)",
+                       "columns_per_commit_batch": args.batch, "rotating_columns": f"{NCOL} committed + {NCOL} transformed, 32 MiB each ({2 * NCOL * 32 >> 10} GiB working set)",
                        "msm_window_bits": plan.get("c"), "msm_windows": windows},
             "roofline": main_roof,
             "rooflines": rooflines,
@@ -536,6 +541,17 @@ def proof_worker(name):
                                     "launches_per_proof": qbig[1], "algorithmic_bytes_per_proof": int(streamed),
                                     "distinct_column_rotation_reads": reads, "cosets": cosets,
                                     "vs_full_domain": {"bytes": int(full), "effective_GBps": round(full / (per_proof_ms * 1e-3) / 1e9, 1)}}
+        try:            # counters of the committed rocprofv3 --pmc passes over the evaluator (profiles/r03_quotient_traffic.md): FETCH_SIZE + WRITE_SIZE, as reported
+            qt = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json"))).get("quotient", {})
+            if name == "supercircuit_shape_k20" and "supercircuit_shape_proof" in qt:
+                t_ = qt["supercircuit_shape_proof"]
+                rec["roofline_quotient"]["traffic"] = t_["fetch_bytes_raw"] + t_["write_bytes"]
+                rec["roofline_quotient"]["traffic_note"] = f"all {t_['launches']} launches of the kernel in one proof (the coset programs AND the theta-compression / permutation / linear-combination programs), rocprofv3 --pmc, profiles/r03_quotient_traffic.md"
+            ql = qt.get("quot_loop")
+            if ql:
+                rec["roofline_quotient"]["counter_over_algorithmic_on_the_gate_loop"] = round((ql["fetch_bytes_raw"] + ql["write_bytes"]) / ql["algorithmic_bytes"], 3)
+        except Exception:
+            pass
     ctx.close()
     return rec
 

@@ -1,6 +1,6 @@
 """Profiling workload: `reps` forward NTTs of size 2^k on one resident buffer (rocprofv3 target)."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import zkevm_circuits_amd as z
 
