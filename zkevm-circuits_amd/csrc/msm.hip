@@ -607,13 +607,30 @@ __global__ void __launch_bounds__(64) k_size_bins_scan(uint32_t* size_hist, cons
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += o; }
     uint32_t run = incl - sum;
+    // lanes (= tasks) of split buckets against all lanes: k_msm_buckets puts split buckets together itself only when they are a
+    // small part of the launch (a dense column: 7 %).  When every bucket is split (a column of small values: few entries, task
+    // size 8, all 262 144 lanes are tasks) the segmented reduction would run on every wave; the combination kernels do that
+    // work better (measured: 0.41 against 0.17 + 0.14 ms for 30-bit values, tools/msm_narrow.py) -- then H = M: all heavy.
+    uint32_t t_split = 0, t_all = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t bin = SIZE_BINS - 1 - (4 * lane + k);
-        if (bin == cap) size_hist[SIZE_BINS] = run;          // M: buckets with more than `cap` points come first
+        const uint32_t per = bin ? (bin + cap - 1) / cap : 1u;
+        t_all += c[k] * per;
+        if (bin > cap) t_split += c[k] * per;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { t_split += __shfl_down(t_split, off); t_all += __shfl_down(t_all, off); }
+    t_split = __shfl(t_split, 0);
+    t_all = __shfl(t_all, 0);
+    const bool inline_ok = (uint64_t)t_split * 8u <= (uint64_t)t_all;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t bin = SIZE_BINS - 1 - (4 * lane + k);
+        if (bin == cap) { size_hist[SIZE_BINS] = run; if (!inline_ok) size_hist[SIZE_BINS + 2] = run; }          // M: buckets with more than `cap` points come first
         // H: the "heavy" ones among them, split into more than TASK_INLINE_MAX tasks (or of unknown size: the last bin); they
-        // come first of all.  Buckets at positions [H, M) below TASK_DONE_MAX are put together inside k_msm_buckets.
-        if (bin == min(TASK_INLINE_MAX * cap, SIZE_BINS - 2)) size_hist[SIZE_BINS + 2] = run;
+        // come first of all.  Buckets at positions [H, M) are put together inside k_msm_buckets.
+        if (inline_ok && bin == min(TASK_INLINE_MAX * cap, SIZE_BINS - 2)) size_hist[SIZE_BINS + 2] = run;
         size_hist[bin] = run;
         run += c[k];
     }
@@ -777,6 +794,10 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     G1Xyzz29 acc = accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi);
     if (ordinary) stg29(buckets + b, acc);
     if ((v & ~63u) >= Tm) return;                // a wave of ordinary buckets only: done
+    if (nmulti[2] >= M) {                        // every split bucket is left to the combination kernels (k_size_bins_scan decided: too many of them)
+        if (v < Tm) stg29(partial + v, acc);
+        return;
+    }
     // ---- a wave that holds tasks of split buckets (they come first).  A bucket that was split into a handful of tasks -- the
     // 12 000 buckets of the scaled top window of a uniform column (three tasks each), the tail of the size distribution -- is put
     // together HERE: its tasks are consecutive lanes, so a segmented shuffle reduction at the end of the wave (two or three
@@ -870,9 +891,9 @@ __device__ __forceinline__ uint32_t leader_count(uint32_t base, uint32_t cnt) { 
 __device__ __forceinline__ uint32_t leader_slot(uint32_t base, uint32_t i) { return i ? (((base >> 6) + i) << 6) : base; }
 
 constexpr uint32_t COMBINE_SMALL = 32;
-// grid of the two grid-stride combination kernels: enough workgroups to fill the chip when there IS work (a selector column:
-// thousands of task partials), few enough that the no-work case costs a couple of microseconds
-static inline unsigned combine_grid(size_t worst_case_blocks) { return (unsigned)std::min<size_t>(std::max<size_t>(worst_case_blocks, 1), 512); }
+// grid of the two grid-stride combination kernels: one lane per task up to a million lanes (a launch that finds nothing to do
+// costs 3 us whatever its grid, tools/launch_cost.hip; a column of small values has 262 144 task partials to reduce)
+static inline unsigned combine_grid(size_t worst_case_blocks) { return (unsigned)std::min<size_t>(std::max<size_t>(worst_case_blocks, 1), 4096); }
 // multi-task buckets with few leaders: one lane each, sequential sum
 __global__ void __launch_bounds__(256) k_msm_combine_small(const uint32_t* __restrict__ nmulti, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ntasks,
                                                            const uint32_t* __restrict__ toff, const G1Xyzz29* __restrict__ partial, G1Xyzz29* __restrict__ buckets) {
