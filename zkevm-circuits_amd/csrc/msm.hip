@@ -716,6 +716,9 @@ __global__ void __launch_bounds__(256) k_build_window_tables(const G1Affine* __r
 // folded[b] = sum_w buckets[w*B + b]: four lanes per bucket (each takes every 4th window), LDS combine
 __global__ void __launch_bounds__(256) k_msm_fold_windows(const G1Xyzz29* __restrict__ buckets, uint32_t B, int W, G1Xyzz29* __restrict__ folded, const uint32_t* __restrict__ wflag) {
     __shared__ G1Xyzz29 sh[256];
+    buckets += (uint64_t)blockIdx.y * W * B;          // several columns per launch: column y owns windows [y W, (y + 1) W) and folded[y B, (y + 1) B)
+    wflag += blockIdx.y * W;
+    folded += (uint64_t)blockIdx.y * B;
     const uint32_t b = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     G1Xyzz29 acc = identity29();
     if (b < B) for (int w = (int)q; w < W; w += 4) if (wflag[w]) acc = add29pt(acc, ldg29(buckets + (uint64_t)w * B + b));   // empty windows were never written
@@ -756,7 +759,8 @@ __device__ __forceinline__ G1Xyzz29 accumulate_run(const G1Affine* __restrict__ 
 __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict__ bases_rp, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ nmulti,
                                                      uint32_t nbuckets, G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ partial,
-                                                     int log_b, uint64_t tab_stride, const uint32_t* __restrict__ wflag) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
+                                                     int log_b, uint64_t tab_stride, const uint32_t* __restrict__ wflag, uint32_t tab_windows = 0) {   // tab_stride != 0: bases_rp is a window table, window = bucket >> log_b
+                                                     // tab_windows != 0: several columns share the launch, column j owns windows [j W, (j + 1) W): table window = window mod W
     const uint32_t M = *nmulti;
     const uint32_t Tm = M ? toff[M] : 0u;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
@@ -791,7 +795,9 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
             if (!(tab_stride && wflag[b >> log_b] == 0u)) { ordinary = true; lo = offsets[b]; hi = offsets[b + 1]; }      // empty window: the fold skips it, nothing to write
         }
     }
-    G1Xyzz29 acc = accumulate_run(bases_rp + (uint64_t)(b >> log_b) * tab_stride, idx, lo, hi);
+    uint32_t twin = b >> log_b;
+    if (tab_windows) twin %= tab_windows;
+    G1Xyzz29 acc = accumulate_run(bases_rp + (uint64_t)twin * tab_stride, idx, lo, hi);
     if (ordinary) stg29(buckets + b, acc);
     if ((v & ~63u) >= Tm) return;                // a wave of ordinary buckets only: done
     if (nmulti[2] >= M) {                        // every split bucket is left to the combination kernels (k_size_bins_scan decided: too many of them)
@@ -1367,17 +1373,31 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint64_t n_narrow = (uint64_t)n - tail_rows;
     // ---- per-window ("narrow") path: sizes and workspace, as in msm_batch_tab with a window table
     const MsmPlan pn = any_narrow ? *pl_n : MsmPlan{4, 64, 8};
-    const uint32_t nbN = (uint32_t)pn.W * pn.B;
+    // Consecutive small-valued columns share ONE launch sequence: column j of a group owns windows [j W, (j + 1) W) of a
+    // (group x W)-window MSM over the same per-window table -- digits, LDS sweeps, scans, task split, accumulation and
+    // combination run once per group, the fold / reduction with the column on blockIdx.y.  Such a column is a chain of sixteen
+    // small, latency-bound launches (a few hundred thousand entries); a group amortises every launch over up to four columns
+    // (64 window flags).  ZK_MSM_NARROW_GROUP=1 turns it off (measurement knob).
+    uint32_t NG = 1;
+    if (any_narrow) {
+        NG = std::min<uint32_t>(4u, 64u / (uint32_t)pn.W);
+        if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4) NG = std::min<uint32_t>(NG, (uint32_t)v); }
+        if (const char* e = getenv("ZK_MSM_SORT_AHEAD")) if (atoi(e) == 1) NG = 1;
+        while (NG > 1 && (uint64_t)n * pn.W * NG >= (1ull << 32)) --NG;
+        if (NG < 1) NG = 1;
+    }
+    const uint32_t Wg = (uint32_t)pn.W * NG;
+    const uint32_t nbN = Wg * pn.B;
     const uint32_t scan_blocks_N = (nbN + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), scan_blocks_sN = (nbN + SCAN_T - 1) / SCAN_T;
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
-    const size_t dig_words = (size_t)(n_pad * pn.W + 1) / 2 + 4;
-    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * pn.W;
+    const size_t dig_words = (size_t)(n_pad * Wg + 1) / 2 + 4;
+    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * Wg;
     const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
     const uint32_t red_blocks_N = ((pn.B + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
-    const size_t max_tasks_N = (size_t)nbN + std::max(((size_t)n * pn.W) / TASK_CAP, (size_t)TASK_TARGET) + 1;
-    const size_t npts29_N = any_narrow ? (size_t)nbN + red_blocks_N + max_tasks_N + pn.B : 0;
+    const size_t max_tasks_N = (size_t)nbN + std::max(((size_t)n * Wg) / TASK_CAP, (size_t)TASK_TARGET) + 1;
+    const size_t npts29_N = any_narrow ? (size_t)nbN + (size_t)red_blocks_N * NG + max_tasks_N + (size_t)pn.B * NG : 0;
     const uint32_t nb = pl.B;
     const uint64_t max_entries = (uint64_t)n * pl.W;
     // table indices carry the sign in bit 31, cursors are 32-bit
@@ -1420,7 +1440,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // Graph mode (below): the launch sequence of a column is captured once per pipeline and replayed -- at these sizes the
     // host's launch rate, ~30 API calls per column, is what bounds a batch.  ZK_MSM_GRAPH=0 disables it.
     const char* env_graph = getenv("ZK_MSM_GRAPH");
-    const bool want_graph = n <= ((size_t)1 << 19) && n >= 1024 && count >= 4 && !ctx->prof_on && !ctx->msm_graph_broken && !(env_graph && atoi(env_graph) == 0);
+    const bool want_graph = n <= ((size_t)1 << 19) && n >= 1024 && count >= 4 && !ctx->prof_on && !ctx->msm_graph_broken && !(env_graph && atoi(env_graph) == 0) && !(any_narrow && NG > 1);
     constexpr int GP = 4;                     // pipelines of the graph mode: the context's stream and the three side streams
     const char* env_sa = getenv("ZK_MSM_SORT_AHEAD");
     const int ws_copies = want_graph ? GP : ((npipe == 2 || (count >= 2 && env_sa && atoi(env_sa) == 1)) ? 2 : 1);
@@ -1523,7 +1543,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 uint32_t* idxN = block_tot2N + scan_blocks_N;
                 uint16_t* dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
                 G1Xyzz29* partialN = buckets + nbN;
-                G1Xyzz29* task_partialN = partialN + red_blocks_N;
+                G1Xyzz29* task_partialN = partialN + (size_t)red_blocks_N * NG;
                 G1Xyzz29* folded = task_partialN + max_tasks_N;
                 const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
                 ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
@@ -1746,27 +1766,39 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
     auto is_narrow = [&](size_t it) { return any_narrow && narrow[it] == 1; };
     // ---- the sort of MSM `it` into workspace `slot`, enqueued on `st`
+    // the group of columns column `it` starts: up to NG consecutive small-valued columns, or the column alone
+    auto group_of = [&](size_t it) -> size_t {
+        if (!is_narrow(it)) return 1;
+        size_t g = 1;
+        while (g < NG && it + g < count && is_narrow(it + g)) ++g;
+        return g;
+    };
     auto enqueue_sort = [&](size_t it, int slot, hipStream_t st) -> int {
         const Fr* d_scalars = d_scalar_ptrs[it];
         ZkProfScope ps(ctx, "msm_sort", st);
         if (is_narrow(it)) {
-            // per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with empty windows skipped
+            // per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with empty windows skipped;
+            // the columns of a group are windows [j W, (j + 1) W) of one sort
+            const uint32_t cnt = (uint32_t)group_of(it), wins = cnt * (uint32_t)pn.W, nbc = wins * pn.B;      // this group's windows and buckets
+            const uint32_t sb_s = (nbc + SCAN_T - 1) / SCAN_T, sb = (nbc + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+            const dim3 grid_sw(8u * ((wins + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
             const WsN w = ws_narrow(slot);
             uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
             ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
-            launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, d_scalars, n_narrow, n_pad, w.dig, w.wflag);
-            hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, w.slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)w.wflag, (uint32_t)pn.W);
+            for (uint32_t j = 0; j < cnt; ++j)
+                launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, d_scalar_ptrs[it + j], n_narrow, n_pad, w.dig + (size_t)j * pn.W * n_pad, w.wflag + j * pn.W);
+            hipLaunchKernelGGL((k_msm_lds_sweep<false>), grid_sw, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, w.slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)w.wflag, wins);
             ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbN * MSM_SLICES, w.slice_off, w.block_tot);
-            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot, scan_blocks_sN, w.slice_off, nbN * MSM_SLICES, w.offsets + nbN);
-            hipLaunchKernelGGL(k_scan_u32_c, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbN, w.slice_off, (const uint32_t*)w.block_tot, w.offsets, w.counts, w.size_hist);
-            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, w.size_hist, (const uint32_t*)(w.offsets + nbN));
-            hipLaunchKernelGGL(k_order_buckets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)w.counts, nbN, w.size_hist, w.order, w.ntasks);
-            hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, (const uint32_t*)w.ntasks, nbN, w.toff, w.block_tot2);
-            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot2, scan_blocks_N, w.toff, nbN, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_task_offsets, dim3(scan_blocks_N), dim3(SCAN_T), 0, st, nbN, w.toff, (const uint32_t*)w.block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(sb_s), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbc * MSM_SLICES, w.slice_off, w.block_tot);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot, sb_s, w.slice_off, nbc * MSM_SLICES, w.offsets + nbc);
+            hipLaunchKernelGGL(k_scan_u32_c, dim3(sb_s), dim3(SCAN_T), 0, st, (const uint32_t*)w.slice_counts, nbc, w.slice_off, (const uint32_t*)w.block_tot, w.offsets, w.counts, w.size_hist);
+            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, w.size_hist, (const uint32_t*)(w.offsets + nbc));
+            hipLaunchKernelGGL(k_order_buckets, dim3(sb), dim3(SCAN_T), 0, st, (const uint32_t*)w.counts, nbc, w.size_hist, w.order, w.ntasks);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(sb), dim3(SCAN_T), 0, st, (const uint32_t*)w.ntasks, nbc, w.toff, w.block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot2, sb, w.toff, nbc, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(sb), dim3(SCAN_T), 0, st, nbc, w.toff, (const uint32_t*)w.block_tot2);
             ZK_CHECK_LAUNCH(ctx);
-            hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)w.slice_off, w.idx, (const uint32_t*)w.wflag, (uint32_t)pn.W);
+            hipLaunchKernelGGL((k_msm_lds_sweep<true>), grid_sw, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)w.slice_off, w.idx, (const uint32_t*)w.wflag, wins);
             ZK_CHECK_LAUNCH(ctx);
             ZK_HIP(ctx, hipMemcpyAsync(wflag_it, w.wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
             return ZK_OK;
@@ -1814,33 +1846,40 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         PK_TRY_MSM(enqueue_sort(0, 0, sort_st));
         ZK_HIP(ctx, hipEventRecord(ctx->ev_sorted[0], sort_st));
     }
-    for (size_t it = 0; it < count; ++it) {
-        const int par = (int)(it % 3), pipe = (int)(it % (size_t)npipe);
+    size_t staged = stage ? 1 : count;            // columns [0, staged) have been handed to the staging callback
+    size_t stepno = 0;                            // groups / columns enqueued so far: rotates bucket buffers, side streams, pipelines
+    for (size_t it = 0; it < count; ++stepno) {
+        const size_t grp = sort_ahead ? 1 : group_of(it);          // columns this step commits (a group of small-valued columns, or one column)
+        const int par = (int)(stepno % 3), pipe = (int)(stepno % (size_t)npipe);
         const int slot = sort_ahead ? (int)(it & 1) : pipe;
-        hipStream_t side = npipe == 2 ? ((it & 1) ? ctx->stream2b : ctx->stream2) : (par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c);
+        hipStream_t side = npipe == 2 ? ((stepno & 1) ? ctx->stream2b : ctx->stream2) : (par == 0 ? ctx->stream2 : par == 1 ? ctx->stream2b : ctx->stream2c);
         ctx->stream = mains[pipe];
+        for (; staged < it + grp; ++staged) { int rc = stage(stage_user, staged); if (rc) return rc; }      // every column of the group is on its way before its sort is enqueued
         G1Xyzz29* buckets = (G1Xyzz29*)bkbuf[par];
         if (sort_ahead) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[slot], 0));
         else PK_TRY_MSM(enqueue_sort(it, slot, ctx->stream));
-        // reduce(it-3) must be done with this bucket buffer -- but only the accumulation writes it: the sort of this MSM
+        // reduce(step - 3) must be done with this bucket buffer -- but only the accumulation writes it: the sort of this MSM
         // runs while that reduction finishes
-        if (it >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
+        if (stepno >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
         if (is_narrow(it)) {
-            // ---- per-window path: bucket accumulation, fold of the occupied windows, one window reduced
+            // ---- per-window path: bucket accumulation, fold of the occupied windows of every column of the group, one window reduced per column
+            const uint32_t cnt = (uint32_t)grp, wins = cnt * (uint32_t)pn.W, nbc = wins * pn.B;
+            const size_t tasks_c = (size_t)nbc + std::max(((size_t)n * wins) / TASK_CAP, (size_t)TASK_TARGET) + 1;
             const WsN w = ws_narrow(slot);
             G1Xyzz29* partialN = buckets + nbN;
-            G1Xyzz29* task_partialN = partialN + red_blocks_N;
+            G1Xyzz29* task_partialN = partialN + (size_t)red_blocks_N * NG;
             G1Xyzz29* folded = task_partialN + max_tasks_N;
             uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
             {
                 ZkProfScope ps(ctx, "msm_buckets_narrow");
-                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
-                                   (const uint32_t*)w.order, (const uint32_t*)w.toff, (const uint32_t*)w.nmulti, nbN, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag_it);
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((tasks_c + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
+                                   (const uint32_t*)w.order, (const uint32_t*)w.toff, (const uint32_t*)w.nmulti, nbc, buckets, task_partialN, pn.c - 1, (uint64_t)tab_stride, (const uint32_t*)wflag_it,
+                                   cnt > 1 ? (uint32_t)pn.W : 0u);
             }
             {
                 ZkProfScope ps(ctx, "msm_combine");
-                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((max_tasks_N + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.toff, task_partialN);
-                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nbN + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((tasks_c + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.toff, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nbc + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
                                    (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
                 hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
                                    (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
@@ -1850,10 +1889,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
             {
                 ZkProfScope ps(ctx, "msm_reduce_narrow", side);
-                hipLaunchKernelGGL(k_msm_fold_windows, dim3((pn.B + 63) / 64), dim3(256), 0, side, (const G1Xyzz29*)buckets, pn.B, pn.W, folded, (const uint32_t*)wflag_it);
-                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, 1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)folded, pn.B, partialN);
+                hipLaunchKernelGGL(k_msm_fold_windows, dim3((pn.B + 63) / 64, cnt), dim3(256), 0, side, (const G1Xyzz29*)buckets, pn.B, pn.W, folded, (const uint32_t*)wflag_it);
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, cnt), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)folded, pn.B, partialN);
                 ZK_CHECK_LAUNCH(ctx);
-                hipLaunchKernelGGL(k_msm_window_sum, dim3(1), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, red_blocks_N, wsum_all + it);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(cnt), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, red_blocks_N, wsum_all + it);
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
@@ -1894,21 +1933,23 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
         }
-        if (it + 1 < count) {
+        if (it + grp < count) {
             if (sort_ahead) {
                 // the next column: its staging (upload) is fenced into the sort stream, its sort goes into the other workspace copy,
                 // free once the accumulation + combination of MSM it - 1 (recorded as ev_p1 of that iteration) are through
                 ctx->stream = sort_st;
-                if (stage) { int rc = stage(stage_user, it + 1); if (rc) return rc; }
+                for (; staged < it + 2; ++staged) { int rc = stage(stage_user, staged); if (rc) return rc; }
                 if (it >= 1) ZK_HIP(ctx, hipStreamWaitEvent(sort_st, ctx->ev_p1[(it - 1) % 3], 0));
                 PK_TRY_MSM(enqueue_sort(it + 1, (int)((it + 1) & 1), sort_st));
                 ZK_HIP(ctx, hipEventRecord(ctx->ev_sorted[(it + 1) & 1], sort_st));
             } else if (stage) {
-                ctx->stream = mains[(it + 1) % (size_t)npipe];
-                int rc = stage(stage_user, it + 1);
-                if (rc) return rc;
+                // the columns of the NEXT step start crossing the link now, under this step's accumulation
+                ctx->stream = mains[(stepno + 1) % (size_t)npipe];
+                const size_t upto = it + grp + group_of(it + grp);
+                for (; staged < upto; ++staged) { int rc = stage(stage_user, staged); if (rc) return rc; }
             }
         }
+        it += grp;
     }
     ctx->stream = mains[0];
     if (npipe == 2) {
@@ -1916,8 +1957,8 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         ZK_HIP(ctx, hipStreamWaitEvent(mains[0], ctx->ev_pipe, 0));
     }
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[0], 0));
-    if (count > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
-    if (count > 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[2], 0));
+    if (stepno > 1) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[1], 0));
+    if (stepno > 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[2], 0));
     PK_TRY_MSM(enqueue_tails());
     std::vector<G1Xyzz> hw(count), ht(tail_rows ? count : 0);
     if (tail_rows) ZK_HIP(ctx, hipMemcpyAsync(ht.data(), tails_dev, sizeof(G1Xyzz) * count, hipMemcpyDeviceToHost, ctx->stream));
