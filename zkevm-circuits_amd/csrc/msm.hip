@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_u32_b(uint32_t* block_tot, uint
 // counts[b] = sum of its slices) and bins every bucket by size (descending order of size -> a wave
 // works on buckets of equal length; big ones start first).
 constexpr uint32_t SIZE_BINS = 256;
-constexpr uint32_t TASK_DONE_MAX = 1u << 17;   // done-counters (behind nmulti + 68) of the split buckets that straddle a wave boundary inside k_msm_buckets: positions below this
+constexpr uint32_t MSM_WFLAGS = 256;           // window flags of one sort (behind nmulti + 4): up to eight small-valued columns of 16 windows share a launch sequence
+constexpr uint32_t TASK_DONE_MAX = 1u << 17;   // done-counters (behind nmulti + 4 + MSM_WFLAGS) of the split buckets that straddle a wave boundary inside k_msm_buckets: positions below this
 constexpr uint32_t TASK_INLINE_MAX = 8;    // ... when they were split into at most this many tasks
 constexpr uint32_t TASK_CAP = 48;       // points per task, see "skew-proof work split" below
 __global__ void __launch_bounds__(SCAN_T) k_scan_u32_c(const uint32_t* __restrict__ slice_counts, uint32_t nbuckets, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
@@ -821,7 +822,7 @@ __global__ void __launch_bounds__(256) k_msm_buckets(const G1Affine* __restrict_
     if (mode == HEAVY || mode == LEFT) stg29(partial + v, acc);
     if (mode == LEFT && chunk == 0) atomicAdd(const_cast<uint32_t*>(nmulti) + 3, 1u);       // a straddling bucket beyond the done-counters: the combination kernels take it (and must run)
     if (mode == STRADDLE) {
-        uint32_t* done = const_cast<uint32_t*>(nmulti) + 4 + 64;            // zeroed with the size histogram before every MSM
+        uint32_t* done = const_cast<uint32_t*>(nmulti) + 4 + MSM_WFLAGS;            // zeroed with the size histogram before every MSM
         stg29(partial + v, acc);
         __threadfence();
         if (atomicAdd(done + lo_p, 1u) + 1u == nt) {
@@ -1135,7 +1136,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     const uint32_t scan_blocks_s = (nb + SCAN_T - 1) / SCAN_T;                    // scan over the [bucket][slice] counters: one bucket per thread
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * pl.W + 1) / 2 + 4;
-    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + (size_t)n * pl.W;
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + (size_t)n * pl.W;
     const size_t words = head_words + 4 + dig_words;
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4);
     if (!ws) return ZK_ERR_OOM;
@@ -1144,8 +1145,8 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
-    uint32_t* wflag = nmulti + 4;          // 64 words: W <= 64 windows (c >= 4)
-    uint32_t* offsets = wflag + 64 + TASK_DONE_MAX;
+    uint32_t* wflag = nmulti + 4;          // MSM_WFLAGS words: W <= 64 windows (c >= 4)
+    uint32_t* offsets = wflag + MSM_WFLAGS + TASK_DONE_MAX;
     uint32_t* order = offsets + nb + 1;
     uint32_t* ntasks = order + nb;
     uint32_t* toff = ntasks + nb;
@@ -1171,7 +1172,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
     // window sums of every MSM of the batch, then one private copy of the window flags per MSM (the
     // fold on the side stream reads them while the main stream already recodes the next column)
-    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count + 256 * count);
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * pl.W * count + 4 * MSM_WFLAGS * count);
     if (!bkbuf[0] || !bkbuf[1] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     if (!ctx->ev_p1[0])
@@ -1198,11 +1199,11 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
     G1Xyzz29* task_partial = partial + (size_t)pl.W * red_blocks;
     G1Xyzz29* folded = task_partial + max_tasks;
     G1Xyzz* wsum = wsum_all + it * pl.W;
-    uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + (size_t)pl.W * count) + it * 64;
+    uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + (size_t)pl.W * count) + it * MSM_WFLAGS;
     if (it >= 2) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));   // reduce(it-2) must be done with this buffer
     {
         ZkProfScope ps(ctx, "msm_sort");
-        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, ctx->stream));   // size_hist + nmulti + wflag
+        ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, ctx->stream));   // size_hist + nmulti + wflag
         launch_digits(pl.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), ctx->stream, d_scalars, (uint64_t)n, n_pad, dig, wflag);
         hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
@@ -1218,7 +1219,7 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
         hipLaunchKernelGGL((k_msm_lds_sweep<true>), sweep_grid, dim3(1024), 0, ctx->stream, (const uint16_t*)dig, n_pad, range_bits, pl.B, (uint32_t*)nullptr, (const uint32_t*)slice_off, idx, (const uint32_t*)wflag, (uint32_t)pl.W);
         ZK_CHECK_LAUNCH(ctx);
     }
-    ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(wflag_it, wflag, MSM_WFLAGS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     {
         ZkProfScope ps(ctx, "msm_buckets");
         // multi-task buckets first (they are the long poles), then one lane per ordinary bucket
@@ -1376,12 +1377,13 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // Consecutive small-valued columns share ONE launch sequence: column j of a group owns windows [j W, (j + 1) W) of a
     // (group x W)-window MSM over the same per-window table -- digits, LDS sweeps, scans, task split, accumulation and
     // combination run once per group, the fold / reduction with the column on blockIdx.y.  Such a column is a chain of sixteen
-    // small, latency-bound launches (a few hundred thousand entries); a group amortises every launch over up to four columns
-    // (64 window flags).  ZK_MSM_NARROW_GROUP=1 turns it off (measurement knob).
+    // small, latency-bound launches (a few hundred thousand entries); a group amortises every launch over up to eight columns
+    // (MSM_WFLAGS window flags).  ZK_MSM_NARROW_GROUP=1 turns it off, 2 / 4 / 8 set the group size (measurement knob; 2^20 rows,
+    // 30-bit values: 0.68 / 0.51 / 0.43 / 0.38 ms per column, tools/gpu_r3u.sh).
     uint32_t NG = 1;
     if (any_narrow) {
-        NG = std::min<uint32_t>(4u, 64u / (uint32_t)pn.W);
-        if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4) NG = std::min<uint32_t>(NG, (uint32_t)v); }
+        NG = std::min<uint32_t>(8u, MSM_WFLAGS / (uint32_t)pn.W);
+        if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) NG = std::min<uint32_t>((uint32_t)v, MSM_WFLAGS / (uint32_t)pn.W); }
         if (const char* e = getenv("ZK_MSM_SORT_AHEAD")) if (atoi(e) == 1) NG = 1;
         while (NG > 1 && (uint64_t)n * pn.W * NG >= (1ull << 32)) --NG;
         if (NG < 1) NG = 1;
@@ -1391,7 +1393,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t scan_blocks_N = (nbN + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), scan_blocks_sN = (nbN + SCAN_T - 1) / SCAN_T;
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * Wg + 1) / 2 + 4;
-    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * Wg;
+    const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * Wg;
     const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
@@ -1430,7 +1432,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint32_t scan_blocks_h = (hist_cnt + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
     // u32 workspace: slice_counts[4 nb] | slice_off[4 nb + 4] | counts[nb] | size_hist[256] nmulti[4] pad[64] | offsets[nb+1] | order[nb] |
     //                ntasks[nb] | toff[nb+1] | block_tot[...] | hist[hist_cnt] | hist_off[hist_cnt + 1] | idx[n W] | (8-B aligned) entries[n W] u64
-    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 68 + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
+    const size_t head_words = (size_t)nb * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + (size_t)scan_blocks_s + scan_blocks + scan_blocks_h + 2 * (size_t)hist_cnt + 2 + max_entries;
     const size_t words = (std::max(head_words + 4 + 2 * max_entries, words_N) + 63) & ~(size_t)63;
     // Below 2^20 points an MSM does not fill the device: its sort / accumulation / combination is a chain of some twenty
     // short launches.  Two such chains then run side by side -- even columns on the context's stream, odd columns on the
@@ -1451,7 +1453,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
     uint32_t* size_hist = counts + nb;
     uint32_t* nmulti = size_hist + SIZE_BINS;
-    uint32_t* offsets = nmulti + 4 + 64 + TASK_DONE_MAX;
+    uint32_t* offsets = nmulti + 4 + MSM_WFLAGS + TASK_DONE_MAX;
     uint32_t* order = offsets + nb + 1;
     uint32_t* ntasks = order + nb;
     uint32_t* toff = ntasks + nb;
@@ -1472,7 +1474,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     bkbuf[1] = count > 1 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS2, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
     bkbuf[2] = count > 2 ? (char*)ctx->get_scratch(SC_MSM_BUCKETS3, sizeof(G1Xyzz29) * npts29) : bkbuf[0];
     // one window sum per MSM, then one private copy of the window flags per MSM of the per-window path
-    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count + 256 * count);
+    G1Xyzz* wsum_all = (G1Xyzz*)ctx->get_scratch(SC_MSM_RESULTS, sizeof(G1Xyzz) * count + 4 * MSM_WFLAGS * count);
     if (!bkbuf[0] || !bkbuf[1] || !bkbuf[2] || !wsum_all) return ZK_ERR_OOM;
     if (!ctx->stream2) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     if (!ctx->ev_p1[0])
@@ -1534,7 +1536,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 uint32_t* size_histN = countsN + nbN;
                 uint32_t* nmultiN = size_histN + SIZE_BINS;
                 uint32_t* wflag = nmultiN + 4;
-                uint32_t* offsetsN = wflag + 64 + TASK_DONE_MAX;
+                uint32_t* offsetsN = wflag + MSM_WFLAGS + TASK_DONE_MAX;
                 uint32_t* orderN = offsetsN + nbN + 1;
                 uint32_t* ntasksN = orderN + nbN;
                 uint32_t* toffN = ntasksN + nbN;
@@ -1546,7 +1548,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                 G1Xyzz29* task_partialN = partialN + (size_t)red_blocks_N * NG;
                 G1Xyzz29* folded = task_partialN + max_tasks_N;
                 const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
-                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+                ZK_HIP(ctx, hipMemsetAsync(size_histN, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
                 launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, (const Fr*)nullptr, n_narrow, n_pad, dig, wflag, cols_dev, ctr);
                 hipLaunchKernelGGL((k_msm_lds_sweep<false>), sweep_grid, dim3(1024), 0, st, (const uint16_t*)dig, n_pad, range_bits_N, pn.B, slice_countsN, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)wflag, (uint32_t)pn.W);
                 hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_sN), dim3(SCAN_T), 0, st, (const uint32_t*)slice_countsN, nbN * MSM_SLICES, slice_offN, block_totN);
@@ -1578,7 +1580,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             uint32_t* counts = slice_off + (size_t)nb * MSM_SLICES + 4;
             uint32_t* size_hist = counts + nb;
             uint32_t* nmulti = size_hist + SIZE_BINS;
-            uint32_t* offsets = nmulti + 4 + 64 + TASK_DONE_MAX;
+            uint32_t* offsets = nmulti + 4 + MSM_WFLAGS + TASK_DONE_MAX;
             uint32_t* order = offsets + nb + 1;
             uint32_t* ntasks = order + nb;
             uint32_t* toff = ntasks + nb;
@@ -1592,7 +1594,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             G1Xyzz29* partial = buckets + nb;
             G1Xyzz29* task_partial = partial + red_pts;
             const bool bs_it = kind == 1;
-            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+            ZK_HIP(ctx, hipMemsetAsync(size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
             launch_partition<false>(pl.c, dim3(nwg), st, (const Fr*)nullptr, (uint64_t)n, range_bits, hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift, cols_dev, ctr);
             hipLaunchKernelGGL(k_scan_u32_a, dim3(scan_blocks_h), dim3(SCAN_T), 0, st, (const uint32_t*)hist, hist_cnt, hist_off, block_tot3);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, block_tot3, scan_blocks_h, hist_off, hist_cnt, (uint32_t*)nullptr);
@@ -1731,7 +1733,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         w.counts = w.slice_off + (size_t)nb * MSM_SLICES + 4;
         w.size_hist = w.counts + nb;
         w.nmulti = w.size_hist + SIZE_BINS;
-        w.offsets = w.nmulti + 4 + 64 + TASK_DONE_MAX;
+        w.offsets = w.nmulti + 4 + MSM_WFLAGS + TASK_DONE_MAX;
         w.order = w.offsets + nb + 1;
         w.ntasks = w.order + nb;
         w.toff = w.ntasks + nb;
@@ -1753,7 +1755,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         w.size_hist = w.counts + nbN;
         w.nmulti = w.size_hist + SIZE_BINS;
         w.wflag = w.nmulti + 4;
-        w.offsets = w.wflag + 64 + TASK_DONE_MAX;
+        w.offsets = w.wflag + MSM_WFLAGS + TASK_DONE_MAX;
         w.order = w.offsets + nbN + 1;
         w.ntasks = w.order + nbN;
         w.toff = w.ntasks + nbN;
@@ -1783,8 +1785,8 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             const uint32_t sb_s = (nbc + SCAN_T - 1) / SCAN_T, sb = (nbc + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
             const dim3 grid_sw(8u * ((wins + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
             const WsN w = ws_narrow(slot);
-            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
-            ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * MSM_WFLAGS;
+            ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
             for (uint32_t j = 0; j < cnt; ++j)
                 launch_digits(pn.c, dim3((unsigned)((n_pad / 2 + 255) / 256)), st, d_scalar_ptrs[it + j], n_narrow, n_pad, w.dig + (size_t)j * pn.W * n_pad, w.wflag + j * pn.W);
             hipLaunchKernelGGL((k_msm_lds_sweep<false>), grid_sw, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, w.slice_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)w.wflag, wins);
@@ -1800,11 +1802,11 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_CHECK_LAUNCH(ctx);
             hipLaunchKernelGGL((k_msm_lds_sweep<true>), grid_sw, dim3(1024), 0, st, (const uint16_t*)w.dig, n_pad, range_bits_N, pn.B, (uint32_t*)nullptr, (const uint32_t*)w.slice_off, w.idx, (const uint32_t*)w.wflag, wins);
             ZK_CHECK_LAUNCH(ctx);
-            ZK_HIP(ctx, hipMemcpyAsync(wflag_it, w.wflag, 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            ZK_HIP(ctx, hipMemcpyAsync(wflag_it, w.wflag, MSM_WFLAGS * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
             return ZK_OK;
         }
         const WsM w = ws_merged(slot);
-        ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 68 + TASK_DONE_MAX) * 4, st));
+        ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
         // 1. partition by the high bucket bits while recoding: histogram, scan, scatter
         launch_partition<false>(pl.c, dim3(nwg), st, d_scalars, (uint64_t)n, range_bits, w.hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, pl.top_shift);
         ZK_CHECK_LAUNCH(ctx);
@@ -1869,7 +1871,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             G1Xyzz29* partialN = buckets + nbN;
             G1Xyzz29* task_partialN = partialN + (size_t)red_blocks_N * NG;
             G1Xyzz29* folded = task_partialN + max_tasks_N;
-            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * 64;
+            uint32_t* wflag_it = reinterpret_cast<uint32_t*>(wsum_all + count) + it * MSM_WFLAGS;
             {
                 ZkProfScope ps(ctx, "msm_buckets_narrow");
                 hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((tasks_c + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
