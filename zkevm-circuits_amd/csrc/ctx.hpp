@@ -204,7 +204,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14, SC_MSM_TAILS = 15 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14, SC_MSM_TAILS = 15, SC_NTT_AUX = 16 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);

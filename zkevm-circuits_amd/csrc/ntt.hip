@@ -541,7 +541,9 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
     }
     Fr* scratch = nullptr;
     if (P > 1) {
-        scratch = (Fr*)ctx->get_scratch(SC_NTT, sizeof(Fr) * n * per_launch);
+        // transforms on the auxiliary stream run BESIDE transforms of the main stream (coset transforms ahead of the quotient,
+        // prover.hip): the intermediate buffer of a multi-pass transform is per stream
+        scratch = (Fr*)ctx->get_scratch(ctx->stream_aux && ctx->stream == ctx->stream_aux ? SC_NTT_AUX : SC_NTT, sizeof(Fr) * n * per_launch);
         if (!scratch) return ZK_ERR_OOM;
     }
     for (size_t first = 0; first < count; first += per_launch) {

@@ -1264,6 +1264,75 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     StageTrace trace(ctx);
     Env lag{pk, nullptr, &adv_lag, &inst_lag, nullptr, nullptr, nullptr, one, one, one, one, {}, pr->challenges};
     lag.theta = tr.squeeze();
+    // ---- more cosets of the advice columns, ahead of the quotient: what the advice phases could not fit (or afford) is
+    // computed NOW on the auxiliary stream, beside the lookup / permutation / grand-sum stages below -- hash joins, scans,
+    // batch inversions and chains of small-valued commitments that leave most of the device idle.  Same plan, same budget
+    // rule as in the advice phase, with the memory that is free at this point; the quotient waits for the stream before its
+    // first coset.  OFF by default (ZK_ADVICE_COSET_LATE_GB=<GiB> turns it on): measured on the SuperCircuit shape with 48 GiB
+    // (tools/gpu_r3v.sh) the quotient's transform stage drops from 237 to 149 ms and the lookup stage beside which the transforms
+    // run grows from 46 to 118 ms -- 1.437 -> 1.424 s for 25 GiB of device memory: these stages are not idle enough to hide them.
+    bool late_cosets = false;
+    // whatever way this function is left, the auxiliary stream must be through with the session's buffers before they go back to the pool
+    struct AuxJoin { zk_ctx* c; bool* on; ~AuxJoin() { if (*on && c->stream_aux) (void)hipStreamSynchronize(c->stream_aux); } } aux_join{ctx, &late_cosets};
+    {
+        const bool sharded_ = pr->world > 1 && pr->gather;
+        const char* env = getenv("ZK_ADVICE_COSET_LATE_GB");
+        const double cap = (env ? atof(env) : 0.0) * (double)(1ull << 30);
+        const uint32_t E_ = ext_k - k, R_ = 1u << E_;
+        if (!sharded_ && cap > 0 && pk->A && E_ <= 5 && ctx->ensure_aux()) {
+            std::vector<uint32_t> mask;
+            size_t key_slots = 0;
+            PK_TRY(advice_coset_plan(ctx, pk, false, mask, &key_slots));
+            if (pr->adv_coset.empty()) { pr->adv_coset.resize(R_); for (auto& v : pr->adv_coset) v.resize(pk->A); }
+            const double col_bytes = (double)n * 32.0;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            // still to come: m / phi / Z in Lagrange and coefficient form with their temporaries, their coset buffers, h, slack;
+            // the key's own cosets if its cache is still empty
+            double avail = (double)free_b + (double)ctx->pool_bytes - (4.0 * (2.0 * pk->L + pk->C) + (2.0 * pk->L + pk->C + pk->I + 8.0) + 2.0 * R_ + 32.0) * col_bytes - 24.0 * (double)(1ull << 30);
+            if (pk->part_cache_state < 0 || (pk->part_cache_state == 1 && pk->part_cache_bytes == 0)) avail -= (double)key_slots * col_bytes;
+            std::vector<std::pair<uint32_t, uint32_t>> by_count;          // (columns still to transform, coset)
+            for (uint32_t r = 0; r < R_; ++r) {
+                uint32_t cnt = 0;
+                for (uint32_t c = 0; c < pk->A; ++c) cnt += (mask[c] >> r & 1u) && !pr->adv_coset[r][c].p && adv_coeff[c].p;
+                if (cnt) by_count.push_back({cnt, r});
+            }
+            std::sort(by_count.begin(), by_count.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            double used = 0;
+            hipStream_t main_stream = ctx->stream;
+            struct Back { zk_ctx* c; hipStream_t s; ~Back() { c->stream = s; } } back{ctx, main_stream};
+            const Fr w_ext = fr_root_of_unity(ext_k);
+            for (const auto& cr : by_count) {
+                if (used + cr.first * col_bytes > std::min(cap, avail)) continue;          // a smaller coset further down may still fit
+                Fr g = fr_zeta();
+                for (uint32_t i = 0; i < cr.second; ++i) g = g * w_ext;
+                std::vector<const void*> csrc;
+                std::vector<void*> cdst;
+                bool ok = true;
+                for (uint32_t c = 0; c < pk->A && ok; ++c) {
+                    if (!(mask[c] >> cr.second & 1u) || pr->adv_coset[cr.second][c].p || !adv_coeff[c].p) continue;
+                    DevBuf& slot = pr->adv_coset[cr.second][c];
+                    if (!slot.alloc(n * 32)) { ok = false; break; }
+                    csrc.push_back(adv_coeff[c].p);
+                    cdst.push_back(slot.p);
+                }
+                if (!late_cosets) {          // first batch: the stream starts behind everything the main stream has enqueued (pooled blocks)
+                    ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, main_stream));
+                    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
+                }
+                ctx->stream = ctx->stream_aux;
+                late_cosets = true;
+                if (!csrc.empty()) PK_TRY(zk_coeff_to_coset_batch(ctx, csrc.data(), k, &g, cdst.data(), csrc.size()));
+                ctx->stream = main_stream;
+                used += csrc.size() * col_bytes;
+                if (!ok) break;
+            }
+            if (late_cosets) {
+                ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream_aux));
+                if (getenv("ZK_PROVER_TRACE")) fprintf(stderr, "[zk prover] advice cosets computed beside the lookup / permutation stages: %.1f GiB\n", used / (double)(1ull << 30));
+            }
+        }
+    }
 
     // ---- lookups, round 1 (mv_lookup::prover::Argument::prepare): theta-compressed table and input tuples,
     // multiplicities m over ALL input tuples of the argument.  Every lookup is enqueued back to back
@@ -1524,6 +1593,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         };
         DevBuf hpart;
         if (!hpart.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        if (late_cosets) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));          // the cosets computed beside the earlier stages are complete
         std::unordered_map<uint32_t, const void*> part_of;
         Env part = lag;
         part.part = &part_of;
