@@ -341,3 +341,36 @@ def test_msm_2_20_random_bases_all_config2_scalar_sets(ctx, cref):
     for b in list(dev.values()) + [dP]:
         b.free()
     srs.destroy()
+
+
+@pytest.mark.parametrize("group", ["1", "3", "8"])
+def test_groups_of_small_valued_columns(ctx, cref, group):
+    """Consecutive small-valued columns share one launch sequence (up to eight columns as one (8 x W)-window MSM over the
+    per-window table, csrc/msm.hip group_of): runs of 1, 3, 8 + 5 and 9 hinted columns with dense columns between them, every
+    group size the knob allows, n below the SRS size -- every commitment bit-exact, and identical whatever the grouping."""
+    import os
+    k = 13
+    n = (1 << k) - 37
+    rng = random.Random(99)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(0x7777))
+    basis = srs.download_g_lagrange()[:n]
+    pattern = [1, 0, 1, 1, 1, 0] + [1] * 13 + [0, 0] + [1] * 9 + [2, 1]
+    cols = []
+    for i, h in enumerate(pattern):
+        if h == 1:
+            bits = rng.choice([1, 8, 16, 30, 64])
+            cols.append(cref.to_mont([rng.randrange(1 << bits) if rng.random() < 0.7 else 0 for _ in range(n)]))
+        else:
+            cols.append(cref.rand_fr_stream(500 + i, n))
+    want = np.stack([cref.best_multiexp(c, basis) for c in cols])
+    bufs = [ctx.to_device(c) for c in cols]
+    os.environ["ZK_MSM_NARROW_GROUP"] = group
+    try:
+        got = ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=True, narrow=pattern)
+    finally:
+        os.environ.pop("ZK_MSM_NARROW_GROUP", None)
+    bad = [i for i in range(len(cols)) if not np.array_equal(got[i], want[i])]
+    assert not bad, f"group size {group}: columns {bad} differ from best_multiexp"
+    for b_ in bufs:
+        b_.free()
+    srs.destroy()

@@ -660,3 +660,27 @@ def test_coset_cache_running_out_of_memory_falls_back_uncached(ctx, cref, srs8):
         pk.destroy()
     finally:
         os.environ.pop("ZK_PK_COSET_CACHE_FAIL_AFTER", None)
+
+
+def test_cosets_computed_ahead_leave_the_proof_unchanged(ctx, cref, srs8):
+    """Round 3: cosets of the advice columns are computed during the advice phases (ZK_ADVICE_COSET_GB) and, optionally, beside
+    the lookup / permutation stages (ZK_ADVICE_COSET_LATE_GB) -- scheduling only: with everything off, with the defaults and with
+    both on the proof bytes are the same, and they are the oracle prover's."""
+    from oracle import plonk_prover as pp
+    circ, adv, inst = build_circuit(8, seed=31, wide=True)
+    seed = bytes(range(16))
+    proofs = {}
+    for tag, env in (("off", {"ZK_ADVICE_COSET_GB": "0"}), ("default", {}), ("both", {"ZK_ADVICE_COSET_GB": "64", "ZK_ADVICE_COSET_LATE_GB": "8"}),
+                     ("late only", {"ZK_ADVICE_COSET_GB": "0", "ZK_ADVICE_COSET_LATE_GB": "8"})):
+        os.environ.update(env)
+        try:
+            pk = ctx.pk_create(srs8[circ.k], circ.blob())
+            _, rep = pk.vk(circ.F + len(circ.perm_cols))
+            proofs[tag] = [_session_proof(ctx, pk, adv, inst, seed, "shplonk") for _ in range(2)]      # second proof: the key's cosets are cached
+            pk.destroy()
+        finally:
+            for name in env:
+                os.environ.pop(name, None)
+    want = pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), adv, inst, cref.from_mont(rep.reshape(1, 4))[0], seed, "shplonk")
+    for tag, (first, second) in proofs.items():
+        assert first == want and second == want, tag
