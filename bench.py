@@ -321,7 +321,9 @@ def cpu_baseline(srs, column):
     }
 
 
-PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20", "keccak_shape_k16_cpu_vs_gpu")
+PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20", "keccak_shape_k16_cpu_vs_gpu", "evm_shape_k14_mock")
+MOCK_SHAPES = {"evm_shape_k14_mock": ("build_large", (14, 53)),                           # BASELINE configs[0] stand-in: k = 14, 159 advice columns
+               "supercircuit_shape_k20_mock": ("build_shape", (20, 1000, 150, 150, 100, 9))}      # only with ZK_BENCH_PROOFS=supercircuit_shape_k20_mock
 
 
 def proof_section():
@@ -477,6 +479,44 @@ def cpu_vs_gpu_worker(k=16):
     }
 
 
+def mock_worker(name):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): MockProver over the EVM sub-circuit at k = 14
+    [REF circuit-benchmarks/src/evm_circuit.rs:44-60] -- here zk_mock_verify (dev::MockProver::verify_par restated for the
+    device) over the same-size stand-in: the satisfied witness, then one cell changed (the path that lists failures)."""
+    import numpy as np
+    import bench_proof as bp
+    import zkevm_circuits_amd as z
+    from zkevm_circuits_amd import plonk
+
+    ctx = z.Context(0)
+    builder, args = MOCK_SHAPES[name]
+    circ, blob, adv_m, inst_m, inst = getattr(bp, builder)(ctx, *args)
+    srs = ctx.srs_setup_with_s(circ.k, np.frombuffer(plonk.fr_mont_bytes(0x5EC2E7), dtype=np.uint64).copy())
+    pk = ctx.pk_create(srs, blob)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got, total = ctx.mock_verify(pk, adv_m, inst_m)
+        times.append(time.perf_counter() - t0)
+        assert total == 0, got[:4]
+    bad = [np.array(c, copy=True) for c in adv_m]
+    row = int(np.flatnonzero(np.asarray(bad[2]).any(axis=1))[0])            # a cell a gate reads: first non-zero cell of advice column 2
+    bad[2][row, 0] ^= np.uint64(1)
+    t0 = time.perf_counter()
+    got, total = ctx.mock_verify(pk, bad, inst_m)
+    t_bad = time.perf_counter() - t0
+    assert total >= 1
+    rec = {"metric": "MockProver-style witness check wall-clock (s), zk_mock_verify on 1 x MI355X, witness columns uploaded from host memory inside the timed call", "value": round(min(times), 4),
+           "unit": "s", "higher_is_better": False, "k": circ.k, "advice_columns": circ.A, "gate_polynomials": len(circ.gates), "lookups": len(circ.lookups),
+           "permutation_columns": len(circ.perm_cols), "runs_s": [round(t, 4) for t in times],
+           "one_cell_changed": {"wall_s": round(t_bad, 4), "failures": total, "first": list(got[0]) if got else None},
+           "data": "synthetic circuit of the configuration's size class (the EVM circuit itself needs the Rust exporter)"}
+    pk.destroy()
+    srs.destroy()
+    ctx.close()
+    return rec
+
+
 def proof_worker(name):
     """One proof shape, measured in this (fresh) process.  The quotient evaluator's roofline comes from one extra,
     profiled proof: bytes = what the launches really stream (counted by the library) over their time."""
@@ -485,6 +525,8 @@ def proof_worker(name):
 
     if name == "keccak_shape_k16_cpu_vs_gpu":
         return cpu_vs_gpu_worker(16)
+    if name in MOCK_SHAPES:
+        return mock_worker(name)
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     ctx = z.Context(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)

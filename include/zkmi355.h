@@ -301,6 +301,32 @@ int zk_pk_shape(zk_ctx* ctx, const zk_pk* pk, uint32_t* out16);
 int zk_create_proof(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const uint8_t* seed16,
                     void* h_proof, size_t proof_cap, size_t* proof_len);
 
+/* ---- dev::MockProver on the device: halo2_proofs::dev::MockProver::{run, verify_par, verify_at_rows_par}
+ * [REF zkevm-circuits/src/test_util.rs:272], [REF prover/src/common/prover/mock.rs:18-19], [REF testool/src/statetest/executor.rs:703-714]
+ * -- SURVEY 8a A9.  No commitments, no transcript: checks that the witness satisfies the key's circuit and says where it does not.
+ *   ZK_MOCK_GATE         VerifyFailure::ConstraintNotSatisfied: gate polynomial `index` (position in the key's flat list of
+ *                        gate polynomials = the blob's order) is not zero at `row`
+ *   ZK_MOCK_LOOKUP       VerifyFailure::Lookup: input tuple `sub` of lookup argument `index` at `row` occurs in no usable row of the table
+ *   ZK_MOCK_PERMUTATION  VerifyFailure::Permutation: cell `row` of permutation column `index` (position in the key's list of
+ *                        permutation columns) differs from the cell sigma maps it to (sub 0); sub 1: sigma names no cell (a broken key)
+ * gate_rows / lookup_rows: the row ids of verify_at_rows_par (each must be a usable row, else ZK_ERR_INVALID_ARG -- upstream
+ * panics); NULL = every usable row (verify_par).  Copy constraints are always checked on all rows, as upstream does.
+ * h_advice / h_instance: host pointers to n x 32-byte columns (as zk_create_proof); h_challenges: the circuit's challenges
+ * (32 B each, Montgomery Fr, zk_pk_shape's count) or NULL for MockProver's own (zk_host_mock_challenges).
+ * out receives the first `cap` failures sorted by (kind, index, sub, row); *count the number found (may exceed cap: then
+ * which ones were kept is unspecified).  Region bookkeeping (CellNotAssigned, ConstraintPoisoned) is not modelled: the
+ * witness arrives as finished columns.  Gate failures are detected with a random fold first (a satisfied witness costs one
+ * evaluation pass; a failing one is missed with probability < gates / 2^253) and then listed exactly, one pass per polynomial. */
+typedef struct zk_mock_failure { uint32_t kind, index, sub, row; } zk_mock_failure;
+enum { ZK_MOCK_GATE = 1, ZK_MOCK_LOOKUP = 2, ZK_MOCK_PERMUTATION = 3 };
+int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const void* h_challenges,
+                   const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                   zk_mock_failure* out, size_t cap, size_t* count);
+/* Host only: the challenges MockProver hands a circuit (halo2 dev.rs: h = Blake2b-512("Halo2-MockProver"), then
+ * challenge i = Fr::from_uniform_bytes(h = Blake2b-512(h)); the third one is the constant the reference pins at
+ * [REF zkevm-circuits/src/super_circuit.rs:729]).  out: count x 32 B Montgomery Fr.                       */
+int zk_host_mock_challenges(uint32_t count, void* out_fr32);
+
 /* Phase-by-phase proving session (what the Rust shim drives: Circuit::synthesize runs on the host
  * once per phase and needs the challenges of the earlier phases -- the SuperCircuit has three
  * phases, zkevm-circuits/src/util.rs:120-133).  begin -> zk_proof_advice_phase x num_phases ->

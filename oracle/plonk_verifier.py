@@ -97,6 +97,55 @@ def check_witness(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequ
     return None
 
 
+MOCK_GATE, MOCK_LOOKUP, MOCK_PERMUTATION = 1, 2, 3
+
+
+def mock_failures(circ, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]], challenges=None, gate_rows=None, lookup_rows=None):
+    """halo2 ``dev::MockProver::verify_at_rows_par`` restated (``dev.rs``: gates on `gate_row_ids`, lookups on
+    `lookup_input_row_ids`, the permutation over the whole mapping), as the sorted list of
+    (kind, index, sub, row) that include/zkmi355.h:zk_mock_verify reports:
+      (1, gate polynomial, 0, row)              VerifyFailure::ConstraintNotSatisfied
+      (2, lookup argument, input tuple, row)    VerifyFailure::Lookup (tuples compared exactly, table = its usable rows)
+      (3, permutation column, 0, row)           VerifyFailure::Permutation (cell differs from the cell the mapping names)
+    Row ids default to every usable row (``verify_par``)."""
+    n, u = circ.n, circ.u
+    consts = Consts(circ.consts, challenges)
+    cols = {FIXED: circ.fixed, ADVICE: advice, INSTANCE: [list(c) + [0] * (circ.n - len(c)) for c in instance]}
+    gates = [circ.compile(g) for g in circ.gates]
+    lookups = [([circ.compile(e) for e in lk.table], [[circ.compile(e) for e in i] for i in lk.inputs]) for lk in circ.lookups]
+    gate_rows = range(u) if gate_rows is None else gate_rows
+    lookup_rows = range(u) if lookup_rows is None else lookup_rows
+    assert all(0 <= r < u for r in gate_rows) and all(0 <= r < u for r in lookup_rows), "row ids must be usable rows"
+    out = []
+
+    def looker(row):
+        return lambda t, i, rot: cols[t][i][(row + rot) % n]
+
+    for row in gate_rows:
+        look = looker(row)
+        for gi, g in enumerate(gates):
+            if eval_program(g, look, consts) != 0:
+                out.append((MOCK_GATE, gi, 0, row))
+    for li, (tabs, inputs) in enumerate(lookups):
+        table = set()
+        for row in range(u):
+            look = looker(row)
+            table.add(tuple(eval_program(p, look, consts) for p in tabs))
+        for ii, ins in enumerate(inputs):
+            for row in lookup_rows:
+                look = looker(row)
+                if tuple(eval_program(p, look, consts) for p in ins) not in table:
+                    out.append((MOCK_LOOKUP, li, ii, row))
+    mapping = circ.permutation_mapping()
+    for j, (t, c) in enumerate(circ.perm_cols):
+        for i in range(n):
+            j2, i2 = mapping[j][i]
+            t2, c2 = circ.perm_cols[j2]
+            if cols[t][c][i] != cols[t2][c2][i2]:
+                out.append((MOCK_PERMUTATION, j, 0, i))
+    return sorted(out)
+
+
 # ------------------------------------------------------------------------------------ verifier
 def _interpolate(xs, ys):
     """halo2 arithmetic::lagrange_interpolate: coefficients (low first) of the polynomial through (xs[i], ys[i])"""

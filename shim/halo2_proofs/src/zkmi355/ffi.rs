@@ -51,6 +51,19 @@ pub struct zk_transcript_vtable {
     pub squeeze_challenge: unsafe extern "C" fn(user: *mut c_void, fr32_out: *mut c_void) -> c_int,
 }
 
+/// `zk_mock_failure`: one record of `zk_mock_verify` (kind 1 gate polynomial / 2 lookup / 3 permutation; index; sub; row)
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct zk_mock_failure {
+    pub kind: u32,
+    pub index: u32,
+    pub sub: u32,
+    pub row: u32,
+}
+pub const ZK_MOCK_GATE: u32 = 1;
+pub const ZK_MOCK_LOOKUP: u32 = 2;
+pub const ZK_MOCK_PERMUTATION: u32 = 3;
+
 pub type zk_allgather_fn = unsafe extern "C" fn(user: *mut c_void, send: *const c_void, bytes: usize, recv: *mut c_void) -> c_int;
 
 extern "C" {
@@ -74,6 +87,12 @@ extern "C" {
     pub fn zk_pk_vk(ctx: *mut zk_ctx, pk: *const zk_pk, h_commitments: *mut c_void, h_vk_repr: *mut c_void) -> c_int;
     pub fn zk_pk_set_transcript_repr(ctx: *mut zk_ctx, pk: *mut zk_pk, h_repr_fr32: *const c_void) -> c_int;
     pub fn zk_pk_shape(ctx: *mut zk_ctx, pk: *const zk_pk, out16: *mut u32) -> c_int;
+
+    /// dev::MockProver::verify_par / verify_at_rows_par on the device (NULL row lists = every usable row)
+    pub fn zk_mock_verify(ctx: *mut zk_ctx, pk: *const zk_pk, h_advice: *const *const c_void, h_instance: *const *const c_void, h_challenges: *const c_void,
+                          gate_rows: *const u32, num_gate_rows: usize, lookup_rows: *const u32, num_lookup_rows: usize,
+                          out: *mut zk_mock_failure, cap: usize, count: *mut usize) -> c_int;
+    pub fn zk_host_mock_challenges(count: u32, out_fr32: *mut c_void) -> c_int;
 
     pub fn zk_proof_begin_instances(ctx: *mut zk_ctx, pk: *const zk_pk, h_instance: *const *const c_void, h_instance_len: *const u32, seed16: *const u8, out: *mut *mut zk_proof) -> c_int;
     pub fn zk_proof_set_multiopen(ctx: *mut zk_ctx, proof: *mut zk_proof, kind: c_int) -> c_int;

@@ -1,0 +1,167 @@
+"""GPU: zk_mock_verify (halo2 dev::MockProver::verify_par / verify_at_rows_par on the device) against the oracle's
+restatement of the same checks (oracle/plonk_verifier.py:mock_failures): the same failure records, field by field, for satisfied
+witnesses, for witnesses with cells changed at random, for row subsets, for keys exported with shared intermediates, for a
+two-phase circuit under MockProver's own challenges, and for the k = 14 / 159-column stand-in of BASELINE configs[0]."""
+import os
+import random
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from oracle import bn254 as b  # noqa: E402
+from oracle import plonk_verifier as pv  # noqa: E402
+from plonk_fixtures import build_circuit, build_multi_lookup_circuit, build_rotation_circuit  # noqa: E402
+from zkevm_circuits_amd import binding, plonk  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+R = plonk.R_MOD
+S_SECRET = 0x5EC2E7
+
+
+@pytest.fixture(scope="module")
+def srs_by_k(ctx, cref):
+    class PerK(dict):
+        def __missing__(self, k):
+            self[k] = ctx.srs_setup_with_s(k, cref.fr_const(S_SECRET))
+            return self[k]
+    cache = PerK()
+    yield cache
+    for s in cache.values():
+        s.destroy()
+
+
+def _gpu(ctx, pk, adv, inst, **kw):
+    return ctx.mock_verify(pk, [plonk.column_to_mont(c) for c in adv], [plonk.column_to_mont(c) for c in inst], **kw)
+
+
+FIXTURES = {
+    "plain": lambda: build_circuit(6, 1, False),
+    "wide": lambda: build_circuit(7, 2, True),
+    "rotations": lambda: build_rotation_circuit(6, 1),
+    "lookups3": lambda: build_multi_lookup_circuit(6, 1, 3, 1, 3),
+    "lookups2_deg2": lambda: build_multi_lookup_circuit(6, 1, 2, 2, 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_same_failures_as_the_oracle(ctx, srs_by_k, name):
+    circ, adv, inst = FIXTURES[name]()
+    pk = ctx.pk_create(srs_by_k[circ.k], circ.blob())
+    try:
+        assert _gpu(ctx, pk, adv, inst) == ([], 0)
+        rng = random.Random(zlib.crc32(name.encode()))
+        for trial in range(6):
+            a2, i2 = [list(c) for c in adv], [list(c) for c in inst]
+            for _ in range(rng.randrange(1, 4)):                       # change one to three cells: advice mostly, a public input now and then
+                if i2 and rng.random() < 0.2:
+                    i2[0][rng.randrange(4)] = rng.randrange(R)
+                else:
+                    a2[rng.randrange(circ.A)][rng.randrange(circ.u)] = rng.randrange(R) if rng.random() < 0.5 else rng.randrange(70)
+            want = pv.mock_failures(circ, a2, i2)
+            got, total = _gpu(ctx, pk, a2, i2)
+            assert total == len(want) and got == want, (name, trial)
+            # verify_at_rows_par: a subset of the usable rows for the gates, another for the lookups
+            gr = sorted(rng.sample(range(circ.u), circ.u // 3))
+            lr = sorted(rng.sample(range(circ.u), circ.u // 2))
+            want = pv.mock_failures(circ, a2, i2, gate_rows=gr, lookup_rows=lr)
+            got, total = _gpu(ctx, pk, a2, i2, gate_rows=gr, lookup_rows=lr)
+            assert total == len(want) and got == want, (name, trial, "rows")
+    finally:
+        pk.destroy()
+
+
+def test_keys_with_shared_intermediates_report_the_same(ctx, srs_by_k):
+    """a key exported with cross-gate common sub-expressions (TEE_TMP in one gate, PUSH_TMP in later ones): the per-gate passes
+    re-materialise what a gate reads, the records are those of the plain export"""
+    circ, adv, inst = build_circuit(6, seed=11, wide=True)
+    q_mul, a, b_, cc = circ.fixed_col(0), circ.advice_col(0), circ.advice_col(1), circ.advice_col(2)
+    circ.add_gate((q_mul * (a * b_ - cc)) * (a * b_ + 5))
+    circ.add_gate(q_mul * ((a * b_ - cc) * (a * b_ - cc)))
+    assert plonk.Q_PUSH_TMP in [op for p in circ.compile_gates_cse() for op, _, _ in p]
+    row = next(r for r in range(circ.u) if circ.fixed[0][r] == 1)
+    a2 = [list(c) for c in adv]
+    a2[2][row] = (a2[2][row] + 9) % R
+    want = pv.mock_failures(circ, a2, inst)
+    assert {f[1] for f in want if f[0] == pv.MOCK_GATE and f[3] == row} >= {0, len(circ.gates) - 2, len(circ.gates) - 1}
+    for cse in (False, True):
+        pk = ctx.pk_create(srs_by_k[circ.k], circ.blob(cse=cse))
+        try:
+            assert _gpu(ctx, pk, adv, inst) == ([], 0)
+            got, total = _gpu(ctx, pk, a2, inst)
+            assert got == want and total == len(want), cse
+        finally:
+            pk.destroy()
+
+
+def test_two_phase_circuit_under_mockprover_challenges(ctx, cref, srs_by_k):
+    """challenges in gate expressions: NULL = the chain halo2's MockProver hands the circuit (the witness generator of a mock run
+    uses the same values); explicit challenges; a witness made for other challenges fails every enabled row"""
+    import t1_kit
+    circ, phase_witness, inst = t1_kit.two_phase_case(6)
+    mock = [b.mock_prover_challenge(i + 1) for i in range(2)]
+    cols = dict(phase_witness(0, []))
+    cols.update(phase_witness(1, mock))
+    adv = [cols[i] for i in range(circ.A)]
+    assert pv.mock_failures(circ, adv, inst, challenges=mock) == []
+    pk = ctx.pk_create(srs_by_k[circ.k], circ.blob())
+    try:
+        assert _gpu(ctx, pk, adv, inst) == ([], 0)
+        assert _gpu(ctx, pk, adv, inst, challenges=cref.to_mont(mock)) == ([], 0)
+        other = [123456789, 987654321]
+        want = pv.mock_failures(circ, adv, inst, challenges=other)
+        assert len(want) == 2 * circ.u
+        got, total = _gpu(ctx, pk, adv, inst, challenges=cref.to_mont(other))
+        assert got == want and total == len(want)
+        # fewer record slots than failures: the count is complete, the records kept are real ones
+        got, total = _gpu(ctx, pk, adv, inst, challenges=cref.to_mont(other), cap=7)
+        assert total == len(want) and len(got) == 7 and set(got) <= set(want)
+    finally:
+        pk.destroy()
+
+
+def test_row_ids_outside_the_usable_rows_are_refused(ctx, srs_by_k):
+    circ, adv, inst = build_circuit(6, 1, False)
+    pk = ctx.pk_create(srs_by_k[circ.k], circ.blob())
+    try:
+        with pytest.raises(binding.ZkError, match="usable row"):
+            _gpu(ctx, pk, adv, inst, gate_rows=[0, circ.u])
+        with pytest.raises(binding.ZkError, match="usable row"):
+            _gpu(ctx, pk, adv, inst, lookup_rows=[circ.n - 1])
+        assert _gpu(ctx, pk, adv, inst, gate_rows=[], lookup_rows=[]) == ([], 0)
+    finally:
+        pk.destroy()
+
+
+def test_evm_circuit_sized_mock_run_k14(ctx):
+    """BASELINE configs[0]: the reference's CPU-runnable case is MockProver over the EVM sub-circuit at k = 14
+    [REF circuit-benchmarks/src/evm_circuit.rs:44-60].  Same stand-in as the proof test (k = 14, 159 advice columns, 107 gate
+    polynomials, a lookup, 160 permutation columns): satisfied, then three cells changed -- the records equal the oracle's on
+    the rows around the changes, and the full run finds nothing else."""
+    import bench_proof
+    circ, blob, adv_m, inst_m, inst = bench_proof.build_large(ctx, 14, 53)
+    srs = ctx.srs_setup_with_s(14, np.frombuffer(plonk.fr_mont_bytes(S_SECRET), dtype=np.uint64).copy())
+    pk = ctx.pk_create(srs, blob)
+    try:
+        assert ctx.mock_verify(pk, adv_m, inst_m) == ([], 0)
+        from_mont = lambda col: [int.from_bytes(np.ascontiguousarray(v).tobytes(), "little") * pow(1 << 256, -1, R) % R for v in col]
+        adv = [from_mont(c) for c in adv_m]
+        off = len(circ.cs_blob())                      # the circuit object of the bench builder carries no fixed values: they are in the blob
+        for i in range(circ.F):
+            circ.fixed[i] = from_mont(np.frombuffer(blob, dtype=np.uint64, count=circ.n * 4, offset=off + i * circ.n * 32).reshape(-1, 4))
+        rng = random.Random(14)
+        touched = []
+        for _ in range(3):
+            c, r = rng.randrange(circ.A), rng.randrange(8, circ.u - 8)
+            adv[c][r] = (adv[c][r] + 1 + rng.randrange(1000)) % R
+            touched.append(r)
+        near = sorted({r + d for r in touched for d in (-1, 0, 1)})
+        want = pv.mock_failures(circ, adv, inst, gate_rows=near, lookup_rows=near)
+        got, total = ctx.mock_verify(pk, [plonk.column_to_mont(c) for c in adv], inst_m)
+        assert got == want and total == len(want) and total >= 1
+    finally:
+        pk.destroy()
+        srs.destroy()

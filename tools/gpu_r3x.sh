@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_proof.py -x -q -m gpu -k "groups_of_small or cosets_computed_ahead" 2>&1 | tail -3
+timeout 300 python bench.py --proof-worker evm_shape_k14_mock 2>&1 | tail -3
+timeout 600 python bench.py --proof-worker supercircuit_shape_k20_mock 2>&1 | tail -3

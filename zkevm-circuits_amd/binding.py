@@ -668,6 +668,26 @@ class Context:
         self._ck(lib().zk_create_proof(self.h, pk.h, pa, pi, ctypes.c_char_p(seed), out, ctypes.c_size_t(cap), ctypes.byref(n)))
         return out.raw[:n.value]
 
+    def mock_verify(self, pk: "ProvingKey", advice: Sequence[np.ndarray], instance: Sequence[np.ndarray], challenges: Optional[np.ndarray] = None,
+                    gate_rows: Optional[Sequence[int]] = None, lookup_rows: Optional[Sequence[int]] = None, cap: int = 4096):
+        """zk_mock_verify (halo2 dev::MockProver::verify_par / verify_at_rows_par): (failures, total) with failures the first
+        `cap` records (kind, index, sub, row), sorted; kinds 1 gate, 2 lookup, 3 permutation.  challenges: (c, 4) u64
+        Montgomery or None for MockProver's own."""
+        adv = [np.ascontiguousarray(a, dtype=np.uint64) for a in advice]
+        ins = [np.ascontiguousarray(a, dtype=np.uint64) for a in instance]
+        pa = (ctypes.c_void_p * max(len(adv), 1))(*[a.ctypes.data for a in adv])
+        pi = (ctypes.c_void_p * max(len(ins), 1))(*[a.ctypes.data for a in ins])
+        ch = None if challenges is None else np.ascontiguousarray(challenges, dtype=np.uint64)
+        gr = None if gate_rows is None else np.ascontiguousarray(gate_rows, dtype=np.uint32)
+        lr = None if lookup_rows is None else np.ascontiguousarray(lookup_rows, dtype=np.uint32)
+        out = np.zeros((max(cap, 1), 4), dtype=np.uint32)
+        total = ctypes.c_size_t()
+        self._ck(lib().zk_mock_verify(self.h, pk.h, pa, pi, None if ch is None else _host_ptr(ch),
+                                      None if gr is None else _host_ptr(gr), ctypes.c_size_t(0 if gr is None else len(gr)),
+                                      None if lr is None else _host_ptr(lr), ctypes.c_size_t(0 if lr is None else len(lr)),
+                                      _host_ptr(out), ctypes.c_size_t(cap), ctypes.byref(total)))
+        return [tuple(int(v) for v in r) for r in out[:min(total.value, cap)]], total.value
+
     def proof_session(self, pk: "ProvingKey", instance: Sequence[np.ndarray], seed: bytes = bytes(16), instance_slices: bool = False) -> "ProofSession":
         return ProofSession(self, pk, instance, seed, instance_slices)
 
@@ -677,6 +697,15 @@ class Context:
 
     def g1_mul(self, bases: DeviceBuffer, scalars: DeviceBuffer, out: DeviceBuffer, n: int):
         self._ck(lib().zk_g1_mul_vec(self.h, ctypes.c_void_p(bases.ptr), ctypes.c_void_p(scalars.ptr), ctypes.c_void_p(out.ptr), ctypes.c_size_t(n)))
+
+
+def mock_challenges(count: int) -> np.ndarray:
+    """zk_host_mock_challenges: the challenges halo2's MockProver hands a circuit, (count, 4) u64 Montgomery Fr (host only)"""
+    out = np.zeros((max(count, 1), 4), dtype=np.uint64)
+    rc = lib().zk_host_mock_challenges(ctypes.c_uint32(count), _host_ptr(out))
+    if rc != 0:
+        raise ZkError(f"zk_host_mock_challenges failed with status {rc}")
+    return out[:count]
 
 
 def version() -> str:

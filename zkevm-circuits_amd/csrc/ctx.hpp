@@ -236,6 +236,14 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow = nullptr);
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = every sampled value is below 2^64
 int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status);   // lookup.hip, no sync
+// row checks of zk_mock_verify (lookup.hip; enqueued on the context's stream, no sync)
+struct MockFail { uint32_t kind, index, sub, row; };          // == zk_mock_failure
+int mock_hash_build(zk_ctx* ctx, const Fr* d_table, size_t rows, int scratch_slot, const uint32_t** slots_out, uint32_t* mask_out);
+int mock_nonzero_enqueue(zk_ctx* ctx, const Fr* d_vals, const uint32_t* d_row_ids, uint32_t count, uint32_t kind, uint32_t index, uint32_t sub, MockFail* d_out, uint32_t cap, uint32_t* d_counter);
+int mock_probe_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, const uint32_t* d_slots, uint32_t mask, const uint32_t* d_row_ids, uint32_t count,
+                       uint32_t kind, uint32_t index, uint32_t sub, MockFail* d_out, uint32_t cap, uint32_t* d_counter);
+int mock_perm_enqueue(zk_ctx* ctx, const Fr* const* d_sigma, const Fr* const* d_cols, const Fr* d_ids, const uint32_t* d_slots, uint32_t mask, uint32_t num_cols, uint32_t k,
+                      uint32_t kind, MockFail* d_out, uint32_t cap, uint32_t* d_counter);
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1
 bool comm_ready(const zk_ctx* ctx);                                                              // comm.hip: in-library RCCL collectives
 int comm_allgather_dev(zk_ctx* ctx, const void* d_send, size_t bytes, void* d_recv);             // stream-ordered, no host sync

@@ -148,6 +148,100 @@ int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t
     return ZK_OK;
 }
 
+
+// ---- row checks of zk_mock_verify (prover.hip): halo2 dev::MockProver::verify_at_rows_par restated for the device -----------
+// Every kernel appends {kind, index, sub, row} records to `out` (first `cap` of them; *counter keeps counting).
+
+// selected rows (row_ids, or 0 .. count - 1) whose value is not zero: VerifyFailure::ConstraintNotSatisfied
+__global__ void __launch_bounds__(256) k_mock_nonzero(const Fr* __restrict__ vals, const uint32_t* __restrict__ row_ids, uint32_t count, uint32_t kind, uint32_t index, uint32_t sub,
+                                                      MockFail* __restrict__ out, uint32_t cap, uint32_t* __restrict__ counter) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t row = row_ids ? row_ids[t] : t;
+    if (fr_same(ldg(vals + row), Fr::zero())) return;
+    const uint32_t pos = atomicAdd(counter, 1u);
+    if (pos < cap) out[pos] = MockFail{kind, index, sub, row};
+}
+// selected rows whose (compressed) input is in none of the table rows the hash was built from: VerifyFailure::Lookup
+__global__ void __launch_bounds__(256) k_mock_probe(const Fr* __restrict__ inputs, const Fr* __restrict__ table, const uint32_t* __restrict__ slots, uint32_t mask,
+                                                    const uint32_t* __restrict__ row_ids, uint32_t count, uint32_t kind, uint32_t index, uint32_t sub,
+                                                    MockFail* __restrict__ out, uint32_t cap, uint32_t* __restrict__ counter) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t row = row_ids ? row_ids[t] : t;
+    const Fr key = ldg(inputs + row);
+    uint32_t h = fr_hash(key) & mask;
+    for (;;) {
+        const uint32_t owner = slots[h];
+        if (owner == LK_EMPTY) break;
+        if (fr_same(ldg(table + owner), key)) return;
+        h = (h + 1) & mask;
+    }
+    const uint32_t pos = atomicAdd(counter, 1u);
+    if (pos < cap) out[pos] = MockFail{kind, index, sub, row};
+}
+// Copy constraints from the key's sigma columns alone: sigma_j[i] = delta^j' w^i' names the cell (j', i') that cell (j, i) must
+// equal; `ids` holds delta^j w^i for every cell (cell j n + i) and `slots` the hash over it, so one probe inverts sigma.
+// VerifyFailure::Permutation {column j, row i} where the two values differ (sub 0) or sigma names no cell at all (sub 1).
+__global__ void __launch_bounds__(256) k_mock_perm(const Fr* const* __restrict__ sigma, const Fr* const* __restrict__ cols, const Fr* __restrict__ ids,
+                                                   const uint32_t* __restrict__ slots, uint32_t mask, uint32_t cells, uint32_t k, uint32_t kind,
+                                                   MockFail* __restrict__ out, uint32_t cap, uint32_t* __restrict__ counter) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells) return;
+    const uint32_t j = cell >> k, i = cell & ((1u << k) - 1u);
+    const Fr key = ldg(sigma[j] + i);
+    uint32_t h = fr_hash(key) & mask, owner;
+    for (;;) {
+        owner = slots[h];
+        if (owner == LK_EMPTY || fr_same(ldg(ids + owner), key)) break;
+        h = (h + 1) & mask;
+    }
+    uint32_t sub = 1;
+    if (owner != LK_EMPTY) {
+        if (owner == cell) return;
+        if (fr_same(ldg(cols[j] + i), ldg(cols[owner >> k] + (owner & ((1u << k) - 1u))))) return;
+        sub = 0;
+    }
+    const uint32_t pos = atomicAdd(counter, 1u);
+    if (pos < cap) out[pos] = MockFail{kind, j, sub, i};
+}
+
+// open-addressing hash over table[0 .. rows) in scratch `slot` (2 x rows slots, rounded up to a power of two); enqueued, no sync
+int mock_hash_build(zk_ctx* ctx, const Fr* d_table, size_t rows, int scratch_slot, const uint32_t** slots_out, uint32_t* mask_out) {
+    if (rows > ((size_t)1 << 30)) return ctx->fail(ZK_ERR_UNSUPPORTED, "mock verify: %zu rows exceed the 2^30 a device hash holds", rows);
+    size_t cap = 16;
+    while (cap < 2 * rows) cap <<= 1;
+    uint32_t* slots = (uint32_t*)ctx->get_scratch(scratch_slot, cap * 4);
+    if (!slots) return ZK_ERR_OOM;
+    ZK_HIP(ctx, hipMemsetAsync(slots, 0xFF, cap * 4, ctx->stream));
+    if (rows) hipLaunchKernelGGL(k_lk_insert, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_table, (uint32_t)rows, slots, (uint32_t)(cap - 1));
+    ZK_CHECK_LAUNCH(ctx);
+    *slots_out = slots;
+    *mask_out = (uint32_t)(cap - 1);
+    return ZK_OK;
+}
+int mock_nonzero_enqueue(zk_ctx* ctx, const Fr* d_vals, const uint32_t* d_row_ids, uint32_t count, uint32_t kind, uint32_t index, uint32_t sub, MockFail* d_out, uint32_t cap, uint32_t* d_counter) {
+    if (!count) return ZK_OK;
+    hipLaunchKernelGGL(k_mock_nonzero, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_vals, d_row_ids, count, kind, index, sub, d_out, cap, d_counter);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+int mock_probe_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, const uint32_t* d_slots, uint32_t mask, const uint32_t* d_row_ids, uint32_t count,
+                       uint32_t kind, uint32_t index, uint32_t sub, MockFail* d_out, uint32_t cap, uint32_t* d_counter) {
+    if (!count) return ZK_OK;
+    hipLaunchKernelGGL(k_mock_probe, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_inputs, d_table, d_slots, mask, d_row_ids, count, kind, index, sub, d_out, cap, d_counter);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+int mock_perm_enqueue(zk_ctx* ctx, const Fr* const* d_sigma, const Fr* const* d_cols, const Fr* d_ids, const uint32_t* d_slots, uint32_t mask, uint32_t num_cols, uint32_t k,
+                      uint32_t kind, MockFail* d_out, uint32_t cap, uint32_t* d_counter) {
+    const uint32_t cells = num_cols << k;
+    if (!cells) return ZK_OK;
+    hipLaunchKernelGGL(k_mock_perm, dim3((cells + 255) / 256), dim3(256), 0, ctx->stream, d_sigma, d_cols, d_ids, d_slots, mask, cells, k, kind, d_out, cap, d_counter);
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;

@@ -34,6 +34,8 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <random>
+#include <tuple>
 #include "ctx.hpp"
 #include "host_hash.hpp"
 
@@ -2072,6 +2074,177 @@ int zk_host_poseidon_permute_width3(void* state3_fr32) {
     memcpy(st, state3_fr32, sizeof st);
     host::PoseidonWidth3::get().permute(st);
     memcpy(state3_fr32, st, sizeof st);
+    return ZK_OK;
+}
+
+// ---- dev::MockProver restated for the device ------------------------------------------------------------------
+// halo2 `MockProver::run(k, &circuit, instances)` + `verify_par / verify_at_rows_par` [REF zkevm-circuits/src/test_util.rs:272],
+// [REF prover/src/common/prover/mock.rs:18-19]: no commitments, no transcript -- every gate polynomial must vanish on the selected
+// usable rows, every lookup input must occur among the usable rows of its table, every cell of a permutation column must equal
+// the cell sigma maps it to.  What upstream derives from its region bookkeeping (CellNotAssigned, ConstraintPoisoned) has no
+// counterpart here: the witness arrives as finished columns.
+//   gates: one pass over all constraints folded with a random y finds out WHETHER any selected row fails (a satisfied witness
+//     costs that one pass); only then one pass per constraint lists them (exact: no randomness in what is reported);
+//   lookups: theta-compressed table and inputs (random theta), the hash join of the multiplicity computation with a probe that
+//     reports instead of counting;
+//   copies: sigma inverted with the same hash over the identity values delta^j w^i -- the key carries no cell mapping.
+int zk_host_mock_challenges(uint32_t count, void* out_fr32) {
+    if (count && !out_fr32) return ZK_ERR_INVALID_ARG;
+    // halo2 dev.rs: hash = blake2b("Halo2-MockProver"); challenge_i = Fr::from_uniform_bytes(hash = blake2b(hash))   (golden G3: the third one)
+    uint8_t h[64];
+    host::Blake2b b;
+    b.init(nullptr);
+    b.update("Halo2-MockProver", 16);
+    b.finalize(h);
+    for (uint32_t i = 0; i < count; ++i) {
+        host::Blake2b c;
+        c.init(nullptr);
+        c.update(h, 64);
+        c.finalize(h);
+        const F4 v = host::fr_from_uniform(h);
+        memcpy((uint8_t*)out_fr32 + (size_t)i * 32, &v, 32);
+    }
+    return ZK_OK;
+}
+
+int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const void* h_challenges,
+                   const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                   zk_mock_failure* out, size_t cap, size_t* count) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && count && (out || !cap) && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
+    ZK_REQUIRE(ctx, (gate_rows || !num_gate_rows) && (lookup_rows || !num_lookup_rows), "row list without rows");
+    ZK_REQUIRE(ctx, cap <= ((size_t)1 << 24), "at most 2^24 failure records");
+    static_assert(sizeof(zk_mock_failure) == sizeof(MockFail), "failure records are copied as they are");
+    *count = 0;
+    const size_t n = (size_t)1 << pk->k;
+    // upstream panics on a row id outside the usable rows ("invalid gate row id")
+    for (size_t i = 0; i < num_gate_rows; ++i) if (gate_rows[i] >= pk->u) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: gate row id %u is not a usable row (%u of them)", gate_rows[i], pk->u);
+    for (size_t i = 0; i < num_lookup_rows; ++i) if (lookup_rows[i] >= pk->u) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: lookup row id %u is not a usable row (%u of them)", lookup_rows[i], pk->u);
+    PoolScope pool(ctx);
+    std::vector<DevBuf> adv(pk->A), inst(pk->I);
+    for (uint32_t c = 0; c < pk->A; ++c) {
+        ZK_REQUIRE(ctx, h_advice[c], "null advice column");
+        if (!adv[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(adv[c].p, h_advice[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (uint32_t c = 0; c < pk->I; ++c) {
+        ZK_REQUIRE(ctx, h_instance[c], "null instance column");
+        if (!inst[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(inst[c].p, h_instance[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    Env lag{};
+    lag.pk = pk;
+    lag.advice = &adv;
+    lag.instance = &inst;
+    lag.challenges.resize(pk->chal_phase.size());
+    if (h_challenges) memcpy(lag.challenges.data(), h_challenges, lag.challenges.size() * 32);
+    else PK_TRY(zk_host_mock_challenges((uint32_t)lag.challenges.size(), lag.challenges.data()));
+    {   // y and theta of this call: fresh randomness, nothing a witness could have been fitted to
+        std::random_device rd;
+        uint8_t b[128];
+        for (size_t i = 0; i < sizeof b; i += 4) { const uint32_t v = rd(); memcpy(b + i, &v, 4); }
+        lag.y = host::fr_from_uniform(b);
+        lag.theta = host::fr_from_uniform(b + 64);
+        lag.beta = lag.gamma = host::fr_zero();
+    }
+    // failure records and counters on the device; selected rows
+    const uint32_t cap32 = (uint32_t)cap;
+    DevBuf fails, ctrs, rows_g, rows_l, vals;
+    if (!fails.alloc((cap ? cap : 1) * sizeof(MockFail)) || !ctrs.alloc(64) || !vals.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+    ZK_HIP(ctx, hipMemsetAsync(ctrs.p, 0, 64, ctx->stream));
+    uint32_t* d_total = (uint32_t*)ctrs.p;            // every failure
+    uint32_t* d_any = d_total + 1;                    // rows the folded gate pass flags
+    const uint32_t* d_rows_g = nullptr;
+    const uint32_t* d_rows_l = nullptr;
+    const uint32_t cnt_g = gate_rows ? (uint32_t)num_gate_rows : pk->u, cnt_l = lookup_rows ? (uint32_t)num_lookup_rows : pk->u;
+    if (gate_rows && num_gate_rows) {
+        if (!rows_g.alloc(num_gate_rows * 4)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(rows_g.p, gate_rows, num_gate_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_rows_g = (const uint32_t*)rows_g.p;
+    }
+    if (lookup_rows && num_lookup_rows) {
+        if (!rows_l.alloc(num_lookup_rows * 4)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(rows_l.p, lookup_rows, num_lookup_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_rows_l = (const uint32_t*)rows_l.p;
+    }
+    MockFail* d_fails = (MockFail*)fails.p;
+
+    // ---- gates
+    if (!pk->gates.empty() && cnt_g) {
+        Prog all;
+        for (const Prog& g : pk->gates) { all.insert(all.end(), g.begin(), g.end()); all.push_back({Q_FOLD, C_Y, 0}); }       // in order: an intermediate is parked before it is read
+        PK_TRY(run_program(ctx, lag, all, vals.p));
+        PK_TRY(mock_nonzero_enqueue(ctx, vals.fr(), d_rows_g, cnt_g, 0, 0, 0, d_fails, 0, d_any));
+        uint32_t any = 0;
+        PK_TRY(zk_d2h(ctx, &any, d_any, 4));
+        if (any) {
+            // one pass per constraint; a constraint that reads intermediates other constraints parked computes them itself
+            TmpSplit tmps(1);
+            for (uint32_t i = 0; i < pk->gates.size(); ++i) {
+                for (auto& h : tmps.have) std::fill(h.begin(), h.end(), 0u);
+                Prog one;
+                tmps.append(pk->gates[i], 0, one);
+                one.push_back({Q_FOLD, C_ONE, 0});
+                PK_TRY(run_program(ctx, lag, one, vals.p));
+                PK_TRY(mock_nonzero_enqueue(ctx, vals.fr(), d_rows_g, cnt_g, ZK_MOCK_GATE, i, 0, d_fails, cap32, d_total));
+            }
+            if (tmps.conflict) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: a gate reads an intermediate no earlier gate defined");
+        }
+    }
+    // ---- lookups
+    if (pk->L && cnt_l) {
+        DevBuf tab, inp;
+        if (!tab.alloc(n * 32) || !inp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        for (uint32_t l = 0; l < pk->L; ++l) {
+            const auto& lk = pk->lookups[l];
+            PB pt;
+            push_compressed(pt, lk.tables); pt.fold(C_ONE);
+            PK_TRY(run_program(ctx, lag, pt.g, tab.p));
+            const uint32_t* slots = nullptr;
+            uint32_t mask = 0;
+            PK_TRY(mock_hash_build(ctx, tab.fr(), pk->u, SC_TMP, &slots, &mask));
+            for (size_t a = 0; a < lk.inputs.size(); ++a) {
+                PB pf;
+                push_compressed(pf, lk.inputs[a]); pf.fold(C_ONE);
+                PK_TRY(run_program(ctx, lag, pf.g, inp.p));
+                PK_TRY(mock_probe_enqueue(ctx, inp.fr(), tab.fr(), slots, mask, d_rows_l, cnt_l, ZK_MOCK_LOOKUP, l, (uint32_t)a, d_fails, cap32, d_total));
+            }
+        }
+    }
+    // ---- copy constraints (all rows: upstream walks the whole mapping, unusable rows map to themselves)
+    if (pk->P) {
+        const size_t cells = (size_t)pk->P << pk->k;
+        if (cells > ((size_t)1 << 30)) return ctx->fail(ZK_ERR_UNSUPPORTED, "mock verify: %u permutation columns of 2^%u rows exceed the 2^30 cells one device hash holds", pk->P, pk->k);
+        DevBuf ids, ptrs;
+        if (!ids.alloc(cells * 32) || !ptrs.alloc((size_t)pk->P * 16)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        const F4 omega_h = [&] { Fr w = fr_root_of_unity(pk->k); F4 o; memcpy(&o, &w, 32); return o; }();
+        const F4 delta = host::fr_pow(host::fr_from_u64(7), 1ull << 28);
+        F4 dj = host::fr_one();
+        std::vector<const void*> hp(2 * (size_t)pk->P);
+        for (uint32_t j = 0; j < pk->P; ++j) {
+            PK_TRY(zk_fr_powers(ctx, &omega_h, &dj, (char*)ids.p + ((size_t)j << pk->k) * 32, n));                // delta^j w^i
+            dj = host::fr_mul(dj, delta);
+            hp[j] = pk->sigma_lag[j].p;
+            hp[pk->P + j] = resolve_col(lag, colref(pk->perm_cols[j].first, pk->perm_cols[j].second));
+            if (!hp[pk->P + j]) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: unresolved permutation column %u", j);
+        }
+        ZK_HIP(ctx, hipMemcpyAsync(ptrs.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t* slots = nullptr;
+        uint32_t mask = 0;
+        PK_TRY(mock_hash_build(ctx, ids.fr(), cells, SC_TMP, &slots, &mask));
+        PK_TRY(mock_perm_enqueue(ctx, (const Fr* const*)ptrs.p, (const Fr* const*)ptrs.p + pk->P, ids.fr(), slots, mask, pk->P, pk->k, ZK_MOCK_PERMUTATION, d_fails, cap32, d_total));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // hp is stack-owned
+    }
+    uint32_t total = 0;
+    PK_TRY(zk_d2h(ctx, &total, d_total, 4));
+    const size_t got = std::min<size_t>(total, cap);
+    std::vector<MockFail> h(got);
+    if (got) PK_TRY(zk_d2h(ctx, h.data(), d_fails, got * sizeof(MockFail)));
+    // the device appends in whatever order its waves finish: sort (kind, index, sub, row) so that equal inputs give equal outputs
+    // (when more failures exist than `cap` holds, WHICH ones were kept is still up to the device; *count says so)
+    std::sort(h.begin(), h.end(), [](const MockFail& a, const MockFail& b) { return std::tie(a.kind, a.index, a.sub, a.row) < std::tie(b.kind, b.index, b.sub, b.row); });
+    if (got) memcpy(out, h.data(), got * sizeof(MockFail));
+    *count = total;
     return ZK_OK;
 }
 

@@ -486,9 +486,9 @@ class Circuit:
         assert circ.degree() == int(head["degree"][0]) and circ.bf == int(head["blinding_factors"][0])
         return circ
 
-    def sigma_columns(self) -> List[List[int]]:
-        """halo2 ``permutation::keygen::Assembly``: cycles of equal cells -> sigma_j(omega^i) =
-        delta^j' * omega^i' of the next cell in the cycle."""
+    def permutation_mapping(self) -> List[List[tuple]]:
+        """halo2 ``permutation::keygen::Assembly::mapping``: mapping[j][i] = (j', i'), the next cell in the cycle of equal
+        cells that cell i of permutation column j belongs to (itself when the cell takes part in no copy constraint)."""
         P, n = len(self.perm_cols), self.n
         pos = {c: j for j, c in enumerate(self.perm_cols)}
         mapping = [[(j, i) for i in range(n)] for j in range(P)]
@@ -510,6 +510,13 @@ class Circuit:
                 if i == (rc, rr):
                     break
             mapping[lc][lr], mapping[rc][rr] = mapping[rc][rr], mapping[lc][lr]
+        return mapping
+
+    def sigma_columns(self) -> List[List[int]]:
+        """halo2 ``permutation::keygen::Assembly``: cycles of equal cells -> sigma_j(omega^i) =
+        delta^j' * omega^i' of the next cell in the cycle."""
+        P, n = len(self.perm_cols), self.n
+        mapping = self.permutation_mapping()
         w = self.omega()
         wp = [1] * n
         for i in range(1, n):
