@@ -12,7 +12,8 @@
 //   halo2_proofs::poly::EvaluationDomain          -> zk::halo2::EvaluationDomain
 //   halo2_proofs::poly::kzg::commitment::ParamsKZG-> zk::halo2::ParamsKZG
 //   halo2_proofs::plonk::{keygen_pk, create_proof}-> zk::halo2::{ProvingKey, create_proof}
-//   (reference call sites: circuit-benchmarks/src/super_circuit.rs:104-132,
+//   halo2_proofs::dev::MockProver::{run, verify_par, verify_at_rows_par} -> zk::halo2::mock_verify
+//   (reference call sites: circuit-benchmarks/src/super_circuit.rs:104-132, zkevm-circuits/src/test_util.rs:272,
 //    prover/src/common/prover/utils.rs:31,55, prover/src/utils.rs:77)
 #pragma once
 #include <array>
@@ -220,6 +221,21 @@ inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk,
     c.check(zk_create_proof(c.raw(), pk.raw(), advice_columns.data(), instance_columns.data(), rng_seed.data(), proof.data(), proof.size(), &len));
     proof.resize(len);
     return proof;
+}
+
+// dev::MockProver::run(k, &circuit, instances) + verify_par() / verify_at_rows_par(gate_rows, lookup_rows): the failures, sorted
+// (empty = assert_satisfied_par passes).  challenges empty = MockProver's own chain (zk_host_mock_challenges).
+inline std::vector<zk_mock_failure> mock_verify(const Context& c, const ProvingKey& pk, const std::vector<const void*>& advice_columns,
+                                                const std::vector<const void*>& instance_columns, const std::vector<Fr>& challenges = {},
+                                                const std::vector<uint32_t>* gate_rows = nullptr, const std::vector<uint32_t>* lookup_rows = nullptr,
+                                                size_t max_records = 4096) {
+    std::vector<zk_mock_failure> out(max_records ? max_records : 1);
+    size_t count = 0;
+    c.check(zk_mock_verify(c.raw(), pk.raw(), advice_columns.data(), instance_columns.data(), challenges.empty() ? nullptr : challenges.data(),
+                           gate_rows ? gate_rows->data() : nullptr, gate_rows ? gate_rows->size() : 0, lookup_rows ? lookup_rows->data() : nullptr,
+                           lookup_rows ? lookup_rows->size() : 0, out.data(), max_records, &count));
+    out.resize(count < max_records ? count : max_records);
+    return out;
 }
 
 // The same with `instances: &[&[Fr]]` as halo2 takes them -- exactly these values are absorbed into
