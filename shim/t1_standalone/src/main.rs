@@ -66,7 +66,7 @@ fn fr_from_hex(h: &str) -> Fr {
     for i in 0..32 {
         le[31 - i] = u8::from_str_radix(&padded[2 * i..2 * i + 2], 16).expect("hex digit");
     }
-    Fr::from_repr(le.into()).expect("canonical field element")
+    Option::<Fr>::from(Fr::from_repr(le)).expect("canonical field element")
 }
 
 fn fr_to_hex(v: &Fr) -> String {
@@ -197,7 +197,7 @@ impl Circuit<Fr> for KitCircuit {
         let advice: Vec<Column<Advice>> = d
             .advice_phase
             .iter()
-            .map(|p| match p {
+            .map(|p| match *p {
                 0 => meta.advice_column_in(FirstPhase),
                 1 => meta.advice_column_in(SecondPhase),
                 2 => meta.advice_column_in(ThirdPhase),
@@ -208,7 +208,7 @@ impl Circuit<Fr> for KitCircuit {
         let challenges: Vec<Challenge> = d
             .challenge_phase
             .iter()
-            .map(|p| match p {
+            .map(|p| match *p {
                 0 => meta.challenge_usable_after(FirstPhase),
                 1 => meta.challenge_usable_after(SecondPhase),
                 2 => meta.challenge_usable_after(ThirdPhase),
