@@ -269,6 +269,7 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine);
 /* ---- full proof: halo2_proofs::plonk::{keygen_pk, create_proof} with the GWC or SHPLONK multi-open
  * (poly::kzg::multiopen::{ProverGWC, ProverSHPLONK})  -- SURVEY 8a A1, A4, K6-K11; csrc/prover.hip -- */
 typedef struct zk_pk zk_pk;
+typedef struct zk_proof zk_proof;       /* a proving session, see below */
 /* keygen_pk over a flat circuit description (the "pk blob", version 3, filled by the Rust shim from
  * halo2's ConstraintSystem / by zkevm-circuits_amd/plonk.py in tests: header, phases, the advice /
  * fixed / instance query lists in registration order, permutation columns, constants, gate programs,
@@ -322,6 +323,11 @@ enum { ZK_MOCK_GATE = 1, ZK_MOCK_LOOKUP = 2, ZK_MOCK_PERMUTATION = 3 };
 int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const void* h_challenges,
                    const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
                    zk_mock_failure* out, size_t cap, size_t* count);
+/* The same checks inside a proving session, after its last advice phase and before zk_proof_finish: over the columns the
+ * session holds on the device and with the challenges its transcript produced (no second upload).  What a rejected proof
+ * leaves open -- which constraint the witness breaks, and where -- in one call; the session stays usable.            */
+int zk_proof_mock_verify(zk_ctx* ctx, zk_proof* proof, const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                         zk_mock_failure* out, size_t cap, size_t* count);
 /* Host only: the challenges MockProver hands a circuit (halo2 dev.rs: h = Blake2b-512("Halo2-MockProver"), then
  * challenge i = Fr::from_uniform_bytes(h = Blake2b-512(h)); the third one is the constant the reference pins at
  * [REF zkevm-circuits/src/super_circuit.rs:729]).  out: count x 32 B Montgomery Fr.                       */
@@ -331,7 +337,6 @@ int zk_host_mock_challenges(uint32_t count, void* out_fr32);
  * once per phase and needs the challenges of the earlier phases -- the SuperCircuit has three
  * phases, zkevm-circuits/src/util.rs:120-133).  begin -> zk_proof_advice_phase x num_phases ->
  * finish.  zk_create_proof is begin + all phases + finish for witnesses known up front.          */
-typedef struct zk_proof zk_proof;
 /* multi-open scheme of the session: GWC (ProverGWC, what north_star names; default) or SHPLONK
  * (ProverSHPLONK / BDFG21, what the reference's call sites instantiate: two commitments in total) */
 enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };

@@ -92,6 +92,8 @@ extern "C" {
     pub fn zk_mock_verify(ctx: *mut zk_ctx, pk: *const zk_pk, h_advice: *const *const c_void, h_instance: *const *const c_void, h_challenges: *const c_void,
                           gate_rows: *const u32, num_gate_rows: usize, lookup_rows: *const u32, num_lookup_rows: usize,
                           out: *mut zk_mock_failure, cap: usize, count: *mut usize) -> c_int;
+    pub fn zk_proof_mock_verify(ctx: *mut zk_ctx, proof: *mut zk_proof, gate_rows: *const u32, num_gate_rows: usize, lookup_rows: *const u32, num_lookup_rows: usize,
+                                out: *mut zk_mock_failure, cap: usize, count: *mut usize) -> c_int;
     pub fn zk_host_mock_challenges(count: u32, out_fr32: *mut c_void) -> c_int;
 
     pub fn zk_proof_begin_instances(ctx: *mut zk_ctx, pk: *const zk_pk, h_instance: *const *const c_void, h_instance_len: *const u32, seed16: *const u8, out: *mut *mut zk_proof) -> c_int;

@@ -165,3 +165,41 @@ def test_evm_circuit_sized_mock_run_k14(ctx):
     finally:
         pk.destroy()
         srs.destroy()
+
+
+def test_inside_a_proving_session(ctx, cref, srs_by_k):
+    """zk_proof_mock_verify: the same checks over the columns a session holds, under the challenges ITS transcript produced -- a
+    two-phase circuit (the second phase's witness depends on them): clean, then one second-phase cell changed; the session still
+    finishes afterwards and the clean session's proof is the oracle prover's."""
+    import t1_kit
+    from oracle import plonk_prover as pp
+    circ, phase_witness, inst = t1_kit.two_phase_case(6)
+    pk = ctx.pk_create(srs_by_k[circ.k], circ.blob())
+    seed = bytes(range(16))
+    try:
+        _, rep = pk.vk(circ.F + len(circ.perm_cols))
+        for corrupt in (False, True):
+            sess = ctx.proof_session(pk, [], seed)
+            sess.set_multiopen(1)
+            with pytest.raises(binding.ZkError, match="advice phases"):
+                sess.mock_verify()                                    # before the phases are through
+            ch = sess.advice_phase({i: plonk.column_to_mont(c) for i, c in phase_witness(0, []).items()})
+            chal = [int(v) for v in cref.from_mont(ch)]
+            cols = {i: list(c) for i, c in phase_witness(1, chal).items()}
+            if corrupt:
+                cols[3][5] = (cols[3][5] + 1) % R
+            sess.advice_phase({i: plonk.column_to_mont(c) for i, c in cols.items()})
+            adv = [phase_witness(0, [])[0], phase_witness(0, [])[1], cols[2], cols[3]]
+            want = pv.mock_failures(circ, adv, inst, challenges=chal)
+            got, total = sess.mock_verify()
+            assert got == want and total == len(want)
+            assert (want == []) == (not corrupt)
+            if corrupt:
+                assert want == [(pv.MOCK_GATE, 1, 0, 5)]
+                assert sess.mock_verify(gate_rows=[4, 6]) == ([], 0)
+            proof = sess.finish()
+            if not corrupt:
+                assert proof == pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), [[0] * circ.n for _ in range(circ.A)], inst, cref.from_mont(rep.reshape(1, 4))[0], seed, "shplonk",
+                                                phase_witness=phase_witness)
+    finally:
+        pk.destroy()

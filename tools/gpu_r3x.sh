@@ -1,7 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); O=$ROOT/gpurun_out/r3x; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 400 python bench.py > $O/bench_full.json 2> $O/bench_full.err; echo "bench rc=$? t=${SECONDS}"; cut -c1-300 $O/bench_full.json
+timeout 900 python -m pytest tests/test_gpu_mock.py -x -q -m gpu 2>&1 | tail -30

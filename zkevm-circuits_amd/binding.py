@@ -325,6 +325,18 @@ class ProofSession:
         self.ctx._ck(lib().zk_proof_advice_phase(self.ctx.h, self.h, ci, pc, ctypes.c_uint32(len(idx)), _host_ptr(out), ctypes.byref(cnt)))
         return out[:cnt.value].copy()
 
+    def mock_verify(self, gate_rows: Optional[Sequence[int]] = None, lookup_rows: Optional[Sequence[int]] = None, cap: int = 4096):
+        """zk_proof_mock_verify: MockProver's row checks over the columns this session holds, with the challenges its transcript
+        produced; after the last advice phase, before finish().  Returns (records, total) like Context.mock_verify."""
+        gr = None if gate_rows is None else np.ascontiguousarray(gate_rows, dtype=np.uint32)
+        lr = None if lookup_rows is None else np.ascontiguousarray(lookup_rows, dtype=np.uint32)
+        out = np.zeros((max(cap, 1), 4), dtype=np.uint32)
+        total = ctypes.c_size_t()
+        self.ctx._ck(lib().zk_proof_mock_verify(self.ctx.h, self.h, None if gr is None else _host_ptr(gr), ctypes.c_size_t(0 if gr is None else len(gr)),
+                                            None if lr is None else _host_ptr(lr), ctypes.c_size_t(0 if lr is None else len(lr)),
+                                            _host_ptr(out), ctypes.c_size_t(cap), ctypes.byref(total)))
+        return [tuple(int(v) for v in r) for r in out[:min(total.value, cap)]], total.value
+
     def finish(self) -> bytes:
         cap = 1 << 20
         out = ctypes.create_string_buffer(cap)

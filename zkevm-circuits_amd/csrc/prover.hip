@@ -2107,46 +2107,22 @@ int zk_host_mock_challenges(uint32_t count, void* out_fr32) {
     return ZK_OK;
 }
 
-int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const void* h_challenges,
-                   const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
-                   zk_mock_failure* out, size_t cap, size_t* count) {
-    if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, pk && count && (out || !cap) && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
-    ZK_REQUIRE(ctx, (gate_rows || !num_gate_rows) && (lookup_rows || !num_lookup_rows), "row list without rows");
-    ZK_REQUIRE(ctx, cap <= ((size_t)1 << 24), "at most 2^24 failure records");
-    static_assert(sizeof(zk_mock_failure) == sizeof(MockFail), "failure records are copied as they are");
-    *count = 0;
+// y and theta of one call: fresh randomness, nothing a witness could have been fitted to
+static void mock_randomise(Env& lag) {
+    std::random_device rd;
+    uint8_t b[128];
+    for (size_t i = 0; i < sizeof b; i += 4) { const uint32_t v = rd(); memcpy(b + i, &v, 4); }
+    lag.y = host::fr_from_uniform(b);
+    lag.theta = host::fr_from_uniform(b + 64);
+    lag.beta = lag.gamma = host::fr_zero();
+}
+// the checks themselves, over columns that are on the device already (lag: advice, instance, challenges, theta and y set)
+static int mock_verify_core(zk_ctx* ctx, const zk_pk* pk, const Env& lag, const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                            zk_mock_failure* out, size_t cap, size_t* count) {
     const size_t n = (size_t)1 << pk->k;
     // upstream panics on a row id outside the usable rows ("invalid gate row id")
     for (size_t i = 0; i < num_gate_rows; ++i) if (gate_rows[i] >= pk->u) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: gate row id %u is not a usable row (%u of them)", gate_rows[i], pk->u);
     for (size_t i = 0; i < num_lookup_rows; ++i) if (lookup_rows[i] >= pk->u) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: lookup row id %u is not a usable row (%u of them)", lookup_rows[i], pk->u);
-    PoolScope pool(ctx);
-    std::vector<DevBuf> adv(pk->A), inst(pk->I);
-    for (uint32_t c = 0; c < pk->A; ++c) {
-        ZK_REQUIRE(ctx, h_advice[c], "null advice column");
-        if (!adv[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
-        ZK_HIP(ctx, hipMemcpyAsync(adv[c].p, h_advice[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
-    }
-    for (uint32_t c = 0; c < pk->I; ++c) {
-        ZK_REQUIRE(ctx, h_instance[c], "null instance column");
-        if (!inst[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
-        ZK_HIP(ctx, hipMemcpyAsync(inst[c].p, h_instance[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
-    }
-    Env lag{};
-    lag.pk = pk;
-    lag.advice = &adv;
-    lag.instance = &inst;
-    lag.challenges.resize(pk->chal_phase.size());
-    if (h_challenges) memcpy(lag.challenges.data(), h_challenges, lag.challenges.size() * 32);
-    else PK_TRY(zk_host_mock_challenges((uint32_t)lag.challenges.size(), lag.challenges.data()));
-    {   // y and theta of this call: fresh randomness, nothing a witness could have been fitted to
-        std::random_device rd;
-        uint8_t b[128];
-        for (size_t i = 0; i < sizeof b; i += 4) { const uint32_t v = rd(); memcpy(b + i, &v, 4); }
-        lag.y = host::fr_from_uniform(b);
-        lag.theta = host::fr_from_uniform(b + 64);
-        lag.beta = lag.gamma = host::fr_zero();
-    }
     // failure records and counters on the device; selected rows
     const uint32_t cap32 = (uint32_t)cap;
     DevBuf fails, ctrs, rows_g, rows_l, vals;
@@ -2246,6 +2222,63 @@ int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, co
     if (got) memcpy(out, h.data(), got * sizeof(MockFail));
     *count = total;
     return ZK_OK;
+}
+
+
+int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, const void* const* h_instance, const void* h_challenges,
+                   const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                   zk_mock_failure* out, size_t cap, size_t* count) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && count && (out || !cap) && (h_advice || !pk->A) && (h_instance || !pk->I), "null pointer");
+    ZK_REQUIRE(ctx, (gate_rows || !num_gate_rows) && (lookup_rows || !num_lookup_rows), "row list without rows");
+    ZK_REQUIRE(ctx, cap <= ((size_t)1 << 24), "at most 2^24 failure records");
+    static_assert(sizeof(zk_mock_failure) == sizeof(MockFail), "failure records are copied as they are");
+    *count = 0;
+    const size_t n = (size_t)1 << pk->k;
+    PoolScope pool(ctx);
+    std::vector<DevBuf> adv(pk->A), inst(pk->I);
+    for (uint32_t c = 0; c < pk->A; ++c) {
+        ZK_REQUIRE(ctx, h_advice[c], "null advice column");
+        if (!adv[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(adv[c].p, h_advice[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (uint32_t c = 0; c < pk->I; ++c) {
+        ZK_REQUIRE(ctx, h_instance[c], "null instance column");
+        if (!inst[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
+        ZK_HIP(ctx, hipMemcpyAsync(inst[c].p, h_instance[c], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    Env lag{};
+    lag.pk = pk;
+    lag.advice = &adv;
+    lag.instance = &inst;
+    lag.challenges.resize(pk->chal_phase.size());
+    if (h_challenges) memcpy(lag.challenges.data(), h_challenges, lag.challenges.size() * 32);
+    else PK_TRY(zk_host_mock_challenges((uint32_t)lag.challenges.size(), lag.challenges.data()));
+    mock_randomise(lag);
+    return mock_verify_core(ctx, pk, lag, gate_rows, num_gate_rows, lookup_rows, num_lookup_rows, out, cap, count);
+}
+
+// The same checks inside a proving session, after its last advice phase: the columns the session holds on the device, the
+// challenges its transcript produced.  What a failed verify_proof leaves open -- WHICH constraint the witness breaks -- without
+// a second upload.
+int zk_proof_mock_verify(zk_ctx* ctx, zk_proof* pr, const uint32_t* gate_rows, size_t num_gate_rows, const uint32_t* lookup_rows, size_t num_lookup_rows,
+                         zk_mock_failure* out, size_t cap, size_t* count) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && count && (out || !cap), "null pointer");
+    ZK_REQUIRE(ctx, (gate_rows || !num_gate_rows) && (lookup_rows || !num_lookup_rows), "row list without rows");
+    ZK_REQUIRE(ctx, cap <= ((size_t)1 << 24), "at most 2^24 failure records");
+    const zk_pk* pk = pr->pk;
+    *count = 0;
+    if (pr->phase < pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: %u of the session's %u advice phases are committed", pr->phase, pk->num_phases);
+    PoolScope pool(ctx);
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // uploads and transforms of the last phase (copy / auxiliary streams are joined by the phase itself)
+    Env lag{};
+    lag.pk = pk;
+    lag.advice = &pr->adv_lag;
+    lag.instance = &pr->inst_lag;
+    lag.challenges = pr->challenges;
+    mock_randomise(lag);
+    return mock_verify_core(ctx, pk, lag, gate_rows, num_gate_rows, lookup_rows, num_lookup_rows, out, cap, count);
 }
 
 // One-shot create_proof: every advice column is known up front (no column depends on a challenge,
