@@ -145,6 +145,10 @@ int zk_poly_eval(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_x, v
 /* eval_polynomial of `count` polynomials (device pointers, n coefficients each) at one point:
  * one power table and one synchronisation for all of them; h_out receives count Fr               */
 int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t count, size_t n, const void* h_x, void* h_out);
+/* eval_polynomial for (polynomial, point) pairs in one pass: h_out[j] = d_coeff_ptrs[j](h_points[point_index[j]]).  The evaluations
+ * of a proof (plonk/prover.rs: every advice / fixed / permutation / lookup query at x w^rot) open a dozen distinct points when a
+ * column is read at many rotations; this is one table build, one Horner launch and one download for all of them.              */
+int zk_poly_eval_pairs(zk_ctx* ctx, const void* const* d_coeff_ptrs, const uint32_t* point_index, size_t count, const void* h_points, size_t num_points, size_t n, void* h_out);
 /* kate_division(coeffs, z): d_q receives n-1 coefficients of (f(X) - f(z)) / (X - z)             */
 int zk_kate_division(zk_ctx* ctx, const void* d_coeffs, size_t n, const void* h_z, void* d_q);
 /* z[0] = 1 (product) / 0 (sum); z[i+1] = z[i] (*|+) a[i]: the permutation / lookup grand product

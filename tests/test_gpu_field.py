@@ -85,6 +85,28 @@ def test_eval_polynomial_batch(ctx, cref, n, count):
             assert vals[i] == cref.eval_polynomial(polys[i], x), (n, i, x)
 
 
+@pytest.mark.parametrize("n,count,npoints", [(1, 2, 2), (100, 5, 3), (512, 4, 4), (513, 9, 5), (70001, 6, 3), (1 << 16, 40, 15)])
+def test_eval_polynomial_pairs(ctx, cref, n, count, npoints):
+    """zk_poly_eval_pairs == eval_polynomial of polynomial j at point point_index[j] (all pairs in one pass; below 512 coefficients
+    it goes point by point): the shape of a proof's evaluations -- many polynomials at x, a few at each rotated point, points
+    0 and r - 1 among them, a point nobody uses"""
+    rng = random.Random(n * 31 + count)
+    polys = [cref.rand_fr_stream(8100 + 17 * i + n, n) for i in range(count)]
+    bufs = [ctx.to_device(p) for p in polys]
+    points = [rng.randrange(bn254.R_MOD) for _ in range(npoints)]
+    points[-1] = 0
+    if npoints > 2:
+        points[1] = bn254.R_MOD - 1
+    idx = [0 if rng.random() < 0.5 else rng.randrange(npoints) for _ in range(count)]
+    idx = [i if i != npoints - 2 or npoints < 4 else 0 for i in idx]              # point npoints - 2 stays unused
+    got = cref.from_mont(ctx.poly_eval_pairs(bufs, idx, cref.to_mont(points), n))
+    for j in range(count):
+        assert got[j] == cref.eval_polynomial(polys[j], points[idx[j]]), (n, j, idx[j])
+    # the same polynomial at several points
+    got = cref.from_mont(ctx.poly_eval_pairs([bufs[0]] * npoints, list(range(npoints)), cref.to_mont(points), n))
+    assert [int(v) for v in got] == [cref.eval_polynomial(polys[0], x) for x in points]
+
+
 @pytest.mark.parametrize("n,first", [(1, 0), (1000, 0), (4099, (1 << 32) - 7)])
 def test_fr_random_chacha(ctx, cref, n, first):
     """zk_fr_random == ChaCha20 block (RFC 7539 KAT-pinned oracle) -> from_uniform_bytes."""

@@ -498,6 +498,16 @@ class Context:
         self._ck(lib().zk_poly_eval_batch(self.h, ptrs, ctypes.c_size_t(count), ctypes.c_size_t(n), _host_ptr(np.ascontiguousarray(x_mont)), _host_ptr(out)))
         return out
 
+    def poly_eval_pairs(self, polys, point_index: Sequence[int], points_mont: np.ndarray, n: int) -> np.ndarray:
+        """zk_poly_eval_pairs: polys[j] (device, n coefficients) at points_mont[point_index[j]] -> (count, 4) u64, one pass"""
+        count = len(polys)
+        out = np.empty((max(count, 1), 4), dtype=np.uint64)
+        ptrs = (ctypes.c_void_p * max(count, 1))(*[ctypes.c_void_p(p.ptr) for p in polys])
+        idx = np.ascontiguousarray(point_index, dtype=np.uint32)
+        pts = np.ascontiguousarray(points_mont, dtype=np.uint64).reshape(-1, 4)
+        self._ck(lib().zk_poly_eval_pairs(self.h, ptrs, _host_ptr(idx), ctypes.c_size_t(count), _host_ptr(pts), ctypes.c_size_t(len(pts)), ctypes.c_size_t(n), _host_ptr(out)))
+        return out[:count]
+
     def fr_random(self, key32: bytes, stream_id: int, first_block: int, out: DeviceBuffer, n: int):
         """n uniform Fr from ChaCha20 blocks (counter mode) + from_uniform_bytes."""
         assert len(key32) == 32

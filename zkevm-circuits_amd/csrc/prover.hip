@@ -52,6 +52,7 @@ extern "C" int zk_fr_scatter_scaled(zk_ctx*, const void*, size_t, const void*, v
 extern "C" int zk_msm_g1(zk_ctx*, const void*, const void*, size_t, void*);
 extern "C" int zk_g1_sum_host(const void*, size_t, void*);
 extern "C" int zk_poly_eval_batch(zk_ctx*, const void* const*, size_t, size_t, const void*, void*);
+extern "C" int zk_poly_eval_pairs(zk_ctx*, const void* const*, const uint32_t*, size_t, const void*, size_t, size_t, void*);
 
 namespace {
 
@@ -1794,18 +1795,21 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         for (int32_t rot : {0, 1}) evals.push_back({phi_coeff[l].fr(), rot, host::fr_zero()});
         evals.push_back({m_coeff[l].fr(), 0, host::fr_zero()});
     }
-    {   // one batched multi-polynomial reduction per distinct point
+    {   // every (polynomial, point) pair in one pass: one table per distinct point, one Horner launch, one download
         std::vector<int32_t> distinct;
-        for (const Open& o : evals) if (std::find(distinct.begin(), distinct.end(), norm_rot(o.rot)) == distinct.end()) distinct.push_back(norm_rot(o.rot));
-        for (int32_t rot : distinct) {
-            std::vector<const void*> ptrs;
-            std::vector<size_t> where;
-            for (size_t i = 0; i < evals.size(); ++i) if (norm_rot(evals[i].rot) == rot) { ptrs.push_back(evals[i].poly); where.push_back(i); }
-            std::vector<F4> vals(ptrs.size());
-            const F4 pt = rotate(evals[where[0]].rot);
-            PK_TRY(zk_poly_eval_batch(ctx, ptrs.data(), ptrs.size(), n, &pt, vals.data()));
-            for (size_t j = 0; j < where.size(); ++j) evals[where[j]].eval = vals[j];
+        std::vector<F4> points;
+        std::vector<uint32_t> pidx(evals.size());
+        std::vector<const void*> ptrs(evals.size());
+        for (size_t i = 0; i < evals.size(); ++i) {
+            const int32_t nr = norm_rot(evals[i].rot);
+            size_t at = std::find(distinct.begin(), distinct.end(), nr) - distinct.begin();
+            if (at == distinct.size()) { distinct.push_back(nr); points.push_back(rotate(evals[i].rot)); }
+            pidx[i] = (uint32_t)at;
+            ptrs[i] = evals[i].poly;
         }
+        std::vector<F4> vals(evals.size());
+        PK_TRY(zk_poly_eval_pairs(ctx, ptrs.data(), pidx.data(), evals.size(), points.data(), points.size(), n, vals.data()));
+        for (size_t i = 0; i < evals.size(); ++i) evals[i].eval = vals[i];
         for (const Open& o : evals) tr.write_scalar(o.eval);
     }
     trace.mark("evaluations");

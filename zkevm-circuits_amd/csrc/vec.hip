@@ -226,6 +226,42 @@ __global__ void __launch_bounds__(256) k_sum_final_multi(const Fr* __restrict__ 
     Fr s = block_sum(acc, sh);
     if (threadIdx.x == 0) stg(out + blockIdx.x, s);
 }
+// ---- several points in one pass (zk_poly_eval_pairs): the evaluations of a proof open ~15 distinct points at k = 18 (a column read at 13
+// rotations), most of them for one or two polynomials; one batched call per point was a dozen launches and a host round trip each.
+// tabs: per point a two-level table, nlo + nhi entries; blockIdx.y = point
+__global__ void __launch_bounds__(256) k_pow_tables_multi(const Fr* __restrict__ xs, const Fr* __restrict__ steps, Fr* __restrict__ tabs, uint32_t nlo, uint32_t nhi) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nlo + nhi) return;
+    Fr b = j < nlo ? ldg(xs + blockIdx.y) : ldg(steps + blockIdx.y), r = Fr::one();
+    uint32_t e = j < nlo ? j : j - nlo;
+    while (e) {
+        if (e & 1) r = r * b;
+        b = sqr(b);
+        e >>= 1;
+    }
+    stg(tabs + (size_t)blockIdx.y * (nlo + nhi) + j, r);
+}
+// k_eval_horner_multi with a point per polynomial: blockIdx.y = pair (polys[y] at the point whose table is tabs + pidx[y] * stride)
+__global__ void __launch_bounds__(256) k_eval_horner_pairs(const Fr* const* __restrict__ polys, const uint32_t* __restrict__ pidx, uint64_t n, uint64_t seg,
+                                                           const Fr* __restrict__ tabs, uint32_t nlo, uint32_t stride, int h, Fr* __restrict__ partial) {
+    __shared__ Fr sh[256];
+    const Fr* c = polys[blockIdx.y];
+    const Fr* lo = tabs + (size_t)pidx[blockIdx.y] * stride;
+    const Fr* hi = lo + nlo;
+    const uint64_t start = (uint64_t)blockIdx.x * seg, end = min(n, start + seg);
+    auto rprime = [](Fr x) { for (int i = 0; i < 5; ++i) x = dbl(x); return x; };
+    const Fr29 xs = unpack29<Fr29P>(rprime(two_level_pow(lo, hi, h, 256)));
+    Fr29 acc = unpack29<Fr29P>(Fr::zero());
+    const int64_t iters = start < end ? (int64_t)((end - start + 255) / 256) : 0;
+    for (int64_t j = iters - 1; j >= 0; --j) {
+        const uint64_t i = start + (uint64_t)j * 256 + threadIdx.x;
+        acc = mul29(acc, xs);
+        if (i < end) acc = add29(acc, unpack29<Fr29P>(ldg(c + i)));
+    }
+    const Fr mine = pack29_lt2p(mul29(acc, unpack29<Fr29P>(rprime(two_level_pow(lo, hi, h, threadIdx.x)))));
+    Fr s = block_sum(mine, sh);
+    if (threadIdx.x == 0) stg(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, start < end ? s * two_level_pow(lo, hi, h, start) : Fr::zero());
+}
 __global__ void __launch_bounds__(256) k_sum_final(const Fr* __restrict__ partial, uint32_t cnt, Fr* out) {
     __shared__ Fr sh[256];
     Fr acc = Fr::zero();
@@ -392,6 +428,65 @@ int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t coun
     ZK_CHECK_LAUNCH(ctx);
     ZK_HIP(ctx, hipMemcpyAsync(h_out, results, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int zk_poly_eval_pairs(zk_ctx* ctx, const void* const* d_coeff_ptrs, const uint32_t* point_index, size_t count, const void* h_points, size_t num_points, size_t n, void* h_out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (d_coeff_ptrs && point_index || !count) && (h_points || !num_points) && (h_out || !count), "null pointer");
+    if (count == 0) return ZK_OK;
+    for (size_t j = 0; j < count; ++j) ZK_REQUIRE(ctx, point_index[j] < num_points, "point index out of range");
+    if (n == 0) { memset(h_out, 0, sizeof(Fr) * count); return ZK_OK; }
+    if (n < 512 || num_points > 4096 || count > 65535) {
+        // short polynomials (the single-product kernel has no Horner stride to fill) and oversized batches: point by point
+        const Fr* pts = (const Fr*)h_points;
+        for (size_t p = 0; p < num_points; ++p) {
+            std::vector<const void*> ptrs;
+            std::vector<size_t> where;
+            for (size_t j = 0; j < count; ++j) if (point_index[j] == p) { ptrs.push_back(d_coeff_ptrs[j]); where.push_back(j); }
+            if (ptrs.empty()) continue;
+            std::vector<Fr> vals(ptrs.size());
+            int rc = zk_poly_eval_batch(ctx, ptrs.data(), ptrs.size(), n, pts + p, vals.data());
+            if (rc) return rc;
+            for (size_t t = 0; t < where.size(); ++t) ((Fr*)h_out)[where[t]] = vals[t];
+        }
+        return ZK_OK;
+    }
+    int bits = 1;
+    while ((1ull << bits) < n) ++bits;
+    const int h = (bits + 1) / 2;
+    const uint32_t nlo = 1u << h, nhi = 1u << (bits - h), stride = nlo + nhi;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    // scratch: [tables P x stride][partials count x blocks][results count][points P][steps P][polys count][pidx count]
+    const size_t fr_words = (size_t)num_points * stride + (size_t)blocks * count + count + 2 * num_points;
+    char* sc = (char*)ctx->get_scratch(SC_POLY2, sizeof(Fr) * fr_words + 12 * count + 64);
+    if (!sc) return ZK_ERR_OOM;
+    Fr* tabs = (Fr*)sc;
+    Fr* partial = tabs + (size_t)num_points * stride;
+    Fr* results = partial + (size_t)blocks * count;
+    Fr* d_xs = results + count;
+    Fr* d_steps = d_xs + num_points;
+    const Fr** d_ptrs = (const Fr**)(d_steps + num_points);
+    uint32_t* d_pidx = (uint32_t*)(d_ptrs + count);
+    std::vector<Fr> steps(num_points);
+    for (size_t p = 0; p < num_points; ++p) {
+        Fr st = ((const Fr*)h_points)[p];
+        for (int i = 0; i < h; ++i) st = sqr(st);
+        steps[p] = st;
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(d_xs, h_points, sizeof(Fr) * num_points, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(d_steps, steps.data(), sizeof(Fr) * num_points, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_coeff_ptrs, 8 * count, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(d_pidx, point_index, 4 * count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pow_tables_multi, dim3((stride + 255) / 256, (unsigned)num_points), dim3(256), 0, ctx->stream, (const Fr*)d_xs, (const Fr*)d_steps, tabs, nlo, nhi);
+    const uint64_t seg = (((uint64_t)n + blocks - 1) / blocks + 255) & ~(uint64_t)255;
+    hipLaunchKernelGGL(k_eval_horner_pairs, dim3(blocks, (unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)d_ptrs, (const uint32_t*)d_pidx, (uint64_t)n, seg,
+                       (const Fr*)tabs, nlo, stride, h, partial);
+    hipLaunchKernelGGL(k_sum_final_multi, dim3((unsigned)count), dim3(256), 0, ctx->stream, (const Fr*)partial, blocks, results);
+    ZK_CHECK_LAUNCH(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(h_out, results, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));          // also covers the staging vector `steps`
     return ZK_OK;
 }
 
