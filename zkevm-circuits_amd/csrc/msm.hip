@@ -595,11 +595,27 @@ static_assert(SCAN_ITEMS == MSM_SLICES, "k_scan_u32_a scans MSM_SLICES entries p
 // 2^18 tasks exist either way.  nmulti[0] = M = buckets with more points than one task,
 // nmulti[1] = the task size.
 constexpr uint32_t TASK_MIN = 8, TASK_TARGET = 1u << 18;
+#ifndef ZK_TASK_TMIN
+#define ZK_TASK_TMIN (1u << 16)
+#endif
 __global__ void __launch_bounds__(64) k_size_bins_scan(uint32_t* size_hist, const uint32_t* __restrict__ total_points) {
     const uint32_t lane = threadIdx.x;
     const uint32_t total = *total_points;
     uint32_t cap = TASK_CAP;
     if (total < TASK_CAP * TASK_TARGET) cap = max(TASK_MIN, (total + TASK_TARGET - 1) / TASK_TARGET);
+    // ... unless whole buckets already make enough tasks.  A dense column at 2^18 (3.9 M entries over 2^17 buckets of ~30) got task
+    // size 15 from the rule above: EVERY bucket split in two or three, and the combination kernels behind the accumulation took
+    // longer than the accumulation itself (0.47 against 0.40 ms per MSM, kernel statistics of tools/msm_graph_pipes.py).  When
+    // tasks of TASK_CAP points -- one per bucket for such a column -- still number ZK_TASK_TMIN, they win: 2^18 dense 0.61 -> 0.55 ms,
+    // 2^19 0.91 -> 0.77 ms per MSM in a batch.  A column of bits (a few giant buckets) or a 2^16 column keeps the small tasks
+    // (an in-between size -- every bucket split AND fewer lanes -- measured worse there: 0.24 -> 0.27 ms).
+    if ((ZK_TASK_TMIN) != 0u && cap < TASK_CAP) {
+        uint32_t tasks = 0;
+        for (uint32_t bin = 1 + lane; bin < SIZE_BINS; bin += 64) tasks += size_hist[bin] * ((bin + TASK_CAP - 1) / TASK_CAP);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tasks += __shfl_down(tasks, off);
+        if (__shfl(tasks, 0) >= (uint32_t)(ZK_TASK_TMIN)) cap = TASK_CAP;
+    }
     // descending order: position p = SIZE_BINS - 1 - bin; lane owns positions 4 lane .. 4 lane + 3
     uint32_t c[4], sum = 0;
 #pragma unroll
