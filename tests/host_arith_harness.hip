@@ -73,6 +73,13 @@ int h_is_zero_mod_p(int maxk, const uint32_t* a) {
     const Fq29 x = ld<Fq29P>(a);
     return maxk == 3 ? (int)is_zero_mod_p29<3>(x) : maxk == 9 ? (int)is_zero_mod_p29<9>(x) : -1;
 }
+// plain-integer inverse by binary extended Euclid (ff.hip.hpp: what one lane of a wave runs in the batch inversion)
+void h_inv_xgcd(int which, const uint32_t* a8, uint32_t* out8) {
+    uint32_t x[8], y[8];
+    memcpy(x, a8, 32);
+    if (which) inv_xgcd<FrP>(y, x); else inv_xgcd<FqP>(y, x);
+    memcpy(out8, y, 32);
+}
 void h_inv_via29(int which, const uint32_t* a8, uint32_t* out8) {
     if (which) { Fr v; memcpy(v.l, a8, 32); v = inv_via29<Fr29P>(v); memcpy(out8, v.l, 32); }
     else { Fq v; memcpy(v.l, a8, 32); v = inv_via29<Fq29P>(v); memcpy(out8, v.l, 32); }

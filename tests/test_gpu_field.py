@@ -37,12 +37,16 @@ def test_large_random_mul_million(zk, ctx, cref):
     assert np.array_equal(dO.download(A.shape), cref.fe_binop("mul", 0, A, B))
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 5000, (1 << 16) + 3])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1000, 5000, (1 << 16) + 3, (1 << 18) - 59])
 def test_batch_invert(ctx, cref, n):
     A = cref.rand_fr_stream(100 + n, n)
     if n > 4:
         A[1] = 0
         A[n - 1] = 0
+    if n > 600:
+        A[64:192] = 0                 # whole lanes, a whole wave's worth of one stride, hold nothing but zeros
+        A[300] = cref.to_mont([1])[0]
+        A[301] = cref.to_mont([bn254.R_MOD - 1])[0]
     dA = ctx.to_device(A)
     ctx.fr_batch_invert(dA, n)
     assert np.array_equal(dA.download(A.shape), cref.batch_invert(A))

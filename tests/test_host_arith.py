@@ -167,6 +167,24 @@ def test_lazy_reduction_and_inverse(h, which):
         assert got == pow(x, -1, mod) * r256 % mod
 
 
+@pytest.mark.parametrize("which", [0, 1])
+def test_binary_euclid_inverse(h, which):
+    """inv_xgcd (ff.hip.hpp): x^-1 mod m of a plain integer -- what the lone inverting lane of the batch inversion runs instead of
+    the 381-product Fermat ladder; 0 maps to 0; the edges: 1, 2, m - 1, (m + 1) / 2, powers of two (long halving runs), values
+    one subtraction away from the modulus"""
+    rng = random.Random(23 + which)
+    mod = MOD[which]
+    xs = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, 1 << 253, 1 << 128, (1 << 253) + 1, (1 << 200) - 1] + [rng.randrange(1, mod) for _ in range(200)]
+    for x in xs:
+        o8 = U8()
+        h.h_inv_xgcd(which, U8(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)]), o8)
+        got = sum(int(v) << (32 * i) for i, v in enumerate(o8))
+        assert got == pow(x, -1, mod), hex(x)
+    o8 = U8(*([7] * 8))
+    h.h_inv_xgcd(which, U8(*([0] * 8)), o8)
+    assert list(o8) == [0] * 8
+
+
 def test_subtractions_keep_limbs_non_negative(h):
     """sub_n<K>(a, b) = a - b + K p for a normalised b < K p: no limb may wrap, the result is normalised."""
     rng = random.Random(3)

@@ -1,4 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_msm.py -x -q -m gpu -k "commit_paths" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_field.py -x -q -m gpu 2>&1 | tail -3
+timeout 200 python tools/bi_time.py
+timeout 900 python -m pytest tests/test_gpu_proof.py -x -q -m gpu 2>&1 | tail -2
+timeout 300 python bench_proof.py --keccak --k 18 --shplonk --pinned --repeat 4 --no-verify 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('keccak k18', d['create_proof_s'])"

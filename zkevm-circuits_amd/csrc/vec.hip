@@ -39,27 +39,85 @@ static int vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void
 }
 
 // ---------------------------------------------------------------------------- batch inversion
-// Thread t owns the strided set {t, t+NT, t+2NT, ...} (coalesced): forward prefix products into
-// scratch, one Fermat inversion per thread, backward sweep.  Zeros are skipped (stay zero).
-constexpr int BI_PER_THREAD = 32;
-__global__ void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ pre, uint64_t n, uint64_t nt) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    Fr acc = Fr::one();
-    for (uint64_t i = t; i < n; i += nt) {
-        stg(pre + i, acc);
-        Fr v = ldg(a + i);
-        if (!v.is_zero()) acc = acc * v;
+// Lane t owns the strided set {t, t + NT, ...} of BI_K elements (coalesced), all held in registers: prefix products inside the
+// lane, a product scan across the 64 lanes of the wave (shuffles), ONE Fermat inversion per wave, and back: every lane gets the
+// inverse of its own product from the wave's, then walks its elements backwards.  Zeros are skipped (stay zero).
+// Round 3: the first form gave every thread 32 elements and an inversion of its own -- 0.5 waves per SIMD at 2^20, two dependent
+// global loads per element and step with nothing to hide them behind, an inversion per 32 elements: 290 us whatever the size
+// (36 ms of the SuperCircuit-shape proof in 122 calls) -- most of it the inversion itself: a wave issues its ~95 000 instructions
+// at the same pace whether one lane or all of them are live.  Now: 8 + 12 + 8 products on 29-bit limbs around ONE inversion per
+// wave by binary extended Euclid (inv_xgcd, a quarter of the instructions), loads issued up front.
+constexpr int BI_K = 8;
+__device__ __forceinline__ Fr29 shfl_up29(const Fr29& v, int off) {
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = __shfl_up(v.l[k], off);
+    return r;
+}
+__device__ __forceinline__ Fr29 shfl_down29(const Fr29& v, int off) {
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = __shfl_down(v.l[k], off);
+    return r;
+}
+__device__ __forceinline__ Fr29 shfl29(const Fr29& v, int src) {
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = __shfl(v.l[k], src);
+    return r;
+}
+// 1 / b for b in R' = 2^261 form, result in R' form: the residue as a plain integer X = B 2^261 has X^-1 = B^-1 2^-261 (binary
+// extended Euclid, ff.hip.hpp), and one product by c783 = 2^783 brings it to B^-1 2^261.  A lone lane runs this while its wave
+// waits: the Fermat ladder (381 products, ~95 000 instructions) took 250 us there, this takes a quarter of the instructions.
+__device__ inline Fr29 inv29_rp(const Fr29& b, const Fr29& c783) {
+    const Fr x = pack29_lt2p(b);
+    Fr y;
+    inv_xgcd<FrP>(y.l, x.l);
+    return mul29(unpack29<Fr29P>(y), c783);
+}
+__global__ void __launch_bounds__(256) k_batch_invert(Fr* __restrict__ a, uint64_t n, uint64_t nt, Fr c783_plain) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;                       // nt is a multiple of 64: whole waves leave
+    const uint32_t lane = threadIdx.x & 63u;
+    auto rprime = [](Fr x) { for (int i = 0; i < 5; ++i) x = dbl(x); return x; };       // R -> R' = 2^261 form: x 32
+    const Fr29 one_rp = unpack29<Fr29P>(rprime(Fr::one()));
+    Fr x[BI_K];
+#pragma unroll
+    for (int k = 0; k < BI_K; ++k) {           // every load in flight before the first product
+        const uint64_t i = (uint64_t)k * nt + t;
+        x[k] = i < n ? ldg(a + i) : Fr::zero();
     }
-    Fr iv = inv_via29<Fr29P>(acc);
-    uint64_t cnt = (n - t + nt - 1) / nt;
-    for (uint64_t k = cnt; k-- > 0;) {
-        uint64_t i = t + k * nt;
-        Fr v = ldg(a + i);
-        if (v.is_zero()) continue;
-        Fr p = ldg(pre + i);
-        stg(a + i, iv * p);
-        iv = iv * v;
+    Fr29 v[BI_K], pre[BI_K];
+    Fr29 acc = one_rp;
+#pragma unroll
+    for (int k = 0; k < BI_K; ++k) {
+        pre[k] = acc;
+        if (!x[k].is_zero()) { v[k] = unpack29<Fr29P>(rprime(x[k])); acc = mul29(acc, v[k]); }
+    }
+    // inclusive products over the lanes from both ends
+    Fr29 up = acc, down = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fr29 u = shfl_up29(up, off), d = shfl_down29(down, off);
+        if (lane >= (uint32_t)off) up = mul29(up, u);
+        if (lane + off < 64u) down = mul29(down, d);
+    }
+    // one inversion per wave: of the product of all its lanes
+    Fr29 inv_total = one_rp;
+    if (lane == 63u) inv_total = inv29_rp(up, unpack29<Fr29P>(c783_plain));
+    inv_total = shfl29(inv_total, 63);
+    // 1 / acc of this lane = 1 / total x (product of the lanes below) x (product of the lanes above)
+    const Fr29 below = shfl_up29(up, 1), above = shfl_down29(down, 1);
+    Fr29 iv = inv_total;
+    if (lane > 0u) iv = mul29(iv, below);
+    if (lane < 63u) iv = mul29(iv, above);
+    const Fr29 one_r = unpack29<Fr29P>(Fr::one());                     // x 2^256 / 2^261: R' -> R on the way out
+#pragma unroll
+    for (int k = BI_K; k-- > 0;) {
+        if (x[k].is_zero()) continue;
+        const uint64_t i = (uint64_t)k * nt + t;
+        stg(a + i, pack29_lt2p(mul29(mul29(iv, pre[k]), one_r)));
+        iv = mul29(iv, v[k]);
     }
 }
 
@@ -361,11 +419,10 @@ int zk_fr_batch_invert(zk_ctx* ctx, void* d_a, size_t n) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, d_a, "null pointer");
     if (!n) return ZK_OK;
-    Fr* pre = (Fr*)ctx->get_scratch(SC_POLY, sizeof(Fr) * n);
-    if (!pre) return ZK_ERR_OOM;
-    uint64_t nt = (n + BI_PER_THREAD - 1) / BI_PER_THREAD;
+    uint64_t nt = (n + BI_K - 1) / BI_K;
     nt = (nt + 63) / 64 * 64;
-    hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_a, pre, (uint64_t)n, nt);
+    static const Fr c783 = [] { Fr c = Fr::one(); for (int i = 0; i < 783 - 256; ++i) c = dbl(c); return c; }();      // the integer 2^783 mod r (Fr::one() holds 2^256)
+    hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_a, (uint64_t)n, nt, c783);
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
 }
