@@ -523,15 +523,22 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     const Fr** d_cols = (const Fr**)(d + al(prog_bytes));
     Fr* d_consts = (Fr*)(d + al(prog_bytes) + al(col_bytes));
     Fr* d_tev = (Fr*)(d + al(prog_bytes) + al(col_bytes) + al(const_bytes));
-    std::vector<uint32_t> prog;
-    prog.reserve((size_t)(low_len + 3) * 3);
-    for (const LowInstr& in : low) { prog.push_back(in.w0); prog.push_back(in.a); prog.push_back(in.b); }
-    for (int e = 0; e < 3; ++e) { prog.push_back(Q_END); prog.push_back(0); prog.push_back(0); }      // END + the two triples the kernel fetches ahead
-    ZK_HIP(ctx, hipMemcpyAsync(d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!col_tab.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_cols, col_tab.data(), col_tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts, h_consts, (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    if (num_consts) ZK_HIP(ctx, hipMemcpyAsync(d_consts + num_consts, consts_rp.data(), (size_t)num_consts * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    if (!tev.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_tev, tev.data(), tev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // program, column table, constants (R and R' forms) and vanishing inverses travel as ONE upload: the proof makes hundreds of
+    // these calls (compressions, linear combinations, class programs), and five small copies each were 2 500 copies per
+    // SuperCircuit-shape proof at ~8 us of device time apiece
+    const size_t total_bytes = al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes);
+    std::vector<char> staging(total_bytes, 0);
+    {
+        uint32_t* hp = (uint32_t*)staging.data();
+        size_t w = 0;
+        for (const LowInstr& in : low) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; }
+        for (int e = 0; e < 3; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; }      // END + the two triples the kernel fetches ahead
+        if (!col_tab.empty()) memcpy(staging.data() + al(prog_bytes), col_tab.data(), col_tab.size() * 8);
+        char* hc = staging.data() + al(prog_bytes) + al(col_bytes);
+        if (num_consts) { memcpy(hc, h_consts, (size_t)num_consts * sizeof(Fr)); memcpy(hc + (size_t)num_consts * sizeof(Fr), consts_rp.data(), (size_t)num_consts * sizeof(Fr)); }
+        if (!tev.empty()) memcpy(staging.data() + al(prog_bytes) + al(col_bytes) + al(const_bytes), tev.data(), tev_bytes);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(d, staging.data(), total_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
     const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
