@@ -2240,9 +2240,10 @@ int zk_mock_verify(zk_ctx* ctx, const zk_pk* pk, const void* const* h_advice, co
     *count = 0;
     const size_t n = (size_t)1 << pk->k;
     PoolScope pool(ctx);
-    // the uploads read the caller's columns asynchronously: whatever way this function is left, they are through first
-    struct DrainOnExit { zk_ctx* c; ~DrainOnExit() { (void)hipStreamSynchronize(c->stream); } } drain{ctx};
     std::vector<DevBuf> adv(pk->A), inst(pk->I);
+    // the uploads read the caller's columns asynchronously: whatever way this function is left, they are through before the device
+    // buffers above go back to the pool (declared after them: destroyed first) and before the caller gets its columns back
+    struct DrainOnExit { zk_ctx* c; ~DrainOnExit() { (void)hipStreamSynchronize(c->stream); } } drain{ctx};
     for (uint32_t c = 0; c < pk->A; ++c) {
         ZK_REQUIRE(ctx, h_advice[c], "null advice column");
         if (!adv[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "mock verify: alloc failed");
