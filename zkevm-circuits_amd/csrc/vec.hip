@@ -467,7 +467,9 @@ int zk_poly_eval_batch(zk_ctx* ctx, const void* const* d_coeff_ptrs, size_t coun
     Fr *lo, *hi; int h;
     int rc = build_pow_table(ctx, SC_TMP, *(const Fr*)h_x, n, &lo, &hi, &h);
     if (rc) return rc;
-    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    // segments of >= 4096 coefficients (16 Horner steps per thread) where the polynomial has them: a thread pays three table look-ups
+    // and two lifting products whatever its share, and at 2^18 a 1024-coefficient segment made those the larger half of its work
+    uint32_t blocks = n >= 512 ? (uint32_t)((n + 4095) / 4096) : (uint32_t)((n + 255) / 256);
     if (blocks > 256) blocks = 256;
     char* sc = (char*)ctx->get_scratch(SC_POLY2, sizeof(Fr) * ((size_t)blocks + 1) * count + 8 * count + 64);
     if (!sc) return ZK_ERR_OOM;
@@ -513,7 +515,7 @@ int zk_poly_eval_pairs(zk_ctx* ctx, const void* const* d_coeff_ptrs, const uint3
     while ((1ull << bits) < n) ++bits;
     const int h = (bits + 1) / 2;
     const uint32_t nlo = 1u << h, nhi = 1u << (bits - h), stride = nlo + nhi;
-    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    uint32_t blocks = (uint32_t)((n + 4095) / 4096);          // >= 16 Horner steps per thread (see zk_poly_eval_batch)
     if (blocks > 256) blocks = 256;
     // scratch: [tables P x stride][partials count x blocks][results count][points P][steps P][polys count][pidx count]
     const size_t fr_words = (size_t)num_points * stride + (size_t)blocks * count + count + 2 * num_points;
