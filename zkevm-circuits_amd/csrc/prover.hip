@@ -44,6 +44,8 @@ using zk::host::F4;
 
 extern "C" int zk_quotient_eval(zk_ctx*, const uint32_t*, uint32_t, const void* const*, uint32_t, const void*, uint32_t, uint32_t, uint32_t, int, void*);
 extern "C" int zk_fr_powers(zk_ctx*, const void*, const void*, void*, size_t);
+extern "C" int zk_ntt(zk_ctx*, void*, uint32_t, int);
+extern "C" int zk_fr_batch_invert(zk_ctx*, void*, size_t);
 extern "C" int zk_fr_random(zk_ctx*, const uint8_t*, uint64_t, uint64_t, void*, size_t);
 extern "C" int zk_lookup_multiplicities(zk_ctx*, const void*, const void*, size_t, void*, size_t, uint64_t*);
 extern "C" int zk_coeff_to_coset(zk_ctx*, const void*, uint32_t, const void*, void*);
@@ -1875,10 +1877,12 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             for (int32_t r_ : key) if (std::find(super.begin(), super.end(), r_) == super.end()) super.push_back(r_);
         }
         const F4 v = tr.squeeze();
-        // r_ij(X): interpolation of polynomial j's evaluations over its set's points (degree < |S|), host side
-        auto interpolate = [&](const std::vector<F4>& xs, const std::vector<F4>& ys) {
+        // r_ij(X): interpolation of polynomial j's evaluations over its set's points (degree < |S|), host side.  The Lagrange basis
+        // of a set -- L_a(X) = prod_{b != a} (X - x_b) / (x_a - x_b), |S|^3 products -- is built ONCE per set; a member then costs
+        // |S|^2.  (Per member it was 3.9 ms of the Keccak-shape proof: 48 columns opened at the same 14 points.)
+        auto lagrange_basis = [&](const std::vector<F4>& xs) {
             const size_t m = xs.size();
-            std::vector<F4> out(m, host::fr_zero());
+            std::vector<std::vector<F4>> basis(m);
             for (size_t a = 0; a < m; ++a) {
                 std::vector<F4> num{host::fr_one()};       // prod_{b != a} (X - x_b)
                 F4 den = host::fr_one();
@@ -1889,13 +1893,23 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                     num.swap(nx);
                     den = host::fr_mul(den, host::fr_sub(xs[a], xs[b2]));
                 }
-                const F4 sc = host::fr_mul(ys[a], host::fr_inv(den));
-                for (size_t t = 0; t < num.size(); ++t) out[t] = host::fr_add(out[t], host::fr_mul(num[t], sc));
+                const F4 dinv = host::fr_inv(den);
+                for (F4& c : num) c = host::fr_mul(c, dinv);
+                basis[a] = std::move(num);
             }
+            return basis;
+        };
+        auto interpolate = [&](const std::vector<std::vector<F4>>& basis, const std::vector<F4>& ys) {
+            const size_t m = basis.size();
+            std::vector<F4> out(m, host::fr_zero());
+            for (size_t a = 0; a < m; ++a)
+                for (size_t t = 0; t < m; ++t) out[t] = host::fr_add(out[t], host::fr_mul(basis[a][t], ys[a]));
             return out;
         };
         auto eval_small = [&](const std::vector<F4>& c, const F4& at) { F4 acc = host::fr_zero(); for (size_t t = c.size(); t-- > 0;) acc = host::fr_add(host::fr_mul(acc, at), c[t]); return acc; };
         std::vector<DevBuf> qfull(sets.size()), hset(sets.size());
+        DevBuf coset_x, coset_ginv, coset_den;                 // division of large rotation sets on a coset of the domain (below)
+        const F4 coset_g = host::fr_from_u64(7);
         std::vector<std::vector<F4>> Rset(sets.size());       // R_i(X) = sum_j y^j r_ij(X)
         DevBuf tmp;
         if (!tmp.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
@@ -1905,6 +1919,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             for (int32_t r_ : st.rots) zs.push_back(point_of(r_));
             // N_i(X) = sum_j y^j (P_ij(X) - r_ij(X)):  Qfull_i = sum_j y^j P_ij on the device, R_i on the host
             std::vector<const void*> members;
+            const std::vector<std::vector<F4>> basis = lagrange_basis(zs);
             std::vector<F4> R(st.rots.size(), host::fr_zero());
             F4 ypow = host::fr_one();
             for (size_t pi : st.members) {
@@ -1914,26 +1929,70 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                     const size_t where = std::find(polys[pi].rots.begin(), polys[pi].rots.end(), st.rots[a]) - polys[pi].rots.begin();
                     ys[a] = polys[pi].evals[where];
                 }
-                const std::vector<F4> rj = interpolate(zs, ys);
+                const std::vector<F4> rj = interpolate(basis, ys);
                 for (size_t t = 0; t < R.size(); ++t) R[t] = host::fr_add(R[t], host::fr_mul(ypow, rj[t]));
                 ypow = host::fr_mul(ypow, y);
             }
             Rset[si] = R;
             if (!qfull[si].alloc(n * 32) || !hset[si].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            trace.mark("  shplonk: interpolation (host)");
             PK_TRY(lincomb(members, y, qfull[si].p));
+            trace.mark("  shplonk: set combination");
             // Q_i = N_i / prod (X - z): subtract R_i from the low coefficients, divide point by point
             PK_TRY(zk_d2d(ctx, hset[si].p, qfull[si].p, n * 32));
             std::vector<F4> low(R.size());
             PK_TRY(zk_d2h(ctx, low.data(), hset[si].p, R.size() * 32));
             for (size_t t = 0; t < R.size(); ++t) low[t] = host::fr_sub(low[t], R[t]);
             PK_TRY(zk_h2d(ctx, hset[si].p, low.data(), R.size() * 32));
-            size_t len = n;
-            for (const F4& z : zs) {
-                PK_TRY(zk_kate_division(ctx, hset[si].p, len, &z, tmp.p));
-                --len;
-                PK_TRY(zk_d2d(ctx, hset[si].p, tmp.p, len * 32));
-                ZK_HIP(ctx, hipMemsetAsync((char*)hset[si].p + len * 32, 0, (n - len) * 32, ctx->stream));
+            // Division by Z_S(X) = prod (X - z).  Few points: one synthetic division per point.  Many (a column opened at 14
+            // rotations: 14 dependent scans, 1.7 ms of the Keccak-shape proof at k = 18): N_i has degree < n and vanishes on S,
+            // so Q_i = N_i / Z_S is fixed by its values on a coset g H of the domain -- transform, divide point by point by
+            // Z_S(g w^j) (one batch inversion), transform back: the cost no longer depends on |S|.
+            bool by_coset = zs.size() >= 4 && n >= 4 * zs.size();
+            if (by_coset) {
+                // no point of S may lie on the coset (z = x w^rot for a random x: z^n = g^n has probability n / r)
+                F4 gn = coset_g;
+                for (uint32_t i = 0; i < k; ++i) gn = host::fr_mul(gn, gn);
+                for (const F4& z : zs) { F4 zn = z; for (uint32_t i = 0; i < k; ++i) zn = host::fr_mul(zn, zn); if (host::fr_eq(zn, gn)) by_coset = false; }
             }
+            if (by_coset) {
+                if (!coset_x.p) {        // g w^j and g^-i, once per proof
+                    if (!coset_x.alloc(n * 32) || !coset_ginv.alloc(n * 32) || !coset_den.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                    const F4 ginv = host::fr_inv(coset_g), one = host::fr_one();
+                    PK_TRY(zk_fr_powers(ctx, &w, &coset_g, coset_x.p, n));
+                    PK_TRY(zk_fr_powers(ctx, &ginv, &one, coset_ginv.p, n));
+                }
+                std::vector<uint32_t> words;
+                std::vector<F4> cs;
+                for (size_t t = 0; t < zs.size(); ++t) {
+                    words.insert(words.end(), {Q_PUSH_COL, 0u, 0u, Q_ADD_CONST, (uint32_t)t, 0u});
+                    if (t) words.insert(words.end(), {Q_MUL, 0u, 0u});
+                    cs.push_back(host::fr_sub(host::fr_zero(), zs[t]));
+                }
+                words.insert(words.end(), {Q_FOLD, (uint32_t)zs.size(), 0u});
+                cs.push_back(host::fr_one());
+                const void* xcol[1] = {coset_x.p};
+                PK_TRY(zk_quotient_eval(ctx, words.data(), (uint32_t)(words.size() / 3), xcol, 1, cs.data(), (uint32_t)cs.size(), k, k, 0, coset_den.p));     // Z_S(g w^j)
+                PK_TRY(zk_fr_batch_invert(ctx, coset_den.p, n));
+                PK_TRY(zk_coeff_to_coset(ctx, hset[si].p, k, &coset_g, tmp.p));                                                                          // N_i(g w^j)
+                const uint32_t mulw[] = {Q_PUSH_COL, 0u, 0u, Q_PUSH_COL, 1u, 0u, Q_MUL, 0u, 0u, Q_FOLD, 0u, 0u};
+                const F4 one = host::fr_one();
+                const void* c2[2] = {tmp.p, coset_den.p};
+                PK_TRY(zk_quotient_eval(ctx, mulw, 4, c2, 2, &one, 1, k, k, 0, hset[si].p));                                                              // Q_i(g w^j)
+                PK_TRY(zk_ntt(ctx, hset[si].p, k, 1));                                                                                                  // q_i g^i
+                const void* c3[2] = {hset[si].p, coset_ginv.p};
+                PK_TRY(zk_quotient_eval(ctx, mulw, 4, c3, 2, &one, 1, k, k, 0, tmp.p));
+                PK_TRY(zk_d2d(ctx, hset[si].p, tmp.p, n * 32));
+            } else {
+                size_t len = n;
+                for (const F4& z : zs) {
+                    PK_TRY(zk_kate_division(ctx, hset[si].p, len, &z, tmp.p));
+                    --len;
+                    PK_TRY(zk_d2d(ctx, hset[si].p, tmp.p, len * 32));
+                    ZK_HIP(ctx, hipMemsetAsync((char*)hset[si].p + len * 32, 0, (n - len) * 32, ctx->stream));
+                }
+            }
+            trace.mark("  shplonk: set division");
         }
         // h = sum_i v^i Q_i; commit
         {
@@ -1944,6 +2003,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             PK_TRY(commit_coeff(ctx, srs, batch.fr(), n, &com));
             tr.write_point(com);
         }
+        trace.mark("  shplonk: h");
         const F4 u = tr.squeeze();
         // L(X) = sum_i v^i Z_{T \ S_i}(u) (Qfull_i(X) - R_i(u)) - Z_T(u) h(X);  the proof's second point commits to
         // L(X) / (X - u), normalised by 1 / Z_{T \ S_0}(u) (the verifier scales the first set's term to one)
