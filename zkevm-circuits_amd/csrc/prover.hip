@@ -829,6 +829,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     if (!blind_pinned.alloc(sg.blind_v.size() * sizeof(F4))) return ctx->fail(ZK_ERR_OOM, "prover: pinned staging allocation failed");
     memcpy(blind_pinned.p, sg.blind_v.data(), sg.blind_v.size() * sizeof(F4));
     sg.blind = (const F4*)blind_pinned.p;
+    trace.mark("  advice: blinding rows drawn and staged");
     PK_TRY(copy_stream_open(ctx));
     if (!ctx->ensure_aux()) return ctx->fail(ZK_ERR_HIP, "could not create the auxiliary stream");
     ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));                 // pooled blocks: everything enqueued so far comes first
@@ -838,6 +839,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     // `world` columns hides one MSM.
     sg.world = pr->world > 1 && pr->gather ? pr->world : 1;
     if (!pr->pre_planned) PK_TRY(plan_advice_cosets(ctx, pr));
+    trace.mark("  advice: coset plan");
     if (sg.world == 1 && !pr->adv_coset.empty()) {
         const Fr w_ext = fr_root_of_unity(pk->ext_k);
         Fr g = fr_zeta();
@@ -875,6 +877,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     std::vector<G1Affine> coms(sg.dst.size());
     std::vector<uint8_t> narrow(sg.src.size());
     sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of small values take the per-window MSM path
+    trace.mark("  advice: columns sampled");
     // ... and their blinding rows (the last blinding_factors + 1, field-sized) are committed apart, so that they do not occupy every window
     struct TailGuard { zk_ctx* c; ~TailGuard() { c->msm_blinded_tail = 0; } } tail_guard{ctx};
     ctx->msm_blinded_tail = pk->bf + 1;
