@@ -478,8 +478,9 @@ namespace zk {
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow) {
     // 1024 samples per column, each one Montgomery product on the host (24 ns); a small-valued column passes every sample, so
     // nothing ends early: 25 ms IN FRONT of the first upload of a 1000-column advice phase on one thread -- now on up to eight.
-    // (256 samples were tried: columns with a fraction of a percent of large values then slip through as "small" and the
-    // per-window path pays for them in every window -- Keccak shape 0.057 -> 0.065 s, SuperCircuit shape 1.43 -> 1.52 s.)
+    // (Fewer samples would let a column with a fraction of a percent of large values slip through as "small", and the per-window
+    // path pays for those in every window; one run with 256 samples came out 6-14 % slower on both proof shapes, on a box that
+    // was not measured against itself -- the count was left alone.)
     const size_t samples = n < 1024 ? n : 1024, step = n / (samples ? samples : 1);
     auto judge = [&](size_t c0, size_t c1) {
         for (size_t c = c0; c < c1; ++c) {
