@@ -126,18 +126,21 @@ __global__ void __launch_bounds__(256) k_lk_to_fr(const uint32_t* __restrict__ c
 // prover runs every lookup of a proof back to back and reads all status words at once.
 // d_inputs: `num_inputs` theta-compressed input vectors looked up in the same table (mv-lookup
 // arguments carry one or more input tuples).
-int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status) {
+// reuse_hash: the previous call on this context was for the SAME table values and row count (consecutive lookup arguments into
+// one table -- what chunk_lookups() leaves when a table has more inputs than one argument's degree allows): its hash is still in
+// the scratch, only the counters start over.
+int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status, bool reuse_hash) {
     uint32_t cap = 16;
     while (cap < 2 * usable_rows) cap <<= 1;
     // scratch: slots[cap] | counts[usable_rows]   (reused by the next enqueue: same stream, so ordered)
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_TMP, ((size_t)cap + usable_rows + 4) * 4);
     if (!ws) return ZK_ERR_OOM;
     uint32_t *slots = ws, *counts = ws + cap;
-    ZK_HIP(ctx, hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, ctx->stream));
+    if (!reuse_hash) ZK_HIP(ctx, hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, ctx->stream));
     ZK_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)usable_rows * 4, ctx->stream));
     const uint32_t rows = (uint32_t)usable_rows;
     if (rows) {
-        hipLaunchKernelGGL(k_lk_insert, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_table, rows, slots, cap - 1);
+        if (!reuse_hash) hipLaunchKernelGGL(k_lk_insert, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_table, rows, slots, cap - 1);
         for (size_t i = 0; i < num_inputs; ++i)
             hipLaunchKernelGGL(k_lk_count, dim3((rows + LK_COUNT_THREADS - 1) / LK_COUNT_THREADS), dim3(LK_COUNT_THREADS), 0, ctx->stream, d_inputs[i], d_table, rows,
                                (const uint32_t*)slots, cap - 1, counts, d_status);
@@ -255,7 +258,7 @@ extern "C" int zk_lookup_multiplicities(zk_ctx* ctx, const void* d_inputs, const
     if (!status) return ZK_ERR_OOM;
     ZK_HIP(ctx, hipMemsetAsync(status, 0xFF, 4, ctx->stream));
     const Fr* one_input = (const Fr*)d_inputs;
-    int rc = lookup_multiplicities_enqueue(ctx, &one_input, 1, (const Fr*)d_table, usable_rows, (Fr*)d_m, n, status);
+    int rc = lookup_multiplicities_enqueue(ctx, &one_input, 1, (const Fr*)d_table, usable_rows, (Fr*)d_m, n, status, false);
     if (rc) return rc;
     uint32_t st = LK_EMPTY;
     ZK_HIP(ctx, hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, ctx->stream));

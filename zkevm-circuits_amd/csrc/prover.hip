@@ -85,17 +85,21 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     zk_ctx* owner = nullptr;
+    bool borrowed = false;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owner(o.owner) { o.p = nullptr; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; owner = o.owner; o.p = nullptr; } return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owner(o.owner), borrowed(o.borrowed) { o.p = nullptr; o.borrowed = false; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; owner = o.owner; borrowed = o.borrowed; o.p = nullptr; o.borrowed = false; } return *this; }
     ~DevBuf() { release(); }
     void release() {
         if (!p) return;
+        if (borrowed) { p = nullptr; borrowed = false; return; }
         if (owner) owner->pool_put(p, bytes); else (void)hipFree(p);
         p = nullptr;
     }
+    // a view of somebody else's block (never released through this object)
+    void borrow(void* q) { release(); p = q; borrowed = true; }
     bool alloc(size_t n) {
         release();
         bytes = n;
@@ -1348,7 +1352,10 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // of commits.  The unusable rows of m stay zero, as upstream leaves them.
     std::vector<std::vector<DevBuf>> lk_f(pk->L);
     std::vector<DevBuf> lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
+    std::vector<uint8_t> same_table(pk->L, 0);            // lookup l reads the table of lookup l - 1 (lk_t lives at table_owner[l])
+    std::vector<uint32_t> table_owner(pk->L, 0);
     if (pk->L) {
+        Prog prev_table;
         DevBuf status;
         if (!status.alloc((size_t)pk->L * 4)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         ZK_HIP(ctx, hipMemsetAsync(status.p, 0xFF, (size_t)pk->L * 4, ctx->stream));
@@ -1357,8 +1364,17 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             const auto& lk = pk->lookups[l];
             PB pt;
             push_compressed(pt, lk.tables); pt.fold(C_ONE);
-            if (!lk_t[l].alloc(n * 32) || !lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
+            // consecutive arguments into the same table (chunk_lookups() splits a table's inputs over as many arguments as the
+            // degree bound needs; the EVM circuit's 80-odd lookups go into a dozen tables): one compressed table, one hash
+            static const bool share_tables = !(getenv("ZK_LOOKUP_SHARE") && atoi(getenv("ZK_LOOKUP_SHARE")) == 0);      // measurement knob
+            same_table[l] = share_tables && l > 0 && pt.g.size() == prev_table.size() && memcmp(pt.g.data(), prev_table.data(), pt.g.size() * sizeof(Instr)) == 0;
+            table_owner[l] = same_table[l] ? table_owner[l - 1] : l;
+            prev_table = pt.g;
+            if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            if (!same_table[l]) {
+                if (!lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
+            }
             lk_f[l].resize(lk.inputs.size());
             std::vector<const Fr*> fptrs;
             for (size_t a = 0; a < lk.inputs.size(); ++a) {
@@ -1368,7 +1384,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 PK_TRY(run_program(ctx, lag, pf.g, lk_f[l][a].p));
                 fptrs.push_back(lk_f[l][a].fr());
             }
-            PK_TRY(lookup_multiplicities_enqueue(ctx, fptrs.data(), fptrs.size(), lk_t[l].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l));
+            PK_TRY(lookup_multiplicities_enqueue(ctx, fptrs.data(), fptrs.size(), lk_t[table_owner[l]].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l, same_table[l]));
             mptrs[l] = lk_m[l].p;
         }
         std::vector<uint32_t> st(pk->L);
@@ -1451,15 +1467,17 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             // inv = [t + beta | f_0 + beta | ... | f_{N-1} + beta], inverted in one batch
             Env e2 = lag;
             std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
-            ft[0] = std::move(lk_t[l]);
+            ft[0].borrow(lk_t[table_owner[l]].p);
             for (size_t a = 0; a < N; ++a) ft[1 + a] = std::move(lk_f[l][a]);
             e2.lk_phi = &ft;
-            for (size_t a = 0; a <= N; ++a) {
+            // the table's slot keeps 1 / (t + beta) from the previous argument when that one read the same table
+            const size_t first = same_table[l] ? 1 : 0;
+            for (size_t a = first; a <= N; ++a) {
                 PB pb;
                 pb.col(CT_LK_PHI, (uint32_t)a).addc(C_BETA).fold(C_ONE);
                 PK_TRY(run_program(ctx, e2, pb.g, (char*)inv.p + a * n * 32));
             }
-            PK_TRY(zk_fr_batch_invert(ctx, inv.p, (N + 1) * n));
+            PK_TRY(zk_fr_batch_invert(ctx, (char*)inv.p + first * n * 32, (N + 1 - first) * n));
             // g = sum_a inv_f_a - m * inv_t
             PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, inv.p, g.p, n));
             PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, (char*)inv.p + n * 32, g.p, g.p, n));
@@ -1469,6 +1487,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
             ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
             ft.clear(); lk_f[l].clear();                                        // f, t are not needed again (the quotient recomputes them on its cosets)
+            if (l + 1 == pk->L || !same_table[l + 1]) lk_t[table_owner[l]].release();      // the table's last reader
             pptrs[l] = phi.p;
             lk_phi[l] = std::move(phi);
         }
