@@ -497,7 +497,11 @@ void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* n
     if (threads <= 1) { judge(0, count); return; }
     std::vector<std::thread> pool;
     const size_t per = (count + threads - 1) / threads;
-    for (size_t t = 0; t < threads && t * per < count; ++t) pool.emplace_back(judge, t * per, std::min(count, (t + 1) * per));
+    size_t started = 0;                      // columns [0, started) have a thread
+    try {
+        for (size_t t = 0; t < threads && t * per < count; ++t) { pool.emplace_back(judge, t * per, std::min(count, (t + 1) * per)); started = std::min(count, (t + 1) * per); }
+    } catch (...) {}                         // no thread to be had (a process at its limit): the rest is judged here; nothing unwinds across the C ABI
+    if (started < count) judge(started, count);
     for (std::thread& th : pool) th.join();
 }
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
