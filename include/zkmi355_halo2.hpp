@@ -208,6 +208,8 @@ class ProvingKey {
     ProvingKey(const ProvingKey&) = delete;
     ProvingKey& operator=(const ProvingKey&) = delete;
     const zk_pk* raw() const { return pk_; }
+    // install upstream's `vk.transcript_repr()` (the first scalar every proof absorbs)
+    void set_transcript_repr(const Fr& repr) { c_.check(zk_pk_set_transcript_repr(c_.raw(), pk_, repr.data())); }
    private:
     const Context& c_;
     zk_pk* pk_ = nullptr;

@@ -1,13 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); O=$ROOT/gpurun_out/r3x; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed" $O/pytest.log | tail -3
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 400 python bench.py > $O/bench_full.json 2> $O/bench_full.err; echo "bench rc=$? t=${SECONDS}"
-python - <<PY
-import json
-d=json.loads(open("$O/bench_full.json").read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['rooflines'][1]['avg_launch_ms'])
-for k,v in d.get('proof',{}).items(): print(k, {x:v.get(x) for x in ('value','verified_by_oracle','error','gpu_s','same_proof_bytes')})
-PY
+timeout 600 python -m pytest tests/test_gpu_cpp_caller.py -x -q -m gpu 2>&1 | tail -15
