@@ -67,7 +67,13 @@ int main(int argc, char** argv) {
         // instances as halo2 takes them: the values of every usable row of each instance column
         std::vector<std::vector<Fr>> inst(I, std::vector<Fr>(usable));
         for (size_t c = 0; c < I; ++c) std::memcpy(inst[c].data(), instance.data() + c * n * 32, usable * 32);
-        const std::vector<uint8_t> proof = create_proof(ctx, pk, adv_ptrs, inst, seed, shplonk);
+        // the session a multi-phase circuit would drive phase by phase; these files hold a single-phase witness
+        ProofSession session(ctx, pk, inst, seed, shplonk);
+        std::vector<uint32_t> all(A);
+        for (uint32_t c = 0; c < A; ++c) all[c] = c;
+        (void)session.advice_phase(all, adv_ptrs);
+        if (!session.mock_verify().empty()) throw std::runtime_error("the session's own row checks disagree with the stand-alone ones");
+        const std::vector<uint8_t> proof = session.finish();
         std::ofstream(dir + "/proof_cpp.bin", std::ios::binary).write((const char*)proof.data(), (std::streamsize)proof.size());
         std::printf("k = %u, %zu advice / %zu instance columns, mock checks passed, %s proof of %zu bytes written\n", shape[0], A, I, shplonk ? "SHPLONK" : "GWC", proof.size());
         return 0;

@@ -225,6 +225,60 @@ inline std::vector<uint8_t> create_proof(const Context& c, const ProvingKey& pk,
     return proof;
 }
 
+// The phase-by-phase session behind plonk::create_proof for circuits whose later phases depend on challenges (the SuperCircuit has
+// three phases [REF zkevm-circuits/src/util.rs:120-133]): begin -> advice_phase per phase (the host synthesises that phase's columns
+// with the challenges returned so far) -> finish.  What the Rust shim drives through ffi.rs.
+class ProofSession {
+   public:
+    // instances as halo2 takes them: exactly these values are absorbed, the columns are zero-padded on the device
+    ProofSession(const Context& c, const ProvingKey& pk, const std::vector<std::vector<Fr>>& instances, const std::array<uint8_t, 16>& rng_seed, bool shplonk = true) : c_(c) {
+        std::vector<const void*> ptrs;
+        std::vector<uint32_t> lens;
+        for (const auto& col : instances) { ptrs.push_back(col.data()); lens.push_back((uint32_t)col.size()); }
+        c_.check(zk_proof_begin_instances(c_.raw(), pk.raw(), ptrs.data(), lens.data(), rng_seed.data(), &s_));
+        uint32_t shape[16] = {0};
+        int rc = zk_pk_shape(c_.raw(), pk.raw(), shape);
+        if (rc == ZK_OK) rc = zk_proof_set_multiopen(c_.raw(), s_, shplonk ? ZK_MULTIOPEN_SHPLONK : ZK_MULTIOPEN_GWC);
+        if (rc != ZK_OK) { zk_proof_abort(c_.raw(), s_); s_ = nullptr; c_.check(rc); }
+        num_challenges_ = shape[10];
+    }
+    ~ProofSession() { if (s_) zk_proof_abort(c_.raw(), s_); }
+    ProofSession(const ProofSession&) = delete;
+    ProofSession& operator=(const ProofSession&) = delete;
+    // Poseidon (gen_snark_shplonk) or Keccak / EVM (gen_evm_proof_shplonk) instead of Blake2b: right after construction
+    void set_transcript_kind(int kind) { c_.check(zk_proof_set_transcript_kind(c_.raw(), s_, kind)); }
+    // commits the columns of the current phase (column_index[j] -> columns[j], n x 32 B each); returns the challenges that become usable after it
+    std::vector<Fr> advice_phase(const std::vector<uint32_t>& column_index, const std::vector<const void*>& columns) {
+        std::vector<Fr> ch(num_challenges_ ? num_challenges_ : 1);
+        uint32_t cnt = (uint32_t)ch.size();
+        c_.check(zk_proof_advice_phase(c_.raw(), s_, column_index.data(), columns.data(), (uint32_t)column_index.size(), ch.data(), &cnt));
+        ch.resize(cnt);
+        return ch;
+    }
+    // MockProver's row checks over the columns the session holds, under its own challenges (after the last phase)
+    std::vector<zk_mock_failure> mock_verify(size_t max_records = 4096) {
+        std::vector<zk_mock_failure> out(max_records ? max_records : 1);
+        size_t count = 0;
+        c_.check(zk_proof_mock_verify(c_.raw(), s_, nullptr, 0, nullptr, 0, out.data(), max_records, &count));
+        out.resize(count < max_records ? count : max_records);
+        return out;
+    }
+    // the proof bytes; the session is gone afterwards
+    std::vector<uint8_t> finish() {
+        std::vector<uint8_t> proof(size_t(1) << 20);
+        size_t len = 0;
+        zk_proof* s = s_;
+        s_ = nullptr;                       // zk_proof_finish consumes the session on success and on failure
+        c_.check(zk_proof_finish(c_.raw(), s, proof.data(), proof.size(), &len));
+        proof.resize(len);
+        return proof;
+    }
+   private:
+    const Context& c_;
+    zk_proof* s_ = nullptr;
+    uint32_t num_challenges_ = 0;
+};
+
 // dev::MockProver::run(k, &circuit, instances) + verify_par() / verify_at_rows_par(gate_rows, lookup_rows): the failures, sorted
 // (empty = assert_satisfied_par passes).  challenges empty = MockProver's own chain (zk_host_mock_challenges).
 inline std::vector<zk_mock_failure> mock_verify(const Context& c, const ProvingKey& pk, const std::vector<const void*>& advice_columns,
