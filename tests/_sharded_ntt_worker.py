@@ -3,6 +3,7 @@
 sharded transform (forward, then inverse on the result) and writes what it holds to
 <out_dir>/fwd_<rank>.npy and inv_<rank>.npy.  The ranks share cuda:0 and exchange over gloo on the
 one-GPU test box; with backend nccl the same code runs the all-to-all over RCCL / xGMI."""
+import datetime
 import os
 import sys
 
@@ -19,7 +20,7 @@ from zkevm_circuits_amd import sharding  # noqa: E402
 
 def main():
     out_dir, log_n = sys.argv[1], int(sys.argv[2])
-    dist.init_process_group(backend=os.environ.get("ZK_TEST_BACKEND", "gloo"))
+    dist.init_process_group(backend=os.environ.get("ZK_TEST_BACKEND", "gloo"), timeout=datetime.timedelta(seconds=150))      # a collective that never completes is an error, not a wait
     rank, world = dist.get_rank(), dist.get_world_size()
     ctx = z.Context(int(os.environ.get("ZK_TEST_DEVICE", "0")))
     x = np.load(os.path.join(out_dir, "input.npy"))

@@ -5,6 +5,7 @@ on the GPU it is given (the test puts all ranks on cuda:0 -- the box has one GPU
 over gloo; on an 8-GPU node the same code runs with backend nccl = RCCL) and writes its proof to
 <out_dir>/proof_<rank>.bin.  Rank 0 also writes the proof of an unsharded session: the two must be
 byte-identical, because a sharded session produces the same transcript."""
+import datetime
 import os
 import sys
 
@@ -22,7 +23,7 @@ from plonk_fixtures import build_circuit  # noqa: E402
 
 def main():
     out_dir, k, multiopen = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    dist.init_process_group(backend=os.environ.get("ZK_TEST_BACKEND", "gloo"))
+    dist.init_process_group(backend=os.environ.get("ZK_TEST_BACKEND", "gloo"), timeout=datetime.timedelta(seconds=150))      # a collective that never completes is an error, not a wait
     rank, world = dist.get_rank(), dist.get_world_size()
     ctx = z.Context(int(os.environ.get("ZK_TEST_DEVICE", "0")))
     circ, adv, inst = build_circuit(k, seed=5, wide=True)

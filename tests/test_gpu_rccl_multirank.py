@@ -26,7 +26,7 @@ def _gpus() -> int:
     return torch.cuda.device_count()
 
 
-def launch_ranks(world, argv, out_dir, timeout=900):
+def launch_ranks(world, argv, out_dir, timeout=300):
     """A launcher that is a plain loop: what the rendezvous documents as sufficient (no torch.distributed.run)."""
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))

@@ -15,6 +15,7 @@ from oracle import bn254
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 
 
 @pytest.mark.parametrize("world,log_n", [(2, 2), (2, 11), (4, 4), (4, 14), (2, 20), (8, 16)])
@@ -23,13 +24,9 @@ def test_sharded_ntt_matches_best_fft(tmp_path, cref, world, log_n):
     n = 1 << log_n
     x = cref.rand_fr_stream(4242 + log_n, n)
     np.save(tmp_path / "input.npy", x)
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "_sharded_ntt_worker.py"), str(tmp_path), str(log_n)]
+    from _launch import run_ranks
     env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1")
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = run_ranks(world, os.path.join(HERE, "_sharded_ntt_worker.py"), [tmp_path, log_n], env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     want = cref.best_fft(x, bn254.omega_for_k(log_n), log_n)
     got = np.empty_like(want)

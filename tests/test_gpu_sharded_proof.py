@@ -12,19 +12,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 
 
 @pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1), (2, 11, 1, 0), (3, 12, 0, 1)])
 def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather):
-    import socket
-    with socket.socket() as sock:          # a port that is free right now (cases run back to back)
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "_sharded_proof_worker.py"), str(tmp_path), str(k), str(multiopen)]
+    from _launch import run_ranks
     # devgather: the advice columns are uploaded by their owning rank only and all-gathered between devices
     env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1", ZK_TEST_DEVGATHER=str(devgather))
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = run_ranks(world, os.path.join(HERE, "_sharded_proof_worker.py"), [tmp_path, k, multiopen], env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     single = open(tmp_path / "proof_single.bin", "rb").read()
     assert len(single) > 500
