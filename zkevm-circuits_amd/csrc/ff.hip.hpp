@@ -105,8 +105,8 @@ __host__ __device__ __forceinline__ void cond_sub(uint32_t (&x)[8]) {
 // x^-1 mod m for a plain integer 0 < x < m (NOT a Montgomery residue): binary extended Euclid, invariants a x = u, b x = v (mod m).
 // About 1.4 x 254 halvings and 0.7 x 254 subtractions of 8-limb integers -- a quarter of the instructions of the 381-product
 // Fermat ladder, which is what counts where ONE lane computes an inverse and its wave waits (batch inversion, vec.hip).
-// Data-dependent trip counts: not for secrets (the prover inverts public products of witness-dependent values; halo2 does the same
-// with its variable-time `invert`).  x = 0 returns 0.
+// Data-dependent trip counts: the running time depends on the value.  The one caller inverts products of a whole wave's worth of
+// column values inside a proving kernel, where timing is not an interface; do not use it on a lone secret.  x = 0 returns 0.
 template <class P>
 __host__ __device__ inline void inv_xgcd(uint32_t (&out)[8], const uint32_t (&x)[8]) {
     uint32_t u[8], v[8], a[8], b[8], m[8], t[8];
