@@ -25,7 +25,8 @@ def test_the_last_proof_is_tabulated():
     ps = trace_stages.proofs(LOG.splitlines())
     assert len(ps) == 2 and len(ps[0]) == 2
     text = trace_stages.table(ps[-1])
-    rows = {ln.split("  ")[0].strip(): ln for ln in text.splitlines()}
+    import re
+    rows = {re.split(r"\s{2,}", ln.strip())[0]: ln for ln in text.splitlines()}
     assert "22.50" in rows["advice upload + commits"]                      # 20.00 + its sub-mark
     assert "3.00" in rows["quotient eval + ifft"] and "2.00" in rows["quotient: program"]
     assert "29.50" in rows["sum of the marks"]
