@@ -446,6 +446,17 @@ void zk_proof_abort(zk_ctx* ctx, zk_proof* proof);
 /* instances <-> concatenated 32-byte big-endian words [REF prover/src/proof.rs:77-85,126-138]         */
 int zk_host_instances_encode(const void* fr_mont, size_t n, void* out_be);
 int zk_host_instances_decode(const void* in_be, size_t n, void* fr_mont_out);
+/* The prover's `Proof` wire object [REF prover/src/proof.rs:25-35,99-104] -- the body of full_proof_<name>.json:
+ * {"proof": base64, "instances": base64 of the 32-byte big-endian words (zk_host_instances_encode), "vk": base64 of
+ * VerifyingKey::write(Processed) (zk_host_vk_write), "git_version": string or null}, serde_json's compact form in the struct's
+ * field order; base64 as [REF eth-types/src/lib.rs:71-91] (standard alphabet, padded).  write: out may be NULL (size query);
+ * git_version NULL = null.  read: accepts compact or pretty JSON with the four keys in any order (git_version may be absent);
+ * every output buffer is optional, the *_len arguments hold capacities on entry and lengths on return.  The objects built
+ * around it -- ChunkProof / BatchProof with snark-verifier's `protocol` -- stay on the Rust side. */
+int zk_host_proof_json_write(const void* proof, size_t proof_len, const void* instances_be, size_t instances_len, const void* vk, size_t vk_len,
+                             const char* git_version, char* out, size_t cap, size_t* len);
+int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size_t* proof_len, void* instances_be, size_t* instances_len, void* vk, size_t* vk_len,
+                            char* git_version, size_t git_cap, int* has_git_version);
 /* G1 points in halo2curves' SerdeFormat: 32 B compressed (Processed) or 64 B Montgomery limbs       */
 int zk_host_g1_encode(const void* affine64, size_t n, int format, void* out);
 int zk_host_g1_decode(const void* in, size_t n, int format, void* affine64_out);

@@ -161,3 +161,74 @@ def test_accumulate_decide_and_limbs():
     for coord in (got_l[0], got_l[1], got_r[0], got_r[1]):
         want += [(coord >> (88 * i)) & ((1 << 88) - 1) for i in range(3)]
     assert [int(v) for v in cref.from_mont(limbs)] == want
+
+
+def _proof_json(proof: bytes, inst: bytes, vk: bytes, git):
+    n = ctypes.c_size_t()
+    g = None if git is None else git.encode()
+    assert lib().zk_host_proof_json_write(proof, ctypes.c_size_t(len(proof)), inst, ctypes.c_size_t(len(inst)), vk, ctypes.c_size_t(len(vk)), g, None, ctypes.c_size_t(0), ctypes.byref(n)) == 0
+    buf = ctypes.create_string_buffer(n.value)
+    assert lib().zk_host_proof_json_write(proof, ctypes.c_size_t(len(proof)), inst, ctypes.c_size_t(len(inst)), vk, ctypes.c_size_t(len(vk)), g, buf, ctypes.c_size_t(n.value), ctypes.byref(n)) == 0
+    return buf.raw[:n.value]
+
+
+def _proof_json_read(js: bytes):
+    lens = [ctypes.c_size_t(0) for _ in range(3)]
+    has = ctypes.c_int(-1)
+    rc = lib().zk_host_proof_json_read(js, ctypes.c_size_t(len(js)), None, ctypes.byref(lens[0]), None, ctypes.byref(lens[1]), None, ctypes.byref(lens[2]), None, ctypes.c_size_t(0), ctypes.byref(has))
+    if rc:
+        return rc
+    bufs = [ctypes.create_string_buffer(max(ln.value, 1)) for ln in lens]
+    caps = [ctypes.c_size_t(ln.value) for ln in lens]
+    git = ctypes.create_string_buffer(64)
+    assert lib().zk_host_proof_json_read(js, ctypes.c_size_t(len(js)), bufs[0], ctypes.byref(caps[0]), bufs[1], ctypes.byref(caps[1]), bufs[2], ctypes.byref(caps[2]),
+                                         git, ctypes.c_size_t(64), ctypes.byref(has)) == 0
+    return tuple(bf.raw[:c.value] for bf, c in zip(bufs, caps)) + ((git.value.decode() if has.value else None),)
+
+
+def test_proof_wire_object_is_serde_jsons():
+    """`Proof` [REF prover/src/proof.rs:25-35] as dump_as_json writes it: compact serde_json, struct field order, base64 of the
+    `base64` crate (standard alphabet, padded) [REF eth-types/src/lib.rs:71-91] -- byte for byte what Python's json / base64 give
+    for the same object, for every padding length, an empty vk (`Proof::new` without a pk) and no git version."""
+    import base64
+    import json
+    rng = random.Random(7)
+    for plen in (0, 1, 2, 3, 4, 1630, 1631, 1632):
+        proof = bytes(rng.randrange(256) for _ in range(plen))
+        inst = b"".join(rng.randrange(R).to_bytes(32, "big") for _ in range(plen % 5))
+        vk = bytes(rng.randrange(256) for _ in range((plen * 7) % 11))
+        for git in ("a1b2c3d", None, 'odd"ver\\sion'):
+            got = _proof_json(proof, inst, vk, git)
+            want = json.dumps({"proof": base64.b64encode(proof).decode(), "instances": base64.b64encode(inst).decode(), "vk": base64.b64encode(vk).decode(),
+                               "git_version": git}, separators=(",", ":")).encode()
+            assert got == want
+            assert _proof_json_read(got) == (proof, inst, vk, git)
+            # pretty-printed, keys in another order: what a hand-edited or re-serialised file looks like
+            obj = json.loads(got)
+            pretty = json.dumps({k_: obj[k_] for k_ in ("vk", "git_version", "proof", "instances")}, indent=2).encode()
+            assert _proof_json_read(pretty) == (proof, inst, vk, git)
+    # `git_version` is an Option: absent is read as None
+    js = json.dumps({"proof": "", "instances": "", "vk": ""}).encode()
+    assert _proof_json_read(js) == (b"", b"", b"", None)
+
+
+def test_proof_wire_object_refuses_malformed_input():
+    import base64
+    import json
+    good = {"proof": base64.b64encode(b"abc").decode(), "instances": base64.b64encode(bytes(32)).decode(), "vk": "", "git_version": None}
+    assert _proof_json_read(json.dumps(good).encode())[0] == b"abc"
+    bad = [
+        dict(good, proof="YWJj="),                       # length not a multiple of four
+        dict(good, proof="YW=j"),                        # padding in the middle
+        dict(good, proof="YWJ*"),                        # a character outside the alphabet
+        dict(good, proof="YR=="),                        # non-canonical trailing bits ("a" is YQ==)
+        dict(good, instances=base64.b64encode(bytes(31)).decode()),     # not whole 32-byte words
+        dict(good, extra="x"),                           # a key the struct does not have
+        {k_: v for k_, v in good.items() if k_ != "vk"},                # a missing field
+    ]
+    for obj in bad:
+        assert _proof_json_read(json.dumps(obj).encode()) == -1, obj          # ZK_ERR_INVALID_ARG
+    assert _proof_json_read(b'{"proof":"","instances":"","vk":"","proof":""}') == -1      # a repeated key
+    assert _proof_json_read(b'{"proof":"","instances":"","vk":""} x') == -1               # trailing garbage
+    n = ctypes.c_size_t()
+    assert lib().zk_host_proof_json_write(b"", ctypes.c_size_t(0), bytes(31), ctypes.c_size_t(31), b"", ctypes.c_size_t(0), None, None, ctypes.c_size_t(0), ctypes.byref(n)) == -1

@@ -8,6 +8,10 @@
 //     KzgAs::create_proof without blinding), the decider e(lhs, g2) == e(rhs, s_g2), and the
 //     accumulator as 4 x LIMBS = 12 limbs of BITS = 88 bits  [REF aggregator/src/core.rs:48-147],
 //                                                          [REF aggregator/src/constants.rs:77-82]
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cstdio>
 #include "host_pairing.hpp"
 
 using namespace zk;
@@ -220,6 +224,135 @@ int zk_host_accumulator_limbs(const void* lhs, const void* rhs, void* out12_fr) 
             }
         }
     }
+    return ZK_OK;
+}
+
+// ---- the prover's `Proof` wire object [REF prover/src/proof.rs:25-35, 99-104]: what `dump_as_json` writes to
+// full_proof_<name>.json -- {"proof": base64, "instances": base64 of the 32-byte big-endian words, "vk": base64 of
+// VerifyingKey::write(Processed), "git_version": string or null}, serde_json's compact form, the field order of the struct;
+// base64 = the `base64` crate's `encode` [REF eth-types/src/lib.rs:71-91]: standard alphabet, padded.
+static const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+static void b64_encode(const uint8_t* in, size_t n, std::string* out) {
+    for (size_t i = 0; i < n; i += 3) {
+        const uint32_t a = in[i], b = i + 1 < n ? in[i + 1] : 0u, c = i + 2 < n ? in[i + 2] : 0u, v = (a << 16) | (b << 8) | c;
+        out->push_back(B64[v >> 18]);
+        out->push_back(B64[(v >> 12) & 63]);
+        out->push_back(i + 1 < n ? B64[(v >> 6) & 63] : '=');
+        out->push_back(i + 2 < n ? B64[v & 63] : '=');
+    }
+}
+// strict: length a multiple of four, padding only at the end, no stray characters (what the crate's `decode` accepts)
+static bool b64_decode(const char* in, size_t n, std::vector<uint8_t>* out) {
+    if (n % 4) return false;
+    auto val = [](char ch) -> int { const char* p = ch ? strchr(B64, ch) : nullptr; return p ? (int)(p - B64) : -1; };
+    for (size_t i = 0; i < n; i += 4) {
+        const bool last = i + 4 == n;
+        const int pad = last ? (in[i + 3] == '=') + (in[i + 3] == '=' && in[i + 2] == '=') : 0;
+        int v[4] = {val(in[i]), val(in[i + 1]), pad >= 2 ? 0 : val(in[i + 2]), pad >= 1 ? 0 : val(in[i + 3])};
+        if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[3] < 0) return false;
+        const uint32_t w = ((uint32_t)v[0] << 18) | ((uint32_t)v[1] << 12) | ((uint32_t)v[2] << 6) | (uint32_t)v[3];
+        if ((pad >= 1 && (w & 0xFF)) || (pad >= 2 && (w & 0xFFFF))) return false;          // non-canonical trailing bits
+        out->push_back((uint8_t)(w >> 16));
+        if (pad < 2) out->push_back((uint8_t)(w >> 8));
+        if (pad < 1) out->push_back((uint8_t)w);
+    }
+    return true;
+}
+int zk_host_proof_json_write(const void* proof, size_t proof_len, const void* instances_be, size_t instances_len, const void* vk, size_t vk_len,
+                             const char* git_version, char* out, size_t cap, size_t* len) {
+    if (!len || (!proof && proof_len) || (!instances_be && instances_len) || (!vk && vk_len) || instances_len % 32) return ZK_ERR_INVALID_ARG;
+    std::string js = "{\"proof\":\"";
+    b64_encode((const uint8_t*)proof, proof_len, &js);
+    js += "\",\"instances\":\"";
+    b64_encode((const uint8_t*)instances_be, instances_len, &js);
+    js += "\",\"vk\":\"";
+    b64_encode((const uint8_t*)vk, vk_len, &js);
+    js += "\",\"git_version\":";
+    if (git_version) {
+        js += '"';
+        for (const char* q = git_version; *q; ++q) {            // serde_json's escapes for what a version string could hold
+            const unsigned char ch = (unsigned char)*q;
+            if (ch == '"' || ch == '\\') { js += '\\'; js += (char)ch; }
+            else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); js += b; }
+            else js += (char)ch;
+        }
+        js += '"';
+    } else js += "null";
+    js += "}";
+    *len = js.size();
+    if (!out) return ZK_OK;                                      // size query
+    if (cap < js.size()) return ZK_ERR_INVALID_ARG;
+    memcpy(out, js.data(), js.size());
+    return ZK_OK;
+}
+// Reads what the function above (or serde_json, compact or pretty) wrote: the four keys in any order, other keys refused.
+// Each output is optional (NULL buffer = length only); *_len hold the capacities on entry and the lengths on return.
+int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size_t* proof_len, void* instances_be, size_t* instances_len, void* vk, size_t* vk_len,
+                            char* git_version, size_t git_cap, int* has_git_version) {
+    if (!json || !proof_len || !instances_len || !vk_len) return ZK_ERR_INVALID_ARG;
+    size_t i = 0;
+    auto ws = [&] { while (i < json_len && (json[i] == ' ' || json[i] == '\n' || json[i] == '\r' || json[i] == '\t')) ++i; };
+    auto lit = [&](char ch) { ws(); if (i < json_len && json[i] == ch) { ++i; return true; } return false; };
+    auto str = [&](std::string* out) -> bool {           // a JSON string with the escapes serde_json writes
+        ws();
+        if (i >= json_len || json[i] != '"') return false;
+        for (++i; i < json_len && json[i] != '"'; ++i) {
+            if (json[i] != '\\') { out->push_back(json[i]); continue; }
+            if (++i >= json_len) return false;
+            switch (json[i]) {
+                case '"': case '\\': case '/': out->push_back(json[i]); break;
+                case 'n': out->push_back('\n'); break;
+                case 't': out->push_back('\t'); break;
+                case 'r': out->push_back('\r'); break;
+                case 'u': {
+                    if (i + 4 >= json_len) return false;
+                    unsigned v = 0;
+                    for (int d = 1; d <= 4; ++d) { const char h = json[i + d]; v = v * 16 + (h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : 99); }
+                    if (v > 0x7F) return false;          // version strings are ASCII
+                    out->push_back((char)v);
+                    i += 4;
+                    break;
+                }
+                default: return false;
+            }
+        }
+        if (i >= json_len) return false;
+        ++i;
+        return true;
+    };
+    std::vector<uint8_t> parts[3];
+    bool seen[4] = {false, false, false, false};
+    std::string gv;
+    bool gv_present = false;
+    if (!lit('{')) return ZK_ERR_INVALID_ARG;
+    for (bool first = true; !lit('}'); first = false) {
+        if (!first && !lit(',')) return ZK_ERR_INVALID_ARG;
+        std::string key;
+        if (!str(&key) || !lit(':')) return ZK_ERR_INVALID_ARG;
+        const int which = key == "proof" ? 0 : key == "instances" ? 1 : key == "vk" ? 2 : key == "git_version" ? 3 : -1;
+        if (which < 0 || seen[which]) return ZK_ERR_INVALID_ARG;
+        seen[which] = true;
+        if (which == 3) {
+            ws();
+            if (i + 4 <= json_len && !strncmp(json + i, "null", 4)) { i += 4; continue; }
+            if (!str(&gv)) return ZK_ERR_INVALID_ARG;
+            gv_present = true;
+            continue;
+        }
+        std::string b64;
+        if (!str(&b64) || !b64_decode(b64.data(), b64.size(), &parts[which])) return ZK_ERR_INVALID_ARG;
+    }
+    ws();
+    if (i != json_len || !seen[0] || !seen[1] || !seen[2]) return ZK_ERR_INVALID_ARG;       // `git_version` may be absent (Option)
+    if (parts[1].size() % 32) return ZK_ERR_INVALID_ARG;
+    void* outs[3] = {proof, instances_be, vk};
+    size_t* lens[3] = {proof_len, instances_len, vk_len};
+    for (int p = 0; p < 3; ++p) {
+        if (outs[p]) { if (*lens[p] < parts[p].size()) return ZK_ERR_INVALID_ARG; memcpy(outs[p], parts[p].data(), parts[p].size()); }
+        *lens[p] = parts[p].size();
+    }
+    if (has_git_version) *has_git_version = gv_present ? 1 : 0;
+    if (git_version && git_cap) { const size_t c = std::min(git_cap - 1, gv.size()); memcpy(git_version, gv.data(), c); git_version[c] = 0; }
     return ZK_OK;
 }
 
