@@ -457,6 +457,12 @@ int zk_host_proof_json_write(const void* proof, size_t proof_len, const void* in
                              const char* git_version, char* out, size_t cap, size_t* len);
 int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size_t* proof_len, void* instances_be, size_t* instances_len, void* vk, size_t* vk_len,
                             char* git_version, size_t git_cap, int* has_git_version);
+/* Instances as the prover's JSON matrix [REF prover/src/io.rs:28-56]: `serialize_instance` = serde_json (compact) of
+ * Vec<Vec<Vec<u8>>> -- per instance column a list of elements, each the 32 little-endian bytes of Fr::to_bytes as numbers.
+ * (`load_instances` [REF prover/src/io.rs:128-142] holds a list of such matrices: one more pair of brackets.)  write: out may
+ * be NULL (size query).  read: NULL outputs = counts only; values of all columns one after the other, Montgomery Fr. */
+int zk_host_instances_json_write(const void* const* cols_fr_mont, const size_t* lens, size_t ncols, char* out, size_t cap, size_t* len);
+int zk_host_instances_json_read(const char* json, size_t json_len, size_t* ncols, size_t* lens_out, size_t lens_cap, void* fr_mont_out, size_t fr_cap, size_t* total);
 /* G1 points in halo2curves' SerdeFormat: 32 B compressed (Processed) or 64 B Montgomery limbs       */
 int zk_host_g1_encode(const void* affine64, size_t n, int format, void* out);
 int zk_host_g1_decode(const void* in, size_t n, int format, void* affine64_out);

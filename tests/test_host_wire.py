@@ -232,3 +232,35 @@ def test_proof_wire_object_refuses_malformed_input():
     assert _proof_json_read(b'{"proof":"","instances":"","vk":""} x') == -1               # trailing garbage
     n = ctypes.c_size_t()
     assert lib().zk_host_proof_json_write(b"", ctypes.c_size_t(0), bytes(31), ctypes.c_size_t(31), b"", ctypes.c_size_t(0), None, None, ctypes.c_size_t(0), ctypes.byref(n)) == -1
+
+
+def test_instances_json_matrix_is_serde_jsons():
+    """`serialize_instance` [REF prover/src/io.rs:52-56]: serde_json of Vec<Vec<Vec<u8>>> -- the same bytes as Python's json of the
+    little-endian byte lists; reading brings the Montgomery values back, column lengths included (an empty column, no column)."""
+    import json
+    rng = random.Random(3)
+    for shape in ([4], [1, 0, 3], [], [0]):
+        cols = [[rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(ln)] for ln in shape]
+        monts = [cref.to_mont(c) if c else np.zeros((0, 4), dtype=np.uint64) for c in cols]
+        ptrs = (ctypes.c_void_p * max(len(cols), 1))(*[m.ctypes.data for m in monts])
+        lens = (ctypes.c_size_t * max(len(cols), 1))(*[len(c) for c in cols])
+        n = ctypes.c_size_t()
+        assert lib().zk_host_instances_json_write(ptrs, lens, ctypes.c_size_t(len(cols)), None, ctypes.c_size_t(0), ctypes.byref(n)) == 0
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        assert lib().zk_host_instances_json_write(ptrs, lens, ctypes.c_size_t(len(cols)), buf, ctypes.c_size_t(n.value), ctypes.byref(n)) == 0
+        got = buf.raw[:n.value]
+        want = json.dumps([[list(v.to_bytes(32, "little")) for v in c] for c in cols], separators=(",", ":")).encode()
+        assert got == want
+        for text in (got, json.dumps(json.loads(got), indent=1).encode()):
+            ncols, total = ctypes.c_size_t(), ctypes.c_size_t()
+            assert lib().zk_host_instances_json_read(text, ctypes.c_size_t(len(text)), ctypes.byref(ncols), None, ctypes.c_size_t(0), None, ctypes.c_size_t(0), ctypes.byref(total)) == 0
+            assert ncols.value == len(cols) and total.value == sum(shape)
+            lens_out = (ctypes.c_size_t * max(ncols.value, 1))()
+            vals = np.zeros((max(total.value, 1), 4), dtype=np.uint64)
+            assert lib().zk_host_instances_json_read(text, ctypes.c_size_t(len(text)), ctypes.byref(ncols), lens_out, ctypes.c_size_t(ncols.value), _ptr(vals), ctypes.c_size_t(total.value),
+                                                     ctypes.byref(total)) == 0
+            assert list(lens_out)[:ncols.value] == shape
+            assert [int(v) for v in cref.from_mont(vals[:total.value])] == [v for c in cols for v in c]
+    for bad in (b"[[[1,2,3]]]", b"[[[" + b",".join([b"256"] + [b"0"] * 31) + b"]]]", json.dumps([[list(R.to_bytes(32, "little"))]]).encode(), b"[[[", b"[] x"):
+        ncols, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib().zk_host_instances_json_read(bad, ctypes.c_size_t(len(bad)), ctypes.byref(ncols), None, ctypes.c_size_t(0), None, ctypes.c_size_t(0), ctypes.byref(total)) == -1, bad

@@ -356,4 +356,78 @@ int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size
     return ZK_OK;
 }
 
+// ---- instances as the prover's JSON matrix [REF prover/src/io.rs:28-56]: `serialize_instance` = serde_json of
+// Vec<Vec<Vec<u8>>> -- per instance column a list of field elements, each the 32 little-endian bytes of `Fr::to_bytes` written as
+// numbers: [[[1,0,...,0],[...]],[...]] in compact form.  (`load_instances` [REF prover/src/io.rs:128-142] reads a list of such
+// matrices: wrap / unwrap one more pair of brackets.)
+int zk_host_instances_json_write(const void* const* cols_fr_mont, const size_t* lens, size_t ncols, char* out, size_t cap, size_t* len) {
+    if (!len || ((!cols_fr_mont || !lens) && ncols)) return ZK_ERR_INVALID_ARG;
+    std::string js = "[";
+    for (size_t c = 0; c < ncols; ++c) {
+        if (!cols_fr_mont[c] && lens[c]) return ZK_ERR_INVALID_ARG;
+        js += c ? ",[" : "[";
+        for (size_t i = 0; i < lens[c]; ++i) {
+            F4 v;
+            memcpy(v.l, (const uint8_t*)cols_fr_mont[c] + 32 * i, 32);
+            uint8_t le[32];
+            fr_to_repr(v, le);
+            js += i ? ",[" : "[";
+            for (int b = 0; b < 32; ++b) { char t[8]; snprintf(t, sizeof t, b ? ",%u" : "%u", (unsigned)le[b]); js += t; }
+            js += "]";
+        }
+        js += "]";
+    }
+    js += "]";
+    *len = js.size();
+    if (!out) return ZK_OK;
+    if (cap < js.size()) return ZK_ERR_INVALID_ARG;
+    memcpy(out, js.data(), js.size());
+    return ZK_OK;
+}
+// *ncols = number of columns; lens_out[c] (capacity lens_cap) their lengths; fr_mont_out (capacity fr_cap elements) the values of
+// all columns one after the other.  NULL outputs = counts only (*total = number of values).  A value >= r, a byte above 255 or
+// an element that is not 32 numbers is refused.
+int zk_host_instances_json_read(const char* json, size_t json_len, size_t* ncols, size_t* lens_out, size_t lens_cap, void* fr_mont_out, size_t fr_cap, size_t* total) {
+    if (!json || !ncols || !total) return ZK_ERR_INVALID_ARG;
+    size_t i = 0;
+    auto ws = [&] { while (i < json_len && (json[i] == ' ' || json[i] == '\n' || json[i] == '\r' || json[i] == '\t')) ++i; };
+    auto lit = [&](char ch) { ws(); if (i < json_len && json[i] == ch) { ++i; return true; } return false; };
+    std::vector<size_t> lens;
+    std::vector<F4> vals;
+    if (!lit('[')) return ZK_ERR_INVALID_ARG;
+    for (bool first_c = true; !lit(']'); first_c = false) {
+        if (!first_c && !lit(',')) return ZK_ERR_INVALID_ARG;
+        if (!lit('[')) return ZK_ERR_INVALID_ARG;
+        size_t cnt = 0;
+        for (bool first_e = true; !lit(']'); first_e = false) {
+            if (!first_e && !lit(',')) return ZK_ERR_INVALID_ARG;
+            if (!lit('[')) return ZK_ERR_INVALID_ARG;
+            uint8_t le[32];
+            for (int b = 0; b < 32; ++b) {
+                if (b && !lit(',')) return ZK_ERR_INVALID_ARG;
+                ws();
+                unsigned v = 0;
+                size_t digits = 0;
+                while (i < json_len && json[i] >= '0' && json[i] <= '9' && digits < 4) { v = v * 10 + (unsigned)(json[i] - '0'); ++i; ++digits; }
+                if (!digits || v > 255) return ZK_ERR_INVALID_ARG;
+                le[b] = (uint8_t)v;
+            }
+            if (!lit(']')) return ZK_ERR_INVALID_ARG;
+            F4 v;
+            memcpy(v.l, le, 32);
+            if (geq_mod<FrC>(v.l)) return ZK_ERR_INVALID_ARG;            // Fr::from_repr fails
+            vals.push_back(fr_to_mont(v));
+            ++cnt;
+        }
+        lens.push_back(cnt);
+    }
+    ws();
+    if (i != json_len) return ZK_ERR_INVALID_ARG;
+    *ncols = lens.size();
+    *total = vals.size();
+    if (lens_out) { if (lens_cap < lens.size()) return ZK_ERR_INVALID_ARG; memcpy(lens_out, lens.data(), lens.size() * sizeof(size_t)); }
+    if (fr_mont_out) { if (fr_cap < vals.size()) return ZK_ERR_INVALID_ARG; if (!vals.empty()) memcpy(fr_mont_out, vals.data(), vals.size() * 32); }
+    return ZK_OK;
+}
+
 }  // extern "C"
