@@ -208,8 +208,9 @@ int zk_srs_downsize(zk_ctx* ctx, const zk_srs* srs, uint32_t new_k, zk_srs** out
 /* ---- SRS files: ParamsKZG::{read_custom, write_custom}; the reference loads `params{k}` through
  * prover::utils::load_params [REF prover/src/utils.rs:39-84], default format RawBytesUnchecked
  * [REF prover/src/utils.rs:32].  file = u32 k (LE) | g[n] | g_lagrange[n] | g2 | s_g2; G1 is 64 B
- * (formats 1, 2: the in-memory Montgomery image) or 32 B (format 0: x canonical LE, bit 255 = parity
- * of y); G2 is twice that and is handed through untouched (the prover never uses it).              */
+ * (formats 1, 2: the in-memory Montgomery image) or 32 B (format 0: x canonical LE, bit 254 = parity
+ * of y, bit 255 = identity -- halo2curves @ a495a7b, pinned by the vk / proof bytes of
+ * [REF aggregator/data/batch-task.json]); G2 is twice that and is handed through untouched.        */
 #define ZK_SERDE_PROCESSED 0
 #define ZK_SERDE_RAW 1            /* RawBytes: every point is checked (limbs < p, on the curve)      */
 #define ZK_SERDE_RAW_UNCHECKED 2

@@ -257,13 +257,40 @@ def g1_affine_from_bytes_raw(b: bytes) -> Affine:
 
 
 def g1_compress(pt: Affine) -> bytes:
-    """Proof-byte encoding: x canonical LE, bit 255 carries the parity of y."""
+    """Proof-byte / `SerdeFormat::Processed` encoding of halo2curves @ a495a7b (`new_curve_impl!`, flags in the two spare
+    top bits of the last byte): x canonical LE with the parity of y in bit 254 (0x40 of byte 31); the identity is the
+    zero x with bit 255 (0x80) set.  PINNED by the reference's own data: all 7 vk points and all 11 proof points of
+    aggregator/data/batch-task.json carry (y & 1) << 6 and never bit 7 (tests/test_reference_chunk_proof.py).  The
+    identity's image cannot be read off that fixture (no identity in it): it is the encoding the same macro writes
+    [EXT-RECALL derive/curve.rs `to_bytes`]."""
     if pt is None:
-        return bytes(32)
+        return bytes(31) + b"\x80"
     x, y = pt
     b = bytearray(x.to_bytes(32, "little"))
-    b[31] |= (y & 1) << 7
+    b[31] |= (y & 1) << 6
     return bytes(b)
+
+
+def g1_decompress(raw: bytes) -> Affine:
+    """inverse of g1_compress (`from_bytes`): bit 255 = identity flag (then x and the parity flag must be zero), bit 254 = parity
+    of y; x must be canonical; raises ValueError where halo2curves returns `CtOption::none`"""
+    if len(raw) != 32:
+        raise ValueError("compressed G1 is 32 bytes")
+    v = int.from_bytes(raw, "little")
+    is_inf, sign, x = v >> 255, (v >> 254) & 1, v & ((1 << 254) - 1)
+    if is_inf:
+        if x != 0 or sign:
+            raise ValueError("identity flag on a non-zero encoding")
+        return None
+    if x >= P_MOD:
+        raise ValueError("non-canonical x")
+    y2 = (x * x * x + CURVE_B) % P_MOD
+    y = pow(y2, (P_MOD + 1) // 4, P_MOD)
+    if y * y % P_MOD != y2:
+        raise ValueError("x is not the abscissa of a curve point")
+    if (y & 1) != sign:
+        y = P_MOD - y
+    return (x, y)
 
 
 # ----------------------------------------------------------------------------------------------

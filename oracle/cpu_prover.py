@@ -18,8 +18,8 @@ import numpy as np
 
 from . import bn254 as b
 from . import cref
-from .plonk_prover import XorShiftRng, make_transcript
-from .plonk_verifier import ADVICE, FIXED, INSTANCE, _interpolate, _vanishing_at, shplonk_sets
+from .plonk_prover import XorShiftRng, make_transcript, newton_interpolate, product_of_differences, rotation_sets
+from .plonk_verifier import ADVICE, FIXED, INSTANCE
 
 R = b.R_MOD
 
@@ -450,9 +450,9 @@ def create_proof(circ, srs: Srs, advice: Sequence, instance: Sequence[Sequence[i
         mark("multiopen")
         return bytes(tr.proof)
 
-    # ---- SHPLONK: the set construction of the oracle verifier over polynomial INDICES
+    # ---- SHPLONK: the prover-side set construction (plonk_prover.rotation_sets) over polynomial INDICES
     yy = tr.squeeze()
-    sets, super_points, eval_of = shplonk_sets(queries)
+    sets, super_points, eval_of = rotation_sets(queries)
     v = tr.squeeze()
 
     def minus_low(cf, low_coeffs):       # cf(X) - r(X) for a low-degree r
@@ -462,7 +462,7 @@ def create_proof(circ, srs: Srs, advice: Sequence, instance: Sequence[Sequence[i
         return out
     low, quot = [], []
     for points, members in sets:
-        rs = [_interpolate(points, [eval_of(idx, p_) for p_ in points]) for idx in members]
+        rs = [newton_interpolate(points, [eval_of(idx, p_) for p_ in points]) for idx in members]
         numer = lincomb([minus_low(polys[idx], r_) for idx, r_ in zip(members, rs)], yy)
         for z in points:
             numer = kate(numer, z)
@@ -473,12 +473,12 @@ def create_proof(circ, srs: Srs, advice: Sequence, instance: Sequence[Sequence[i
     uu = tr.squeeze()
     l_x, z_diffs, vpow = zeros(n), [], 1
     for (points, members), rs in zip(sets, low):
-        z_i = _vanishing_at([p_ for p_ in super_points if p_ not in points], uu)
+        z_i = product_of_differences(uu, [p_ for p_ in super_points if p_ not in points])
         z_diffs.append(z_i)
         inner = lincomb([minus_low(polys[idx], [b.eval_polynomial(r_, uu)]) for idx, r_ in zip(members, rs)], yy)
         l_x = scale_add(inner, vpow * z_i % R, l_x)
         vpow = vpow * v % R
-    zt_eval = _vanishing_at(super_points, uu)
+    zt_eval = product_of_differences(uu, super_points)
     l_x = scale_add(h_x, (-zt_eval) % R, l_x)
     assert cref.eval_polynomial(l_x, uu) == 0
     z0_inv = b.fr_inv(z_diffs[0])

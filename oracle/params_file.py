@@ -6,7 +6,7 @@ RawBytesUnchecked, the default) and g2 = 2 * g1  [REF prover/src/utils.rs:32,39-
     file = u32 k (LE) | g[0..n) | g_lagrange[0..n) | g2 | s_g2
 
 RawBytes G1 = x | y as Montgomery limbs (oracle/bn254.g1_affine_bytes_raw); Processed G1 = x
-canonical LE with the parity of y in bit 255 (bn254.g1_compress); RawBytes G2 = x.c0 | x.c1 |
+canonical LE with the parity of y in bit 254 and the identity flag in bit 255 (bn254.g1_compress); RawBytes G2 = x.c0 | x.c1 |
 y.c0 | y.c1, Montgomery limbs.  Only tests may import this module.
 """
 from typing import List, Tuple
@@ -51,18 +51,10 @@ def write(k: int, g: List, g_lagrange: List, g2_blob: bytes, s_g2_blob: bytes, f
 
 
 def g1_decompress(data: bytes):
-    assert len(data) == 32
-    v = int.from_bytes(data, "little")
-    sign, x = v >> 255, v & ((1 << 255) - 1)
-    if x == 0 and not sign:
-        return None
-    assert x < b.P_MOD
-    rhs = (x * x * x + 3) % b.P_MOD
-    y = pow(rhs, (b.P_MOD + 1) // 4, b.P_MOD)
-    assert y * y % b.P_MOD == rhs, "not a point of the curve"
-    if (y & 1) != sign:
-        y = b.P_MOD - y
-    return (x, y)
+    try:
+        return b.g1_decompress(data)
+    except ValueError as e:
+        raise AssertionError(str(e))
 
 
 def read(data: bytes, fmt: int) -> Tuple[int, List, List, bytes, bytes]:

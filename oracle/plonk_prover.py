@@ -19,7 +19,7 @@ import struct
 from typing import List, Sequence
 
 from . import bn254 as b
-from .plonk_verifier import (ADVICE, FIXED, INSTANCE, Consts, _interpolate, _vanishing_at, compress, eval_program, shplonk_sets)
+from .plonk_verifier import ADVICE, FIXED, INSTANCE, Consts, compress, eval_program
 
 R = b.R_MOD
 Q_PUSH_COL = 1
@@ -27,6 +27,63 @@ Q_PUSH_COL = 1
 
 # ------------------------------------------------------------------------------------ transcript / RNG
 from .transcripts import Blake2b as Blake2bWrite, make as make_transcript  # noqa: E402,F401
+
+
+# ------------------------------------------------------------------------------------ SHPLONK, prover side
+# Written independently of the verifier's `shplonk_sets` / `_interpolate` / `_vanishing_at` (oracle/plonk_verifier.py), which are
+# pinned by the reference-produced proof (tests/test_reference_chunk_proof.py): a convention this side gets wrong shows up as a
+# proof that verifier rejects.
+def rotation_sets(queries):
+    """halo2 poly::kzg::multiopen::shplonk `construct_intermediate_sets`, prover side.  queries: (polynomial object, point, eval)
+    in the order `create_proof` lists them.  Returns ([(points ascending, [polynomial objects])...] in order of first
+    appearance, all points ascending, eval lookup)."""
+    order, where = [], {}                  # polynomial identity -> its points in query order
+    evals = {}
+    ident = lambda o: ("i", o) if isinstance(o, int) else ("o", id(o))      # coefficient lists by identity, column indices by value
+    for obj, pt, e in queries:
+        key = ident(obj)
+        if key not in where:
+            where[key] = (obj, [])
+            order.append(key)
+        if pt not in where[key][1]:
+            where[key][1].append(pt)
+        evals.setdefault((key, pt), e)
+    grouped, index = [], {}                # frozenset of points -> position
+    for key in order:
+        obj, pts = where[key]
+        fs = frozenset(pts)
+        if fs not in index:
+            index[fs] = len(grouped)
+            grouped.append((sorted(fs), []))
+        grouped[index[fs]][1].append(obj)
+    every = sorted({pt for _, pt, _ in queries})
+    return grouped, every, (lambda obj, pt: evals[(ident(obj), pt)])
+
+
+def newton_interpolate(xs, ys):
+    """coefficients (low first) of the polynomial of degree < len(xs) through (xs[i], ys[i]): divided differences, then the
+    Newton form expanded from the innermost bracket out"""
+    m = len(xs)
+    dd = [v % R for v in ys]
+    for lvl in range(1, m):
+        for i in range(m - 1, lvl - 1, -1):
+            dd[i] = (dd[i] - dd[i - 1]) * b.fr_inv((xs[i] - xs[i - lvl]) % R) % R
+    out = [dd[m - 1]] if m else []
+    for i in range(m - 2, -1, -1):         # out = out * (X - xs[i]) + dd[i]
+        nxt = [0] * (len(out) + 1)
+        for t, c_ in enumerate(out):
+            nxt[t + 1] = (nxt[t + 1] + c_) % R
+            nxt[t] = (nxt[t] - c_ * xs[i]) % R
+        nxt[0] = (nxt[0] + dd[i]) % R
+        out = nxt
+    return out
+
+
+def product_of_differences(at, points):
+    out = 1
+    for z_ in points:
+        out = out * ((at - z_) % R) % R
+    return out
 
 
 class XorShiftRng:
@@ -324,12 +381,12 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
 
     # ---- SHPLONK (BDFG21): poly::kzg::multiopen::shplonk::ProverSHPLONK::create_proof
     yy = tr.squeeze()
-    sets, super_points, eval_of = shplonk_sets(queries)
+    sets, super_points, eval_of = rotation_sets(queries)
     v = tr.squeeze()
     low = []          # per set, per polynomial: r_ij(X), the interpolation of its evaluations over the set's points
     quot = []
     for points, members in sets:
-        rs = [_interpolate(points, [eval_of(cf, p_) for p_ in points]) for cf in members]
+        rs = [newton_interpolate(points, [eval_of(cf, p_) for p_ in points]) for cf in members]
         numer = lincomb([[(c_ - (r_[t] if t < len(r_) else 0)) % R for t, c_ in enumerate(cf)] for cf, r_ in zip(members, rs)], yy)
         for z in points:
             numer = b.kate_division(numer, z)
@@ -340,12 +397,12 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
     uu = tr.squeeze()
     l_x, z_diffs, vpow = [0] * n, [], 1
     for (points, members), rs in zip(sets, low):
-        z_i = _vanishing_at([p_ for p_ in super_points if p_ not in points], uu)
+        z_i = product_of_differences(uu, [p_ for p_ in super_points if p_ not in points])
         z_diffs.append(z_i)
         inner = lincomb([[(c_ - (b.eval_polynomial(r_, uu) if t == 0 else 0)) % R for t, c_ in enumerate(cf)] for cf, r_ in zip(members, rs)], yy)
         l_x = [(a + vpow * z_i % R * c_) % R for a, c_ in zip(l_x, inner)]
         vpow = vpow * v % R
-    zt_eval = _vanishing_at(super_points, uu)
+    zt_eval = product_of_differences(uu, super_points)
     l_x = [(a - zt_eval * c_) % R for a, c_ in zip(l_x, h_x)]
     assert b.eval_polynomial(l_x, uu) == 0
     z0_inv = b.fr_inv(z_diffs[0])

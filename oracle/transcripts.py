@@ -26,17 +26,11 @@ R, P = b.R_MOD, b.P_MOD
 
 
 def decompress_g1(raw: bytes):
-    if raw == bytes(32):
-        return None
-    v = int.from_bytes(raw, "little")
-    sign, x = v >> 255, v & ((1 << 255) - 1)
-    assert x < P
-    y2 = (x * x * x + 3) % P
-    y = pow(y2, (P + 1) // 4, P)
-    assert y * y % P == y2, "point not on curve"
-    if (y & 1) != sign:
-        y = P - y
-    return (x, y)
+    """halo2curves `G1Affine::from_bytes` (bn254.g1_decompress), failing with AssertionError as the readers here do"""
+    try:
+        return b.g1_decompress(raw)
+    except ValueError as e:
+        raise AssertionError(str(e))
 
 
 class _Base:

@@ -6,6 +6,7 @@ line it was found on.
 
 usage: python tests/golden/make_reference_vectors.py [/root/reference]
 """
+import base64
 import json
 import os
 import re
@@ -54,3 +55,29 @@ with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")
 print("wrote", os.path.join(HERE, "reference_vectors.json"), "with", len(out), "vectors")
+
+# ---- the reference-produced proof of the hot path: a production ChunkProof (layer-2 compression snark, k = 25, SHPLONK,
+# Poseidon transcript) held as test data for the batch prover, and s*G2 of the SRS it was made with.
+task = "aggregator/data/batch-task.json"
+cp = json.load(open(os.path.join(REF, task)))["chunk_proofs"][0]
+m, ln = find("prover/src/utils.rs", r'PARAMS_G2_SECRET_POWER: &str = "\(Fq2 \{ c0: (0x[0-9a-f]{64}), c1: (0x[0-9a-f]{64}) \}, Fq2 \{ c0: (0x[0-9a-f]{64}), c1: (0x[0-9a-f]{64}) \}\)"')
+chunk = {
+    "ref": f"{task}: chunk_proofs[0] (struct prover/src/proof/chunk.rs:10-19 flattening prover/src/proof.rs:25-35)",
+    "pins": "compressed G1 encoding, vk Processed layout, BE instance words, PoseidonTranscript<NativeLoader> framing, evaluation and query "
+            "order, blinding-row / l_last conventions, the logUp identity, single-chunk permutation, SHPLONK sets / powers / normalisation, "
+            "accumulator limbs + decider",
+    "protocol": json.loads(base64.b64decode(cp["protocol"])),      # snark-verifier PlonkProtocol, serde_json image
+    "proof": cp["proof"], "instances": cp["instances"], "vk": cp["vk"],          # base64, as the reference's `Proof` holds them
+    "git_version": cp["git_version"],
+    # the flattened ChunkProof object with the bulky out-of-path members dropped: what zk_host_proof_json_read must accept (serde ignores
+    # unknown keys; `proof`, `instances`, `vk`, `git_version` sit beside `protocol`, `chunk_info`, `row_usages`)
+    "flattened_object": json.dumps({"protocol": cp["protocol"], "proof": cp["proof"], "instances": cp["instances"], "vk": cp["vk"],
+                                    "chunk_info": {k_: v for k_, v in cp["chunk_info"].items() if k_ != "tx_bytes"},
+                                    "git_version": cp["git_version"], "row_usages": cp["row_usages"]}, separators=(",", ":")),
+    "s_g2": {"x_c0": m.group(1), "x_c1": m.group(2), "y_c0": m.group(3), "y_c1": m.group(4), "ref": f"prover/src/utils.rs:{ln}",
+             "pins": "s*G2 of Scroll's production SRS (Debug string of a G2Affine), checked by load_params at prover/src/utils.rs:78"},
+}
+with open(os.path.join(HERE, "reference_chunk_proof.json"), "w") as f:
+    json.dump(chunk, f, indent=1)
+    f.write("\n")
+print("wrote", os.path.join(HERE, "reference_chunk_proof.json"))

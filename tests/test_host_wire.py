@@ -223,11 +223,18 @@ def test_proof_wire_object_refuses_malformed_input():
         dict(good, proof="YWJ*"),                        # a character outside the alphabet
         dict(good, proof="YR=="),                        # non-canonical trailing bits ("a" is YQ==)
         dict(good, instances=base64.b64encode(bytes(31)).decode()),     # not whole 32-byte words
-        dict(good, extra="x"),                           # a key the struct does not have
         {k_: v for k_, v in good.items() if k_ != "vk"},                # a missing field
     ]
     for obj in bad:
         assert _proof_json_read(json.dumps(obj).encode()) == -1, obj          # ZK_ERR_INVALID_ARG
+    # keys the struct does not have are parsed and dropped, as serde does without deny_unknown_fields (the reference flattens `Proof`
+    # into ChunkProof / BatchProof [REF prover/src/proof/chunk.rs:10-19]) -- whatever their value; a malformed value is still refused
+    for extra in ("x", 1, -2.5e3, None, True, [1, [2, {"a": "\u00e9\n"}]], {"k": {"l": []}}):
+        assert _proof_json_read(json.dumps(dict(good, extra=extra)).encode())[0] == b"abc", extra
+    for tail in (b'"extra":[1,}', b'"extra":"\\x"', b'"extra":01', b'"extra":tru', b'"extra":"\\u00g0"'):
+        assert _proof_json_read(b'{"proof":"","instances":"","vk":"",' + tail + b'}') == -1, tail
+    assert _proof_json_read(b'{"proof":"","instances":"","vk":"","git_version":"a\\b\\f\\u0041"}')[3] == "a\b\fA"     # serde_json's short escapes
+    assert _proof_json_read(b'{"proof":"","instances":"","vk":"","git_version":"\\u00zz"}') == -1             # not hex digits
     assert _proof_json_read(b'{"proof":"","instances":"","vk":"","proof":""}') == -1      # a repeated key
     assert _proof_json_read(b'{"proof":"","instances":"","vk":""} x') == -1               # trailing garbage
     n = ctypes.c_size_t()
@@ -261,6 +268,6 @@ def test_instances_json_matrix_is_serde_jsons():
                                                      ctypes.byref(total)) == 0
             assert list(lens_out)[:ncols.value] == shape
             assert [int(v) for v in cref.from_mont(vals[:total.value])] == [v for c in cols for v in c]
-    for bad in (b"[[[1,2,3]]]", b"[[[" + b",".join([b"256"] + [b"0"] * 31) + b"]]]", json.dumps([[list(R.to_bytes(32, "little"))]]).encode(), b"[[[", b"[] x"):
+    for bad in (b"[[[1,2,3]]]", b"[[[" + b",".join([b"256"] + [b"0"] * 31) + b"]]]", b"[[[" + b",".join([b"01"] + [b"0"] * 31) + b"]]]", json.dumps([[list(R.to_bytes(32, "little"))]]).encode(), b"[[[", b"[] x"):
         ncols, total = ctypes.c_size_t(), ctypes.c_size_t()
         assert lib().zk_host_instances_json_read(bad, ctypes.c_size_t(len(bad)), ctypes.byref(ncols), None, ctypes.c_size_t(0), None, ctypes.c_size_t(0), ctypes.byref(total)) == -1, bad

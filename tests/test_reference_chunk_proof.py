@@ -1,0 +1,293 @@
+"""CPU: the proof the REFERENCE produced and ships -- `aggregator/data/batch-task.json: chunk_proofs[0]`, a production
+ChunkProof (layer-2 compression snark: k = 25, SHPLONK, Poseidon transcript, 44 instances of which the first 12 are a KZG
+accumulator; struct [REF prover/src/proof/chunk.rs:10-19] flattening [REF prover/src/proof.rs:25-35]) with `s_g2` of the SRS it
+was made with [REF prover/src/utils.rs:36] -- against the oracle AND the product's host code.  The fixture
+tests/golden/reference_chunk_proof.json is extracted by tests/golden/make_reference_vectors.py; nothing here reads /root/reference.
+
+What it pins (the only protocol-level vector the reference tree holds; SURVEY 8c lists none because it missed this file):
+  * compressed G1 = x LE, (y & 1) << 6, identity bit 7          halo2curves @ a495a7b `to_bytes` / `from_bytes`
+  * VerifyingKey::write(Processed): k, #fixed as u32 BE, fixed then sigma commitments, no selector section
+                                                                 [REF prover/src/io.rs:97-106]
+  * instances as 32-byte BE words; the flattened JSON object    [REF prover/src/proof.rs:77-85,126-138]
+  * PoseidonTranscript<NativeLoader> framing and constants, evaluation / query order, blinding rows and l_last, the logUp
+    identity, the single-chunk permutation argument, SHPLONK sets / powers / normalisation, accumulator limbs and decider
+                                                                 verify_snark_shplonk [REF prover/src/common/verifier.rs:35],
+                                                                 extract_accumulators_and_proof [REF aggregator/src/core.rs:48-107]
+What it cannot pin: the Blake2b transcript's framing, GWC, multi-chunk permutations, multi-tuple lookups, user phases.
+"""
+import base64
+import ctypes
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import zkevm_circuits_amd as z
+from zkevm_circuits_amd import plonk
+from oracle import bn254 as b
+from oracle import cref, pairing as pr, params_file, plonk_verifier, snark_verifier as sv, transcripts
+
+R, P = b.R_MOD, b.P_MOD
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    j = json.load(open(os.path.join(HERE, "golden", "reference_chunk_proof.json")))
+    f = type("Fx", (), {})()
+    f.raw = j
+    f.protocol = sv.Protocol(j["protocol"])
+    f.proof = base64.b64decode(j["proof"])
+    f.instances_be = base64.b64decode(j["instances"])
+    f.vk = base64.b64decode(j["vk"])
+    f.instances = sv.instances_from_bytes(f.instances_be, f.protocol.num_instance)
+    g = j["s_g2"]
+    f.s_g2 = sv.g2_from_debug_hex(int(g["x_c0"], 16), int(g["x_c1"], 16), int(g["y_c0"], 16), int(g["y_c1"], 16))
+    return f
+
+
+# ------------------------------------------------------------------------------------ the oracle's verifiers
+def test_snark_verifier_accepts_the_reference_proof(fx):
+    accs = sv.succinct_verify(fx.protocol, fx.instances, fx.proof)
+    assert len(accs) == 2                                      # this proof's own accumulator + the one carried in the instances
+    assert all(sv.decide(a, pr.G2_GEN, fx.s_g2) for a in accs)
+    assert sv.verify_snark(fx.protocol, fx.instances, fx.proof, pr.G2_GEN, fx.s_g2)
+    # the SRS matters: the decider fails under another s
+    assert not sv.decide(accs[0], pr.G2_GEN, pr.ec_mul(pr.G2_GEN, 1234))
+
+
+@pytest.mark.parametrize("word", [0, 1, 2, 4, 5, 9, 13, 17, 21, 25, 26, 27])
+def test_snark_verifier_rejects_single_bit_flips_in_the_proof(fx, word):
+    bad = bytearray(fx.proof)
+    bad[32 * word + 3] ^= 0x10
+    assert not sv.verify_snark(fx.protocol, fx.instances, bytes(bad), pr.G2_GEN, fx.s_g2)
+
+
+@pytest.mark.parametrize("cell", [0, 11, 12, 43])
+def test_snark_verifier_rejects_single_bit_flips_in_the_instances(fx, cell):
+    ins = [list(fx.instances[0])]
+    ins[0][cell] ^= 1
+    assert not sv.verify_snark(fx.protocol, ins, fx.proof, pr.G2_GEN, fx.s_g2)
+
+
+def _expr(e, prot, circ):
+    """snark-verifier Expression -> plonk.Expr over halo2's column numbering"""
+    (kind, v), = e.items()
+    if kind == "Polynomial":
+        p_, rot = v["poly"], v["rotation"]
+        if p_ < prot.instance_offset():
+            return circ.fixed_col(p_, rot)
+        if p_ < prot.witness_offset():
+            return circ.instance_col(p_ - prot.instance_offset(), rot)
+        return circ.advice_col(p_ - prot.witness_offset(), rot)
+    if kind == "Constant":
+        return plonk.Const(sv.fe_from_limbs(v, R))
+    if kind == "Sum":
+        return _expr(v[0], prot, circ) + _expr(v[1], prot, circ)
+    if kind == "Product":
+        return _expr(v[0], prot, circ) * _expr(v[1], prot, circ)
+    if kind == "Negated":
+        return -_expr(v, prot, circ)
+    raise AssertionError(f"not a gate-level variant: {kind}")
+
+
+def halo2_circuit_of(prot) -> "plonk.Circuit":
+    """The fixture's constraint system as a plonk.Circuit (shape only), read off the protocol's quotient numerator, which
+    snark-verifier's `compile` lays out as halo2 does: gates | l_0 (1 - Z) | l_last (Z^2 - Z) | active * permutation | per lookup
+    l_0 phi | l_last phi | active * logUp.  One advice column in the first phase; m, Z, phi and the random polynomial are the
+    argument's own witnesses."""
+    terms, by = prot.quotient["numerator"]["DistributePowers"]
+    assert by == {"Challenge": 3} and len(terms) == 7 and prot.num_witness == [1, 1, 3] and prot.num_challenge == [1, 2, 1]
+    l_last = terms[2]["Product"][0]["CommonPolynomial"]["Lagrange"]
+    circ = plonk.Circuit(prot.k, len(prot.preprocessed) - 3, 1, len(prot.num_instance), blinding_factors=-l_last - 1, shape_only=True)
+    F = circ.F
+    # queries register in the order of the proof's evaluations (advice, then fixed); enable_equality in the order of the
+    # delta powers of the permutation product
+    for p_, rot in prot.evaluations:
+        if p_ == prot.witness_offset():
+            circ.advice_queries.append((0, rot))
+    for p_, rot in prot.evaluations:
+        if p_ < F:
+            circ.fixed_queries.append((p_, rot))
+    assert circ.halo2_blinding_factors() == circ.bf
+    circ.add_gate(_expr(terms[0], prot, circ))
+    left = terms[3]["Product"][1]["Sum"][0]             # Z(wX) * prod (v + beta sigma + gamma)
+    def factors(e):
+        return factors(e["Product"][0]) + factors(e["Product"][1]) if "Product" in e else [e]
+    cols = [fac["Sum"][0]["Sum"][0]["Polynomial"]["poly"] for fac in factors(left) if "Sum" in fac]
+    assert len(cols) == 3
+    for p_ in cols:
+        if p_ < F:
+            circ.perm_cols.append((plonk.FIXED, p_))
+        elif p_ < prot.witness_offset():
+            circ.perm_cols.append((plonk.INSTANCE, p_ - prot.instance_offset()))
+        else:
+            circ.perm_cols.append((plonk.ADVICE, p_ - prot.witness_offset()))
+    lk = terms[6]["Product"][1]["Sum"][0]["Product"][0]["Product"]        # (t + beta) * (f + beta)
+    table = [_expr(t_, prot, circ) for t_ in lk[0]["Sum"][0]["DistributePowers"][0]]
+    inputs = [_expr(t_, prot, circ) for t_ in lk[1]["Sum"][0]["DistributePowers"][0]]
+    circ.lookups.append(plonk.Lookup("lookup", table, [inputs]))
+    assert circ.degree() - 1 == prot.quotient["num_chunk"]
+    return circ
+
+
+def test_halo2_style_oracle_verifier_accepts_the_reference_proof(fx):
+    """oracle/plonk_verifier.verify -- the verifier the GPU proofs are judged by -- derives evaluation order, query order, the
+    folded identity and the SHPLONK sets from the CIRCUIT, as halo2 does; the protocol-driven verifier above is handed them.
+    Both must accept the reference's proof."""
+    circ = halo2_circuit_of(fx.protocol)
+    assert circ.perm_cols == [(plonk.FIXED, 1), (plonk.ADVICE, 0), (plonk.INSTANCE, 0)]
+    ok = plonk_verifier.verify(circ, fx.protocol.preprocessed, fx.protocol.transcript_initial_state, fx.instances, fx.proof, fx.s_g2,
+                               multiopen="shplonk", transcript="poseidon")
+    assert ok
+    bad = bytearray(fx.proof)
+    bad[32 * 12 + 1] ^= 4                              # an evaluation
+    assert not plonk_verifier.verify(circ, fx.protocol.preprocessed, fx.protocol.transcript_initial_state, fx.instances, bytes(bad), fx.s_g2,
+                                     multiopen="shplonk", transcript="poseidon")
+
+
+# ------------------------------------------------------------------------------------ encodings, oracle and product
+def _point_slots(fx):
+    nw = sum(fx.protocol.num_witness) + fx.protocol.quotient["num_chunk"]
+    assert nw + len(fx.protocol.evaluations) + 2 == len(fx.proof) // 32
+    return list(range(nw)) + [28 - 2, 28 - 1]
+
+
+def test_compressed_points_carry_the_parity_in_bit_254(fx):
+    raws = [fx.vk[8 + 32 * i:40 + 32 * i] for i in range(7)] + [fx.proof[32 * s:32 * s + 32] for s in _point_slots(fx)]
+    assert len(raws) == 18
+    for raw in raws:
+        assert raw[31] & 0x80 == 0
+        pt = b.g1_decompress(raw)
+        assert b.g1_is_on_curve(pt) and (raw[31] >> 6) & 1 == pt[1] & 1
+        assert b.g1_compress(pt) == raw
+    # both parities occur, so the flag is not a constant
+    assert {raw[31] >> 6 for raw in raws} == {0, 1}
+    # the "random" polynomial of the vanishing argument is the constant 1 in this fork's prover: its commitment is g[0] = (1, 2)
+    assert b.g1_decompress(fx.proof[32 * 4:32 * 5]) == b.G1_GEN
+
+
+def test_product_g1_codec_on_the_reference_vk(fx):
+    lib = z.lib()
+    pts = np.zeros((7, 8), dtype=np.uint64)
+    raw = np.frombuffer(fx.vk[8:], dtype=np.uint8).copy()
+    assert lib.zk_host_g1_decode(_ptr(raw), ctypes.c_size_t(7), 0, _ptr(pts)) == 0
+    want = np.array([p_["x"] + p_["y"] for p_ in fx.raw["protocol"]["preprocessed"]], dtype=np.uint64)     # Montgomery limbs as serde wrote them
+    assert np.array_equal(pts, want)
+    back = np.zeros(7 * 32, dtype=np.uint8)
+    assert lib.zk_host_g1_encode(_ptr(pts), ctypes.c_size_t(7), 0, _ptr(back)) == 0
+    assert bytes(back) == fx.vk[8:]
+    # identity: bit 255 on a zero image; 32 zero bytes are no point (x = 0 is on no point of the curve)
+    ident = np.zeros((1, 8), dtype=np.uint64)
+    enc = np.zeros(32, dtype=np.uint8)
+    assert lib.zk_host_g1_encode(_ptr(ident), ctypes.c_size_t(1), 0, _ptr(enc)) == 0 and bytes(enc) == bytes(31) + b"\x80" == b.g1_compress(None)
+    out = np.ones((1, 8), dtype=np.uint64)
+    assert lib.zk_host_g1_decode(_ptr(enc), ctypes.c_size_t(1), 0, _ptr(out)) == 0 and not out.any()
+    zeros = np.zeros(32, dtype=np.uint8)
+    assert lib.zk_host_g1_decode(_ptr(zeros), ctypes.c_size_t(1), 0, _ptr(out)) != 0
+    with pytest.raises(ValueError):
+        b.g1_decompress(bytes(32))
+    flagged = np.frombuffer(bytes(31) + b"\xc0", dtype=np.uint8).copy()          # identity and parity flag together
+    assert lib.zk_host_g1_decode(_ptr(flagged), ctypes.c_size_t(1), 0, _ptr(out)) != 0
+
+
+def test_product_vk_codec_round_trips_the_reference_bytes(fx):
+    lib = z.lib()
+    assert struct.unpack(">II", fx.vk[:8]) == (25, 4) and len(fx.vk) == 8 + 32 * 7
+    k, nf = ctypes.c_uint32(), ctypes.c_uint32()
+    fixed, perm = np.zeros((4, 8), dtype=np.uint64), np.zeros((3, 8), dtype=np.uint64)
+    raw = np.frombuffer(fx.vk, dtype=np.uint8).copy()
+    assert lib.zk_host_vk_read(_ptr(raw), ctypes.c_size_t(len(fx.vk)), 0, 3, 0, ctypes.byref(k), ctypes.byref(nf), _ptr(fixed), ctypes.c_size_t(4), _ptr(perm), None) == 0
+    assert (k.value, nf.value) == (25, 4)
+    assert cref.affine_from_mont(np.concatenate([fixed, perm])) == fx.protocol.preprocessed
+    out, n = np.zeros(512, dtype=np.uint8), ctypes.c_size_t()
+    assert lib.zk_host_vk_write(25, _ptr(fixed), 4, _ptr(perm), 3, None, 0, 0, _ptr(out), ctypes.c_size_t(out.size), ctypes.byref(n)) == 0
+    assert bytes(out[:n.value]) == fx.vk
+
+
+def _g2_mont(pt):
+    return np.frombuffer(params_file.g2_raw_bytes(pt), dtype=np.uint64).copy()
+
+
+def test_product_instances_and_accumulator_on_the_reference_proof(fx):
+    lib = z.lib()
+    m = np.zeros((44, 4), dtype=np.uint64)
+    raw = np.frombuffer(fx.instances_be, dtype=np.uint8).copy()
+    assert lib.zk_host_instances_decode(_ptr(raw), ctypes.c_size_t(44), _ptr(m)) == 0
+    assert cref.from_mont(m) == fx.instances[0]
+    back = np.zeros(44 * 32, dtype=np.uint8)
+    assert lib.zk_host_instances_encode(_ptr(m), ctypes.c_size_t(44), _ptr(back)) == 0 and bytes(back) == fx.instances_be
+    # the first 12 cells are [lhs.x, lhs.y, rhs.x, rhs.y] in 3 limbs of 88 bits: zk_host_accumulator_limbs reproduces them,
+    # zk_host_accumulator_check decides them under the reference's s_g2
+    lhs, rhs = sv.accumulator_from_limbs(fx.instances[0][:12])
+    lm, rm = cref.affine_to_mont([lhs]), cref.affine_to_mont([rhs])
+    limbs = np.zeros((12, 4), dtype=np.uint64)
+    assert lib.zk_host_accumulator_limbs(_ptr(lm), _ptr(rm), _ptr(limbs)) == 0
+    assert np.array_equal(limbs, m[:12])
+    ok = ctypes.c_int(-1)
+    g2, s_g2 = _g2_mont(pr.G2_GEN), _g2_mont(fx.s_g2)
+    assert lib.zk_host_accumulator_check(_ptr(lm), _ptr(rm), _ptr(g2), _ptr(s_g2), ctypes.byref(ok)) == 0 and ok.value == 1
+    assert lib.zk_host_accumulator_check(_ptr(rm), _ptr(lm), _ptr(g2), _ptr(s_g2), ctypes.byref(ok)) == 0 and ok.value == 0
+    # and the accumulator the proof itself yields (oracle's succinct verification) passes the product's decider
+    new_lhs, new_rhs = sv.succinct_verify(fx.protocol, fx.instances, fx.proof)[0]
+    assert lib.zk_host_accumulator_check(_ptr(cref.affine_to_mont([new_lhs])), _ptr(cref.affine_to_mont([new_rhs])), _ptr(g2), _ptr(s_g2), ctypes.byref(ok)) == 0 and ok.value == 1
+
+
+def test_product_reads_the_flattened_chunk_proof_object(fx):
+    lib = z.lib()
+    js = fx.raw["flattened_object"].encode()
+    assert b'"protocol"' in js and b'"chunk_info"' in js and b'"row_usages"' in js
+    bufs = [np.zeros(4096, dtype=np.uint8) for _ in range(3)]
+    lens = [ctypes.c_size_t(4096) for _ in range(3)]
+    gv, has = ctypes.create_string_buffer(64), ctypes.c_int(-1)
+    rc = lib.zk_host_proof_json_read(ctypes.c_char_p(js), ctypes.c_size_t(len(js)), _ptr(bufs[0]), ctypes.byref(lens[0]), _ptr(bufs[1]), ctypes.byref(lens[1]),
+                                     _ptr(bufs[2]), ctypes.byref(lens[2]), gv, ctypes.c_size_t(64), ctypes.byref(has))
+    assert rc == 0
+    assert bytes(bufs[0][:lens[0].value]) == fx.proof and bytes(bufs[1][:lens[1].value]) == fx.instances_be and bytes(bufs[2][:lens[2].value]) == fx.vk
+    assert has.value == 1 and gv.value.decode() == fx.raw["git_version"]
+    # writing the `Proof` part back gives serde_json's bytes of those four fields
+    out, n = ctypes.create_string_buffer(8192), ctypes.c_size_t()
+    assert lib.zk_host_proof_json_write(fx.proof, ctypes.c_size_t(len(fx.proof)), fx.instances_be, ctypes.c_size_t(len(fx.instances_be)), fx.vk, ctypes.c_size_t(len(fx.vk)),
+                                        fx.raw["git_version"].encode(), out, ctypes.c_size_t(8192), ctypes.byref(n)) == 0
+    want = json.dumps({"proof": fx.raw["proof"], "instances": fx.raw["instances"], "vk": fx.raw["vk"], "git_version": fx.raw["git_version"]}, separators=(",", ":"))
+    assert out.raw[:n.value].decode() == want
+    # malformed surroundings are still refused: a truncated unknown value, a repeated known key
+    assert lib.zk_host_proof_json_read(ctypes.c_char_p(js[:-3]), ctypes.c_size_t(len(js) - 3), None, ctypes.byref(lens[0]), None, ctypes.byref(lens[1]), None, ctypes.byref(lens[2]), None, ctypes.c_size_t(0), None) != 0
+    dup = js[:-1] + b',"vk":""}'
+    assert lib.zk_host_proof_json_read(ctypes.c_char_p(dup), ctypes.c_size_t(len(dup)), None, ctypes.byref(lens[0]), None, ctypes.byref(lens[1]), None, ctypes.byref(lens[2]), None, ctypes.c_size_t(0), None) != 0
+
+
+def test_product_poseidon_transcript_replays_the_reference_proof(fx):
+    """the same absorb / squeeze sequence through the PRODUCT's transcript object (zk_transcript_*, kind Poseidon) must give the
+    challenges the accepted verification used -- the product's sponge framing and constants against reference data"""
+    t = sv.read_proof(fx.protocol, fx.instances, fx.proof)
+    tr = z.binding.HostTranscript(z.binding.TRANSCRIPT_POSEIDON)
+    fr = lambda v: cref.to_mont([v]).tobytes()
+    pt = lambda p_: cref.affine_to_mont([p_]).tobytes()
+    sq = lambda: cref.from_mont(np.frombuffer(tr.squeeze_challenge(), dtype=np.uint64).reshape(1, 4))[0]
+    tr.common_scalar(fr(fx.protocol.transcript_initial_state))
+    for v in fx.instances[0]:
+        tr.common_scalar(fr(v))
+    got, w = [], iter(t.witnesses)
+    for nw, nc in zip(fx.protocol.num_witness, fx.protocol.num_challenge):
+        for _ in range(nw):
+            tr.write_point(pt(next(w)))
+        got += [sq() for _ in range(nc)]
+    assert got == t.challenges
+    for q in t.quotients:
+        tr.write_point(pt(q))
+    assert sq() == t.z
+    for e in t.evaluations:
+        tr.write_scalar(fr(e))
+    assert (sq(), sq()) == (t.mu, t.gamma)
+    tr.write_point(pt(t.w))
+    assert sq() == t.z_prime
+    tr.write_point(pt(t.w_prime))
+    assert tr.proof() == fx.proof              # and what it wrote along the way is the reference's proof, byte for byte
+    tr.close()

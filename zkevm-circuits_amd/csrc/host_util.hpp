@@ -158,13 +158,17 @@ inline void fq_to_repr(const Fq& a, uint8_t out[32]) {
     F4 c = fmul<FqC>(m, one);
     memcpy(out, c.l, 32);
 }
-// halo2curves compressed G1: x LE, bit 255 = parity of y; identity = zeros  
+// halo2curves @ a495a7b compressed G1 (`new_curve_impl!`, the flags live in the two spare top bits of the last byte): x canonical
+// LE, bit 254 (0x40 of byte 31) = parity of y, bit 255 (0x80) = identity (with a zero x).  Pinned by the reference's own vk / proof
+// bytes  [REF aggregator/data/batch-task.json: chunk_proofs[0]]  (tests/test_reference_chunk_proof.py): 18 of 18 points carry
+// (y & 1) << 6 and never bit 7.  The identity's image is the same macro's, not readable off that fixture.
+constexpr uint8_t G1_FLAG_SIGN = 0x40, G1_FLAG_IDENTITY = 0x80;
 inline void g1_compress(const G1Affine& p, uint8_t out[32]) {
-    if (p.is_identity()) { memset(out, 0, 32); return; }
+    if (p.is_identity()) { memset(out, 0, 32); out[31] = G1_FLAG_IDENTITY; return; }
     uint8_t y[32];
     fq_to_repr(p.x, out);
     fq_to_repr(p.y, y);
-    out[31] |= (uint8_t)((y[0] & 1) << 7);
+    out[31] |= (uint8_t)((y[0] & 1) << 6);
 }
 
 }  // namespace host

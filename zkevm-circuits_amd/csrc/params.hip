@@ -5,7 +5,7 @@
 //
 //   file = u32 k (LE) | g[0..n) | g_lagrange[0..n) | g2 | s_g2
 //   G1: 64 B (RawBytes / RawBytesUnchecked: x | y, Montgomery limbs = the in-memory image, goes to
-//       the device as is) or 32 B (Processed: x canonical LE, bit 255 = parity of y, identity = 0)
+//       the device as is) or 32 B (Processed: x canonical LE, bit 254 = parity of y, bit 255 = identity)
 //   G2: twice the G1 size.  The prover never touches G2; the two blobs are handed through.
 //
 // Decompression (one (p+1)/4 power per point), on-curve checks and compression run on the device:
@@ -45,18 +45,19 @@ __device__ __forceinline__ bool g1_on_curve(const G1Affine& p) {
     return sqr(p.y) == sqr(p.x) * p.x + b3;
 }
 
-// bad[0] counts rejected encodings (x >= p, no square root); identity = 32 zero bytes
+// bad[0] counts rejected encodings (x >= p, no square root, an identity flag on a non-zero image); halo2curves' flag bits:
+// bit 254 = parity of y, bit 255 = identity (host_util.hpp g1_compress has the provenance)
 __global__ void __launch_bounds__(256) k_g1_decompress(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, uint64_t n, uint32_t* __restrict__ bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* q = reinterpret_cast<const uint4*>(in + i * 32);
     const uint4 lo = q[0], hi = q[1];
     Fq x{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-    const uint32_t ysign = x.l[7] >> 31;
-    x.l[7] &= 0x7FFFFFFFu;
+    const uint32_t is_inf = x.l[7] >> 31, ysign = (x.l[7] >> 30) & 1u;
+    x.l[7] &= 0x3FFFFFFFu;
     G1Affine p{Fq::zero(), Fq::zero()};
+    if (is_inf) { if (ysign || !x.is_zero()) atomicAdd(bad, 1u); stg(out + i, p); return; }
     if (!fq_canonical(x)) { atomicAdd(bad, 1u); stg(out + i, p); return; }
-    if (x.is_zero() && !ysign) { stg(out + i, p); return; }
     x = to_mont(x);
     Fq b3 = Fq::one();
     b3 = b3 + b3 + b3;
@@ -75,7 +76,9 @@ __global__ void __launch_bounds__(256) k_g1_compress(const G1Affine* __restrict_
     Fq x = Fq::zero();
     if (!p.is_identity()) {
         x = from_mont(p.x);
-        x.l[7] |= (from_mont(p.y).l[0] & 1u) << 31;
+        x.l[7] |= (from_mont(p.y).l[0] & 1u) << 30;
+    } else {
+        x.l[7] = 0x80000000u;
     }
     uint4* q = reinterpret_cast<uint4*>(out + i * 32);
     q[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);

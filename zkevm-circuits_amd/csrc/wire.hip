@@ -12,6 +12,8 @@
 #include <vector>
 #include <algorithm>
 #include <cstdio>
+#include <functional>
+
 #include "host_pairing.hpp"
 
 using namespace zk;
@@ -19,8 +21,10 @@ using namespace zk::host;
 
 namespace {
 
-// G1 point codecs of halo2curves' SerdeFormat: Processed = 32 B compressed (x little-endian, bit 255 =
-// parity of y, identity = zeros), RawBytes* = x || y Montgomery limbs (the in-memory form)
+// G1 point codecs of halo2curves' SerdeFormat: Processed = 32 B compressed (x little-endian, bit 254 = parity of y,
+// bit 255 = identity: host_util.hpp g1_compress), RawBytes* = x || y Montgomery limbs (the in-memory form).
+// Reading follows `from_bytes`: an identity flag needs a zero x and a clear parity flag; without it x must be the
+// abscissa of a curve point -- 32 zero bytes are refused (x = 0 is on no point of y^2 = x^3 + 3).
 size_t point_len(int format) { return format == 0 ? 32 : 64; }
 void point_write(const G1Affine& p, int format, uint8_t* out) {
     if (format == 0) g1_compress(p, out);
@@ -36,13 +40,15 @@ bool point_read(const uint8_t* in, int format, G1Affine* p) {
         if (geq_mod<FqC>(x.l) || geq_mod<FqC>(y.l)) return false;
         return g1_y_from_x(x, &want) && (memcmp(want.l, y.l, 32) == 0 || memcmp(q_neg(want).l, y.l, 32) == 0);
     }
-    bool zero = true;
-    for (int i = 0; i < 32; ++i) zero &= in[i] == 0;
-    if (zero) { memset((void*)p, 0, 64); return true; }
     F4 xc;
     memcpy(xc.l, in, 32);
-    const bool sign = (xc.l[3] >> 63) & 1;
-    xc.l[3] &= ~(1ull << 63);
+    const bool is_inf = (xc.l[3] >> 63) & 1, sign = (xc.l[3] >> 62) & 1;
+    xc.l[3] &= ~(3ull << 62);
+    if (is_inf) {
+        if (sign || (xc.l[0] | xc.l[1] | xc.l[2] | xc.l[3])) return false;
+        memset((void*)p, 0, 64);
+        return true;
+    }
     if (geq_mod<FqC>(xc.l)) return false;
     const F4 x = fmul<FqC>(xc, [] { F4 r2; static const uint64_t R2[4] = {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}; memcpy(r2.l, R2, 32); return r2; }());
     F4 y;
@@ -273,6 +279,11 @@ int zk_host_proof_json_write(const void* proof, size_t proof_len, const void* in
         for (const char* q = git_version; *q; ++q) {            // serde_json's escapes for what a version string could hold
             const unsigned char ch = (unsigned char)*q;
             if (ch == '"' || ch == '\\') { js += '\\'; js += (char)ch; }
+            else if (ch == 0x08) js += "\\b";                    // serde_json's short escapes, then \u00xx for the other controls
+            else if (ch == 0x09) js += "\\t";
+            else if (ch == 0x0a) js += "\\n";
+            else if (ch == 0x0c) js += "\\f";
+            else if (ch == 0x0d) js += "\\r";
             else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); js += b; }
             else js += (char)ch;
         }
@@ -285,8 +296,12 @@ int zk_host_proof_json_write(const void* proof, size_t proof_len, const void* in
     memcpy(out, js.data(), js.size());
     return ZK_OK;
 }
-// Reads what the function above (or serde_json, compact or pretty) wrote: the four keys in any order, other keys refused.
-// Each output is optional (NULL buffer = length only); *_len hold the capacities on entry and the lengths on return.
+// Reads what the function above (or serde_json, compact or pretty) wrote: the four keys in any order.  Other keys are parsed and
+// dropped, as serde does for a struct without `deny_unknown_fields` -- the reference flattens `Proof` into ChunkProof / BatchProof
+// next to `protocol`, `chunk_info`, `row_usages` [REF prover/src/proof/chunk.rs:10-19], and such an object is accepted here
+// (pinned by the reference's own aggregator/data/batch-task.json, tests/test_reference_chunk_proof.py).  A repeated known key is
+// refused (serde: "duplicate field").  Each output is optional (NULL buffer = length only); *_len hold the capacities on entry and
+// the lengths on return.
 int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size_t* proof_len, void* instances_be, size_t* instances_len, void* vk, size_t* vk_len,
                             char* git_version, size_t git_cap, int* has_git_version) {
     if (!json || !proof_len || !instances_len || !vk_len) return ZK_ERR_INVALID_ARG;
@@ -304,10 +319,16 @@ int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size
                 case 'n': out->push_back('\n'); break;
                 case 't': out->push_back('\t'); break;
                 case 'r': out->push_back('\r'); break;
+                case 'b': out->push_back('\b'); break;
+                case 'f': out->push_back('\f'); break;
                 case 'u': {
                     if (i + 4 >= json_len) return false;
                     unsigned v = 0;
-                    for (int d = 1; d <= 4; ++d) { const char h = json[i + d]; v = v * 16 + (h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : 99); }
+                    for (int d = 1; d <= 4; ++d) {
+                        const char h = json[i + d];
+                        if (!((h >= '0' && h <= '9') || (h >= 'a' && h <= 'f') || (h >= 'A' && h <= 'F'))) return false;
+                        v = v * 16 + (unsigned)(h <= '9' ? h - '0' : (h | 0x20) - 'a' + 10);
+                    }
                     if (v > 0x7F) return false;          // version strings are ASCII
                     out->push_back((char)v);
                     i += 4;
@@ -320,6 +341,48 @@ int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size
         ++i;
         return true;
     };
+    // any JSON value, parsed for well-formedness and dropped (serde's IgnoredAny); depth bounded like serde_json's 128
+    std::function<bool(int)> skip = [&](int depth) -> bool {
+        if (depth > 128) return false;
+        ws();
+        if (i >= json_len) return false;
+        const char ch = json[i];
+        if (ch == '"') {
+            for (++i; i < json_len && json[i] != '"'; ++i) {
+                if ((unsigned char)json[i] < 0x20) return false;
+                if (json[i] != '\\') continue;
+                if (++i >= json_len) return false;
+                if (json[i] == 'u') {
+                    if (i + 4 >= json_len) return false;
+                    for (int d = 1; d <= 4; ++d) { const char h = json[i + d]; if (!((h >= '0' && h <= '9') || (h >= 'a' && h <= 'f') || (h >= 'A' && h <= 'F'))) return false; }
+                    i += 4;
+                } else if (!strchr("\"\\/bfnrt", json[i])) return false;
+            }
+            if (i >= json_len) return false;
+            ++i;
+            return true;
+        }
+        if (ch == '{' || ch == '[') {
+            const char close = ch == '{' ? '}' : ']';
+            ++i;
+            for (bool first = true; !lit(close); first = false) {
+                if (!first && !lit(',')) return false;
+                if (ch == '{') { ws(); if (i >= json_len || json[i] != '"' || !skip(depth + 1) || !lit(':')) return false; }
+                if (!skip(depth + 1)) return false;
+            }
+            return true;
+        }
+        for (const char* w : {"true", "false", "null"}) { const size_t l = strlen(w); if (i + l <= json_len && !strncmp(json + i, w, l)) { i += l; return true; } }
+        // number: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+        size_t j = i;
+        auto digits = [&] { const size_t s0 = j; while (j < json_len && json[j] >= '0' && json[j] <= '9') ++j; return j - s0; };
+        if (j < json_len && json[j] == '-') ++j;
+        if (j < json_len && json[j] == '0') ++j; else if (!digits()) return false;
+        if (j < json_len && json[j] == '.') { ++j; if (!digits()) return false; }
+        if (j < json_len && (json[j] == 'e' || json[j] == 'E')) { ++j; if (j < json_len && (json[j] == '+' || json[j] == '-')) ++j; if (!digits()) return false; }
+        i = j;
+        return true;
+    };
     std::vector<uint8_t> parts[3];
     bool seen[4] = {false, false, false, false};
     std::string gv;
@@ -330,7 +393,8 @@ int zk_host_proof_json_read(const char* json, size_t json_len, void* proof, size
         std::string key;
         if (!str(&key) || !lit(':')) return ZK_ERR_INVALID_ARG;
         const int which = key == "proof" ? 0 : key == "instances" ? 1 : key == "vk" ? 2 : key == "git_version" ? 3 : -1;
-        if (which < 0 || seen[which]) return ZK_ERR_INVALID_ARG;
+        if (which < 0) { if (!skip(0)) return ZK_ERR_INVALID_ARG; continue; }
+        if (seen[which]) return ZK_ERR_INVALID_ARG;
         seen[which] = true;
         if (which == 3) {
             ws();
@@ -408,8 +472,9 @@ int zk_host_instances_json_read(const char* json, size_t json_len, size_t* ncols
                 ws();
                 unsigned v = 0;
                 size_t digits = 0;
+                const bool lead0 = i < json_len && json[i] == '0';
                 while (i < json_len && json[i] >= '0' && json[i] <= '9' && digits < 4) { v = v * 10 + (unsigned)(json[i] - '0'); ++i; ++digits; }
-                if (!digits || v > 255) return ZK_ERR_INVALID_ARG;
+                if (!digits || v > 255 || (lead0 && digits > 1)) return ZK_ERR_INVALID_ARG;      // serde_json refuses leading zeros
                 le[b] = (uint8_t)v;
             }
             if (!lit(']')) return ZK_ERR_INVALID_ARG;

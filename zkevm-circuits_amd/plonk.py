@@ -172,7 +172,9 @@ class Circuit:
     halo2's `query_advice / query_fixed / enable_equality` do: that order is the order of the
     evaluations in the proof, so it is part of the exported key blob."""
 
-    def __init__(self, k: int, num_fixed: int, num_advice: int, num_instance: int, blinding_factors: int = 5):
+    def __init__(self, k: int, num_fixed: int, num_advice: int, num_instance: int, blinding_factors: int = 5, shape_only: bool = False):
+        """shape_only: no fixed assignment is kept (a verifier needs the constraint system alone; at k = 25 the cell lists of a
+        production aggregation circuit would not fit) -- such a circuit cannot be turned into a key blob."""
         self.k, self.n = k, 1 << k
         self.F, self.A, self.I = num_fixed, num_advice, num_instance
         self.bf = blinding_factors
@@ -183,7 +185,7 @@ class Circuit:
         self.minimum_degree = 1
         self.perm_cols: List[Tuple[int, int]] = []
         self.copies: List[Tuple[Tuple[int, int, int], Tuple[int, int, int]]] = []
-        self.fixed = [[0] * self.n for _ in range(num_fixed)]
+        self.fixed = None if shape_only else [[0] * self.n for _ in range(num_fixed)]
         self.consts: List[int] = []
         self._const_index: Dict[int, int] = {}
         self.advice_phase = [0] * num_advice      # halo2 FirstPhase = 0, SecondPhase = 1, ...
@@ -555,6 +557,7 @@ class Circuit:
     def blob(self, cse: bool = False) -> bytes:
         """Serialise for zk_pk_create (layout documented in INTEGRATION.md).  cse: share
         sub-expressions between gates through the evaluator's intermediates (same proof bytes)."""
+        assert self.fixed is not None, "a shape-only circuit has no fixed assignment to export"
         sig = self.sigma_columns()
         out = [self.cs_blob(cse)]
         out += [column_to_mont(col).tobytes() for col in self.fixed]
