@@ -346,6 +346,12 @@ int zk_host_mock_challenges(uint32_t count, void* out_fr32);
  * (ProverSHPLONK / BDFG21, what the reference's call sites instantiate: two commitments in total) */
 enum { ZK_MULTIOPEN_GWC = 0, ZK_MULTIOPEN_SHPLONK = 1 };
 int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* proof, int kind);
+/* The vanishing argument's "random" polynomial (halo2 vanishing::Argument::commit).  ONE (default): the constant 1, commitment
+ * g[0], evaluation 1 -- what the reference's own prover emitted: in [REF aggregator/data/batch-task.json: chunk_proofs[0]] that
+ * commitment is (1, 2) and that evaluation is 1 (Scroll's fork commits no blinding polynomial).  UNIFORM: n uniform coefficients
+ * as upstream PSE halo2 draws them (one more dense commitment).  The verifier accepts either.  Any time before zk_proof_finish.  */
+enum { ZK_VANISHING_UNIFORM = 0, ZK_VANISHING_ONE = 1 };
+int zk_proof_set_vanishing_random(zk_ctx* ctx, zk_proof* proof, int kind);
 int zk_proof_begin(zk_ctx* ctx, const zk_pk* pk, const void* const* h_instance, const uint8_t* seed16, zk_proof** out);
 /* The same with halo2's instance slices as they are: h_instance[i] holds h_instance_len[i] values
  * (not n).  Exactly those values are absorbed into the transcript -- what create_proof and

@@ -158,7 +158,7 @@ def keygen(circ) -> dict:
 
 
 def create_proof(circ, srs: Srs, advice: Sequence, instance: Sequence[Sequence[int]], vk_repr: int, seed16: bytes = bytes(16),
-                 multiopen: str = "gwc", transcript: str = "blake2b", timings: dict = None, key: dict = None) -> bytes:
+                 multiopen: str = "gwc", transcript: str = "blake2b", timings: dict = None, key: dict = None, vanishing: str = "one") -> bytes:
     """advice: integer lists or (n, 4) Montgomery arrays (halo2 holds the witness as field elements: converting Python integers
     is not part of proving).  key: keygen(circ), made on the fly when absent."""
     import time
@@ -296,8 +296,13 @@ def create_proof(circ, srs: Srs, advice: Sequence, instance: Sequence[Sequence[i
     for phi in lk_phi:
         tr.write_point(srs.commit_lagrange(phi))
     mark("lookup phi")
-    chacha_key = b"".join(rng.next_u32().to_bytes(4, "little") for _ in range(8))
-    random_coeff = random_poly_chacha(chacha_key, n)
+    assert vanishing in ("one", "uniform")
+    if vanishing == "one":                 # the constant 1, as in the reference's own proof (plonk_prover.create_proof)
+        random_coeff = zeros(n)
+        random_coeff[0] = arr([1])[0]
+    else:
+        chacha_key = b"".join(rng.next_u32().to_bytes(4, "little") for _ in range(8))
+        random_coeff = random_poly_chacha(chacha_key, n)
     tr.write_point(srs.commit(random_coeff))
     y = tr.squeeze()
     mark("random polynomial")

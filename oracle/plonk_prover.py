@@ -146,8 +146,10 @@ def vk_commitments(circ, srs: Srs):
 
 # ------------------------------------------------------------------------------------ the prover
 def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequence[Sequence[int]], vk_repr: int,
-                 seed16: bytes = bytes(16), multiopen: str = "gwc", transcript: str = "blake2b", phase_witness=None) -> bytes:
-    """phase_witness(phase, challenges so far) -> {advice column: values}: the columns of a later phase, synthesised once
+                 seed16: bytes = bytes(16), multiopen: str = "gwc", transcript: str = "blake2b", phase_witness=None, vanishing: str = "one") -> bytes:
+    """vanishing: the vanishing argument's "random" polynomial -- "one" = the constant 1 (commitment g[0], evaluation 1: what the
+    reference's own proof carries, tests/test_reference_chunk_proof.py), "uniform" = n uniform coefficients (upstream PSE halo2).
+    phase_witness(phase, challenges so far) -> {advice column: values}: the columns of a later phase, synthesised once
     the challenges they depend on exist (what halo2 does by calling Circuit::synthesize once per phase)."""
     n, k, u, bf, d = circ.n, circ.k, circ.u, circ.bf, circ.degree()
     A, Pn, L = circ.A, len(circ.perm_cols), len(circ.lookups)
@@ -251,9 +253,13 @@ def create_proof(circ, srs: Srs, advice: Sequence[Sequence[int]], instance: Sequ
         lk_phi.append(phi)
     for phi in lk_phi:
         tr.write_point(srs.commit_lagrange(phi))
-    # ---- vanishing argument: blinding polynomial from ChaCha20 in counter mode
-    key = b"".join(rng.next_u32().to_bytes(4, "little") for _ in range(8))
-    random_coeff = b.fr_random_chacha(key, 0, 0, n)
+    # ---- vanishing argument: the constant 1, or a blinding polynomial from ChaCha20 in counter mode
+    assert vanishing in ("one", "uniform")
+    if vanishing == "one":
+        random_coeff = [1] + [0] * (n - 1)
+    else:
+        key = b"".join(rng.next_u32().to_bytes(4, "little") for _ in range(8))
+        random_coeff = b.fr_random_chacha(key, 0, 0, n)
     tr.write_point(srs.commit(random_coeff))
     y = tr.squeeze()
 

@@ -250,7 +250,8 @@ class _HostBlake2bWrite:
     def write_point(self, raw64):
         self.common_point(raw64)
         pt = self._point(raw64)
-        self.proof += bytes(32) if pt is None else (pt[0] | ((pt[1] & 1) << 255)).to_bytes(32, "little")
+        from oracle import bn254
+        self.proof += bn254.g1_compress(pt)             # x LE, parity of y in bit 254, identity = bit 255 (pinned by the reference's ChunkProof)
 
     def write_scalar(self, raw32):
         self.common_scalar(raw32)
@@ -288,11 +289,12 @@ def test_external_transcript_matches_builtin(ctx, cref, srs8, multiopen):
     assert len(builtin) > 500 and external == builtin
 
 
-@pytest.mark.parametrize("k,wide,multiopen", [(5, False, "gwc"), (6, True, "shplonk"), (6, True, "gwc")])
-def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen):
+@pytest.mark.parametrize("k,wide,multiopen,vanishing", [(5, False, "gwc", "one"), (6, True, "shplonk", "one"), (6, True, "gwc", "uniform"), (6, True, "shplonk", "uniform")])
+def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen, vanishing):
     """Strongest parity statement for the whole path: for the same key, witness and seed the GPU
     session and the oracle's big-int restatement of create_proof produce the same bytes --
-    every commitment, evaluation and opening agrees, not merely "the verifier accepts"."""
+    every commitment, evaluation and opening agrees, not merely "the verifier accepts".  Both kinds of the
+    vanishing argument's polynomial: the constant 1 of the reference's own proofs (default) and upstream's uniform one."""
     from oracle import plonk_prover as pp
     circ, adv, inst = build_circuit(k, seed=7, wide=wide)
     seed = bytes((3 * i + 1) & 0xFF for i in range(16))
@@ -301,6 +303,8 @@ def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen
         com, rep = pk.vk(circ.F + len(circ.perm_cols))
         sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], seed)
         sess.set_multiopen(1 if multiopen == "shplonk" else 0)
+        if vanishing == "uniform":
+            sess.set_vanishing_random(0)
         sess.advice_phase({i: plonk.column_to_mont(c) for i, c in enumerate(adv)})
         gpu_proof = sess.finish()
     finally:
@@ -308,7 +312,7 @@ def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen
     srs = pp.Srs(circ.k, S_SECRET)
     assert cref.affine_from_mont(com) == pp.vk_commitments(circ, srs)          # keygen agrees first
     vk_repr = cref.from_mont(rep.reshape(1, 4))[0]
-    want = pp.create_proof(circ, srs, adv, inst, vk_repr, seed, multiopen)
+    want = pp.create_proof(circ, srs, adv, inst, vk_repr, seed, multiopen, vanishing=vanishing)
     assert len(gpu_proof) == len(want)
     first_diff = next((i for i, (x, y) in enumerate(zip(gpu_proof, want)) if x != y), None)
     assert first_diff is None, f"proofs differ from byte {first_diff} (32-byte item {first_diff // 32})"

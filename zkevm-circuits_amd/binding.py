@@ -265,6 +265,10 @@ class ProofSession:
         """0 = GWC (default), 1 = SHPLONK."""
         self.ctx._ck(lib().zk_proof_set_multiopen(self.ctx.h, self.h, ctypes.c_int(kind)))
 
+    def set_vanishing_random(self, kind: int):
+        """0 = n uniform coefficients (upstream PSE halo2), 1 = the constant 1 (the reference's own proofs; default)"""
+        self.ctx._ck(lib().zk_proof_set_vanishing_random(self.ctx.h, self.h, ctypes.c_int(kind)))
+
     def set_transcript_kind(self, kind: int):
         """built-in transcript: TRANSCRIPT_BLAKE2B (default), TRANSCRIPT_POSEIDON or TRANSCRIPT_EVM"""
         self.ctx._ck(lib().zk_proof_set_transcript_kind(self.ctx.h, self.h, ctypes.c_int(kind)))

@@ -183,6 +183,7 @@ struct zk_proof {
     bool pre_planned = false;
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
+    int vanishing_random = ZK_VANISHING_ONE;
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
     // commitments and quotient cosets are split over the ranks, results exchanged through `gather`
     std::vector<F4> absorbed;                // what zk_proof_begin fed the transcript (replayed into an external one)
@@ -636,6 +637,13 @@ int zk_proof_set_multiopen(zk_ctx* ctx, zk_proof* pr, int kind) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, pr && (kind == ZK_MULTIOPEN_GWC || kind == ZK_MULTIOPEN_SHPLONK), "unknown multi-open scheme");
     pr->multiopen = kind;
+    return ZK_OK;
+}
+
+int zk_proof_set_vanishing_random(zk_ctx* ctx, zk_proof* pr, int kind) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pr && (kind == ZK_VANISHING_UNIFORM || kind == ZK_VANISHING_ONE), "unknown kind of vanishing-argument polynomial");
+    pr->vanishing_random = kind;
     return ZK_OK;
 }
 
@@ -1501,16 +1509,26 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup phi");
-    // ---- vanishing argument: random polynomial
+    // ---- vanishing argument: the "random" polynomial.  In the reference's own proof it is the CONSTANT 1: the commitment in
+    // [REF aggregator/data/batch-task.json: chunk_proofs[0]] is g[0] = (1, 2) and its evaluation is 1 (tests/test_reference_chunk_proof.py)
+    // -- Scroll's halo2 fork commits no blinding polynomial; upstream PSE halo2 draws n uniform coefficients.  The verifier accepts
+    // either (it only opens the commitment); ZK_VANISHING_ONE (default) does what the reference's prover did, ZK_VANISHING_UNIFORM
+    // what upstream does.
     DevBuf random_coeff;
     {
-        // n uniform coefficients: ChaCha20 in counter mode on the device, keyed from the session RNG
-        uint32_t key[8];
-        for (uint32_t& w_ : key) w_ = rng.next_u32();
         if (!random_coeff.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-        PK_TRY(zk_fr_random(ctx, (const uint8_t*)key, 0, 0, random_coeff.p, n));
         G1Affine com;
-        PK_TRY(commit_coeff(ctx, srs, random_coeff.fr(), n, &com));
+        if (pr->vanishing_random == ZK_VANISHING_ONE) {
+            ZK_HIP(ctx, hipMemsetAsync(random_coeff.p, 0, n * 32, ctx->stream));
+            ZK_HIP(ctx, hipMemcpyAsync(random_coeff.p, &one, 32, hipMemcpyHostToDevice, ctx->stream));
+            PK_TRY(zk_d2h(ctx, &com, srs->g, sizeof com));                    // commit(1) = g[0]
+        } else {
+            // n uniform coefficients: ChaCha20 in counter mode on the device, keyed from the session RNG
+            uint32_t key[8];
+            for (uint32_t& w_ : key) w_ = rng.next_u32();
+            PK_TRY(zk_fr_random(ctx, (const uint8_t*)key, 0, 0, random_coeff.p, n));
+            PK_TRY(commit_coeff(ctx, srs, random_coeff.fr(), n, &com));
+        }
         tr.write_point(com);
     }
     trace.mark("random poly");
