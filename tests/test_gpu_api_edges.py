@@ -178,3 +178,26 @@ def test_ctx_sync_joins_every_library_stream(ctx):
     ctx.debug_delay(4, 20000)
     ctx.sync()
     assert ctx.streams_busy() == 0
+
+
+def test_debug_delay_on_a_fresh_context_leaves_the_prover_usable(zk, cref):
+    """zk_ctx_debug_delay may be the first thing that touches the copy / auxiliary stream of a context: the stream then comes
+    with its event, and a proof on that context still works (it once recorded into a null event: every later proof failed)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from plonk_fixtures import build_circuit
+    from zkevm_circuits_amd import plonk
+    fresh = zk.Context(0)
+    try:
+        fresh.debug_delay(1, 100)
+        fresh.debug_delay(2, 100)
+        circ, adv, inst = build_circuit(5, seed=3, wide=False)
+        srs = fresh.srs_setup_with_s(circ.k, cref.fr_const(5))
+        pk = fresh.pk_create(srs, circ.blob())
+        proof = fresh.create_proof(pk, [plonk.column_to_mont(c) for c in adv], [plonk.column_to_mont(c) for c in inst])
+        assert len(proof) > 500
+        pk.destroy()
+        srs.destroy()
+    finally:
+        fresh.close()

@@ -1,0 +1,92 @@
+"""GPU: full proofs at BASELINE.json's sizes under pytest (configs 3 and 4), so that the driver's own GPU run vouches for them and
+not only bench.py: the Keccak shape at k = 18 and the SuperCircuit shape at k = 20 (synthetic-shape stand-ins, SURVEY 8d: the
+reference's witnesses need its Rust + Go toolchain), SHPLONK as at [REF circuit-benchmarks/src/super_circuit.rs:117-132], verified
+by the oracle verifier that accepts the reference's own ChunkProof (tests/test_reference_chunk_proof.py); the Keccak shape at
+k = 16 byte-equal to the restated CPU prover (oracle/cpu_prover.py).  Shapes: [REF circuit-benchmarks/src/packed_multi_keccak.rs:42-55],
+[REF circuit-benchmarks/src/super_circuit.rs:45-98]."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+S = 0x5EC2E7
+
+
+def _prove(ctx, cref, circ, blob, adv_m, inst_m, inst, transcript_kind=None, seed=bytes(16)):
+    """keygen + one SHPLONK session over the instance slices; returns (proof, vk points, vk repr, instance slices)"""
+    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
+    inst = [list(col[:m]) for col, m in zip(inst, npub)]
+    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
+    srs = ctx.srs_setup_with_s(circ.k, cref.fr_const(S))
+    pk = ctx.pk_create(srs, blob)
+    try:
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        sess = ctx.proof_session(pk, inst_m, seed, instance_slices=True)
+        sess.set_multiopen(1)
+        if transcript_kind is not None:
+            sess.set_transcript_kind(transcript_kind)
+        sess.advice_phase({i: c for i, c in enumerate(adv_m)})
+        proof = sess.finish()
+    finally:
+        pk.destroy()
+        srs.destroy()
+    return proof, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst
+
+
+def _verify(circ, vk_points, vk_repr, inst, proof, transcript="blake2b"):
+    from oracle import pairing as pr, plonk_verifier as pv
+    try:
+        return bool(pv.verify(circ, vk_points, vk_repr, inst, proof, pr.ec_mul(pr.G2_GEN, S), multiopen="shplonk", transcript=transcript))
+    except AssertionError:           # malformed point encodings
+        return False
+
+
+def test_keccak_shape_k18_proof_is_accepted(ctx, cref):
+    """BASELINE configs[2]: Keccak circuit k = 18 (stand-in: 96 advice columns, 59 unusable rows, 13-rotation gates, degree 9, 7 lookups)"""
+    import bench_proof as bp
+    circ, blob, adv_m, inst_m, inst = bp.build_keccak_shape(ctx, 18)
+    assert circ.k == 18 and circ.degree() == 9 and circ.bf == 58
+    proof, vk_points, vk_repr, inst = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst)
+    assert _verify(circ, vk_points, vk_repr, inst, proof)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    assert not _verify(circ, vk_points, vk_repr, inst, bytes(bad))
+    # and under the Poseidon transcript of gen_snark_shplonk [REF prover/src/common/prover/utils.rs:31]
+    proof, vk_points, vk_repr, inst = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst, transcript_kind=1)
+    assert _verify(circ, vk_points, vk_repr, inst, proof, transcript="poseidon")
+
+
+def test_keccak_shape_k16_bytes_equal_the_restated_cpu_prover(ctx, cref):
+    """the same circuit, witness, seed and vk.transcript_repr through the GPU session and through halo2's create_proof restated over
+    arrays on the host (whole-extended-domain evaluate_h): the same bytes"""
+    import bench_proof as bp
+    from oracle import cpu_prover as cp
+    k = 16
+    circ, blob, adv_m, inst_m, inst = bp.build_keccak_shape(ctx, k)
+    proof, vk_points, vk_repr, inst_s = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst)
+    circ_h, adv_h, inst_h = bp.build_keccak_shape(None, k)
+    assert inst_h == inst_s
+    want = cp.create_proof(circ_h, cp.Srs(k, S), adv_h, inst_h, vk_repr, bytes(16), "shplonk", key=cp.keygen(circ_h))
+    assert proof == want
+    assert _verify(circ, vk_points, vk_repr, inst_s, proof)
+
+
+def test_supercircuit_shape_k20_proof_is_accepted(ctx, cref):
+    """BASELINE configs[3] on one GPU: k = 20, 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9
+    (SURVEY 8d config 4 stand-in).  Needs ~45 GiB of host memory for the witness and the key blob."""
+    import psutil
+    if psutil.virtual_memory().available < (64 << 30):
+        pytest.skip("less than 64 GiB of host memory available")
+    import bench_proof as bp
+    circ, blob, adv_m, inst_m, inst = bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9)
+    assert (circ.k, circ.A, circ.F, len(circ.perm_cols), len(circ.lookups), circ.degree()) == (20, 1000, 150, 150, 100, 9)
+    proof, vk_points, vk_repr, inst = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst)
+    assert _verify(circ, vk_points, vk_repr, inst, proof)
+    bad = bytearray(proof)
+    bad[40] ^= 1
+    assert not _verify(circ, vk_points, vk_repr, inst, bytes(bad))

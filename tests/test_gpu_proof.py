@@ -195,6 +195,106 @@ def test_two_phase_proof_with_challenge(zk, ctx, cref, srs8, s_g2):
     assert not pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], [], bad, s_g2)
 
 
+def _three_phase_circuit(k):
+    """The SuperCircuit's phase structure [REF zkevm-circuits/src/util.rs:120-133]: `evm_word` and `keccak_input` usable after the
+    FIRST phase, `lookup_input` after the SECOND; advice columns in each of the three phases.
+      phase 0: a, b                          phase 1: w = a + evm_word * b,  kk = b + keccak_input * a   (the two RLCs)
+      phase 2: t = w + lookup_input * kk,    s with s(row + 1) * w(row) = t(row)^2 * lookup_input on the rows q5 selects,
+               lk = cells of w picked by copy constraints, looked up in w itself (a third-phase column feeding a lookup into a
+               second-phase table, as the EVM circuit's lookup columns do [REF zkevm-circuits/src/evm_circuit/execution.rs:418-431])."""
+    circ = plonk.Circuit(k, num_fixed=3, num_advice=7, num_instance=1, blinding_factors=5)
+    q, q5, ql = circ.fixed_col(0), circ.fixed_col(1), circ.fixed_col(2)
+    a, b_, w, kk, t, s_, lk = (circ.advice_col(i) for i in range(7))
+    circ.advice_phase = [0, 0, 1, 1, 2, 2, 2]
+    evm_word = circ.challenge_usable_after(0)
+    keccak_input = circ.challenge_usable_after(0)
+    lookup_input = circ.challenge_usable_after(1)
+    circ.add_gate(q * (a + evm_word * b_ - w))
+    circ.add_gate(q * (b_ + keccak_input * a - kk))
+    circ.add_gate(q * (w + lookup_input * kk - t))
+    circ.add_gate(q5 * (t * t * lookup_input - s_.rot(1) * w))
+    circ.lookup_any("lk in w", [ql * lk], [w])
+    circ.chunk_lookups()
+    u = circ.u
+    for row in range(u):
+        circ.fixed[0][row] = 1
+    for row in range(0, u - 3, 2):
+        circ.fixed[1][row] = 1
+    picks = [(3 * j + 1, (7 * j + 2) % (u - 1)) for j in range(6)]          # lk(row) == w(src)
+    for row, src in picks:
+        circ.fixed[2][row] = 1
+        circ.copy((plonk.ADVICE, 6, row), (plonk.ADVICE, 2, src))
+    circ.copy((plonk.ADVICE, 0, 0), (plonk.INSTANCE, 0, 0))
+    return circ, picks
+
+
+def test_three_phase_proof_as_the_supercircuit(zk, ctx, cref, srs8, s_g2):
+    """Three zk_proof_advice_phase calls with challenges handed back twice -- the re-synthesis contract of
+    [REF zkevm-circuits/src/super_circuit.rs:728-736] (`synthesize` runs once per phase; what needs `lookup_input` is assigned in
+    the third).  Bytes equal the oracle prover's, which is handed the same per-phase synthesis as a callback; the oracle verifier
+    (pinned by the reference's ChunkProof) accepts; a third phase synthesised with a wrong `lookup_input` is rejected."""
+    import random
+    from oracle import plonk_prover as pp
+    k = 6
+    circ, picks = _three_phase_circuit(k)
+    n, u, R = circ.n, circ.u, b.R_MOD
+    rng = random.Random(5)
+    av = [rng.randrange(1, R) if i < u - 1 else 0 for i in range(n)]          # row u - 1: a = b = 0, so that w holds a zero for the unselected lookup rows
+    bv = [rng.randrange(1, R) if i < u - 1 else 0 for i in range(n)]
+
+    def synth(phase, ch):
+        """what Circuit::synthesize assigns in `phase`, given the challenges squeezed so far"""
+        if phase == 0:
+            return {0: av, 1: bv}
+        wv = [(av[i] + ch[0] * bv[i]) % R if i < u else 0 for i in range(n)]
+        kv = [(bv[i] + ch[1] * av[i]) % R if i < u else 0 for i in range(n)]
+        if phase == 1:
+            return {2: wv, 3: kv}
+        tv = [(wv[i] + ch[2] * kv[i]) % R if i < u else 0 for i in range(n)]
+        sv, lv = [0] * n, [0] * n
+        for row in range(u):
+            if circ.fixed[1][row]:
+                sv[row + 1] = tv[row] * tv[row] % R * ch[2] % R * b.fr_inv(wv[row]) % R
+        for row, src in picks:
+            lv[row] = wv[src]
+        return {4: tv, 5: sv, 6: lv}
+    inst = [[av[0]] + [0] * (n - 1)]
+    pk = ctx.pk_create(srs8[k], circ.blob())
+    com, rep = pk.vk(circ.F + len(circ.perm_cols))
+    vk_points, vk_repr = cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0]
+
+    def gpu_proof(tamper=False):
+        sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst], bytes(range(16)))
+        sess.set_multiopen(1)
+        ch = []
+        got = sess.advice_phase({i: plonk.column_to_mont(c) for i, c in synth(0, ch).items()})
+        assert got.shape == (2, 4)                       # evm_word, keccak_input
+        ch += cref.from_mont(got)
+        got = sess.advice_phase({i: plonk.column_to_mont(c) for i, c in synth(1, ch).items()})
+        assert got.shape == (1, 4)                       # lookup_input
+        ch += cref.from_mont(got)
+        used = ch[:2] + [(ch[2] + 1) % R] if tamper else ch
+        cols = synth(2, used)
+        if tamper:
+            cols[6] = synth(2, ch)[6]                    # keep the lookup and the copies satisfied: only the gates see the wrong challenge
+        got = sess.advice_phase({i: plonk.column_to_mont(c) for i, c in cols.items()})
+        assert got.shape == (0, 4)
+        return sess.finish(), ch
+    try:
+        proof, ch = gpu_proof()
+        bad, _ = gpu_proof(tamper=True)
+    finally:
+        pk.destroy()
+    full = {}
+    for ph in range(3):
+        full.update(synth(ph, ch))
+    assert pv.check_witness(circ, [full[i] for i in range(7)], inst, challenges=ch) is None
+    assert pv.verify(circ, vk_points, vk_repr, inst, proof, s_g2, multiopen="shplonk")
+    want = pp.create_proof(circ, pp.Srs(k, S_SECRET), [[0] * n for _ in range(7)], inst, vk_repr, bytes(range(16)), "shplonk", phase_witness=synth)
+    assert proof == want
+    assert pv.verify(circ, vk_points, vk_repr, inst, bad, s_g2, multiopen="shplonk") is False
+
+
 @pytest.mark.parametrize("multiopen", ["gwc", "shplonk"])
 def test_many_rotations_keccak_like(ctx, cref, srs8, s_g2, multiopen):
     """One column opened at 14 distinct rotations with 17 blinding rows (the Keccak circuit's query

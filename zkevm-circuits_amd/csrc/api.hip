@@ -179,7 +179,9 @@ int zk_ctx_debug_delay(zk_ctx* ctx, int role, uint32_t usec) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     ZK_REQUIRE(ctx, role >= 0 && role <= 5 && usec <= 2000000u, "role 0..5, at most two seconds");
     hipStream_t* slot[6] = {&ctx->stream, &ctx->stream_copy, &ctx->stream_aux, &ctx->stream2, &ctx->stream2b, &ctx->stream2c};
-    if (!*slot[role]) {
+    if (role == 1) { if (int rc = zk::copy_stream_open(ctx)) return rc; }              // copy / auxiliary stream: created with their events,
+    else if (role == 2) { if (!ctx->ensure_aux()) return ctx->fail(ZK_ERR_HIP, "could not create the auxiliary stream"); }     // as the prover expects them
+    else if (!*slot[role]) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(slot[role], hipStreamNonBlocking));
         ctx->owned_streams.push_back(*slot[role]);
     }
@@ -513,10 +515,8 @@ int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* c
     return msm_batch_srs(ctx, srs, basis, (const Fr* const*)d_scalar_ptrs, count, n, (G1Affine*)h_out_affine, stage, stage_user, narrow);
 }
 int copy_stream_open(zk_ctx* ctx) {
-    if (!ctx->stream_copy) {
-        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
-        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
-    }
+    if (!ctx->stream_copy) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+    if (!ctx->ev_copy) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));      // the stream may predate it (zk_ctx_debug_delay)
     ZK_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_copy, 0));
     return ZK_OK;

@@ -57,7 +57,8 @@ struct zk_ctx {
     // (643 -> 940 ms for the SuperCircuit shape, tools/gpu_r3i.sh): a priority stream takes a hardware queue of its own, and which
     // streams share queues decides the upload rate (DESIGN "stream topology").
     bool ensure_aux() {
-        if (stream_aux) return true;
+        // stream and event are a pair: whoever created the stream (zk_ctx_debug_delay can), the event exists when this returns true
+        if (stream_aux) return ev_aux || hipEventCreateWithFlags(&ev_aux, hipEventDisableTiming) == hipSuccess;
         int least = 0, greatest = 0;
         const char* e = getenv("ZK_AUX_PRIORITY");
         const bool prio = e && atoi(e) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
