@@ -238,7 +238,9 @@ int zk_msm_g1(zk_ctx* ctx, const void* d_scalars, const void* d_bases, size_t n,
 int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, size_t n, void* h_out_affine);
 /* `count` commitments over the same basis (ParamsKZG::commit_lagrange over every advice column
  * of a phase): d_scalar_ptrs[i] addresses n Fr on the device, h_out_affine receives count x 64 B.
- * Consecutive MSMs are pipelined on two streams.                                                 */
+ * Consecutive MSMs are pipelined on side streams.  Each column is judged on the device first (4096
+ * sampled cells): columns with at most a quarter of field-sized cells (>= 2^64) take the per-window
+ * path of zk_commit_batch_hint's hint 1 -- a choice that affects speed only, never the result.     */
 int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine);
 /* zk_commit_batch for columns still in host memory: column i+1 is uploaded (copy stream) while the
  * MSM of column i runs; d_cols[i] (n x 32 B device buffers) receive the columns.  This is the shape
@@ -444,6 +446,11 @@ int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* proof, zk_allgather_fn gat
  * refused, nothing is written -- and receives the number written (zk_pk_shape: total challenges). */
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols,
                           void* h_challenges, uint32_t* num_challenges);
+/* The same phase for witness columns RESIDENT ON THE DEVICE (device pointers, n x 32 B each, Montgomery form): a witness generated
+ * on the GPU or uploaded ahead of the proof.  The session copies them device to device into its own buffers (it overwrites the
+ * blinding rows; the caller's columns stay untouched) and judges small / dense columns on the device.  Same proof bytes.        */
+int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols,
+                              void* h_challenges, uint32_t* num_challenges);
 /* consumes the session (freed on success and on failure)                                         */
 int zk_proof_finish(zk_ctx* ctx, zk_proof* proof, void* h_proof, size_t proof_cap, size_t* proof_len);
 void zk_proof_abort(zk_ctx* ctx, zk_proof* proof);

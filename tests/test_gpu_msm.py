@@ -374,3 +374,32 @@ def test_groups_of_small_valued_columns(ctx, cref, group):
     for b_ in bufs:
         b_.free()
     srs.destroy()
+
+
+@pytest.mark.parametrize("k", [14, 20])
+def test_mixed_columns_without_hints(ctx, cref, k):
+    """Witness-like columns (scalar set (b): 60 % zero / 30 % < 2^16 / 10 % uniform per cell, and the same with 0.1 %
+    and 50 % field-sized cells) committed WITHOUT a hint: zk_commit_batch judges each column on the device (at most a quarter of
+    sampled cells >= 2^64 -> per-window path, else merged windows); whatever it picks, the point is best_multiexp's."""
+    n = 1 << k
+    rng = np.random.default_rng(k)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(0xFACE + k))
+    basis = srs.download_g_lagrange()
+    cols = []
+    for frac_large in (0.001, 0.10, 0.50):
+        u = rng.random(n)
+        small = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+        small[u < 0.6] = 0
+        col = cref.to_mont([int(v) for v in small])
+        big = np.flatnonzero(u >= 1 - frac_large)
+        col[big] = cref.rand_fr_stream(int(1000 * frac_large) + k, big.size)         # uniform field elements (Montgomery images of uniform values)
+        cols.append(col)
+    bufs = [ctx.to_device(c) for c in cols]
+    want = np.stack([cref.best_multiexp(c, basis) for c in cols])
+    got = ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=True)                  # hint-free
+    assert np.array_equal(got, want)
+    for hint in ([1, 1, 1], [0, 0, 0]):                                                      # and both paths when forced
+        assert np.array_equal(ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=True, narrow=hint), want)
+    for b_ in bufs:
+        b_.free()
+    srs.destroy()

@@ -418,6 +418,33 @@ def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen
     assert first_diff is None, f"proofs differ from byte {first_diff} (32-byte item {first_diff // 32})"
 
 
+def test_device_resident_witness_gives_the_same_bytes(ctx, cref, srs8):
+    """zk_proof_advice_phase_dev: the witness columns handed over as device buffers (resident in HBM before the session starts)
+    yield the bytes of the host-column call, and the caller's buffers are left as they were (the session blinds its own copies)."""
+    circ, adv, inst = build_circuit(7, seed=21, wide=True)
+    pk = ctx.pk_create(srs8[circ.k], circ.blob())
+    adv_m = [plonk.column_to_mont(c) for c in adv]
+    inst_m = [plonk.column_to_mont(c) for c in inst]
+    try:
+        def run(dev):
+            sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
+            sess.set_multiopen(1)
+            if dev:
+                bufs = {i: ctx.to_device(c) for i, c in enumerate(adv_m)}
+                sess.advice_phase_dev(bufs)
+                out = sess.finish()
+                for i, b_ in bufs.items():
+                    assert np.array_equal(b_.download((circ.n, 4)), adv_m[i])
+                    b_.free()
+                return out
+            sess.advice_phase({i: c for i, c in enumerate(adv_m)})
+            return sess.finish()
+        host, dev = run(False), run(True)
+    finally:
+        pk.destroy()
+    assert len(host) > 500 and host == dev
+
+
 def test_rotation_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8):
     from oracle import plonk_prover as pp
     from plonk_fixtures import build_rotation_circuit

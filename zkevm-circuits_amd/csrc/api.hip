@@ -431,7 +431,12 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine) {
 // bucket reduction of column i runs on a side stream under the sort + accumulation of column i+1).
 int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr);
+    ZK_REQUIRE(ctx, d_scalar_ptrs || !count, "null pointer");
+    // no hints from the caller: the columns are judged on the device (4096 sampled cells each, one launch per batch) and those with
+    // at most a quarter of field-sized cells take the per-window path
+    std::vector<uint8_t> narrow(count);
+    if (int rc = zk::sample_narrow_dev(ctx, d_scalar_ptrs, count, n, narrow.data())) return rc;
+    return zk::commit_batch_staged(ctx, srs, basis, d_scalar_ptrs, count, n, h_out_affine, nullptr, nullptr, narrow.data());
 }
 // The same with a hint per column (nullable): 1 = small integers (selectors, bytes, counters, lookup
 // multiplicities), 2 = long runs of equal values (running products) -- see zkmi355.h.
@@ -477,22 +482,25 @@ namespace zk {
 // (bytes, flags, counters, selectors) and those take the per-window MSM path, which never touches
 // the bucket sets of empty windows; only a sample is inspected (the choice affects speed, never the
 // result).  Columns are in Montgomery form: a sampled value is converted back before it is judged.
+// A column counts as small-valued when at most a quarter of the sampled cells are >= 2^64: the per-window path carries a
+// minority of field-sized cells (RLC accumulators, hash outputs among bytes; SURVEY 8d's "60 % zero / 30 % < 2^16 / 10 % uniform")
+// as a thin layer over all its windows and still beats the merged path -- measured per 2^20 column in a batch (tools/msm_dist.py):
+// 10 % large cells 0.40 against 0.53 ms, 1 % 0.32 / 0.49, a third 0.70 / 0.69 (the break-even).
+static constexpr size_t NARROW_MAX_LARGE_NUM = 1, NARROW_MAX_LARGE_DEN = 4;
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow) {
-    // 1024 samples per column, each one Montgomery product on the host (24 ns); a small-valued column passes every sample, so
-    // nothing ends early: 25 ms IN FRONT of the first upload of a 1000-column advice phase on one thread -- now on up to eight.
-    // (Fewer samples would let a column with a fraction of a percent of large values slip through as "small", and the per-window
-    // path pays for those in every window; one run with 256 samples came out 6-14 % slower on both proof shapes, on a box that
-    // was not measured against itself -- the count was left alone.)
+    // 1024 samples per column, each one Montgomery product on the host (24 ns): 25 ms IN FRONT of the first upload of a
+    // 1000-column advice phase on one thread -- on up to eight.
     const size_t samples = n < 1024 ? n : 1024, step = n / (samples ? samples : 1);
     auto judge = [&](size_t c0, size_t c1) {
         for (size_t c = c0; c < c1; ++c) {
             const host::F4* col = (const host::F4*)h_cols[c];
-            bool small = col != nullptr;
-            for (size_t i = 0; small && i < samples; ++i) {
+            size_t large = 0;
+            const size_t allowed = samples * NARROW_MAX_LARGE_NUM / NARROW_MAX_LARGE_DEN;
+            for (size_t i = 0; col && large <= allowed && i < samples; ++i) {
                 const host::F4 v = host::fr_canon(col[i * step + (i * 7 + c) % (step ? step : 1)]);
-                small = (v.l[1] | v.l[2] | v.l[3]) == 0;
+                large += (v.l[1] | v.l[2] | v.l[3]) != 0;
             }
-            narrow[c] = small ? 1 : 0;
+            narrow[c] = col && large <= allowed ? 1 : 0;
         }
     };
     const size_t threads = count >= 64 ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency())) : 1;
@@ -505,6 +513,38 @@ void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* n
     } catch (...) {}                         // no thread to be had (a process at its limit): the rest is judged here; nothing unwinds across the C ABI
     if (started < count) judge(started, count);
     for (std::thread& th : pool) th.join();
+}
+// The same judgement for columns that are already on the device: one workgroup per column converts 4096 evenly spread cells
+// and counts the ones >= 2^64; one launch and one small download per batch.
+__global__ void __launch_bounds__(256) k_sample_large(const Fr* const* __restrict__ cols, uint64_t n, uint32_t* __restrict__ large) {
+    const Fr* col = cols[blockIdx.x];
+    const uint64_t samples = n < 4096 ? n : 4096, step = n / (samples ? samples : 1);
+    uint32_t cnt = 0;
+    for (uint64_t i = threadIdx.x; i < samples; i += 256) {
+        const Fr v = from_mont(ldg(col + i * step + (i * 7 + blockIdx.x) % (step ? step : 1)));
+        cnt += (v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7]) != 0;
+    }
+    __shared__ uint32_t tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    atomicAdd(&tot, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) large[blockIdx.x] = tot;
+}
+int sample_narrow_dev(zk_ctx* ctx, const void* const* d_cols, size_t count, size_t n, uint8_t* narrow) {
+    if (!count) return ZK_OK;
+    char* scratch = (char*)ctx->get_scratch(SC_TMP, count * 12);
+    if (!scratch) return ctx->fail(ZK_ERR_OOM, "column classification: scratch allocation failed");
+    ZK_HIP(ctx, hipMemcpyAsync(scratch, d_cols, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* d_large = (uint32_t*)(scratch + count * 8);
+    hipLaunchKernelGGL(k_sample_large, dim3((unsigned)count), dim3(256), 0, ctx->stream, (const Fr* const*)scratch, (uint64_t)n, d_large);
+    ZK_CHECK_LAUNCH(ctx);
+    std::vector<uint32_t> large(count);
+    ZK_HIP(ctx, hipMemcpyAsync(large.data(), d_large, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t samples = n < 4096 ? n : 4096;
+    for (size_t c = 0; c < count; ++c) narrow[c] = large[c] <= samples * NARROW_MAX_LARGE_NUM / NARROW_MAX_LARGE_DEN ? 1 : 0;
+    return ZK_OK;
 }
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
     if (count == 0) return ZK_OK;            // an empty batch (a circuit without permutation columns or lookups) commits nothing

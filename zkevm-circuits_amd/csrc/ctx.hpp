@@ -235,7 +235,8 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
 int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr,
                   const uint8_t* narrow = nullptr /*per column: scalars fill few windows*/);
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow = nullptr);
-void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = every sampled value is below 2^64
+void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = at most a quarter of the sampled values are >= 2^64
+int sample_narrow_dev(zk_ctx* ctx, const void* const* d_cols, size_t count, size_t n, uint8_t* narrow);   // the same for columns resident on the device
 int lookup_multiplicities_enqueue(zk_ctx* ctx, const Fr* const* d_inputs, size_t num_inputs, const Fr* d_table, size_t usable_rows, Fr* d_m, size_t n, uint32_t* d_status, bool reuse_hash = false);   // lookup.hip, no sync
 // row checks of zk_mock_verify (lookup.hip; enqueued on the context's stream, no sync)
 struct MockFail { uint32_t kind, index, sub, row; };          // == zk_mock_failure

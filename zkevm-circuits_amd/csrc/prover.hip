@@ -759,7 +759,18 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
 // in challenge-index order).  When h_challenges is given, *num_challenges holds its capacity (in
 // challenges) on entry; on return it holds how many the phase produced.
 static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr);
+static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src);
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
+    return advice_phase_impl(ctx, pr, col_index, h_cols, ncols, h_challenges, num_challenges, false);
+}
+// The same phase for witness columns that are RESIDENT ON THE DEVICE (n x 32 B each, Montgomery, device pointers): a witness
+// generated on the GPU, or one uploaded ahead of the proof.  The columns are copied (device to device, on the copy stream) into
+// the session's own buffers -- the caller's stay untouched: the session overwrites the blinding rows -- and judged small / dense
+// on the device.  Same transcript, same bytes as the host-column call.
+int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
+    return advice_phase_impl(ctx, pr, col_index, d_cols, ncols, h_challenges, num_challenges, true);
+}
+static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
     ZK_REQUIRE(ctx, pr && (ncols == 0 || (col_index && h_cols)), "null pointer");
@@ -785,6 +796,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         zk_ctx* ctx; size_t body, tail;
         std::vector<const void*> src; std::vector<void*> dst; std::vector<F4> blind_v; const F4* blind = nullptr;
         uint32_t world = 1;
+        hipMemcpyKind kind = hipMemcpyHostToDevice;                       // device-resident witness: device to device
         std::vector<size_t> own;                                         // device-gather mode: only these columns are uploaded by this rank
         const zk_pk* pk = nullptr; std::vector<DevBuf*> lag, coeff;     // coefficient forms are produced as the columns arrive
         // plain (unsharded) sessions: coefficient forms AND the planned cosets of the columns, several columns per launch, on the
@@ -827,6 +839,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     } sg{ctx, (size_t)pk->u * 32, (size_t)(pk->bf + 1) * 32, {}, {}, {}};   // halo2: advice_values[n - (blinding_factors + 1)..] are random, row u included
     sg.pk = pk;
     sg.pr = pr;
+    sg.kind = dev_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
         if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
@@ -862,7 +875,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         if (!s_->own.empty()) {      // device-gather mode: one own column per call
             if (it > 0) PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
             const size_t c_ = s_->own[it];
-            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             PK_TRY(copy_stream_fence(s_->ctx));
             ZK_HIP(s_->ctx, hipStreamWaitEvent(s_->ctx->stream_aux, s_->ctx->ev_copy, 0));
@@ -879,7 +892,7 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
         static const bool skip_upload = getenv("ZK_DEBUG_SKIP_UPLOAD") != nullptr;       // measurement only (the proof is garbage): is the phase bound by PCIe or by the device?
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
             if (skip_upload) continue;
-            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, hipMemcpyHostToDevice, s_->ctx->stream_copy));
+            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
         }
         PK_TRY(copy_stream_fence(s_->ctx));
@@ -888,7 +901,8 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, 
     };
     std::vector<G1Affine> coms(sg.dst.size());
     std::vector<uint8_t> narrow(sg.src.size());
-    sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of small values take the per-window MSM path
+    if (dev_src) PK_TRY(sample_narrow_dev(ctx, sg.src.data(), sg.src.size(), n, narrow.data()));
+    else sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of (mostly) small values take the per-window MSM path
     trace.mark("  advice: columns sampled");
     // ... and their blinding rows (the last blinding_factors + 1, field-sized) are committed apart, so that they do not occupy every window
     struct TailGuard { zk_ctx* c; ~TailGuard() { c->msm_blinded_tail = 0; } } tail_guard{ctx};
