@@ -1,27 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json configs[1]: standalone BN254 G1 MSM 2^20 + Fr NTT 2^20 on MI355X.
+"""bench.py -- BASELINE.json's metric: "SuperCircuit proof-gen wall-clock (s) at k; MSM Mscalar/s + NTT Gfield-op/s vs HBM roofline".
 
-A "step" is one pass of the hot path over one column: KZG-commit a 2^20-row column
-(`commit_lagrange` = one 2^20 MSM over g_lagrange) and transform it (`lagrange_to_coeff` = one 2^20
-NTT).  Inputs are resident in HBM before the timed region starts.  The steps walk a ROTATING set of
-32 distinct columns to commit and 32 distinct columns to transform (2 GiB, eight times the 256 MiB
-Infinity Cache), so no step finds its input in a cache the previous step filled.  Columns are
-submitted the way a prover phase submits them: a batch of commitments (pipelined on the device),
-then the batch of transforms (zk_ntt_batch).
+A "step" is ONE FULL PROOF of the SuperCircuit-shape circuit at k = 20 (BASELINE configs[3] -- it fits one MI355X: ~185 of
+288 GB -- stand-in circuit of SURVEY 8d config 4: 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9;
+the reference's own witness needs its Rust + Go toolchain, so every number here is "synthetic-shape"):
+  * witness cells distributed as SURVEY 8d prescribes -- ~60 % zero / ~30 % below 2^16 / 10 % uniform field elements PER CELL;
+  * THREE advice phases with the SuperCircuit's challenges (evm_word, keccak_input after the first, lookup_input after the
+    second [REF zkevm-circuits/src/util.rs:120-133]); the two challenge-dependent columns are computed between the phases;
+  * SHPLONK + Blake2b as at [REF circuit-benchmarks/src/super_circuit.rs:117-132];
+  * the witness columns are RESIDENT IN HBM when the timed region starts (zk_proof_advice_phase_dev).  The same proof from
+    page-locked host memory (what a Rust caller hands over) is timed beside it: `pcie_inclusive_s`.
+`value` = seconds per proof over the K timed steps (lower is better), the proof checked afterwards by the oracle verifier
+(outside the timed region).  The same line carries
+  * `roofline`   -- the dominant kernel class of the proof, the size-2^20 NTT (k_ntt_pass + k_ntt_last), HIP events over the
+                    timed region; `rooflines` -- MSM bucket accumulation and the quotient evaluator beside it;
+  * `proof_roofline` -- sum of the algorithmic bytes of the proof's stages (SURVEY 8d, K1-K10 counts) / wall-clock / 8 TB/s;
+  * `msm_ntt`    -- BASELINE configs[1]: MSM 2^20 Mscalar/s and NTT 2^20 Gfield-op/s over rotating columns (what rounds 1-3 headlined);
+  * `cpu_baseline` -- halo2's create_proof restated on the host cores, Keccak shape at k = 18 (BASELINE configs[2]), with the GPU
+                    time of the same circuit / witness / seed (same bytes required);
+  * `proof`      -- the other shapes and witness distributions, one prover process each.
 
-`python bench.py --gpus N` launches itself as N ranks (torch.distributed.run, one rank per GPU,
-backend nccl = RCCL) when it was not started under a launcher already.  Multi-GPU: the
-prover shards by column -- rank r commits / transforms its own columns, no data-path collective;
-the only exchange is the all-gather of the 64-byte commitments that a transcript round needs, done
-once per commitment batch (`all_gather_into_tensor`), as the prover does per phase.  Weak scaling.
-
-Prints ONE JSON line (rank 0).  `value` = scalars committed per second over all ranks (Mscalar/s)
-with the step's NTT included in the time.  On one GPU the line also carries
-  * `roofline` (dominant kernel, k_msm_buckets) and `rooflines` (every kernel class of the path),
-  * `cpu_baseline` (the C oracle on the host cores),
-  * `proof`: BASELINE's headline metric -- full-proof wall-clock of the SuperCircuit-shape circuit
-    (k = 20) and of the Keccak-shape circuit (k = 18), each verified by the oracle's pairing verifier
-    (synthetic-shape: the reference's witnesses need its Rust + Go toolchain).
+`python bench.py --gpus N` launches itself as N ranks (torch.distributed.run, 127.0.0.1) when not started under a launcher.
+N > 1: ONE proof sharded over the ranks -- commitments by column, quotient by (class, coset), witness uploaded by
+its owner and all-gathered device to device over the library's RCCL communicator; strong scaling, value = seconds per proof.
 """
 import argparse
 import json
@@ -37,13 +38,18 @@ sys.path.insert(0, ROOT)
 
 K = 20
 N = 1 << K
-NCOL = 32                  # rotating set: 32 x 32 MiB committed + 32 x 32 MiB transformed (2 GiB, eight times the Infinity Cache)
+NCOL = 32                  # msm_ntt section: 32 x 32 MiB committed + 32 x 32 MiB transformed (2 GiB, eight times the Infinity Cache)
+SC_SHAPE = (20, 1000, 150, 150, 100, 9)      # k, advice, fixed, permutation columns, lookups, degree
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G) of the library's own product routine (tools/ubench.hip)
 MAD_PEAK_T = 30.4          # measured v_mad_u64_u32 lane-ops/s (T), tools/ubench.hip: the hardware-side bound
 MADS_PER_PRODUCT = 162     # v_mad_u64_u32 per 9 x 29-bit Montgomery product (81 operand + 81 reduction, counted in the ISA)
-MADS_PER_MIXED_ADD = 1476  # per XYZZ mixed addition (csrc/ec29.hip.hpp madd29): 6 products x 162 + 2 squares x 126 + one two-product pass (243) + 9 (k p test)
+MADS_PER_MIXED_ADD = 1476  # per XYZZ mixed addition (csrc/ec29.hip.hpp madd29)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+DTYPE = "u32x8 limbs (254-bit modular integer, Montgomery)"
+METRIC = "SuperCircuit-shape proof-gen wall-clock (s) at k = 20"
+WORKLOAD = ("BASELINE configs[3] stand-in: SuperCircuit shape k = 20 (1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9), "
+            "three advice phases, witness 60/30/10 per cell (SURVEY 8d), SHPLONK, Blake2b; one full proof per step")
 
 
 def relaunch_under_launcher(args) -> int:
@@ -60,247 +66,312 @@ def relaunch_under_launcher(args) -> int:
     return subprocess.call(cmd)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-proof", action="store_true", help="skip the full-proof section (N = 1 only)")
-    ap.add_argument("--proof-worker", default="", help=argparse.SUPPRESS)      # internal: run ONE proof shape in this process and print its record
-    ap.add_argument("--batch", type=int, default=32, help="columns submitted per commit_batch call (pipelined on the device; a prover phase commits tens to a thousand)")
-    args = ap.parse_args()
-
-    if args.proof_worker:
-        print(json.dumps(proof_worker(args.proof_worker)), flush=True)
-        return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(relaunch_under_launcher(args))
-
+def fr_mont(v: int):
     import numpy as np
-    import torch  # device plumbing + torch.distributed only
+    x = (v << 256) % R_MOD
+    return np.array([(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    shared_gpu = world > ndev           # fewer GPUs than ranks (single-GPU test box): ranks share devices, exchange over gloo
-    local_rank %= max(ndev, 1)
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        if shared_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+def hbm_roof(kernel, alg_bytes, ms, note, products=None, launches=None):
+    """roofline record of one kernel class: algorithmic bytes / measured time against the HBM peak (the metric's roof) plus, where
+    given, the integer-ALU roof that binds"""
+    if not ms:
+        return None
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    rec = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "note": note, "traffic": None}
+    if launches is not None:
+        rec["launches_timed"] = launches
+    if products:
+        gps = products / (ms * 1e-3) / 1e9
+        rec["alu"] = {"unit": "G Montgomery-product equivalents/s (162 multiply-adds each)", "achieved": round(gps, 1), "peak_own_routine": MULPEAK_G, "frac_own_routine": round(gps / MULPEAK_G, 3),
+                      "peak_v_mad_u64_u32": round(MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT, 1), "frac_v_mad_u64_u32": round(gps / (MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT), 3)}
+    return rec
+
+
+def committed_traffic(key):
+    """PMC traffic (FETCH_SIZE + WRITE_SIZE per launch) from the newest committed rocprofv3 --pmc passes under profiles/"""
+    for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            try:
+                v = json.load(open(tpath)).get(key)
+            except Exception:
+                v = None
+            if v:
+                return v, tname
+    return None, None
+
+
+def proof_algorithmic_bytes(circ, shplonk=True, uniform_random_poly=False):
+    """SURVEY 8d "ALGORITHMIC bytes per unit of work", summed over one create_proof with the K1-K10 counts of this circuit:
+    what a prover that touched every operand exactly once per stage would move.  n = 2^k rows of 32 B."""
+    n = circ.n
+    d, A, F, I, P, L = circ.degree(), circ.A, circ.F, circ.I, len(circ.perm_cols), len(circ.lookups)
+    C = (P + d - 3) // (d - 2) if P else 0
+    cosets = 1 << (circ.extended_k() - circ.k)
+    inputs = sum(len(lk.inputs) for lk in circ.lookups)
+    committed_lagrange = A + 2 * L + C                               # advice, m and phi per lookup, Z per chunk
+    msm = committed_lagrange + (d - 1) + (2 if shplonk else 0) + (1 if uniform_random_poly else 0)
+    opened = A + F + P + C + 2 * L + 2                               # polynomials the multi-open touches (h and the random polynomial included)
+    b = {
+        "msm (K1): 96 B x n per commitment": 96 * n * msm,
+        "lagrange_to_coeff (K2): 64 B x n per polynomial": 64 * n * (committed_lagrange + I),
+        "coset transforms (K3): 64 B x n per polynomial per coset": 64 * n * (A + I + C + 2 * L) * cosets,
+        "quotient evaluation (K4/K5): 32 B x n x (columns + 1) per coset": 32 * n * (A + F + I + P + C + 2 * L + 3 + 1) * cosets,
+        "extended_to_coeff of h (K6): 64 B x n per coset": 64 * n * cosets,
+        "permutation products (K7): ratio programs + inversion + scan": (32 * n * (2 * P + 2) + 64 * n * 2) * 1 if not C else (32 * n * (2 * P + 2 * C) + 2 * 64 * n * C),
+        "lookups (K8): compression, multiplicities, inversion, scan": 32 * n * (3 * inputs + 3 * L) + 3 * 64 * n * L,
+        "evaluations (K9): 32 B x n per opened polynomial": 32 * n * opened,
+        "multi-open (K10/K11): two linear combinations over the opened polynomials": 2 * 32 * n * (opened + 1),
+    }
+    return b
+
+
+def device_sync(ctx, torch):
+    # the library's streams belong to the HIP runtime it links (/opt/rocm), torch's to the one torch bundles:
+    # torch.cuda.synchronize() alone would not wait for what the library left in flight
+    ctx.sync()
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------ N = 1: the headline
+def headline_single(args, torch):
+    import numpy as np
+
+    import bench_proof as bp
+    import zkevm_circuits_amd as z
+
+    ctx = z.Context(0)
+    t0 = time.perf_counter()
+    circ, blob, adv_m, inst_m, inst, rlc = bp.build_shape(ctx, *SC_SHAPE, dist="survey", phases=True)
+    t_build = time.perf_counter() - t0
+    dist = bp.cell_distribution(adv_m[:SC_SHAPE[1] - 2])
+    npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
+    inst = [list(col[:m]) for col, m in zip(inst, npub)]
+    inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
+    S = 0x5EC2E7
+    srs = ctx.srs_setup_with_s(circ.k, fr_mont(S))
+    t0 = time.perf_counter()
+    pk = ctx.pk_create(srs, blob)
+    ctx.sync()
+    t_keygen = time.perf_counter() - t0
+    del blob
+    # the witness, resident in HBM: one device buffer per advice column (aliased host arrays become distinct device columns)
+    t0 = time.perf_counter()
+    adv_dev = [ctx.to_device(a) for a in adv_m]
+    ctx.sync()
+    t_upload = time.perf_counter() - t0
+    driver = bp.PhaseDriver(ctx, circ, adv_dev, rlc)
+    state = {}
+
+    def step():
+        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+        sess.set_multiopen(1)
+        state["challenges"] = driver.run(sess)
+        state["proof"] = sess.finish()
+
+    for _ in range(args.warmup):
+        step()
+    device_sync(ctx, torch)
+    ctx.prof_reset()
+    ctx.prof_enable(2)           # HIP events around the roofline kernels only (NTT passes, bucket accumulation, quotient evaluator)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    device_sync(ctx, torch)
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    prof = {name: ctx.prof_get(name) for name in ctx.prof_names()}
+    prof_bytes = {name: ctx.prof_get_bytes(name) for name in prof}
+    per_proof = elapsed / args.steps
+
+    # ---- outside the timed region: the proof is checked, the same proof is made from page-locked host memory
+    verified = None
+    if not args.no_verify:
+        from oracle import cref, pairing as pr, plonk_verifier as pv
+        com, rep = pk.vk(circ.F + len(circ.perm_cols))
+        verified = bool(pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst, state["proof"], pr.ec_mul(pr.G2_GEN, S), multiopen="shplonk"))
+    pcie = None
+    try:
+        pinned = {}
+        for a in adv_m[:SC_SHAPE[1] - 2]:
+            if id(a) not in pinned:
+                pinned[id(a)] = ctx.host_alloc(a.shape)
+                pinned[id(a)][:] = a
+        host_cols = [pinned[id(a)] for a in adv_m[:SC_SHAPE[1] - 2]]
+        w_h, t_h = ctx.host_alloc((circ.n, 4)), ctx.host_alloc((circ.n, 4))
+        times = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+            sess.set_multiopen(1)
+            ph = circ.advice_phase
+            ch0 = sess.advice_phase({i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 0})
+            driver._rlc(0, ch0[0], rlc["w"])
+            w_h[:] = adv_dev[rlc["w"]].download((circ.n, 4))          # a host caller synthesises the RLC column on the host; here it comes back from the device
+            ch1 = sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 1}, rlc["w"]: w_h})
+            driver._rlc(rlc["w"], ch1[0], rlc["t"])
+            t_h[:] = adv_dev[rlc["t"]].download((circ.n, 4))
+            sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 2}, rlc["t"]: t_h})
+            host_proof = sess.finish()
+            times.append(time.perf_counter() - t1)
+        pcie = {"value": round(min(times), 4), "unit": "s", "same_proof_bytes": host_proof == state["proof"],
+                "note": "the same proof with the witness in page-locked HOST memory (zk_proof_advice_phase): 33.5 GB cross PCIe inside the proof; what a Rust caller of "
+                        "create_proof pays today.  Never `value` (inputs resident in HBM)."}
+        for a in list(pinned.values()) + [w_h, t_h]:
+            ctx.host_free(a)
+    except Exception as e:       # the headline must survive this side measurement
+        pcie = {"error": repr(e)}
+
+    # ---- rooflines of the proof's kernel classes, from the events of the timed region
+    n = circ.n
+    ntt_ms = prof.get("ntt_pass", (0.0, 0))[0] + prof.get("ntt_last", (0.0, 0))[0]
+    ntt_bytes = prof_bytes.get("ntt_pass", 0) + prof_bytes.get("ntt_last", 0)
+    transforms = ntt_bytes / (64.0 * n) if ntt_bytes else 0
+    traffic_ntt, tsrc_ntt = committed_traffic("ntt_bytes_per_transform")
+    roof_ntt = None
+    if transforms:
+        roof_ntt = hbm_roof("k_ntt_pass + k_ntt_last (one size-2^20 transform: lagrange_to_coeff / coset forms)", 64.0 * n, ntt_ms / transforms,
+                            "dominant kernel class of the proof by device time; algorithmic bytes = 64 B x 2^20 per transform (read once, write once; SURVEY 8d); `avg_launch_ms` is per TRANSFORM "
+                            "(both launches, up to four columns share a launch); VALU-issue bound: 10.5 M Montgomery products per transform", products=n * circ.k / 2.0,
+                            launches=prof.get("ntt_pass", (0, 0))[1] + prof.get("ntt_last", (0, 0))[1])
+        roof_ntt["transforms_per_proof"] = round(transforms / args.steps, 1)
+        roof_ntt["device_ms_per_proof"] = round(ntt_ms / args.steps, 2)
+        roof_ntt["traffic"] = traffic_ntt
+        roof_ntt["traffic_source"] = f"profiles/{tsrc_ntt}" if traffic_ntt else None
+    bk = prof.get("msm_buckets", (0.0, 0))
+    traffic_msm, tsrc_msm = committed_traffic("msm_buckets_bytes_per_launch")
+    roof_msm = hbm_roof("k_msm_buckets (merged-window launches of the proof: dense and mixed columns)", 96.0 * n, bk[0] / bk[1] if bk[1] else 0,
+                        "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 per commitment (SURVEY 8d)", launches=bk[1])
+    if roof_msm:
+        roof_msm["device_ms_per_proof"] = round(bk[0] / args.steps, 2)
+        roof_msm["traffic_dense_column"] = traffic_msm
+    q = prof.get("quotient_coset", (0.0, 0))
+    roof_q = None
+    if q[1]:
+        qb = prof_bytes.get("quotient_coset", 0)
+        roof_q = {"kernel": "k_quotient_eval (degree-class launches)", "bound": "hbm", "achieved": round(qb / (q[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(qb / (q[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "device_ms_per_proof": round(q[0] / args.steps, 2), "launches_timed": q[1],
+                  "algorithmic_bytes_per_proof": int(qb / args.steps), "traffic": None,
+                  "note": "bytes = what the launches stream: 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result), counted by the library"}
+    alg = proof_algorithmic_bytes(circ)
+    alg_total = sum(alg.values())
+    out = {
+        "metric": METRIC,
+        "value": round(per_proof, 4),
+        "unit": "s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(per_proof * 1e3, 2),
+        "higher_is_better": False,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": DTYPE,
+        "data": "synthetic-shape",
+        "config": {"workload": WORKLOAD, "k": circ.k, "advice": circ.A, "fixed": circ.F, "permutation_columns": len(circ.perm_cols), "lookups": len(circ.lookups),
+                   "degree": circ.degree(), "extended_k": circ.extended_k(), "advice_phases": circ.num_phases(), "advice_columns_per_phase": [circ.advice_phase.count(p) for p in range(circ.num_phases())],
+                   "challenges": len(circ.challenge_phase), "advice_queries": len(circ.advice_queries), "fixed_queries": len(circ.fixed_queries),
+                   "witness_cell_distribution": dist, "witness_residency": "HBM (device buffers handed to zk_proof_advice_phase_dev, in place: the session writes its blinding rows into them)", "multiopen": "shplonk", "transcript": "blake2b",
+                   "vanishing_random_polynomial": "constant 1 (as the reference's own proofs)", "parallelism": "single GPU"},
+        "roofline": roof_ntt,
+        "rooflines": [r for r in (roof_ntt, roof_msm, roof_q) if r],
+        "proof_roofline": {"algorithmic_bytes": int(alg_total), "achieved": round(alg_total / per_proof / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(alg_total / per_proof / 1e9 / HBM_PEAK_GBS, 4), "by_stage_bytes": {k_: int(v) for k_, v in alg.items()},
+                           "note": "sum over the stages of one create_proof of SURVEY 8d's algorithmic bytes (every operand once per stage) / wall-clock / 8 TB/s"},
+        "extra": {"proof_bytes": len(state["proof"]), "verified_by_oracle": verified, "create_proof_s_mean": round(per_proof, 4), "keygen_pk_s": round(t_keygen, 3),
+                  "witness_upload_s_outside_timing": round(t_upload, 2), "host_circuit_build_s": round(t_build, 2),
+                  "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + circ.degree() - 3) // (circ.degree() - 2) + (circ.degree() - 1) + 2,
+                  "kernel_class_device_ms_per_proof": {k_: round(v[0] / args.steps, 2) for k_, v in prof.items() if v[1]},
+                  "pcie_inclusive": pcie},
+    }
+    driver.free()
+    for b_ in adv_dev:
+        b_.free()
+    pk.destroy()
+    srs.destroy()
+    ctx.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs[1]: MSM 2^20 + NTT 2^20
+def msm_ntt_section(args, torch):
+    """Standalone BN254 G1 MSM 2^20 + Fr NTT 2^20 (BASELINE configs[1]): a batch of commitments (pipelined on the device) then the
+    batch of transforms, over rotating sets of 32 + 32 distinct columns (2 GiB, eight times the Infinity Cache), inputs resident in HBM."""
+    import numpy as np
 
     import zkevm_circuits_amd as z
 
-    def fr_mont(v: int) -> np.ndarray:
-        x = (v << 256) % R_MOD
-        return np.array([(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+    steps, warmup = 32, 16
+    ctx = z.Context(0)
+    srs = ctx.srs_setup_with_s(K, fr_mont(0xC0FFEE))
 
     def synth_column(seed: int) -> np.ndarray:
-        """n canonical Montgomery-form Fr values (252-bit uniform: always < r): dense scalars, every window occupied"""
         rng = np.random.default_rng(seed)
         a = rng.integers(0, 1 << 63, size=(N, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(N, 4), dtype=np.uint64)
         a[:, 3] &= np.uint64((1 << 60) - 1)
-        bits = int(os.environ.get("ZK_BENCH_SCALAR_BITS", "0"))      # measurement knob: witness-like small values (Montgomery images of integers < 2^bits)
-        if 0 < bits <= 60:
-            vals = rng.integers(0, 1 << bits, size=N, dtype=np.uint64)
-            mont = [(int(v) << 256) % R_MOD for v in vals]           # Montgomery images, big-int arithmetic (a second or two for 2^20)
-            return np.array([[(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)] for x in mont], dtype=np.uint64)
         return a
-
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = z.Context(local_rank, stream=stream if stream else None)
-    srs = ctx.srs_setup_with_s(K, fr_mont(0xC0FFEE))
-    first_column = synth_column(1000 * (rank + 1))
-    d_cols = [ctx.to_device(first_column if i == 0 else synth_column(1000 * (rank + 1) + i)) for i in range(NCOL)]       # committed (read-only)
-    d_work = [ctx.to_device(synth_column(5000 * (rank + 1) + i)) for i in range(NCOL)]                                   # transformed in place
-    gather = None
-    xdev = "cpu" if shared_gpu else "cuda"
-    com_t = torch.zeros(64 * args.batch, dtype=torch.uint8, device=xdev)
-    if world > 1:
-        gather = torch.zeros(64 * args.batch * world, dtype=torch.uint8, device=xdev)
+    first_column = synth_column(1000)
+    d_cols = [ctx.to_device(first_column if i == 0 else synth_column(1000 + i)) for i in range(NCOL)]
+    d_work = [ctx.to_device(synth_column(5000 + i)) for i in range(NCOL)]
     cursor = [0]
 
     def run_steps(count):
-        """`count` steps = `count` columns: the prover commits the columns of a phase as a batch
-        (halo2: commit_lagrange over every advice column), so consecutive MSMs are pipelined."""
         done = 0
         while done < count:
             b = min(args.batch, count - done)
             ids = [(cursor[0] + j) % NCOL for j in range(b)]
             cursor[0] += b
-            coms = ctx.commit_batch(srs, [d_cols[i].ptr for i in ids], N, lagrange=True)    # b x MSM 2^20, b distinct columns
-            ctx.ntt_batch([d_work[i] for i in ids], K, inverse=True)                       # b x NTT 2^20 (lagrange_to_coeff), b distinct buffers, as the prover
-                                                                                          # transforms the columns of a round (zk_ntt_batch: four columns share a launch)
-            if world > 1:
-                # one exchange per commitment round, as in the prover: every rank needs every
-                # commitment of the batch (64 B each) before the next transcript challenge
-                com_t[:64 * b].copy_(torch.from_numpy(np.ascontiguousarray(coms).view(np.uint8).reshape(-1)))
-                dist.all_gather_into_tensor(gather, com_t)
+            ctx.commit_batch(srs, [d_cols[i].ptr for i in ids], N, lagrange=True, narrow=[0] * b)
+            ctx.ntt_batch([d_work[i] for i in ids], K, inverse=True)
             done += b
-
-    def device_sync():
-        # the library's streams belong to the HIP runtime it links (/opt/rocm), torch's to the one torch bundles:
-        # torch.cuda.synchronize() alone would not wait for the transforms the last batch left in flight
-        ctx.sync()
-        torch.cuda.synchronize()
-
-    run_steps(args.warmup)
-    device_sync()
-    if world > 1:
-        dist.barrier()
-    device_sync()
+    run_steps(warmup)
+    device_sync(ctx, torch)
     ctx.prof_reset()
-    ctx.prof_enable(2)           # HIP events around the roofline kernels only (bucket accumulation, the two NTT passes)
+    ctx.prof_enable(2)
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    device_sync()
-    if world > 1:
-        dist.barrier()
-    device_sync()
+    run_steps(steps)
+    device_sync(ctx, torch)
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
-    prof_timed = {name: ctx.prof_get(name) for name in ctx.prof_names()}
-    # the other kernel groups (sort, combine, reduction) are timed in a pass of their own, outside the timed region
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    run_steps(min(args.steps, 2 * args.batch))
-    device_sync()
-    ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     prof = {name: ctx.prof_get(name) for name in ctx.prof_names()}
-    prof.update(prof_timed)      # the roofline kernels keep their timed-region figures
-    # latency of ONE commitment issued alone (nothing to hide its bucket reduction under), wall clock around a synchronous call
     lone = []
     for i in range(6):
         t1 = time.perf_counter()
         ctx.commit(srs, d_cols[i % NCOL], N, lagrange=True)
         lone.append(time.perf_counter() - t1)
-    lone_ms = sorted(lone)[len(lone) // 2] * 1e3
-    # N > 1 on real GPUs: the sharded proving session of the SuperCircuit shape (BASELINE config 4 is quoted on 8 GPUs) and of
-    # the recursion shape (config 5), every rank in a prover process of its own, exchanges through the library's RCCL
-    # communicator.  All ranks take part; only rank 0 gets the records.  Failures and time-outs stay inside the section.
-    sharded = None
-    if world > 1 and not shared_gpu and not args.no_proof:
-        for b_ in d_cols + d_work:
-            b_.free()
-        d_cols, d_work = [], []
-        try:
-            sharded = sharded_proof_section(dist, rank, world, local_rank)
-        except Exception as e:           # the MSM / NTT line must survive whatever happens in here
-            sharded = {"error": repr(e)} if rank == 0 else None
-        dist.barrier()
-    if rank == 0:
-        def avg_ms(name):
-            ms, cnt = prof.get(name, (0.0, 0))
-            return ms / cnt if cnt else None
-
-        def hbm_roof(kernel, alg_bytes, ms, note, products=None):
-            """roofline record of one kernel class: algorithmic bytes per launch / measured launch time
-            against the HBM peak (the metric's roof) plus, where given, the integer-ALU roof that binds"""
-            if not ms:
-                return None
-            ach = alg_bytes / (ms * 1e-3) / 1e9
-            rec = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                   "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "note": note}
-            if products:
-                gps = products / (ms * 1e-3) / 1e9
-                rec["alu"] = {"unit": "G Montgomery-product equivalents/s (162 multiply-adds each)", "achieved": round(gps, 1), "peak_own_routine": MULPEAK_G, "frac_own_routine": round(gps / MULPEAK_G, 3),
-                              "peak_v_mad_u64_u32": round(MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT, 1), "frac_v_mad_u64_u32": round(gps / (MAD_PEAK_T * 1e3 / MADS_PER_PRODUCT), 3)}
-            return rec
-
-        plan = ctx.msm_plan(srs, N) if hasattr(ctx, "msm_plan") else {"c": 16, "windows": 16}
-        windows = plan["windows"]
-        bucket_ms = avg_ms("msm_buckets")
-        sort_ms, comb_ms, red_ms = avg_ms("msm_sort") or 0.0, avg_ms("msm_combine") or 0.0, avg_ms("msm_reduce") or 0.0
-        msm_pipelined_ms = sort_ms + (bucket_ms or 0.0) + comb_ms            # the reduction runs on the side stream under the next MSM
-        msm_lone_ms = lone_ms                                                # what one MSM alone costs (measured above): nothing hides its reduction
-        ntt_ms = (prof.get("ntt_pass", (0, 0))[0] + prof.get("ntt_last", (0, 0))[0]) / max(args.steps, 1)
-        traffic, tsrc = None, None
-        for tname in ("traffic_r03.json", "traffic_r02.json"):           # the newest committed rocprofv3 --pmc pass of this command
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):
-                try:
-                    traffic, tsrc = json.load(open(tpath)).get("msm_buckets_bytes_per_launch"), tname
-                except Exception:
-                    traffic = None
-                if traffic:
-                    break
-        main_roof = hbm_roof("k_msm_buckets", 96.0 * N, bucket_ms,
-                             "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 (SURVEY 8d); integer-ALU bound: one mixed XYZZ addition "
-                             f"({MADS_PER_MIXED_ADD} multiply-adds = {MADS_PER_MIXED_ADD / MADS_PER_PRODUCT:.2f} Montgomery-product equivalents) per (scalar, window), {windows} windows",
-                             products=MADS_PER_MIXED_ADD / MADS_PER_PRODUCT * N * windows)
-        if main_roof:
-            main_roof["traffic"] = traffic            # PMC FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, from the committed rocprofv3 pass (profiles/); null until measured this round
-            main_roof["traffic_source"] = f"profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, per launch, as reported: the guide's x2 FETCH correction is for coalesced streaming reads and these are 64-byte gathers -- profiles/r03_pmc_traffic.md gives both)" if traffic else None
-        rooflines = [r for r in (
-            main_roof,
-            hbm_roof("k_ntt_pass + k_ntt_last (one 2^20 transform)", 64.0 * N, ntt_ms,
-                     "algorithmic bytes = 64 B x 2^20 (read once, write once); VALU-issue bound: 10.5 M Montgomery products per transform", products=N * K / 2.0),
-        ) if r]
-        out = {
-            "metric": "MSM Mscalar/s (step = KZG commit of one 2^20 column: MSM 2^20 + NTT 2^20)",
-            "value": round(world * N * args.steps / elapsed / 1e6, 3),
-            "unit": "Mscalar/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32x8 limbs (254-bit modular integer, Montgomery)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, 1 column per step per GPU", "k": K,
-                       "parallelism": f"column-sharded x{world}, all_gather(64 B commitment per column) once per commit batch, backend {'gloo (ranks share a GPU)' if shared_gpu else 'nccl (RCCL)'}" if world > 1 else "single GPU",
-                       "columns_per_commit_batch": args.batch, "rotating_columns": f"{NCOL} committed + {NCOL} transformed, 32 MiB each ({2 * NCOL * 32 >> 10} GiB working set)",
-                       "msm_window_bits": plan.get("c"), "msm_windows": windows},
-            "roofline": main_roof,
-            "rooflines": rooflines,
-            "extra": {
-                "msm_pipelined_ms": round(msm_pipelined_ms, 4),
-                "msm_pipelined_mscalar_per_s": round(N / (msm_pipelined_ms * 1e-3) / 1e6, 2) if msm_pipelined_ms else None,
-                "msm_lone_ms": round(msm_lone_ms, 4),
-                "msm_reduce_ms_on_side_stream": round(red_ms, 4),
-                "ntt_only_ms": round(ntt_ms, 4),
-                "ntt_gfieldop_per_s": round(1.5 * N * K / (ntt_ms * 1e-3) / 1e9, 2) if ntt_ms else None,
-                "ntt_algorithmic_GBps": round(64.0 * N / (ntt_ms * 1e-3) / 1e9, 1) if ntt_ms else None,
-                "kernel_avg_ms": {k: round(v[0] / v[1], 4) for k, v in prof.items() if v[1]},
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(srs, first_column)
-        for b_ in d_cols + d_work:
-            b_.free()
-        srs.destroy()
-        if world == 1 and not args.no_proof:
-            out["proof"] = proof_section()
-        if sharded is not None:
-            out["proof_sharded"] = sharded
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()          # streams, events and the scratch arenas go before the interpreter tears HIP down
+    plan = ctx.msm_plan(srs, N)
+    bucket = prof.get("msm_buckets", (0.0, 0))
+    bucket_ms = bucket[0] / bucket[1] if bucket[1] else 0
+    ntt_ms = (prof.get("ntt_pass", (0, 0))[0] + prof.get("ntt_last", (0, 0))[0]) / steps
+    traffic, tsrc = committed_traffic("msm_buckets_bytes_per_launch")
+    roof = hbm_roof("k_msm_buckets", 96.0 * N, bucket_ms,
+                    f"algorithmic bytes = 96 B x 2^20 (SURVEY 8d); integer-ALU bound: one mixed XYZZ addition ({MADS_PER_MIXED_ADD} multiply-adds) per (scalar, window), {plan['windows']} windows",
+                    products=MADS_PER_MIXED_ADD / MADS_PER_PRODUCT * N * plan["windows"], launches=bucket[1])
+    if roof:
+        roof["traffic"] = traffic
+        roof["traffic_source"] = f"profiles/{tsrc}" if traffic else None
+    rec = {
+        "workload": "BASELINE configs[1]: BN254 G1 MSM 2^20 + Fr NTT 2^20 per step, uniform scalars, batches of 32 columns",
+        "msm_mscalar_per_s": round(N * steps / elapsed / 1e6, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+        "msm_lone_ms": round(sorted(lone)[len(lone) // 2] * 1e3, 4),
+        "ntt_only_ms": round(ntt_ms, 4), "ntt_gfieldop_per_s": round(1.5 * N * K / (ntt_ms * 1e-3) / 1e9, 2) if ntt_ms else None,
+        "msm_window_bits": plan.get("c"), "msm_windows": plan["windows"],
+        "rooflines": [r for r in (roof, hbm_roof("k_ntt_pass + k_ntt_last (one 2^20 transform)", 64.0 * N, ntt_ms,
+                                                 "algorithmic bytes = 64 B x 2^20; VALU-issue bound: 10.5 M Montgomery products per transform", products=N * K / 2.0)) if r],
+    }
+    if not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline_msm_ntt(srs, first_column)
+    for b_ in d_cols + d_work:
+        b_.free()
+    srs.destroy()
+    ctx.close()
+    return rec
 
 
-def cpu_baseline(srs, column):
-    """Oracle (C restatement of halo2's best_multiexp + best_fft, OpenMP) on the host cores:
-    one 2^20 MSM + one 2^20 NTT = exactly one bench step.  Reported, never the target."""
+def cpu_baseline_msm_ntt(srs, column):
+    """Oracle (C restatement of halo2's best_multiexp + best_fft, OpenMP) on the host cores: one 2^20 MSM + one 2^20 NTT."""
     from oracle import bn254, cref
 
     bases = srs.download_g_lagrange()
@@ -310,41 +381,26 @@ def cpu_baseline(srs, column):
     t1 = time.perf_counter()
     cref.best_fft(column, bn254.omega_for_k(K), K)
     t2 = time.perf_counter()
-    return {
-        "value": round(N / (t2 - t0) / 1e6, 4),
-        "unit": "Mscalar/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"one full step on the host: MSM 2^20 ({t1 - t0:.2f} s) + NTT 2^20 ({t2 - t1:.2f} s), C oracle (halo2 best_multiexp/best_fft restated), OpenMP {threads} threads",
-        "msm_s": round(t1 - t0, 3),
-        "ntt_s": round(t2 - t1, 3),
-    }
+    return {"value": round(N / (t2 - t0) / 1e6, 4), "unit": "Mscalar/s", "cores": threads, "kind": "port",
+            "sample": f"one MSM 2^20 ({t1 - t0:.2f} s) + one NTT 2^20 ({t2 - t1:.2f} s), C oracle (halo2 best_multiexp / best_fft restated), OpenMP {threads} threads"}
 
 
-PROOF_SHAPES = ("keccak_shape_k18", "recursion_shape_k22", "supercircuit_shape_k20", "keccak_shape_k16_cpu_vs_gpu", "evm_shape_k14_mock")
+# ------------------------------------------------------------------------------------ other shapes: one prover process each
+PROOF_SHAPES = ("keccak_shape_k18", "bundle_shape_k21", "supercircuit_shape_k20_dense", "supercircuit_shape_k20_small", "evm_shape_k14_mock")
 MOCK_SHAPES = {"evm_shape_k14_mock": ("build_large", (14, 53)),                           # BASELINE configs[0] stand-in: k = 14, 159 advice columns
-               "supercircuit_shape_k20_mock": ("build_shape", (20, 1000, 150, 150, 100, 9))}      # only with ZK_BENCH_PROOFS=supercircuit_shape_k20_mock
+               "supercircuit_shape_k20_mock": ("build_shape", SC_SHAPE)}                   # only with ZK_BENCH_PROOFS=supercircuit_shape_k20_mock
 
 
-def proof_section():
-    """BASELINE's headline metric on one GPU: full-proof wall-clock of the SuperCircuit-shape circuit
-    (config 4 stand-in, k = 20: 1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9),
-    of the Keccak-shape circuit (config 3 stand-in, k = 18: 59 unusable rows, 13-rotation gates, degree 9)
-    and of the recursion shape (config 5 stand-in), SHPLONK as at [REF circuit-benchmarks/src/super_circuit.rs:117-132];
-    each proof is checked by the oracle's pairing verifier.  Every shape runs in a process of its own
-    (`bench.py --proof-worker <shape>`: a prover process holding the library and nothing else.  This process has
-    torch loaded for the launcher contract, i.e. torch's bundled HIP runtime next to the one the library links; with
-    both in one process the advice-phase uploads measured 30 % slower -- 0.88 against 0.66 ms per 32 MiB column,
-    tools/upload_order.py -- and a Rust / C prover has no torch in it)."""
-    import subprocess
-
+def proof_section(timeout=600):
+    """The other shapes and witness distributions, each in a prover process of its own (`bench.py --proof-worker <shape>`: the
+    library and nothing else -- no torch, as in a Rust / C prover), each proof checked by the oracle verifier."""
     out = {}
     only = os.environ.get("ZK_BENCH_PROOFS", "")          # measurement knob: comma-separated subset of the shapes
     for name in PROOF_SHAPES:
         if only and name not in only.split(","):
             continue
         try:
-            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", name], capture_output=True, text=True, timeout=900)
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", name], capture_output=True, text=True, timeout=timeout)
             lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
             if res.returncode != 0 or not lines:
                 out[name] = {"error": f"worker exited with {res.returncode}: {res.stderr[-400:]}"}
@@ -352,80 +408,29 @@ def proof_section():
                 out[name] = json.loads(lines[-1])
             if os.environ.get("ZK_PROVER_TRACE"):
                 sys.stderr.write(res.stderr)
-        except Exception as e:           # the MSM / NTT line must survive a failure of the proof section
+        except Exception as e:           # the headline must survive a failure here
             out[name] = {"error": repr(e)}
     return out
 
 
-def sharded_proof_section(dist, rank, world, local_rank):
-    """One prover process per rank (`--proof-worker <shape>` with the launcher's RANK / WORLD_SIZE / LOCAL_RANK in its
-    environment): the ranks join the library's own RCCL communicator through a file (zkevm-circuits_amd/rendezvous.py) and
-    run the sharded session -- commitments split by column (by points when there are fewer columns than ranks), quotient
-    split by coset, witness columns uploaded by their owner and all-gathered device to device.  Returns the records on
-    rank 0, None elsewhere."""
-    import subprocess
-
-    def host_bytes_free():
-        """what this container may still take: the cgroup's limit if it has one, the machine's free memory otherwise"""
-        free = None
-        try:
-            import psutil
-            free = psutil.virtual_memory().available
-        except Exception:
-            pass
-        try:
-            lim = open("/sys/fs/cgroup/memory.max").read().strip()
-            if lim != "max":
-                cur = int(open("/sys/fs/cgroup/memory.current").read())
-                free = min(free, int(lim) - cur) if free is not None else int(lim) - cur
-        except Exception:
-            pass
-        return free
-
-    out = {}
-    need = {"supercircuit_shape_k20": 24 << 30, "recursion_shape_k22": 8 << 30}      # host bytes per rank (blob + witness + builder temporaries)
-    for name, limit in (("supercircuit_shape_k20", 150), ("recursion_shape_k22", 120)):      # expected: 20-30 s and 15 s
-        verdict = [None]
-        if rank == 0:
-            free = host_bytes_free()
-            if free is not None and free < world * need[name]:
-                verdict[0] = f"host memory: {free >> 30} GiB free, {world} ranks x {need[name] >> 30} GiB needed"
-        dist.broadcast_object_list(verdict, src=0)               # one verdict for all ranks
-        if verdict[0]:
-            if rank == 0:
-                out[name] = {"skipped": verdict[0]}
-            continue
-        env = dict(os.environ)
-        env["ZK_COMM_ID_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}_{name}")
-        env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
-        failed = False
-        try:
-            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", name], capture_output=True, text=True, timeout=limit, env=env)
-            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-            failed = res.returncode != 0
-            if rank == 0:
-                out[name] = json.loads(lines[-1]) if not failed and lines else {"error": f"rank 0 worker exited with {res.returncode}: {res.stderr[-400:]}"}
-        except Exception as e:           # a time-out here usually means another rank failed and the collectives never completed
-            failed = True
-            if rank == 0:
-                out[name] = {"error": repr(e)}
-        if rank == 0:
-            try:
-                os.remove(env["ZK_COMM_ID_FILE"])
-            except OSError:
-                pass
-        if failed:                       # every rank sees the failure (its own exit code or the common time-out): none starts the next shape
-            break
-    return out if rank == 0 else None
-
-
-def cpu_vs_gpu_worker(k=16):
+def cpu_baseline_proof(k=18):
     """The proof-level CPU baseline, MEASURED (SURVEY 8d last row; the reference's `[Proof generation]` timer
-    [REF circuit-benchmarks/src/super_circuit.rs:115-134] needs Rust): halo2's create_proof restated over arrays with the
-    oracle's C primitives and OpenMP (oracle/cpu_prover.py: whole-extended-domain evaluate_h, as upstream's CPU prover), on the
-    Keccak shape at k = 16 -- a quarter of the rows of BASELINE config 3, so that the run stays around ten to thirty seconds of
-    host time -- beside the GPU session on the SAME circuit, witness, seed and vk.transcript_repr: the two proofs must be the
-    same bytes.  Key generation (fixed / sigma forms, halo2's keygen_pk) and the SRS are outside both timings."""
+    [REF circuit-benchmarks/src/super_circuit.rs:115-134] needs Rust): halo2's create_proof restated over arrays with the oracle's C
+    primitives and OpenMP (oracle/cpu_prover.py: whole-extended-domain evaluate_h, as upstream's CPU prover), on the Keccak shape at
+    k = 18 (BASELINE configs[2]) -- the SuperCircuit shape at k = 20 (1300 MSMs of 2^20) would take the host a quarter of an hour --
+    beside the GPU session on the SAME circuit, witness, seed and vk.transcript_repr: the two proofs must be the same bytes.  Key
+    generation and the SRS are outside both timings.  Runs in a process of its own (`--proof-worker keccak_shape_cpu_vs_gpu`)."""
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", f"keccak_shape_cpu_vs_gpu:{k}"], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not lines:
+            return {"error": f"worker exited with {res.returncode}: {res.stderr[-400:]}"}
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def cpu_vs_gpu_worker(k=18):
     import numpy as np
 
     import bench_proof as bp
@@ -437,23 +442,21 @@ def cpu_vs_gpu_worker(k=16):
     circ, blob, adv_m, inst_m, inst = bp.build_keccak_shape(ctx, k)
     npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
     inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
-    pinned = []
-    for a in adv_m:
-        h = ctx.host_alloc(a.shape)
-        h[:] = a
-        pinned.append(h)
     srs = ctx.srs_setup_with_s(k, cref.fr_const(S))
     pk = ctx.pk_create(srs, blob)
     _, rep = pk.vk(circ.F + len(circ.perm_cols))
     repr_int = cref.from_mont(rep.reshape(1, 4))[0]
+    adv_dev = [ctx.to_device(a) for a in adv_m]
     gpu_times, gpu_proof = [], b""
     for _ in range(4):
         t0 = time.perf_counter()
         sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
         sess.set_multiopen(1)
-        sess.advice_phase({i: c for i, c in enumerate(pinned)})
+        sess.advice_phase_dev({i: c for i, c in enumerate(adv_dev)}, in_place=True)
         gpu_proof = sess.finish()
         gpu_times.append(time.perf_counter() - t0)
+    for b_ in adv_dev:
+        b_.free()
     pk.destroy()
     srs.destroy()
     ctx.close()
@@ -465,18 +468,13 @@ def cpu_vs_gpu_worker(k=16):
     cpu_proof = cp.create_proof(circ_h, srs_h, adv_h, inst_h, repr_int, bytes(16), "shplonk", timings=stages, key=key)
     cpu_s = time.perf_counter() - t0
     threads = cref.num_threads()
-    return {
-        "metric": "synthetic-shape full proof wall-clock (s): restated CPU prover vs 1x MI355X, same circuit / witness / seed",
-        "shape": f"Keccak shape at k = {k} ({circ.A} advice, {circ.F} fixed, {len(circ.perm_cols)} permutation columns, {len(circ.lookups)} lookups, degree {circ.degree()}, {circ.bf} blinding factors)",
-        "cpu_baseline": {"value": round(cpu_s, 3), "unit": "s", "cores": threads, "kind": "port",
-                         "sample": f"ONE full proof of the k = {k} Keccak shape: halo2 create_proof restated over arrays (oracle/cpu_prover.py), C primitives, OpenMP {threads} threads; "
-                                   "keygen and SRS outside the timing; not the reference's Rust prover (no toolchain here)",
-                         "stages_s": {name: round(v, 3) for name, v in stages.items()}},
-        "value": round(min(gpu_times), 4), "unit": "s", "higher_is_better": False,
-        "gpu_s": round(min(gpu_times), 4), "gpu_create_proof_s": [round(t, 4) for t in gpu_times],
-        "speedup_vs_restated_cpu": round(cpu_s / min(gpu_times), 1),
-        "same_proof_bytes": cpu_proof == gpu_proof, "proof_bytes": len(gpu_proof), "data": "synthetic-shape",
-    }
+    return {"value": round(cpu_s, 3), "unit": "s", "cores": threads, "kind": "port",
+            "sample": f"ONE full proof of the Keccak shape at k = {k} (BASELINE configs[2] stand-in: {circ.A} advice, {circ.F} fixed, {len(circ.perm_cols)} permutation columns, {len(circ.lookups)} lookups, "
+                      f"degree {circ.degree()}, {circ.bf} blinding factors): halo2 create_proof restated over arrays (oracle/cpu_prover.py), C primitives, OpenMP {threads} threads; keygen and SRS "
+                      "outside the timing; not the reference's Rust prover (no toolchain here), and not the headline circuit (1300 commitments of 2^20 would take the host a quarter of an hour)",
+            "stages_s": {name: round(v, 3) for name, v in stages.items()},
+            "gpu_same_sample_s": round(min(gpu_times), 4), "gpu_create_proof_s": [round(t, 4) for t in gpu_times],
+            "speedup_vs_restated_cpu": round(cpu_s / min(gpu_times), 1), "same_proof_bytes": cpu_proof == gpu_proof, "proof_bytes": len(gpu_proof)}
 
 
 def mock_worker(name):
@@ -484,6 +482,7 @@ def mock_worker(name):
     [REF circuit-benchmarks/src/evm_circuit.rs:44-60] -- here zk_mock_verify (dev::MockProver::verify_par restated for the
     device) over the same-size stand-in: the satisfied witness, then one cell changed (the path that lists failures)."""
     import numpy as np
+
     import bench_proof as bp
     import zkevm_circuits_amd as z
     from zkevm_circuits_amd import plonk
@@ -518,13 +517,13 @@ def mock_worker(name):
 
 
 def proof_worker(name):
-    """One proof shape, measured in this (fresh) process.  The quotient evaluator's roofline comes from one extra,
-    profiled proof: bytes = what the launches really stream (counted by the library) over their time."""
+    """One proof shape, measured in this (fresh) process; witness resident in HBM (single-GPU shapes) or page-locked on the host
+    (sharded sessions: the owner rank uploads, the ranks all-gather device to device)."""
     import bench_proof as bp
     import zkevm_circuits_amd as z
 
-    if name == "keccak_shape_k16_cpu_vs_gpu":
-        return cpu_vs_gpu_worker(16)
+    if name.startswith("keccak_shape_cpu_vs_gpu"):
+        return cpu_vs_gpu_worker(int(name.split(":")[1]) if ":" in name else 18)
     if name in MOCK_SHAPES:
         return mock_worker(name)
 
@@ -537,66 +536,162 @@ def proof_worker(name):
         rendezvous.comm_init_from_env(ctx)
         hook = lambda sess: sess.set_sharding_comm()
         barrier = lambda: rendezvous.comm_barrier(ctx, rank, world)
-    # (builder, proofs per key, transcript): the recursion shape is BASELINE config 5's stand-in -- k = 22, 9 advice
-    # columns, FOUR sequential proofs sharing one proving key, Poseidon transcript as gen_snark_shplonk uses
-    # [REF prover/src/common/prover/recursion.rs:60-77], [REF aggregator/configs/bundle_circuit.config]
+    repeat_env = int(os.environ.get("ZK_BENCH_STEPS", "0"))
+    # (builder, proofs per key, transcript).  bundle_shape_k21: the recursion / bundle layer (BASELINE configs[4] stand-in) -- halo2-base
+    # layout sized by [REF aggregator/configs/bundle_circuit.config] (degree 21, 5 + 1 advice, 1 fixed), FOUR sequential proofs sharing
+    # one proving key, Poseidon transcript as gen_snark_shplonk uses [REF prover/src/common/prover/recursion.rs:60-77]
     build, repeat, tkind = {"keccak_shape_k18": (lambda: bp.build_keccak_shape(ctx, 18), 3, None),
-                            "recursion_shape_k22": (lambda: bp.build_large(ctx, 22, 3), 4, 1),
-                            "supercircuit_shape_k20": (lambda: bp.build_shape(ctx, 20, 1000, 150, 150, 100, 9), 4, None)}[name]
+                            "bundle_shape_k21": (lambda: bp.build_halo2_base_shape(ctx, 21, 5, 1, 20), 4, 1),
+                            "supercircuit_shape_k20": (lambda: bp.build_shape(ctx, *SC_SHAPE, dist="survey"), 3, None),
+                            "supercircuit_shape_k20_dense": (lambda: bp.build_shape(ctx, *SC_SHAPE, dist="dense"), 3, None),
+                            "supercircuit_shape_k20_small": (lambda: bp.build_shape(ctx, *SC_SHAPE, dist="small"), 3, None)}[name]
+    if repeat_env:
+        repeat = repeat_env
     t0 = time.perf_counter()
     circ, blob, adv_m, inst_m, inst = build()
     t_build = time.perf_counter() - t0
-    rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=True, t_build=t_build, transcript_kind=tkind,
-                         profiled_extra=world == 1,  # timed proofs run without the profiling events; one extra proof feeds the quotient roofline
-                         session_hook=hook, barrier=barrier, report=rank == 0, world=world)
-    if world > 1:
-        if rec is not None:
-            rec["metric"] = f"synthetic-shape full proof wall-clock (s), sharded session on {world} x MI355X (in-library RCCL)"
-            if tkind == 1:
-                rec["transcript"] = "poseidon"
-                rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
-        ctx.close()
-        return rec
-    if tkind == 1:
+    rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=world > 1, resident=world == 1, t_build=t_build,
+                         transcript_kind=tkind, session_hook=hook, barrier=barrier, report=rank == 0, world=world)
+    if rec is not None and tkind == 1:
         rec["transcript"] = "poseidon"
         rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
-    prof = {nm: ctx.prof_get(nm) for nm in ctx.prof_names()}
-    n = 1 << circ.k
-    d, P, L = circ.degree(), len(circ.perm_cols), len(circ.lookups)
-    C = (P + d - 3) // (d - 2) if P else 0
-    # distinct (column, rotation) operands of the quotient program: the circuit's own queries, sigma, Z (x, wx, w^last x),
-    # phi (x, wx) and m per lookup, l_0 / l_last / l_active / X
-    reads = len(circ.advice_queries) + len(circ.fixed_queries) + len(circ.instance_queries) + P + (3 * C - 1 if C else 0) + 3 * L + 4
-    cosets = 1 << (circ.extended_k() - circ.k)
-    qbig = prof.get("quotient_coset", (0.0, 0))
-    if qbig[1]:
-        # The quotient is evaluated by degree class: a proof launches one program per (class, coset of that
-        # class) instead of one per coset.  `achieved` = the bytes those launches really stream (the library counts
-        # 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result) per launch) over their
-        # time.  `vs_full_domain` = what evaluating every constraint on every coset would stream (halo2's evaluate_h)
-        # over the same time: an EFFECTIVE rate, comparable across rounds, that may exceed the HBM peak.
-        per_proof_ms = qbig[0]                       # the profiled proof
-        streamed = ctx.prof_get_bytes("quotient_coset")
-        full = 32.0 * n * (reads + 1) * cosets
-        rec["roofline_quotient"] = {"kernel": "k_quotient_eval (all degree-class launches of one proof)", "bound": "hbm",
-                                    "achieved": round(streamed / (per_proof_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(streamed / (per_proof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_proof": round(per_proof_ms, 2),
-                                    "launches_per_proof": qbig[1], "algorithmic_bytes_per_proof": int(streamed),
-                                    "distinct_column_rotation_reads": reads, "cosets": cosets,
-                                    "vs_full_domain": {"bytes": int(full), "effective_GBps": round(full / (per_proof_ms * 1e-3) / 1e9, 1)}}
-        try:            # counters of the committed rocprofv3 --pmc passes over the evaluator (profiles/r03_quotient_traffic.md): FETCH_SIZE + WRITE_SIZE, as reported
-            qt = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json"))).get("quotient", {})
-            if name == "supercircuit_shape_k20" and "supercircuit_shape_proof" in qt:
-                t_ = qt["supercircuit_shape_proof"]
-                rec["roofline_quotient"]["traffic"] = t_["fetch_bytes_raw"] + t_["write_bytes"]
-                rec["roofline_quotient"]["traffic_note"] = f"all {t_['launches']} launches of the kernel in one proof (the coset programs AND the theta-compression / permutation / linear-combination programs), rocprofv3 --pmc, profiles/r03_quotient_traffic.md"
-            ql = qt.get("quot_loop")
-            if ql:
-                rec["roofline_quotient"]["counter_over_algorithmic_on_the_gate_loop"] = round((ql["fetch_bytes_raw"] + ql["write_bytes"]) / ql["algorithmic_bytes"], 3)
-        except Exception:
-            pass
+    if rec is not None and world > 1:
+        rec["metric"] = f"synthetic-shape full proof wall-clock (s), sharded session on {world} x MI355X (in-library RCCL)"
     ctx.close()
     return rec
+
+
+# ------------------------------------------------------------------------------------ N > 1: one proof sharded over the ranks
+def sharded_headline(args, torch, dist, rank, world, local_rank):
+    """One prover process per rank (`--proof-worker supercircuit_shape_k20` with the launcher's RANK / WORLD_SIZE / LOCAL_RANK in its
+    environment): the ranks join the library's own RCCL communicator through a file (zkevm-circuits_amd/rendezvous.py) and run the
+    sharded session -- commitments split by column (by points when there are fewer columns than ranks), quotient split by
+    (class, coset), witness columns uploaded by their owner and all-gathered device to device.  Every proof is bracketed by the
+    communicator's barrier on all ranks; rank 0 reports."""
+    def host_bytes_free():
+        free = None
+        try:
+            import psutil
+            free = psutil.virtual_memory().available
+        except Exception:
+            pass
+        try:
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            if lim != "max":
+                cur = int(open("/sys/fs/cgroup/memory.current").read())
+                free = min(free, int(lim) - cur) if free is not None else int(lim) - cur
+        except Exception:
+            pass
+        return free
+
+    need = 24 << 30                                               # host bytes per rank (blob + witness + builder temporaries)
+    verdict = [None]
+    if rank == 0:
+        free = host_bytes_free()
+        if free is not None and free < world * need:
+            verdict[0] = f"host memory: {free >> 30} GiB free, {world} ranks x {need >> 30} GiB needed"
+    dist.broadcast_object_list(verdict, src=0)
+    if verdict[0]:
+        return {"error": verdict[0]} if rank == 0 else None
+    env = dict(os.environ)
+    env["ZK_COMM_ID_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}_sc")
+    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+    env["ZK_BENCH_STEPS"] = str(args.steps)
+    rec = None
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", "supercircuit_shape_k20"], capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if rank == 0:
+            rec = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": f"rank 0 worker exited with {res.returncode}: {res.stderr[-400:]}"}
+    except Exception as e:           # a time-out here usually means another rank failed and the collectives never completed
+        if rank == 0:
+            rec = {"error": repr(e)}
+    if rank == 0:
+        try:
+            os.remove(env["ZK_COMM_ID_FILE"])
+        except OSError:
+            pass
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed proofs")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed proofs in front of them")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proof", action="store_true", help="skip the other shapes / distributions (N = 1 only)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle verifier's check of the last timed proof")
+    ap.add_argument("--no-msm-ntt", action="store_true", help="skip the BASELINE configs[1] section")
+    ap.add_argument("--proof-worker", default="", help=argparse.SUPPRESS)      # internal: run ONE proof shape in this process and print its record
+    ap.add_argument("--batch", type=int, default=32, help="msm_ntt section: columns submitted per commit_batch call")
+    args = ap.parse_args()
+
+    if args.proof_worker:
+        print(json.dumps(proof_worker(args.proof_worker)), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_launcher(args))
+
+    import torch  # device plumbing + torch.distributed only
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    shared_gpu = world > ndev           # fewer GPUs than ranks (single-GPU test box): ranks share devices, exchange over gloo
+    local_rank %= max(ndev, 1)
+    torch.cuda.set_device(local_rank)
+
+    if world == 1:
+        out = headline_single(args, torch)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_proof(18)
+        else:
+            out["cpu_baseline"] = None
+        if not args.no_msm_ntt:
+            try:
+                out["msm_ntt"] = msm_ntt_section(args, torch)
+            except Exception as e:
+                out["msm_ntt"] = {"error": repr(e)}
+        if not args.no_proof:
+            out["proof"] = proof_section()
+        print(json.dumps(out), flush=True)
+        return
+
+    import torch.distributed as dist
+
+    if shared_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = sharded_headline(args, torch, dist, rank, world, local_rank)
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        ok = rec is not None and not rec.get("error") and rec.get("create_proof_s")
+        times = rec["create_proof_s"][1:] if ok and len(rec["create_proof_s"]) > 1 else (rec["create_proof_s"] if ok else [])
+        per_proof = sum(times) / len(times) if times else None
+        out = {
+            "metric": METRIC, "value": round(per_proof, 4) if per_proof else None, "unit": "s", "n_gpus": world, "steps": len(times), "warmup": 1 if ok and len(rec["create_proof_s"]) > 1 else 0,
+            "ms_per_step": round(per_proof * 1e3, 2) if per_proof else None, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic-shape",
+            "config": {"workload": WORKLOAD.replace("three advice phases, ", "one advice phase, "), "witness_residency": "page-locked host memory: every column uploaded by its owner rank, all-gathered device to device",
+                       "parallelism": f"one proof sharded x{world}: commitments by column, quotient by (class, coset), 64-byte commitments and witness columns all-gathered over the library's RCCL communicator"
+                                      + (" (ranks share a GPU: gloo-free in-library path on one device)" if shared_gpu else "")},
+            "roofline": None, "cpu_baseline": None,
+            "proof_sharded": rec, "section_wall_s": round(wall, 1),
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -447,9 +447,13 @@ int zk_proof_set_device_gather(zk_ctx* ctx, zk_proof* proof, zk_allgather_fn gat
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols,
                           void* h_challenges, uint32_t* num_challenges);
 /* The same phase for witness columns RESIDENT ON THE DEVICE (device pointers, n x 32 B each, Montgomery form): a witness generated
- * on the GPU or uploaded ahead of the proof.  The session copies them device to device into its own buffers (it overwrites the
- * blinding rows; the caller's columns stay untouched) and judges small / dense columns on the device.  Same proof bytes.        */
-int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols,
+ * on the GPU or uploaded ahead of the proof; small / dense columns are judged on the device.  Same proof bytes.  flags = 0: the
+ * session copies the columns device to device into its own buffers (the caller's stay untouched).  ZK_ADVICE_DEV_IN_PLACE: the
+ * session works in the caller's buffers -- it overwrites their last blinding_factors + 1 rows (halo2 puts blinding values there; a
+ * witness holds nothing in them) and reads them until zk_proof_finish / zk_proof_abort returns; no copy, n x 32 B less device
+ * memory per column.                                                                                                              */
+#define ZK_ADVICE_DEV_IN_PLACE 1u
+int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols, uint32_t flags,
                               void* h_challenges, uint32_t* num_challenges);
 /* consumes the session (freed on success and on failure)                                         */
 int zk_proof_finish(zk_ctx* ctx, zk_proof* proof, void* h_proof, size_t proof_cap, size_t* proof_len);

@@ -418,31 +418,42 @@ def test_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8, k, wide, multiopen
     assert first_diff is None, f"proofs differ from byte {first_diff} (32-byte item {first_diff // 32})"
 
 
-def test_device_resident_witness_gives_the_same_bytes(ctx, cref, srs8):
+def test_device_resident_witness_gives_the_same_bytes(zk, ctx, cref, srs8):
     """zk_proof_advice_phase_dev: the witness columns handed over as device buffers (resident in HBM before the session starts)
-    yield the bytes of the host-column call, and the caller's buffers are left as they were (the session blinds its own copies)."""
+    yield the bytes of the host-column call.  Copy mode leaves the caller's buffers as they were; in-place mode works in them and
+    touches only their last blinding_factors + 1 rows; the same buffer given for two columns is refused there."""
     circ, adv, inst = build_circuit(7, seed=21, wide=True)
     pk = ctx.pk_create(srs8[circ.k], circ.blob())
     adv_m = [plonk.column_to_mont(c) for c in adv]
     inst_m = [plonk.column_to_mont(c) for c in inst]
     try:
-        def run(dev):
+        def run(mode):
             sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
             sess.set_multiopen(1)
-            if dev:
-                bufs = {i: ctx.to_device(c) for i, c in enumerate(adv_m)}
-                sess.advice_phase_dev(bufs)
-                out = sess.finish()
-                for i, b_ in bufs.items():
-                    assert np.array_equal(b_.download((circ.n, 4)), adv_m[i])
-                    b_.free()
-                return out
-            sess.advice_phase({i: c for i, c in enumerate(adv_m)})
-            return sess.finish()
-        host, dev = run(False), run(True)
+            if mode == "host":
+                sess.advice_phase({i: c for i, c in enumerate(adv_m)})
+                return sess.finish()
+            bufs = {i: ctx.to_device(c) for i, c in enumerate(adv_m)}
+            sess.advice_phase_dev(bufs, in_place=mode == "in_place")
+            out = sess.finish()
+            for i, b_ in bufs.items():
+                got = b_.download((circ.n, 4))
+                if mode == "copy":
+                    assert np.array_equal(got, adv_m[i])
+                else:
+                    assert np.array_equal(got[:circ.u], adv_m[i][:circ.u]) and got[circ.u:].any()          # usable rows untouched, blinding rows written
+                b_.free()
+            return out
+        host, copy, in_place = run("host"), run("copy"), run("in_place")
+        sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
+        shared = ctx.to_device(adv_m[0])
+        with pytest.raises(zk.ZkError, match="distinct"):
+            sess.advice_phase_dev({i: shared for i in range(len(adv_m))}, in_place=True)
+        sess.abort()
+        shared.free()
     finally:
         pk.destroy()
-    assert len(host) > 500 and host == dev
+    assert len(host) > 500 and host == copy == in_place
 
 
 def test_rotation_proof_bytes_equal_the_oracle_prover(ctx, cref, srs8):

@@ -329,8 +329,9 @@ class ProofSession:
         self.ctx._ck(lib().zk_proof_advice_phase(self.ctx.h, self.h, ci, pc, ctypes.c_uint32(len(idx)), _host_ptr(out), ctypes.byref(cnt)))
         return out[:cnt.value].copy()
 
-    def advice_phase_dev(self, columns: dict) -> np.ndarray:
-        """{advice column index: DeviceBuffer (n x 32 B, Montgomery)}: the phase's witness columns resident on the device"""
+    def advice_phase_dev(self, columns: dict, in_place: bool = False) -> np.ndarray:
+        """{advice column index: DeviceBuffer (n x 32 B, Montgomery)}: the phase's witness columns resident on the device.
+        in_place: the session works in these buffers (it overwrites their blinding rows) until finish() / abort() returns."""
         idx = sorted(columns)
         ci = (ctypes.c_uint32 * max(len(idx), 1))(*idx)
         ptrs = (ctypes.c_void_p * max(len(idx), 1))(*[columns[i].ptr for i in idx])
@@ -339,7 +340,7 @@ class ProofSession:
             cap = self._challenge_cap = max(1, self.pk.shape()["challenges"])
         out = np.zeros((cap, 4), dtype=np.uint64)
         cnt = ctypes.c_uint32(cap)
-        self.ctx._ck(lib().zk_proof_advice_phase_dev(self.ctx.h, self.h, ci, ptrs, ctypes.c_uint32(len(idx)), _host_ptr(out), ctypes.byref(cnt)))
+        self.ctx._ck(lib().zk_proof_advice_phase_dev(self.ctx.h, self.h, ci, ptrs, ctypes.c_uint32(len(idx)), ctypes.c_uint32(1 if in_place else 0), _host_ptr(out), ctypes.byref(cnt)))
         return out[:cnt.value].copy()
 
     def mock_verify(self, gate_rows: Optional[Sequence[int]] = None, lookup_rows: Optional[Sequence[int]] = None, cap: int = 4096):

@@ -576,6 +576,7 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             const unsigned blocks = (unsigned)(n >> (ps.log_np + log_t));
             const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
             ZkProfScope pscope(ctx, "ntt_pass");
+            pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;      // a transform's algorithmic 64 B per element (read once, write once), spread over its P launches
             hipLaunchKernelGGL(k_ntt_pass, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
                                dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw);
             ZK_CHECK_LAUNCH(ctx);
@@ -597,6 +598,7 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             NttIo io{};
             for (size_t j = 0; j < nb; ++j) { io.src[j] = cur_io.src[j]; io.dst[j] = d_datas[first + j]; }
             ZkProfScope pscope(ctx, "ntt_last");
+            pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;
             hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
                                ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0,
                                (log_mid == 0 && blocks % 8 == 0 && blocks >= 16 && ntt_xcd_remap()) ? 1 : 0);

@@ -184,6 +184,8 @@ struct zk_proof {
     uint32_t phase = 0;
     int multiopen = ZK_MULTIOPEN_GWC;
     int vanishing_random = ZK_VANISHING_ONE;
+    bool advice_on_device = false;            // the witness came as device buffers (zk_proof_advice_phase_dev)
+    bool advice_in_place = false;             // the Lagrange forms of the advice columns are the caller's device buffers (zk_proof_advice_phase_dev, IN_PLACE)
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
     // commitments and quotient cosets are split over the ranks, results exchanged through `gather`
     std::vector<F4> absorbed;                // what zk_proof_begin fed the transcript (replayed into an external one)
@@ -759,18 +761,25 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
 // in challenge-index order).  When h_challenges is given, *num_challenges holds its capacity (in
 // challenges) on entry; on return it holds how many the phase produced.
 static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr);
-static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src);
+static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src, bool in_place);
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
-    return advice_phase_impl(ctx, pr, col_index, h_cols, ncols, h_challenges, num_challenges, false);
+    return advice_phase_impl(ctx, pr, col_index, h_cols, ncols, h_challenges, num_challenges, false, false);
 }
 // The same phase for witness columns that are RESIDENT ON THE DEVICE (n x 32 B each, Montgomery, device pointers): a witness
-// generated on the GPU, or one uploaded ahead of the proof.  The columns are copied (device to device, on the copy stream) into
-// the session's own buffers -- the caller's stay untouched: the session overwrites the blinding rows -- and judged small / dense
-// on the device.  Same transcript, same bytes as the host-column call.
-int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
-    return advice_phase_impl(ctx, pr, col_index, d_cols, ncols, h_challenges, num_challenges, true);
+// generated on the GPU, or one uploaded ahead of the proof.  Judged small / dense on the device.  Same transcript, same bytes as the
+// host-column call.  flags:
+//   0                        the columns are copied (device to device, on the copy stream) into the session's own buffers; the caller's
+//                            stay untouched
+//   ZK_ADVICE_DEV_IN_PLACE   the session works IN the caller's buffers: it overwrites their last blinding_factors + 1 rows (the rows
+//                            halo2 fills with blinding values; a witness has nothing there) and reads them until zk_proof_finish /
+//                            zk_proof_abort returns.  No copy, and n x 32 B per column less device memory -- which is what lets a
+//                            1000-column session keep two cosets of every column computed ahead.
+int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols, uint32_t flags, void* h_challenges, uint32_t* num_challenges) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, (flags & ~(uint32_t)ZK_ADVICE_DEV_IN_PLACE) == 0, "unknown flag");
+    return advice_phase_impl(ctx, pr, col_index, d_cols, ncols, h_challenges, num_challenges, true, (flags & ZK_ADVICE_DEV_IN_PLACE) != 0);
 }
-static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src) {
+static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src, bool in_place) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
     PoolScope pool_scope(ctx);
     ZK_REQUIRE(ctx, pr && (ncols == 0 || (col_index && h_cols)), "null pointer");
@@ -788,6 +797,13 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
         const uint32_t c = col_index[j];
         if (c >= pk->A || pk->adv_phase[c] != pr->phase || by_col[c] || !h_cols[j]) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u does not belong to phase %u (or is repeated)", c, pr->phase);
         by_col[c] = h_cols[j];
+    }
+    if (dev_src) pr->advice_on_device = true;
+    if (in_place) {
+        std::vector<const void*> sorted_ptrs(h_cols, h_cols + ncols);
+        std::sort(sorted_ptrs.begin(), sorted_ptrs.end());
+        if (std::adjacent_find(sorted_ptrs.begin(), sorted_ptrs.end()) != sorted_ptrs.end()) return ctx->fail(ZK_ERR_INVALID_ARG, "in-place witness columns must be distinct buffers (each gets its own blinding rows)");
+        pr->advice_in_place = true;
     }
     StageTrace trace(ctx);
     // Column c+1 is uploaded on the copy stream while the MSM of column c runs; the last bf + 1 rows
@@ -842,7 +858,8 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
     sg.kind = dev_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
         if (!by_col[c]) continue;
-        if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
+        if (in_place) pr->adv_lag[c].borrow(const_cast<void*>(by_col[c]));
+        else if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
         sg.src.push_back(by_col[c]);
         sg.dst.push_back(pr->adv_lag[c].p);
         sg.lag.push_back(&pr->adv_lag[c]);
@@ -875,7 +892,7 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
         if (!s_->own.empty()) {      // device-gather mode: one own column per call
             if (it > 0) PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[s_->own[it - 1]], s_->coeff[s_->own[it - 1]]));
             const size_t c_ = s_->own[it];
-            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));
+            if (s_->dst[c_] != s_->src[c_]) ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
             PK_TRY(copy_stream_fence(s_->ctx));
             ZK_HIP(s_->ctx, hipStreamWaitEvent(s_->ctx->stream_aux, s_->ctx->ev_copy, 0));
@@ -892,7 +909,7 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
         static const bool skip_upload = getenv("ZK_DEBUG_SKIP_UPLOAD") != nullptr;       // measurement only (the proof is garbage): is the phase bound by PCIe or by the device?
         for (size_t c_ = it * s_->world; c_ < std::min((it + 1) * (size_t)s_->world, s_->dst.size()); ++c_) {
             if (skip_upload) continue;
-            ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));
+            if (s_->dst[c_] != s_->src[c_]) ZK_HIP(s_->ctx, hipMemcpyAsync(s_->dst[c_], s_->src[c_], s_->body, s_->kind, s_->ctx->stream_copy));      // in place: only the blinding rows move
             ZK_HIP(s_->ctx, hipMemcpyAsync((char*)s_->dst[c_] + s_->body, s_->blind + c_ * (s_->tail / 32), s_->tail, hipMemcpyHostToDevice, s_->ctx->stream_copy));
         }
         PK_TRY(copy_stream_fence(s_->ctx));
@@ -1193,7 +1210,10 @@ static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
     const zk_pk* pk = pr->pk;
     const bool sharded = pr->world > 1 && pr->gather;
     const char* env = getenv("ZK_ADVICE_COSET_GB");
-    const double cap = (env ? atof(env) : 64.0) * (double)(1ull << 30);
+    // A witness that is already on the device leaves no PCIe wait to fill: the phase is bound by the device's arithmetic, and cosets
+    // computed ahead only compete with the commitments (measured on the SuperCircuit shape, 60/30/10 witness, resident columns: two
+    // cosets ahead 1.54 s per proof, none 1.41 s).  Off for such sessions unless asked for.
+    const double cap = (env ? atof(env) : (pr->advice_on_device ? 0.0 : 64.0)) * (double)(1ull << 30);
     if (sharded || cap <= 0 || pk->A == 0) return ZK_OK;
     std::vector<uint32_t> mask;
     size_t key_slots = 0;
@@ -1205,7 +1225,8 @@ static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ZK_OK; }
     // columns' worth of buffers still to come, the advice columns' own coset buffers aside (counted below, per choice of cosets):
     // Lagrange + coefficient forms of the advice columns, of m / phi / Z with their temporaries, their coset buffers, h, slack
-    const double cols_ahead = 2.0 * pk->A + 3.0 * (2.0 * pk->L + pk->C) + (2.0 * pk->L + pk->C + pk->I + 8.0) + 2.0 * R + 32.0;
+    // (a witness handed over in place brings its Lagrange forms along)
+    const double cols_ahead = (pr->advice_in_place ? 1.0 : 2.0) * pk->A + 3.0 * (2.0 * pk->L + pk->C) + (2.0 * pk->L + pk->C + pk->I + 8.0) + 2.0 * R + 32.0;
     double avail = (double)free_b + (double)ctx->pool_bytes - cols_ahead * col_bytes - 16.0 * (double)(1ull << 30);
     if (pk->part_cache_state < 0 || (pk->part_cache_state == 1 && pk->part_cache_bytes == 0)) {
         // the key's own cosets (fixed, sigma, l_0 ...) are still to be cached by this proof's quotient: reserved, counted from the
