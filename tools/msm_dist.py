@@ -1,6 +1,6 @@
 """MSM cost per column by value distribution ("witness-like" = 60 % zero / 30 % < 2^16 / 10 % uniform per cell), on the
 paths a caller can ask for: wall time per MSM inside a pipelined batch, kernel groups, a lone commitment.
-usage: python tools/msm_dist.py [k] [columns]"""
+usage: python tools/msm_dist.py [k] [columns] [dist,dist,...] [hint,hint]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,10 +37,12 @@ def column(dist):
     return col
 
 
-for dist in ("uniform", "third_uniform", "survey_60_30_10", "one_percent", "tenth_percent", "small16"):
+dists = sys.argv[3].split(",") if len(sys.argv) > 3 else ("uniform", "third_uniform", "survey_60_30_10", "one_percent", "tenth_percent", "small16")
+hints = [int(h) for h in sys.argv[4].split(",")] if len(sys.argv) > 4 else (0, 1)
+for dist in dists:
     bufs = [ctx.to_device(column(dist)) for _ in range(ncol)]
     ptrs = [b.ptr for b in bufs]
-    for hint in (0, 1):
+    for hint in hints:
         ctx.commit_batch(srs, ptrs, n, lagrange=True, narrow=[hint] * ncol)
         ctx.sync()
         t0 = time.perf_counter()

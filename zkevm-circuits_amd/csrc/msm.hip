@@ -271,13 +271,13 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* lds, uint32_t slot, bool 
 // (recoding again costs one Montgomery product per scalar; keeping the digits would cost a write
 // and a read of W words per scalar).
 template <int C, bool SCATTER>
-__global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars_arg, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
-                                                          uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift, const MsmCol* __restrict__ cols = nullptr, const uint32_t* __restrict__ ctr = nullptr) {
+__device__ __forceinline__ void partition_body(const Fr* __restrict__ scalars, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
+                                               uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift, uint32_t bin_base, uint32_t set_mask, uint32_t nwg, uint32_t g, uint32_t* lds) {
+    // grouped columns (GM sort): this column's partitions start at bin_base in the shared histogram, and its windows are dealt over
+    // set_mask + 1 bucket sets (window w -> set w & set_mask, key = set * 2^(C-1) + bucket): more, shorter buckets
     constexpr int W = (256 + C - 1) / C;
-    const Fr* __restrict__ scalars = cols ? cols[*ctr].scalars : scalars_arg;
-    __shared__ uint32_t lds[MSM_M_MAX_BINS];
-    const uint32_t nbins = 1u << (C - 1 - range_bits), nwg = gridDim.x, g = blockIdx.x;
-    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = SCATTER ? hist_off[(uint64_t)t * nwg + g] : 0u;
+    const uint32_t nbins = (set_mask + 1u) << (C - 1 - range_bits);
+    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = SCATTER ? hist_off[(uint64_t)(bin_base + t) * nwg + g] : 0u;
     __syncthreads();
     const uint64_t chunk = (n + nwg - 1) / nwg;                    // scalars per workgroup (the host sizes the grid)
     const uint64_t lo = min(n, (uint64_t)g * chunk), hi = min(n, lo + chunk);
@@ -295,15 +295,32 @@ __global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ 
         for (int w = 0; w < W; ++w) {
             const bool nz = code[w] != CODE_ZERO;
             if (!__ballot(nz)) continue;
-            const uint32_t bucket = code[w] & 0x3FFFFFu;
+            const uint32_t bucket = (code[w] & 0x3FFFFFu) | (((uint32_t)w & set_mask) << (C - 1));
             const uint32_t pos = lds_take(lds, bucket >> range_bits, nz);
             if (SCATTER && nz) entries[pos] = ((uint64_t)(bucket & rmask) << 32) | (uint64_t)((uint32_t)((uint64_t)w * tab_stride + i) | (code[w] & NEG_BIT));
         }
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) hist[(uint64_t)t * nwg + g] = lds[t];
+        for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) hist[(uint64_t)(bin_base + t) * nwg + g] = lds[t];
     }
+}
+template <int C, bool SCATTER>
+__global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ scalars_arg, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
+                                                          uint64_t* __restrict__ entries, uint64_t tab_stride, int top_shift, const MsmCol* __restrict__ cols = nullptr, const uint32_t* __restrict__ ctr = nullptr) {
+    const Fr* __restrict__ scalars = cols ? cols[*ctr].scalars : scalars_arg;
+    __shared__ uint32_t lds[MSM_M_MAX_BINS];
+    partition_body<C, SCATTER>(scalars, n, range_bits, hist, hist_off, entries, tab_stride, top_shift, 0u, 0u, gridDim.x, blockIdx.x, lds);
+}
+// The same pass over the columns of a GM group in ONE launch (blockIdx.y = column of the group): a column's 512 workgroups of 256
+// threads leave three quarters of the device's wave slots empty; eight columns fill them.
+constexpr int GM_MAX_COLS = 8;
+struct GmCols { const Fr* p[GM_MAX_COLS]; };
+template <int C, bool SCATTER>
+__global__ void __launch_bounds__(256) k_msm_gm_partition(GmCols cols, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
+                                                           uint64_t* __restrict__ entries, uint64_t tab_stride, uint32_t bins_per_col, uint32_t set_mask) {
+    __shared__ uint32_t lds[MSM_M_MAX_BINS];
+    partition_body<C, SCATTER>(cols.p[blockIdx.y], n, range_bits, hist, hist_off, entries, tab_stride, 0, blockIdx.y * bins_per_col, set_mask, gridDim.x, blockIdx.x, lds);
 }
 // Scatter pass of the partition step with the runs staged in LDS.  k_msm_m_partition<C, true> lets every lane
 // write its 8-byte entry to the cursor of its own partition: 64 lanes, 64 partitions, 64 separate 32-byte
@@ -1357,6 +1374,15 @@ static void launch_partition(int c, dim3 grid, hipStream_t st, const Fr* scalars
     }
 #undef ZK_PART_CASE
 }
+template <bool SCATTER>
+static void launch_gm_partition(int c, dim3 grid, hipStream_t st, const GmCols& cols, uint64_t n, int range_bits, uint32_t* hist, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride,
+                                uint32_t bins_per_col, uint32_t set_mask) {
+#define ZK_GMP_CASE(C) case C: hipLaunchKernelGGL((k_msm_gm_partition<C, SCATTER>), grid, dim3(256), 0, st, cols, n, range_bits, hist, hist_off, entries, tab_stride, bins_per_col, set_mask); break;
+    switch (c) {
+        ZK_GMP_CASE(8) ZK_GMP_CASE(9) ZK_GMP_CASE(10) ZK_GMP_CASE(11) ZK_GMP_CASE(12) ZK_GMP_CASE(13) ZK_GMP_CASE(14) ZK_GMP_CASE(15) ZK_GMP_CASE(16)
+    }
+#undef ZK_GMP_CASE
+}
 static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift,
                                  const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr, hipStream_t st = nullptr) {
     const size_t lds = scatter_staged_lds(W);
@@ -1410,12 +1436,38 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const uint64_t n_pad = ((uint64_t)n + 16 * MSM_SLICES - 1) & ~(uint64_t)(16 * MSM_SLICES - 1);
     const size_t dig_words = (size_t)(n_pad * Wg + 1) / 2 + 4;
     const size_t head_words_N = (size_t)nbN * (2 * MSM_SLICES + 5) + 4 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + (size_t)scan_blocks_sN + scan_blocks_N + (size_t)n * Wg;
-    const size_t words_N = any_narrow ? head_words_N + 4 + dig_words : 0;
+    // Groups of small-valued columns, sorted like the merged path ("GM"; ZK_MSM_NARROW_GM=0 keeps the digit matrix + LDS sweeps):
+    // the digit matrix of a group is 16 x n codes per column of which a witness-like column fills a tenth, and every row of it
+    // was streamed by sixteen range workgroups, twice -- 0.22 ms of sort per column for 0.12 ms of accumulation.  Here the non-zero
+    // digits become entries keyed by (column, bucket) -- the per-window table gives every window's bucket b the same weight, so a
+    // column needs ONE set of 2^(c-1) buckets, not one per window -- and go through the merged path's partition / one-launch
+    // counting sort: column j of the group owns partitions [j * bpc, (j + 1) * bpc) and buckets [j B, (j + 1) B); the fold of the
+    // windows disappears (the accumulation already sums them), reduction and window sum run per column as before.
+    const bool gm = any_narrow && pn.c >= MSM_M_MIN_C && pn.c <= 16 && NG <= (uint32_t)GM_MAX_COLS && !(getenv("ZK_MSM_NARROW_GM") && atoi(getenv("ZK_MSM_NARROW_GM")) == 0);
+    // A column's windows are dealt over SG bucket sets (window w -> set w mod SG): a witness-like column (10 % field-sized cells) puts
+    // ~2 M entries into its buckets -- 61 per bucket with one set of 2^15, every bucket split into two unequal tasks and put together
+    // again afterwards (accumulation + combination 2.2 ms per group of eight against the 1.0 ms the additions cost); with two sets
+    // the buckets hold 26-35 entries, one task each.  ZK_MSM_GM_SETS = 1 / 2 / 4 (measurement knob).
+    uint32_t SG = 2;
+    if (const char* e = getenv("ZK_MSM_GM_SETS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) SG = (uint32_t)v; }
+    int range_bits_G = pn.c - 1 - 7;                                  // 128 * SG partitions per column of 2^(c-8) buckets each
+    if (range_bits_G < 0) range_bits_G = 0;
+    const uint32_t bpcG = (SG * pn.B) >> range_bits_G;                // partitions per column
+    const uint32_t nwgG = (uint32_t)((n_narrow + MSM_M_CHUNK - 1) / MSM_M_CHUNK);      // partition workgroups per column
+    const uint32_t nbG = NG * SG * pn.B;
+    const uint64_t entG = (uint64_t)n * pn.W * NG;                    // worst case: every digit of every column non-zero
+    const uint32_t hist_cnt_G = NG * bpcG * nwgG;
+    const uint32_t scan_blocks_G = (nbG + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), scan_blocks_hG = (hist_cnt_G + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+    // u32 workspace of the GM sort: counts[nbG] | size_hist nmulti wflags done | offsets[nbG + 1] | order[nbG] | ntasks[nbG] | toff[nbG + 1] | block_tot2 | block_tot3 |
+    //                               hist[hist_cnt_G] | hist_off[hist_cnt_G + 1] | idx[entG] | (8-B aligned) entries[entG] u64
+    const size_t head_words_G = (size_t)nbG * 5 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + scan_blocks_G + scan_blocks_hG + 2 * (size_t)hist_cnt_G + 2 + (size_t)entG;
+    const size_t words_G = gm ? head_words_G + 4 + 2 * (size_t)entG : 0;
+    const size_t words_N = any_narrow ? std::max(head_words_N + 4 + dig_words, words_G) : 0;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
     const uint32_t red_blocks_N = ((pn.B + RED_G_WIDE - 1) / RED_G_WIDE + RED_THREADS - 1) / RED_THREADS;
     const size_t max_tasks_N = (size_t)nbN + std::max(((size_t)n * Wg) / TASK_CAP, (size_t)TASK_TARGET) + 1;
-    const size_t npts29_N = any_narrow ? (size_t)nbN + (size_t)red_blocks_N * NG + max_tasks_N + (size_t)pn.B * NG : 0;
+    const size_t npts29_N = any_narrow ? (size_t)nbN + (size_t)red_blocks_N * NG * 4 + max_tasks_N + (size_t)pn.B * NG : 0;      // x 4: the GM path reduces up to four bucket sets per column
     const uint32_t nb = pl.B;
     const uint64_t max_entries = (uint64_t)n * pl.W;
     // table indices carry the sign in bit 31, cursors are 32-bit
@@ -1781,6 +1833,25 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         w.dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
         return w;
     };
+    struct WsG { uint32_t *counts, *size_hist, *nmulti, *offsets, *order, *ntasks, *toff, *block_tot2, *block_tot3, *hist, *hist_off, *idx; uint64_t* entries; };
+    auto ws_gm = [&](int slot) {
+        WsG w;
+        uint32_t* wsb = ws + (size_t)slot * words;
+        w.counts = wsb;
+        w.size_hist = w.counts + nbG;
+        w.nmulti = w.size_hist + SIZE_BINS;
+        w.offsets = w.nmulti + 4 + MSM_WFLAGS + TASK_DONE_MAX;
+        w.order = w.offsets + nbG + 1;
+        w.ntasks = w.order + nbG;
+        w.toff = w.ntasks + nbG;
+        w.block_tot2 = w.toff + nbG + 1;
+        w.block_tot3 = w.block_tot2 + scan_blocks_G;
+        w.hist = w.block_tot3 + scan_blocks_hG;
+        w.hist_off = w.hist + hist_cnt_G;
+        w.idx = w.hist_off + hist_cnt_G + 1;
+        w.entries = reinterpret_cast<uint64_t*>(wsb + ((head_words_G + 3) & ~(size_t)3));
+        return w;
+    };
     const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
     auto is_narrow = [&](size_t it) { return any_narrow && narrow[it] == 1; };
     // ---- the sort of MSM `it` into workspace `slot`, enqueued on `st`
@@ -1794,6 +1865,32 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     auto enqueue_sort = [&](size_t it, int slot, hipStream_t st) -> int {
         const Fr* d_scalars = d_scalar_ptrs[it];
         ZkProfScope ps(ctx, "msm_sort", st);
+        if (is_narrow(it) && gm) {
+            // GM sort of the group (see above): per column a histogram and a scatter pass over its scalars into the group's shared
+            // partition space, then ONE counting sort, size ordering and task split over the cnt * B buckets of the group
+            const uint32_t cnt = (uint32_t)group_of(it), nbc = cnt * SG * pn.B, nbins_c = cnt * bpcG, hist_c = nbins_c * nwgG;
+            const uint32_t sb = (nbc + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS), sb_h = (hist_c + SCAN_T * SCAN_ITEMS - 1) / (SCAN_T * SCAN_ITEMS);
+            const WsG w = ws_gm(slot);
+            ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
+            GmCols gcols{};
+            for (uint32_t j = 0; j < cnt; ++j) gcols.p[j] = d_scalar_ptrs[it + j];
+            launch_gm_partition<false>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, w.hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, bpcG, SG - 1);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(sb_h), dim3(SCAN_T), 0, st, (const uint32_t*)w.hist, hist_c, w.hist_off, w.block_tot3);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot3, sb_h, w.hist_off, hist_c, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(sb_h), dim3(SCAN_T), 0, st, hist_c, w.hist_off, (const uint32_t*)w.block_tot3);
+            launch_gm_partition<true>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, (uint32_t*)nullptr, (const uint32_t*)w.hist_off, w.entries, (uint64_t)tab_stride, bpcG, SG - 1);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins_c), dim3(1024), 0, st, (const uint64_t*)w.entries, (const uint32_t*)w.hist_off, nwgG, range_bits_G, nbc, w.offsets, w.counts, w.size_hist, w.idx);
+            ZK_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_size_bins_scan, dim3(1), dim3(64), 0, st, w.size_hist, (const uint32_t*)(w.offsets + nbc));
+            hipLaunchKernelGGL(k_order_buckets, dim3(sb), dim3(SCAN_T), 0, st, (const uint32_t*)w.counts, nbc, w.size_hist, w.order, w.ntasks);
+            hipLaunchKernelGGL(k_scan_u32_a, dim3(sb), dim3(SCAN_T), 0, st, (const uint32_t*)w.ntasks, nbc, w.toff, w.block_tot2);
+            hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot2, sb, w.toff, nbc, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_task_offsets, dim3(sb), dim3(SCAN_T), 0, st, nbc, w.toff, (const uint32_t*)w.block_tot2);
+            ZK_CHECK_LAUNCH(ctx);
+            return ZK_OK;
+        }
         if (is_narrow(it)) {
             // per-window path over the narrow table (see msm_batch_tab): digits, LDS-privatised sort with empty windows skipped;
             // the columns of a group are windows [j W, (j + 1) W) of one sort
@@ -1879,7 +1976,39 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         // reduce(step - 3) must be done with this bucket buffer -- but only the accumulation writes it: the sort of this MSM
         // runs while that reduction finishes
         if (stepno >= 3) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_p2[par], 0));
-        if (is_narrow(it)) {
+        if (is_narrow(it) && gm) {
+            // ---- GM: one bucket set per column, accumulated like a merged MSM (idx holds table indices); reduction and window sum per column
+            const uint32_t cnt = (uint32_t)grp, nbc = cnt * SG * pn.B;
+            const size_t tasks_c = (size_t)nbc + std::max(((size_t)n * cnt * pn.W) / TASK_CAP, (size_t)TASK_TARGET) + 1;
+            const WsG w = ws_gm(slot);
+            G1Xyzz29* partialN = buckets + nbN;
+            G1Xyzz29* task_partialN = partialN + (size_t)red_blocks_N * NG * 4;
+            {
+                ZkProfScope ps(ctx, "msm_buckets_narrow");
+                hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)((tasks_c + 255) / 256)), dim3(256), 0, ctx->stream, d_table_n, (const uint32_t*)w.offsets, (const uint32_t*)w.idx,
+                                   (const uint32_t*)w.order, (const uint32_t*)w.toff, (const uint32_t*)w.nmulti, nbc, buckets, task_partialN, 0, (uint64_t)0, (const uint32_t*)nullptr);
+            }
+            {
+                ZkProfScope ps(ctx, "msm_combine");
+                hipLaunchKernelGGL(k_msm_combine_wave, dim3(combine_grid((tasks_c + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.toff, task_partialN);
+                hipLaunchKernelGGL(k_msm_combine_small, dim3(combine_grid((nbc + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
+                hipLaunchKernelGGL(k_msm_combine, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)w.nmulti, (const uint32_t*)w.order,
+                                   (const uint32_t*)w.ntasks, (const uint32_t*)w.toff, (const G1Xyzz29*)task_partialN, buckets);
+                ZK_CHECK_LAUNCH(ctx);
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p1[par], ctx->stream));
+            ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
+            {
+                ZkProfScope ps(ctx, "msm_reduce_narrow", side);
+                // the SG sets of a column are SG "windows" of equal weight: reduced separately, their partials summed with the column's
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, cnt * SG), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, pn.B, partialN);
+                ZK_CHECK_LAUNCH(ctx);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(cnt), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, red_blocks_N * SG, wsum_all + it);
+                ZK_CHECK_LAUNCH(ctx);
+            }
+            ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));
+        } else if (is_narrow(it)) {
             // ---- per-window path: bucket accumulation, fold of the occupied windows of every column of the group, one window reduced per column
             const uint32_t cnt = (uint32_t)grp, wins = cnt * (uint32_t)pn.W, nbc = wins * pn.B;
             const size_t tasks_c = (size_t)nbc + std::max(((size_t)n * wins) / TASK_CAP, (size_t)TASK_TARGET) + 1;
