@@ -5,7 +5,9 @@ not on disk).  The KZG *verifier* half of the path stays on the CP
 reference [REF circuit-benchmarks/src/super_circuit.rs:141-154]; this module exists so the
 tests can run a real pairing-based acceptance check on proofs produced by the HIP prover.
 
-Restated from the textbook construction: Fq2 = Fq[u]/(u^2+1); Fq12 = Fq[w]/(w^12-18w^6+82);
+Layout and names (`FQP` polynomial-quotient fields, `twist`, `cast_g1_to_fq12`, `linefunc`, `ATE_LOOP_COUNT`, the modulus
+coefficients 82 / -18) follow the public py_ecc `bn128` module (Ethereum Foundation, MIT licence), written out again here from
+its structure; the mathematics is the textbook construction: Fq2 = Fq[u]/(u^2+1); Fq12 = Fq[w]/(w^12-18w^6+82);
 D-type sextic twist with xi = 9+u; Miller loop over 6t+2 = 29793968203157093288 followed by
 the two Frobenius line steps; final exponentiation (p^12-1)/r done naively.
 

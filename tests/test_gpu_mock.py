@@ -203,3 +203,46 @@ def test_inside_a_proving_session(ctx, cref, srs_by_k):
                                                 phase_witness=phase_witness)
     finally:
         pk.destroy()
+
+
+def test_keys_that_reuse_an_intermediate_slot_across_gates(ctx, srs_by_k):
+    """A key whose gate programs REUSE a TMP slot across constraints -- t0 = a b (gate 0), t1 = t0 a (gate 1), t0 := b b (gate 2), gate 3
+    reads t1 -- cannot be checked gate by gate by re-materialising definitions (t1 would expand the NEW t0): zk_mock_verify then
+    evaluates constraint i by running constraints 0 .. i in order.  Same records as the oracle on the plain expressions."""
+    k = 6
+    circ = plonk.Circuit(k, num_fixed=1, num_advice=6, num_instance=0, blinding_factors=5)
+    q = circ.fixed_col(0)
+    a, b_, c, d, e, f = (circ.advice_col(i) for i in range(6))
+    circ.add_gate(q * (a * b_ - c))
+    circ.add_gate(q * (a * b_ * a - d))
+    circ.add_gate(q * (b_ * b_ - f))
+    circ.add_gate(q * (a * b_ * a - e))
+    n, u = circ.n, circ.u
+    rng = random.Random(11)
+    av = [rng.randrange(R) if i < u else 0 for i in range(n)]
+    bv = [rng.randrange(R) if i < u else 0 for i in range(n)]
+    cols = [av, bv, [x * y % R for x, y in zip(av, bv)], [x * y % R * x % R for x, y in zip(av, bv)], [x * y % R * x % R for x, y in zip(av, bv)], [y * y % R for y in bv]]
+    for row in range(u):
+        circ.fixed[0][row] = 1
+    PC, MUL, SUB, TEE, PT = plonk.Q_PUSH_COL, plonk.Q_MUL, plonk.Q_SUB, plonk.Q_TEE_TMP, plonk.Q_PUSH_TMP
+    col = lambda t, i: (PC, plonk.colref(t, i), 0)
+    A, F = plonk.ADVICE, plonk.FIXED
+    progs = [
+        [col(F, 0), col(A, 0), col(A, 1), (MUL, 0, 0), (TEE, 0, 0), col(A, 2), (SUB, 0, 0), (MUL, 0, 0)],                      # q (t0 = a b) - c
+        [col(F, 0), (PT, 0, 0), col(A, 0), (MUL, 0, 0), (TEE, 1, 0), col(A, 3), (SUB, 0, 0), (MUL, 0, 0)],                     # q (t1 = t0 a) - d
+        [col(F, 0), col(A, 1), col(A, 1), (MUL, 0, 0), (TEE, 0, 0), col(A, 5), (SUB, 0, 0), (MUL, 0, 0)],                      # q (t0 := b b) - f
+        [col(F, 0), (PT, 1, 0), col(A, 4), (SUB, 0, 0), (MUL, 0, 0)],                                                          # q (t1 - e)
+    ]
+    circ.compile_gates_cse = lambda: progs
+    pk = ctx.pk_create(srs_by_k[k], circ.blob(cse=True))
+    try:
+        assert _gpu(ctx, pk, cols, []) == ([], 0)
+        bad = [list(x) for x in cols]
+        bad[4][7] = (bad[4][7] + 1) % R                  # e: only gate 3 sees it
+        bad[5][9] = (bad[5][9] + 1) % R                  # f: only gate 2
+        got, total = _gpu(ctx, pk, bad, [])
+        want = pv.mock_failures(circ, bad, [])
+        assert want == [(pv.MOCK_GATE, 2, 0, 9), (pv.MOCK_GATE, 3, 0, 7)]
+        assert total == len(want) and sorted(got) == want
+    finally:
+        pk.destroy()

@@ -28,7 +28,7 @@ def test_unique_id_reaches_every_rank_without_torch(tmp_path):
     assert [g[0] for g in got] == [0, 1, 2]
     assert all(g[1] == bytes(range(128)) for g in got)
     assert not any(g[2] for g in got), "the rendezvous must not pull torch into a prover rank"
-    assert os.path.getsize(path) == 136          # the id + rank 0's pid (stale-file check)
+    assert os.path.getsize(path) == 160          # the id + rank 0's pid, host tag and the launch nonce (stale-file checks)
 
 
 def test_missing_id_times_out(tmp_path):
@@ -51,9 +51,20 @@ def test_stale_id_of_a_finished_launch_is_refused(tmp_path):
     dead = subprocess.Popen([sys.executable, "-c", "pass"])
     dead.wait()
     with open(path, "wb") as f:
-        f.write(bytes(128) + struct.pack("<Q", dead.pid))           # left behind by a rank 0 that has exited
+        f.write(bytes(128) + struct.pack("<QQ", dead.pid, rendezvous._host_tag()) + bytes(16))           # left behind by a rank 0 of this host that has exited
     with pytest.raises(TimeoutError):
         rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
+    # written on ANOTHER host (shared file system): its pid cannot be looked up here -- accepted on the nonce alone ...
+    with open(path, "wb") as f:
+        f.write(bytes(range(128)) + struct.pack("<QQ", dead.pid, rendezvous._host_tag() ^ 1) + bytes(16))
+    assert rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3) == bytes(range(128))
+    # ... and refused when the launcher's nonce differs (ZK_COMM_NONCE), whoever wrote it
+    os.environ["ZK_COMM_NONCE"] = "launch-2"
+    try:
+        with pytest.raises(TimeoutError):
+            rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
+    finally:
+        del os.environ["ZK_COMM_NONCE"]
     with open(path, "wb") as f:
         f.write(bytes(128))                                          # the old format (no pid) is not accepted either
     with pytest.raises(TimeoutError):

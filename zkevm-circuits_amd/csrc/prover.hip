@@ -62,7 +62,7 @@ enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECI
 enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
 enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
 // abstract constant operands: user constants are [0, num_consts); challenges live above
-constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_DELTA0 = 0xFFFE0000u,   // C_DELTA0 + j = beta * delta^j
+constexpr uint32_t C_THETA = 0xFFFF0000u, C_BETA = 0xFFFF0001u, C_GAMMA = 0xFFFF0002u, C_Y = 0xFFFF0003u, C_ONE = 0xFFFF0004u, C_ZERO = 0xFFFF0005u, C_DELTA0 = 0xFFFE0000u,   // C_DELTA0 + j = beta * delta^j
                    C_CHAL0 = 0xFFFD0000u,                                                                                      // C_CHAL0 + i = user challenge i
                    C_YPOW0 = 0xFFFC0000u;                                                                                      // C_YPOW0 + g = y^g (folding constraints that are g positions apart)
 
@@ -311,6 +311,7 @@ bool resolve_const(const Env& e, uint32_t ref, F4* out) {
         case C_GAMMA: *out = e.gamma; return true;
         case C_Y: *out = e.y; return true;
         case C_ONE: *out = host::fr_one(); return true;
+        case C_ZERO: *out = host::fr_zero(); return true;
         default: break;
     }
     if (ref >= C_DELTA0 && ref - C_DELTA0 < e.beta_delta.size()) { *out = e.beta_delta[ref - C_DELTA0]; return true; }
@@ -2294,10 +2295,21 @@ static int mock_verify_core(zk_ctx* ctx, const zk_pk* pk, const Env& lag, const 
         PK_TRY(zk_d2h(ctx, &any, d_any, 4));
         if (any) {
             // one pass per constraint; a constraint that reads intermediates other constraints parked computes them itself
+            // (TmpSplit re-materialises their definitions).  A key that REUSES a slot across constraints (a later TEE_TMP of a
+            // slot an earlier constraint's intermediate still depends on) cannot be re-materialised that way -- the latest
+            // definition would be expanded: for such keys constraint i is evaluated by running constraints 0 .. i in order, every
+            // value but the last folded away (acc = acc * 0 + value), exactly the sequence the folded pass above saw.
+            const bool reuse = tmp_slots_conflict(pk->gates);
             TmpSplit tmps(1);
             for (uint32_t i = 0; i < pk->gates.size(); ++i) {
                 for (auto& h : tmps.have) std::fill(h.begin(), h.end(), 0u);
                 Prog one;
+                if (reuse) {
+                    for (uint32_t j = 0; j <= i; ++j) { one.insert(one.end(), pk->gates[j].begin(), pk->gates[j].end()); one.push_back({Q_FOLD, C_ZERO, 0}); }
+                    PK_TRY(run_program(ctx, lag, one, vals.p));
+                    PK_TRY(mock_nonzero_enqueue(ctx, vals.fr(), d_rows_g, cnt_g, ZK_MOCK_GATE, i, 0, d_fails, cap32, d_total));
+                    continue;
+                }
                 tmps.append(pk->gates[i], 0, one);
                 one.push_back({Q_FOLD, C_ONE, 0});
                 PK_TRY(run_program(ctx, lag, one, vals.p));

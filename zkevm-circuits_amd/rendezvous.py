@@ -15,12 +15,31 @@ def _alive(pid: int) -> bool:
     return True
 
 
+def _host_tag() -> int:
+    import hashlib
+    import socket
+    return int.from_bytes(hashlib.blake2b(socket.gethostname().encode(), digest_size=8).digest(), "little")
+
+
+def _launch_nonce() -> bytes:
+    """16 bytes that every rank of ONE launch derives alike and another launch does not: ZK_COMM_NONCE when the launcher
+    exports one (any string), else zeros (the pid check below is then the only guard against a stale file)."""
+    import hashlib
+    v = os.environ.get("ZK_COMM_NONCE", "")
+    return hashlib.blake2b(v.encode(), digest_size=16).digest() if v else bytes(16)
+
+
+ID_FILE_LEN = 128 + 8 + 8 + 16
+
+
 def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float = 120.0) -> bytes:
     """Rank 0's 128-byte RCCL id to every rank through a file: the whole out-of-band channel a launcher needs to
     provide (no torch, no MPI).  `make_id` is only called on rank 0.  The file appears atomically (write + rename)
-    and carries the id followed by rank 0's pid: a file whose writer is gone is a leftover of an earlier launch
-    (same shell, same port, or a fixed ZK_COMM_ID_FILE) and is never accepted -- rank 0 also removes whatever is
-    at `path` before it even creates its id, and `retire_unique_id` removes the file once every rank has joined."""
+    and carries the id followed by rank 0's pid, a tag of its host name and the launch nonce.  A file whose nonce
+    differs is another launch's; with equal nonces, a reader ON RANK 0's HOST also requires the writer to be alive (a
+    leftover of an earlier launch from the same shell / port / fixed ZK_COMM_ID_FILE is never accepted), while a reader
+    on ANOTHER host (a path on a shared file system) cannot see that pid and relies on the nonce.  Rank 0 removes
+    whatever is at `path` before it even creates its id, and `retire_unique_id` removes the file once every rank has joined."""
     import struct
     import time
 
@@ -34,7 +53,7 @@ def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float
         if world > 1:
             tmp = f"{path}.{os.getpid()}.tmp"
             with open(tmp, "wb") as f:
-                f.write(uid + struct.pack("<Q", os.getpid()))
+                f.write(uid + struct.pack("<QQ", os.getpid(), _host_tag()) + _launch_nonce())
             os.replace(tmp, path)
         return uid
     deadline = time.monotonic() + timeout
@@ -42,8 +61,10 @@ def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float
         try:
             with open(path, "rb") as f:
                 blob = f.read()
-            if len(blob) == 136 and _alive(struct.unpack("<Q", blob[128:])[0]):
-                return blob[:128]
+            if len(blob) == ID_FILE_LEN and blob[144:] == _launch_nonce():
+                pid, host = struct.unpack("<QQ", blob[128:144])
+                if host != _host_tag() or _alive(pid):
+                    return blob[:128]
         except FileNotFoundError:
             pass
         if time.monotonic() > deadline:
