@@ -1498,42 +1498,72 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // ---- lookups, round 2 (Prepared::commit_grand_sum): phi[0] = 0, phi[i+1] = phi[i] + sum_a 1/(f_a[i]+beta) - m[i]/(t[i]+beta),
     // the last bf rows random; enqueued back to back with one closing check and one commit batch
     if (pk->L) {
-        size_t max_inputs = 1;
-        for (const auto& lk : pk->lookups) max_inputs = std::max(max_inputs, lk.inputs.size());
-        DevBuf inv, g, closing_d;
-        if (!inv.alloc((max_inputs + 1) * n * 32) || !g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        // ONE batch inversion for all arguments of the proof: every (t + beta) and (f_a + beta) column is written into one buffer --
+        // slot list below; an argument that reads the table of the one before it has no table slot of its own --, inverted by a
+        // single call (a batch inversion is one field inversion per wave behind two passes of products: a hundred calls of
+        // 2-3 M elements each were a hundred inversion latencies, 16 ms on the SuperCircuit shape), then every argument forms
+        // g = sum_a 1 / (f_a + beta) - m / (t + beta) and its prefix sum.  When the buffer would exceed a quarter of the free device
+        // memory the arguments are processed in several such batches.
+        std::vector<size_t> slot0(pk->L), tslot(pk->L), nslots(pk->L);
+        DevBuf g, closing_d;
+        if (!g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         std::vector<F4> blind((size_t)pk->L * pk->bf);
         std::vector<const void*> pptrs(pk->L);
-        for (uint32_t l = 0; l < pk->L; ++l) {
-            DevBuf phi;
-            if (!phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            const size_t N = lk_f[l].size();
-            // inv = [t + beta | f_0 + beta | ... | f_{N-1} + beta], inverted in one batch
-            Env e2 = lag;
-            std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
-            ft[0].borrow(lk_t[table_owner[l]].p);
-            for (size_t a = 0; a < N; ++a) ft[1 + a] = std::move(lk_f[l][a]);
-            e2.lk_phi = &ft;
-            // the table's slot keeps 1 / (t + beta) from the previous argument when that one read the same table
-            const size_t first = same_table[l] ? 1 : 0;
-            for (size_t a = first; a <= N; ++a) {
-                PB pb;
-                pb.col(CT_LK_PHI, (uint32_t)a).addc(C_BETA).fold(C_ONE);
-                PK_TRY(run_program(ctx, e2, pb.g, (char*)inv.p + a * n * 32));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const size_t max_slots = std::max<size_t>(4, (free_b + ctx->pool_bytes) / 4 / (n * 32));
+        for (uint32_t l0 = 0; l0 < pk->L;) {
+            // arguments [l0, l1) share one inversion; an argument is never separated from the owner of its table
+            size_t slots = 0;
+            uint32_t l1 = l0;
+            while (l1 < pk->L) {
+                const size_t need = lk_f[l1].size() + (same_table[l1] && l1 > l0 ? 0 : 1);
+                if (l1 > l0 && slots + need > max_slots && !same_table[l1]) break;
+                slot0[l1] = slots;
+                tslot[l1] = (same_table[l1] && l1 > l0) ? tslot[l1 - 1] : slots;
+                nslots[l1] = need;
+                slots += need;
+                ++l1;
             }
-            PK_TRY(zk_fr_batch_invert(ctx, (char*)inv.p + first * n * 32, (N + 1 - first) * n));
-            // g = sum_a inv_f_a - m * inv_t
-            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, inv.p, g.p, n));
-            PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, (char*)inv.p + n * 32, g.p, g.p, n));
-            for (size_t a = 1; a < N; ++a) PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_ADD, g.p, (char*)inv.p + (1 + a) * n * 32, g.p, n));
-            PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
-            ZK_HIP(ctx, hipMemcpyAsync((char*)closing_d.p + (size_t)l * 32, (char*)phi.p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
-            for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
-            ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
-            ft.clear(); lk_f[l].clear();                                        // f, t are not needed again (the quotient recomputes them on its cosets)
-            if (l + 1 == pk->L || !same_table[l + 1]) lk_t[table_owner[l]].release();      // the table's last reader
-            pptrs[l] = phi.p;
-            lk_phi[l] = std::move(phi);
+            DevBuf inv;
+            if (!inv.alloc(slots * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            for (uint32_t l = l0; l < l1; ++l) {
+                const size_t N = lk_f[l].size();
+                Env e2 = lag;
+                std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
+                ft[0].borrow(lk_t[table_owner[l]].p);
+                for (size_t a = 0; a < N; ++a) ft[1 + a].borrow(lk_f[l][a].p);
+                e2.lk_phi = &ft;
+                const bool own_t = tslot[l] == slot0[l];
+                for (size_t a = own_t ? 0 : 1; a <= N; ++a) {
+                    PB pb;
+                    pb.col(CT_LK_PHI, (uint32_t)a).addc(C_BETA).fold(C_ONE);
+                    const size_t slot = a == 0 ? tslot[l] : slot0[l] + (own_t ? a : a - 1);
+                    PK_TRY(run_program(ctx, e2, pb.g, (char*)inv.p + slot * n * 32));
+                }
+            }
+            PK_TRY(zk_fr_batch_invert(ctx, inv.p, slots * n));
+            for (uint32_t l = l0; l < l1; ++l) {
+                DevBuf phi;
+                if (!phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                const size_t N = lk_f[l].size();
+                const bool own_t = tslot[l] == slot0[l];
+                const char* inv_t = (const char*)inv.p + tslot[l] * n * 32;
+                const char* inv_f = (const char*)inv.p + (slot0[l] + (own_t ? 1 : 0)) * n * 32;
+                // g = sum_a inv_f_a - m * inv_t
+                PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_MUL, lk_m[l].p, inv_t, g.p, n));
+                PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_SUB, inv_f, g.p, g.p, n));
+                for (size_t a = 1; a < N; ++a) PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_ADD, g.p, inv_f + a * n * 32, g.p, n));
+                PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
+                ZK_HIP(ctx, hipMemcpyAsync((char*)closing_d.p + (size_t)l * 32, (char*)phi.p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
+                for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
+                ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
+                lk_f[l].clear();                                                    // f, t are not needed again (the quotient recomputes them on its cosets)
+                if (l + 1 == pk->L || !same_table[l + 1]) lk_t[table_owner[l]].release();      // the table's last reader
+                pptrs[l] = phi.p;
+                lk_phi[l] = std::move(phi);
+            }
+            l0 = l1;
         }
         std::vector<F4> closing(pk->L);
         PK_TRY(zk_d2h(ctx, closing.data(), closing_d.p, (size_t)pk->L * 32));
