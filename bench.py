@@ -588,7 +588,9 @@ def sharded_headline(args, torch, dist, rank, world, local_rank):
     verdict = [None]
     if rank == 0:
         free = host_bytes_free()
-        if free is not None and free < world * need:
+        if torch.cuda.device_count() < world:
+            verdict[0] = f"{world} ranks on {torch.cuda.device_count()} GPU(s): the sharded proof needs one GPU per rank (RCCL ranks cannot share a device; 150 GB of session state each)"
+        elif free is not None and free < world * need:
             verdict[0] = f"host memory: {free >> 30} GiB free, {world} ranks x {need >> 30} GiB needed"
     dist.broadcast_object_list(verdict, src=0)
     if verdict[0]:
@@ -623,6 +625,7 @@ def main():
     ap.add_argument("--no-proof", action="store_true", help="skip the other shapes / distributions (N = 1 only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle verifier's check of the last timed proof")
     ap.add_argument("--no-msm-ntt", action="store_true", help="skip the BASELINE configs[1] section")
+    ap.add_argument("--only-msm-ntt", action="store_true", help="run the BASELINE configs[1] section alone and print its record (profiling passes)")
     ap.add_argument("--proof-worker", default="", help=argparse.SUPPRESS)      # internal: run ONE proof shape in this process and print its record
     ap.add_argument("--batch", type=int, default=32, help="msm_ntt section: columns submitted per commit_batch call")
     args = ap.parse_args()
@@ -647,6 +650,9 @@ def main():
     local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
 
+    if world == 1 and args.only_msm_ntt:
+        print(json.dumps(msm_ntt_section(args, torch)), flush=True)
+        return
     if world == 1:
         out = headline_single(args, torch)
         if not args.no_cpu_baseline:
