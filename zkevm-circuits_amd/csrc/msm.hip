@@ -473,11 +473,19 @@ __global__ void __launch_bounds__(1024) k_msm_m_binsort(const uint64_t* __restri
             (void)lds_take(cnt, (uint32_t)(ent_r[j] >> 32), live);
         }
     } else {
-        for (uint32_t base = lo; base < hi; base += blockDim.x) {
-            const uint32_t e = base + threadIdx.x;
-            const bool live = e < hi;
-            const uint64_t ent = live ? entries[e] : 0ull;
-            (void)lds_take(cnt, (uint32_t)(ent >> 32), live);
+        // an oversize partition (skewed scalars: e.g. the carry digit of every small value >= 2^(c-1) lands in ONE bucket of the next
+        // window -- 150 000 entries in one partition of a witness-like column) is streamed by this one workgroup: eight loads in
+        // flight per trip, or its two passes are a chain of a few hundred load latencies that the whole launch waits for
+        constexpr int UNR = 8;
+        for (uint32_t base = lo; base < hi; base += blockDim.x * UNR) {
+            uint64_t ent[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { const uint32_t e = base + (uint32_t)j * blockDim.x + threadIdx.x; ent[j] = e < hi ? entries[e] : ~0ull; }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                if (base + (uint32_t)j * blockDim.x >= hi) break;                     // uniform
+                (void)lds_take(cnt, (uint32_t)(ent[j] >> 32), ent[j] != ~0ull);
+            }
         }
     }
     __syncthreads();
@@ -518,12 +526,18 @@ __global__ void __launch_bounds__(1024) k_msm_m_binsort(const uint64_t* __restri
             if (live) stage[pos] = (uint32_t)ent_r[j];
         }
     } else {
-        for (uint32_t base = lo; base < hi; base += blockDim.x) {
-            const uint32_t e = base + threadIdx.x;
-            const bool live = e < hi;
-            const uint64_t ent = live ? entries[e] : 0ull;
-            const uint32_t pos = lds_take(cnt, (uint32_t)(ent >> 32), live);
-            if (live) idx[lo + pos] = (uint32_t)ent;
+        constexpr int UNR = 8;
+        for (uint32_t base = lo; base < hi; base += blockDim.x * UNR) {
+            uint64_t ent[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { const uint32_t e = base + (uint32_t)j * blockDim.x + threadIdx.x; ent[j] = e < hi ? entries[e] : ~0ull; }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                if (base + (uint32_t)j * blockDim.x >= hi) break;                     // uniform
+                const bool live = ent[j] != ~0ull;
+                const uint32_t pos = lds_take(cnt, (uint32_t)(ent[j] >> 32), live);
+                if (live) idx[lo + pos] = (uint32_t)ent[j];
+            }
         }
     }
     if (staged) {
