@@ -291,3 +291,30 @@ def test_product_poseidon_transcript_replays_the_reference_proof(fx):
     tr.write_point(pt(t.w_prime))
     assert tr.proof() == fx.proof              # and what it wrote along the way is the reference's proof, byte for byte
     tr.close()
+
+
+def test_oracle_prover_satisfies_the_references_protocol():
+    """The oracle PROVER (the byte-level yardstick of every GPU proof) on the fixture's constraint system at k = 8, verified by the
+    protocol-driven verifier with the REFERENCE's protocol object (quotient expression, query and evaluation order as snark-verifier
+    compiled them; only domain, key commitments, initial state and instance count replaced): what it emits is what the reference's
+    verifier expects for this circuit.  tests/test_gpu_reference_protocol.py requires the same of the product's proof."""
+    import importlib.util
+    from oracle import plonk_prover as pp
+    spec = importlib.util.spec_from_file_location("ref_protocol_case", os.path.join(HERE, "test_gpu_reference_protocol.py"))
+    case = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(case)
+    fixture = json.load(open(os.path.join(HERE, "golden", "reference_chunk_proof.json")))
+    circ, adv, inst = case.build_reference_cs(8)
+    srs = pp.Srs(8, case.S_SECRET)
+    vk = pp.vk_commitments(circ, srs)
+    rep = plonk_verifier.default_vk_repr(circ, vk)
+    proof = pp.create_proof(circ, srs, adv, inst, rep, bytes(range(16)), "shplonk", transcript="poseidon")
+    prot = sv.Protocol(case.protocol_for(fixture["protocol"], circ, vk, rep, len(inst[0])))
+    s_g2 = pr.ec_mul(pr.G2_GEN, case.S_SECRET)
+    assert len(proof) == 896 and sv.verify_snark(prot, inst, proof, pr.G2_GEN, s_g2)
+    bad = bytearray(proof)
+    bad[32 * 9 + 2] ^= 1
+    assert not sv.verify_snark(prot, inst, bytes(bad), pr.G2_GEN, s_g2)
+    # upstream's uniform "random" polynomial is accepted as well (the verifier only opens the commitment)
+    proof_u = pp.create_proof(circ, srs, adv, inst, rep, bytes(range(16)), "shplonk", transcript="poseidon", vanishing="uniform")
+    assert proof_u != proof and sv.verify_snark(prot, inst, proof_u, pr.G2_GEN, s_g2)
