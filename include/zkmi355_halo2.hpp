@@ -255,6 +255,17 @@ class ProofSession {
         ch.resize(cnt);
         return ch;
     }
+    // the same for columns resident on the device (device pointers); in_place: the session works in those buffers (it overwrites their
+    // blinding rows) until finish() or the destructor returns
+    std::vector<Fr> advice_phase_dev(const std::vector<uint32_t>& column_index, const std::vector<const void*>& device_columns, bool in_place = false) {
+        std::vector<Fr> ch(num_challenges_ ? num_challenges_ : 1);
+        uint32_t cnt = (uint32_t)ch.size();
+        c_.check(zk_proof_advice_phase_dev(c_.raw(), s_, column_index.data(), device_columns.data(), (uint32_t)column_index.size(), in_place ? ZK_ADVICE_DEV_IN_PLACE : 0u, ch.data(), &cnt));
+        ch.resize(cnt);
+        return ch;
+    }
+    // the vanishing argument's "random" polynomial: ZK_VANISHING_ONE (the reference's own proofs; default) or ZK_VANISHING_UNIFORM (upstream halo2)
+    void set_vanishing_random(int kind) { c_.check(zk_proof_set_vanishing_random(c_.raw(), s_, kind)); }
     // MockProver's row checks over the columns the session holds, under its own challenges (after the last phase)
     std::vector<zk_mock_failure> mock_verify(size_t max_records = 4096) {
         std::vector<zk_mock_failure> out(max_records ? max_records : 1);

@@ -229,7 +229,7 @@ def test_g_to_lagrange_2_16_timing(ctx, cref):
         s_.destroy()
 
 
-@pytest.mark.parametrize("k", [10, 14, 16, 17, 19])      # 19: window size 19 -- one-launch partition sort + LDS-staged scatter; 17, 19: dense columns take whole-bucket tasks (17 sits on the threshold)
+@pytest.mark.parametrize("k", [10, 12, 13, 14, 16, 17, 19])      # 12, 13: the grouped small-value sort at its narrowest partitions (one / two buckets each); 19: window size 19 -- one-launch partition sort + LDS-staged scatter; 17, 19: dense columns take whole-bucket tasks (17 sits on the threshold)
 def test_commit_paths_agree_with_the_oracle(ctx, cref, k):
     """Commitments over an SRS take the merged-window path (one bucket set for all windows, over the
     SRS's window table) or, for columns hinted as small-valued, the per-window path; both must give
