@@ -24,6 +24,9 @@ extern "C" {
 void h_mul29(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     if (which) st(out, mul29(ld<Fr29P>(a), ld<Fr29P>(b))); else st(out, mul29(ld<Fq29P>(a), ld<Fq29P>(b)));
 }
+void h_mul29_ub(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    if (which) st(out, mul29_ub(ld<Fr29P>(a), ld<Fr29P>(b))); else st(out, mul29_ub(ld<Fq29P>(a), ld<Fq29P>(b)));
+}
 void h_sqr29(int which, const uint32_t* a, uint32_t* out) {
     if (which) st(out, sqr29(ld<Fr29P>(a))); else st(out, sqr29(ld<Fq29P>(a)));
 }

@@ -106,6 +106,9 @@ def test_montgomery_product_and_square(h, which):
             v = val(out)
             assert v % mod == a * b * rinv % mod
             assert normalised(out) and v * RP < a * b + mod * RP, (hex(a), hex(b))
+            ub = U9()
+            h.h_mul29_ub(which, U9(*la), U9(*limbs(b)), ub)      # the wave-uniform-factor form (evaluator constants): same limbs
+            assert list(ub) == list(out)
     for a in a_vals:
         if a * a >= RP * mod:
             continue

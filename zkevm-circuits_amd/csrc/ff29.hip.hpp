@@ -367,6 +367,33 @@ __host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& 
     return t;
 }
 
+// The same product with a wave-uniform second factor (a constant of a program, a challenge): its limbs stay in scalar
+// registers and enter the multiply-adds as the scalar operand, like the modulus -- no vector copies of b.
+template <class P>
+__host__ __device__ __forceinline__ F29<P> mul29_ub(const F29<P>& a, const F29<P>& b) {
+    uint32_t m[9];
+    F29<P> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8, nm = k < 9 ? k : 17 - k;
+        uint32_t ys[9], ks[9];
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) { ys[i - lo] = b.l[k - i]; ks[i - lo] = P::M(k - i); }
+        acc = dotk(a.l + lo, ys, hi - lo + 1, acc);
+        acc = dotk(m + lo, ks, nm, acc);
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * P::INV) & MASK29;
+            acc += (uint64_t)m[k] * P::M(0);
+        } else {
+            t.l[k - 9] = (uint32_t)acc & MASK29;
+        }
+        acc >>= 29;
+    }
+    t.l[8] = (uint32_t)acc;
+    return t;
+}
+
 // (a*b + c*d) * 2^-261 mod p in one pass: the second product joins the column sums of the first, one reduction serves both
 // (243 v_mad_u64_u32 instead of 324 + the subtraction or addition that would have combined two reduced products).
 // a, b, c normalised (limbs < 2^29), d with limbs < 2^30 (e.g. K*p - x taken limb-wise, see neg29k), a*b + c*d < 2^261 * p:

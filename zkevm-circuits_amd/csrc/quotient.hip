@@ -108,6 +108,10 @@ enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_
 constexpr uint32_t K_SETTLE0 = 0x100, K_SETTLE1 = 0x200;      // word 0 of a lowered instruction: settle t0 / t1 before executing
 constexpr int K_CONST_SHIFT = 12;                              // K_FOLD_COL keeps its constant index in the bits above
 
+// A program constant as the kernel reads it: the nine 29-bit limbs, unpacked on the host once per launch (the kernel used to
+// spend 27 vector instructions per constant operand on it).  The index is wave-uniform, so the limbs arrive by scalar loads
+// and stay in scalar registers (mul29_ub).  64-byte records.
+struct QC29 { uint32_t l[16]; };
 constexpr int Q_THREADS = 256;
 constexpr int Q_MAX_STACK = 16;
 constexpr uint32_t Q_MAX_TMP = 4096;     // intermediates live in HBM, [slot][row]: 32 MiB per slot at 2^20 rows
@@ -151,8 +155,8 @@ __device__ __forceinline__ bool k_has_mem(uint32_t w0) {
 // FULL: the grid covers the domain exactly (2^ext_k >= Q_THREADS), no lane needs masking.
 template <bool FULL>
 __global__ void __launch_bounds__(Q_THREADS)
-k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const Fr* __restrict__ consts,
-                const Fr* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
+k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const QC29* __restrict__ consts,
+                const QC29* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
                 Fr* __restrict__ out, Fr* tmp /* [slot][row]: the row's intermediates, written and read by its own lane */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     QStack st{smem};
@@ -176,10 +180,29 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         t0 = top;
         if (sp >= 2) t1 = st.get(sp - 2);
     };
+    // A column pointer comes out of a table in memory, so the compiler cannot tell its address space and would emit FLAT loads;
+    // those count on lgkmcnt as well as vmcnt, and every wait for a scalar load (instruction words, constants) would then also wait
+    // for the operand that is being prefetched.  The columns are device memory: say so (global_load, vmcnt only).
+    typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+    using GU4 = const U32x4 __attribute__((address_space(1)));
+    auto load_row = [&](uint32_t a, uint32_t row) -> Fr {
+        GU4* q = (GU4*)(uintptr_t)(cols[a] + row);
+        const U32x4 lo = q[0], hi = q[1];
+        Fr r;
+        r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
+        r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+        return r;
+    };
     auto load = [&](uint32_t a, uint32_t b) -> Fr {
         const uint32_t row = (i + b * rot_scale) & row_mask;          // b = the rotation as a two's complement word: wraps like the domain
-        if (FULL) return ldg(cols[a] + row);
-        return live ? ldg(cols[a] + row) : Fr::zero();
+        if (FULL) return load_row(a, row);
+        return live ? load_row(a, row) : Fr::zero();
+    };
+    auto cst = [&](const QC29* __restrict__ tab, uint32_t j) -> Q29 {
+        Q29 r;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) r.l[q] = tab[j].l[q];
+        return r;
     };
     // instruction words are fetched two ahead, the memory operand one ahead: the load of instruction pc + 1 is
     // in flight while instruction pc computes
@@ -196,22 +219,22 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         if (w0 & K_SETTLE1) t1 = q_settle(t1);
         switch (op) {
             case Q_PUSH_COL: push_shift(); t0 = unpack29<Fr29P>(m_cur); break;
-            case Q_PUSH_CONST: push_shift(); t0 = unpack29<Fr29P>(ldg(consts + w1)); break;
+            case Q_PUSH_CONST: push_shift(); t0 = cst(consts, w1); break;
             case Q_ADD: drop_to(add29(t1, t0)); break;
             case Q_SUB: { Q29 d = sub29k<2>(t1, t0); normalize29(d); drop_to(d); break; }     // the top limb of a settled subtrahend may borrow: carry it out before anyone multiplies
             case Q_MUL: drop_to(mul29(t1, q_shl5(t0))); break;
             case Q_NEG: t0 = sub29k<2>(zero29, t0); normalize29(t0); break;
             case Q_SQUARE: t0 = mul29(t0, q_shl5(t0)); break;
             case Q_DOUBLE: t0 = add29(t0, t0); break;
-            case Q_FOLD: acc = add29(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + w1))), t0); drop_to(t1); break;
-            case Q_MUL_CONST: t0 = mul29(t0, unpack29<Fr29P>(ldg(consts_rp + w1))); break;
-            case Q_ADD_CONST: t0 = add29(t0, unpack29<Fr29P>(ldg(consts + w1))); break;
+            case Q_FOLD: acc = add29(mul29_ub(acc, cst(consts_rp, w1)), t0); drop_to(t1); break;
+            case Q_MUL_CONST: t0 = mul29_ub(t0, cst(consts_rp, w1)); break;
+            case Q_ADD_CONST: t0 = add29(t0, cst(consts, w1)); break;
             case Q_TEE_TMP: if (live) stg(tmp + (((uint64_t)w1 << ext_k) + i), pack29_lt2p(t0)); break;             // parked canonical: read back as a column
             case K_ADD_COL: t0 = add29(t0, unpack29<Fr29P>(m_cur)); break;
             case K_SUB_COL: t0 = sub29k<2>(t0, unpack29<Fr29P>(m_cur)); break;                                  // canonical subtrahend: its top limb is below that of 2p, no borrow
             case K_RSUB_COL: t0 = sub29k<2>(unpack29<Fr29P>(m_cur), t0); normalize29(t0); break;
             case K_MUL_COL: t0 = mul29(t0, unpack29_x32(m_cur)); break;
-            case K_FOLD_COL: acc = add29(mul29(acc, unpack29<Fr29P>(ldg(consts_rp + (w0 >> K_CONST_SHIFT)))), unpack29<Fr29P>(m_cur)); break;
+            case K_FOLD_COL: acc = add29(mul29_ub(acc, cst(consts_rp, w0 >> K_CONST_SHIFT)), unpack29<Fr29P>(m_cur)); break;
             default: break;
         }
         w0 = n0; w1 = n1; w2 = n2;
@@ -515,13 +538,13 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     std::vector<const void*> col_tab(h_col_ptrs, h_col_ptrs + num_cols);
     for (uint32_t t = 0; t < num_tmp; ++t) col_tab.push_back(d_tmp + ((size_t)t << ext_k));
     const size_t prog_bytes = (size_t)(low_len + 3) * 12, col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
-    const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(Fr) * 2, tev_bytes = tev.size() * sizeof(Fr);
+    const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(QC29) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
     if (!d) return ZK_ERR_OOM;
     uint32_t* d_prog = (uint32_t*)d;
     const Fr** d_cols = (const Fr**)(d + al(prog_bytes));
-    Fr* d_consts = (Fr*)(d + al(prog_bytes) + al(col_bytes));
+    QC29* d_consts = (QC29*)(d + al(prog_bytes) + al(col_bytes));
     Fr* d_tev = (Fr*)(d + al(prog_bytes) + al(col_bytes) + al(const_bytes));
     // program, column table, constants (R and R' forms) and vanishing inverses travel as ONE upload: the proof makes hundreds of
     // these calls (compressions, linear combinations, class programs), and five small copies each were 2 500 copies per
@@ -535,7 +558,11 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         for (int e = 0; e < 3; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; }      // END + the two triples the kernel fetches ahead
         if (!col_tab.empty()) memcpy(staging.data() + al(prog_bytes), col_tab.data(), col_tab.size() * 8);
         char* hc = staging.data() + al(prog_bytes) + al(col_bytes);
-        if (num_consts) { memcpy(hc, h_consts, (size_t)num_consts * sizeof(Fr)); memcpy(hc + (size_t)num_consts * sizeof(Fr), consts_rp.data(), (size_t)num_consts * sizeof(Fr)); }
+        QC29* hq = (QC29*)hc;                                  // limb form: the R-form constants, then their R' images
+        for (uint32_t j = 0; j < num_consts; ++j) {
+            const Q29 a = unpack29<Fr29P>(((const Fr*)h_consts)[j]), b = unpack29<Fr29P>(consts_rp[j]);
+            for (int q = 0; q < 9; ++q) { hq[j].l[q] = a.l[q]; hq[num_consts + j].l[q] = b.l[q]; }
+        }
         if (!tev.empty()) memcpy(staging.data() + al(prog_bytes) + al(col_bytes) + al(const_bytes), tev.data(), tev_bytes);
     }
     ZK_HIP(ctx, hipMemcpyAsync(d, staging.data(), total_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -564,10 +591,10 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     }
     if (ne >= (uint64_t)Q_THREADS) {
         hipLaunchKernelGGL(k_quotient_eval<true>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                           low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+                           low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
     } else {
         hipLaunchKernelGGL(k_quotient_eval<false>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                           low_len + 1, (const Fr* const*)d_cols, (const Fr*)d_consts, (const Fr*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+                           low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
     }
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;
