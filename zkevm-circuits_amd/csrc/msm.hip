@@ -322,104 +322,6 @@ __global__ void __launch_bounds__(256) k_msm_gm_partition(GmCols cols, uint64_t 
     __shared__ uint32_t lds[MSM_M_MAX_BINS];
     partition_body<C, SCATTER>(cols.p[blockIdx.y], n, range_bits, hist, hist_off, entries, tab_stride, 0, blockIdx.y * bins_per_col, set_mask, gridDim.x, blockIdx.x, lds);
 }
-// The GM partition step in "collect / place" form (default; ZK_MSM_GM_SLAB=0 keeps the two recoding passes above).  The columns of
-// a GM group are mostly zeros and one-digit cells: a wave of the recoding passes walks all W windows with a handful of active
-// lanes in each (ballots, shuffles and an LDS atomic per window for ~2 entries per cell), and does so twice -- histogram pass and
-// scatter pass, each with its own from_mont + recoding of every cell.  Here a workgroup recodes its chunk ONCE: the non-zero
-// digits of 256 cells are appended to an LDS queue (one LDS atomic per wave and window), then the queue is walked with every
-// lane busy: histogram update and a coalesced copy of the entries to the workgroup's slab in HBM.  The placing pass reads the
-// slab (8 B per entry instead of 32 B per cell), with no field arithmetic, and scatters to the partition cursors.
-// Slab entry: (full key = set * 2^(C-1) + bucket) << 32 | sign | table index.
-constexpr int GM_WFL = 16;                      // windows between two walks of the queue: 256 x 16 entries of 8 B = 32 KiB of LDS
-template <int C>
-__global__ void __launch_bounds__(256) k_msm_gm_collect(GmCols cols, uint64_t n, int range_bits, uint32_t* __restrict__ hist, uint64_t* __restrict__ slab, uint32_t* __restrict__ slab_cnt,
-                                                         uint64_t slab_stride, uint64_t tab_stride, uint32_t bins_per_col, uint32_t set_mask) {
-    constexpr int W = (256 + C - 1) / C;
-    __shared__ uint32_t lds[MSM_M_MAX_BINS];
-    __shared__ uint64_t queue[256 * GM_WFL];
-    __shared__ uint32_t qn[2];
-    const Fr* __restrict__ scalars = cols.p[blockIdx.y];
-    const uint32_t nwg = gridDim.x, g = blockIdx.x, bin_base = blockIdx.y * bins_per_col;
-    const uint32_t nbins = (set_mask + 1u) << (C - 1 - range_bits);
-    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = 0u;
-    if (threadIdx.x < 2) qn[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint64_t chunk = (n + nwg - 1) / nwg;                    // cells per workgroup (the host sizes the grid and the slabs)
-    const uint64_t lo = min(n, (uint64_t)g * chunk), hi = min(n, lo + chunk);
-    uint64_t* __restrict__ out = slab + ((uint64_t)blockIdx.y * nwg + g) * slab_stride;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t written = 0, phase = 0;
-    Fr s_next = Fr::zero();
-    if (lo + threadIdx.x < hi) s_next = ldg(scalars + lo + threadIdx.x);
-    for (uint64_t base = lo; base < hi; base += blockDim.x) {          // uniform trip count
-        const uint64_t i = base + threadIdx.x;
-        const bool live = i < hi;
-        const Fr s_cur = s_next;
-        if (i + blockDim.x < hi) s_next = ldg(scalars + i + blockDim.x);          // the next trip's cell is on its way while this one is recoded
-        uint32_t code[W];
-        if (live) recode_wide<C>(from_mont(s_cur), code, 0);
-        else {
-#pragma unroll
-            for (int w = 0; w < W; ++w) code[w] = CODE_ZERO;
-        }
-#pragma unroll
-        for (int w0 = 0; w0 < W; w0 += GM_WFL) {
-            uint32_t* cnt = &qn[phase & 1u];
-#pragma unroll
-            for (int w = w0; w < (w0 + GM_WFL < W ? w0 + GM_WFL : W); ++w) {
-                const bool nz = code[w] != CODE_ZERO;
-                const uint64_t bal = __ballot(nz);
-                if (!bal) continue;
-                const int first = (int)__builtin_ctzll(bal);
-                uint32_t wbase = 0;
-                if ((int)lane == first) wbase = atomicAdd(cnt, (uint32_t)__popcll(bal));
-                wbase = __shfl(wbase, first);
-                if (nz) {
-                    const uint32_t key = (code[w] & 0x3FFFFFu) | (((uint32_t)w & set_mask) << (C - 1));
-                    queue[wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = ((uint64_t)key << 32) | (uint64_t)((uint32_t)((uint64_t)w * tab_stride + i) | (code[w] & NEG_BIT));
-                }
-            }
-            __syncthreads();
-            const uint32_t total = *cnt;
-            if (threadIdx.x == 0) qn[(phase + 1u) & 1u] = 0u;         // the other counter was last read one walk ago: every thread has passed two barriers since
-            for (uint32_t q0 = 0; q0 < total; q0 += blockDim.x) {     // uniform trip count: lds_take's ballots see whole waves
-                const uint32_t q = q0 + threadIdx.x;
-                const bool lv = q < total;
-                const uint64_t e = lv ? queue[q] : 0ull;
-                (void)lds_take(lds, (uint32_t)(e >> 32) >> range_bits, lv);
-                if (lv) out[written + q] = e;
-            }
-            written += total;
-            ++phase;
-            __syncthreads();
-        }
-    }
-    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) hist[(uint64_t)(bin_base + t) * nwg + g] = lds[t];
-    if (threadIdx.x == 0) slab_cnt[blockIdx.y * nwg + g] = written;
-}
-__global__ void __launch_bounds__(256) k_msm_gm_place(const uint64_t* __restrict__ slab, const uint32_t* __restrict__ slab_cnt, uint64_t slab_stride, int range_bits, uint32_t nbins,
-                                                       const uint32_t* __restrict__ hist_off, uint64_t* __restrict__ entries, uint32_t bins_per_col) {
-    __shared__ uint32_t lds[MSM_M_MAX_BINS];
-    const uint32_t nwg = gridDim.x, g = blockIdx.x, bin_base = blockIdx.y * bins_per_col;
-    for (uint32_t t = threadIdx.x; t < nbins; t += blockDim.x) lds[t] = hist_off[(uint64_t)(bin_base + t) * nwg + g];
-    __syncthreads();
-    const uint32_t total = slab_cnt[blockIdx.y * nwg + g], rmask = (1u << range_bits) - 1u;
-    const uint64_t* __restrict__ in = slab + ((uint64_t)blockIdx.y * nwg + g) * slab_stride;
-    constexpr int UNR = 4;
-    for (uint32_t q0 = 0; q0 < total; q0 += blockDim.x * UNR) {
-        uint64_t e[UNR];
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) { const uint32_t q = q0 + (uint32_t)j * blockDim.x + threadIdx.x; e[j] = q < total ? in[q] : ~0ull; }      // no entry is all ones (bit 63 is never set in a key)
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            if (q0 + (uint32_t)j * blockDim.x >= total) break;                    // uniform
-            const bool lv = e[j] != ~0ull;
-            const uint32_t key = (uint32_t)(e[j] >> 32);
-            const uint32_t pos = lds_take(lds, key >> range_bits, lv);
-            if (lv) entries[pos] = ((uint64_t)(key & rmask) << 32) | (uint64_t)(uint32_t)e[j];
-        }
-    }
-}
 // Scatter pass of the partition step with the runs staged in LDS.  k_msm_m_partition<C, true> lets every lane
 // write its 8-byte entry to the cursor of its own partition: 64 lanes, 64 partitions, 64 separate 32-byte
 // sectors -- 343 MiB written for 104 MiB of entries.  Here a workgroup (one scalar per thread) ranks its entries
@@ -1495,14 +1397,6 @@ static void launch_gm_partition(int c, dim3 grid, hipStream_t st, const GmCols& 
     }
 #undef ZK_GMP_CASE
 }
-static void launch_gm_collect(int c, dim3 grid, hipStream_t st, const GmCols& cols, uint64_t n, int range_bits, uint32_t* hist, uint64_t* slab, uint32_t* slab_cnt, uint64_t slab_stride,
-                              uint64_t tab_stride, uint32_t bins_per_col, uint32_t set_mask) {
-#define ZK_GMC_CASE(C) case C: hipLaunchKernelGGL((k_msm_gm_collect<C>), grid, dim3(256), 0, st, cols, n, range_bits, hist, slab, slab_cnt, slab_stride, tab_stride, bins_per_col, set_mask); break;
-    switch (c) {
-        ZK_GMC_CASE(8) ZK_GMC_CASE(9) ZK_GMC_CASE(10) ZK_GMC_CASE(11) ZK_GMC_CASE(12) ZK_GMC_CASE(13) ZK_GMC_CASE(14) ZK_GMC_CASE(15) ZK_GMC_CASE(16)
-    }
-#undef ZK_GMC_CASE
-}
 static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr* scalars, uint64_t n, int range_bits, const uint32_t* hist_off, uint64_t* entries, uint64_t tab_stride, int top_shift,
                                  const MsmCol* cols = nullptr, const uint32_t* ctr = nullptr, hipStream_t st = nullptr) {
     const size_t lds = scatter_staged_lds(W);
@@ -1570,8 +1464,6 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // the buckets hold 26-35 entries, one task each.  ZK_MSM_GM_SETS = 1 / 2 / 4 (measurement knob).
     uint32_t SG = 2;
     if (const char* e = getenv("ZK_MSM_GM_SETS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) SG = (uint32_t)v; }
-    uint32_t gm_red_g = 32;                                           // buckets per lane of the group's reduction (see the launch)
-    if (const char* e = getenv("ZK_MSM_GM_REDG")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) gm_red_g = (uint32_t)v; }
     int range_bits_G = pn.c - 1 - 7;                                  // 128 * SG partitions per column of 2^(c-8) buckets each
     if (range_bits_G < 0) range_bits_G = 0;
     const uint32_t bpcG = (SG * pn.B) >> range_bits_G;                // partitions per column
@@ -1583,13 +1475,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // u32 workspace of the GM sort: counts[nbG] | size_hist nmulti wflags done | offsets[nbG + 1] | order[nbG] | ntasks[nbG] | toff[nbG + 1] | block_tot2 | block_tot3 |
     //                               hist[hist_cnt_G] | hist_off[hist_cnt_G + 1] | idx[entG] | (8-B aligned) entries[entG] u64
     const size_t head_words_G = (size_t)nbG * 5 + 2 + SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX + scan_blocks_G + scan_blocks_hG + 2 * (size_t)hist_cnt_G + 2 + (size_t)entG;
-    // collect / place form of the partition step: one slab of chunk x W entries per (column, workgroup), and its fill count
-    const bool gm_slab = gm && !(getenv("ZK_MSM_GM_SLAB") && atoi(getenv("ZK_MSM_GM_SLAB")) == 0);
-    const uint64_t chunkG = nwgG ? (n_narrow + nwgG - 1) / nwgG : 0;
-    const uint64_t slab_stride_G = chunkG * (uint64_t)pn.W;
-    const bool gm_slab_fits = (uint64_t)NG * nwgG * slab_stride_G * 8ull <= (4ull << 30);      // worst-case sizing (every digit non-zero): beyond 4 GiB per workspace copy the two-pass form stays
-    const size_t slab_entries_G = gm_slab && gm_slab_fits ? (size_t)NG * nwgG * slab_stride_G : 0;
-    const size_t words_G = gm ? head_words_G + 4 + 2 * (size_t)entG + 4 + 2 * slab_entries_G + (size_t)NG * nwgG : 0;
+    const size_t words_G = gm ? head_words_G + 4 + 2 * (size_t)entG : 0;
     const size_t words_N = any_narrow ? std::max(head_words_N + 4 + dig_words, words_G) : 0;
     int range_bits_N = pn.c - 1;
     if (range_bits_N > MSM_RANGE_MAX_BITS) range_bits_N = MSM_RANGE_MAX_BITS;
@@ -1961,7 +1847,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         w.dig = reinterpret_cast<uint16_t*>(wsb + ((head_words_N + 3) & ~(size_t)3));
         return w;
     };
-    struct WsG { uint32_t *counts, *size_hist, *nmulti, *offsets, *order, *ntasks, *toff, *block_tot2, *block_tot3, *hist, *hist_off, *idx; uint64_t* entries; uint64_t* slab; uint32_t* slab_cnt; };
+    struct WsG { uint32_t *counts, *size_hist, *nmulti, *offsets, *order, *ntasks, *toff, *block_tot2, *block_tot3, *hist, *hist_off, *idx; uint64_t* entries; };
     auto ws_gm = [&](int slot) {
         WsG w;
         uint32_t* wsb = ws + (size_t)slot * words;
@@ -1978,8 +1864,6 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
         w.hist_off = w.hist + hist_cnt_G;
         w.idx = w.hist_off + hist_cnt_G + 1;
         w.entries = reinterpret_cast<uint64_t*>(wsb + ((head_words_G + 3) & ~(size_t)3));
-        w.slab = w.entries + entG;
-        w.slab_cnt = reinterpret_cast<uint32_t*>(w.slab + slab_entries_G);
         return w;
     };
     const dim3 sweep_grid(8u * ((pn.W + 7) / 8) * (pn.B >> range_bits_N) * MSM_SLICES);
@@ -2004,14 +1888,12 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_HIP(ctx, hipMemsetAsync(w.size_hist, 0, (size_t)(SIZE_BINS + 4 + MSM_WFLAGS + TASK_DONE_MAX) * 4, st));
             GmCols gcols{};
             for (uint32_t j = 0; j < cnt; ++j) gcols.p[j] = d_scalar_ptrs[it + j];
-            if (slab_entries_G) launch_gm_collect(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, w.hist, w.slab, w.slab_cnt, slab_stride_G, (uint64_t)tab_stride, bpcG, SG - 1);
-            else launch_gm_partition<false>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, w.hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, bpcG, SG - 1);
+            launch_gm_partition<false>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, w.hist, (const uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)tab_stride, bpcG, SG - 1);
             ZK_CHECK_LAUNCH(ctx);
             hipLaunchKernelGGL(k_scan_u32_a, dim3(sb_h), dim3(SCAN_T), 0, st, (const uint32_t*)w.hist, hist_c, w.hist_off, w.block_tot3);
             hipLaunchKernelGGL(k_scan_u32_b, dim3(1), dim3(SCAN_T), 0, st, w.block_tot3, sb_h, w.hist_off, hist_c, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_offsets, dim3(sb_h), dim3(SCAN_T), 0, st, hist_c, w.hist_off, (const uint32_t*)w.block_tot3);
-            if (slab_entries_G) hipLaunchKernelGGL(k_msm_gm_place, dim3(nwgG, cnt), dim3(256), 0, st, (const uint64_t*)w.slab, (const uint32_t*)w.slab_cnt, slab_stride_G, range_bits_G, bpcG, (const uint32_t*)w.hist_off, w.entries, bpcG);
-            else launch_gm_partition<true>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, (uint32_t*)nullptr, (const uint32_t*)w.hist_off, w.entries, (uint64_t)tab_stride, bpcG, SG - 1);
+            launch_gm_partition<true>(pn.c, dim3(nwgG, cnt), st, gcols, n_narrow, range_bits_G, (uint32_t*)nullptr, (const uint32_t*)w.hist_off, w.entries, (uint64_t)tab_stride, bpcG, SG - 1);
             ZK_CHECK_LAUNCH(ctx);
             hipLaunchKernelGGL(k_msm_m_binsort, dim3(nbins_c), dim3(1024), 0, st, (const uint64_t*)w.entries, (const uint32_t*)w.hist_off, nwgG, range_bits_G, nbc, w.offsets, w.counts, w.size_hist, w.idx);
             ZK_CHECK_LAUNCH(ctx);
@@ -2133,16 +2015,10 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
             ZK_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_p1[par], 0));
             {
                 ZkProfScope ps(ctx, "msm_reduce_narrow", side);
-                // the SG sets of a column are SG "windows" of equal weight: reduced separately, their partials summed with the column's.
-                // A group's reduction hides under the next groups (three bucket buffers in rotation), so what counts is its work, not its
-                // chain: 32 buckets per lane instead of 8 -- per bucket two additions of the running sums plus 1 / 32 instead of 1 / 8 of the
-                // lane's lift (a ~10-bit scalar multiplication) and of its share of the tree sum.  ZK_MSM_GM_REDG = 8 / 16 / 32 (measurement knob).
-                const uint32_t rbg = ((pn.B + gm_red_g - 1) / gm_red_g + RED_THREADS - 1) / RED_THREADS;       // <= red_blocks_N: fits the partials' scratch
-                if (gm_red_g == 32) hipLaunchKernelGGL((k_msm_reduce<32>), dim3(rbg, cnt * SG), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, pn.B, partialN);
-                else if (gm_red_g == 16) hipLaunchKernelGGL((k_msm_reduce<16>), dim3(rbg, cnt * SG), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, pn.B, partialN);
-                else hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(rbg, cnt * SG), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, pn.B, partialN);
+                // the SG sets of a column are SG "windows" of equal weight: reduced separately, their partials summed with the column's
+                hipLaunchKernelGGL((k_msm_reduce<RED_G_WIDE>), dim3(red_blocks_N, cnt * SG), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)buckets, pn.B, partialN);
                 ZK_CHECK_LAUNCH(ctx);
-                hipLaunchKernelGGL(k_msm_window_sum, dim3(cnt), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, rbg * SG, wsum_all + it);
+                hipLaunchKernelGGL(k_msm_window_sum, dim3(cnt), dim3(RED_THREADS), 0, side, (const G1Xyzz29*)partialN, red_blocks_N * SG, wsum_all + it);
                 ZK_CHECK_LAUNCH(ctx);
             }
             ZK_HIP(ctx, hipEventRecord(ctx->ev_p2[par], side));

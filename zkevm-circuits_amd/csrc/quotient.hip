@@ -527,6 +527,15 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     }
     if (depth < 1) depth = 1;
     const uint32_t low_len = (uint32_t)low.size();
+    if (getenv("ZK_QUOTIENT_TRACE") && low_len >= 64) {        // what the kernel will run: lowered instructions by opcode, settle bits, stack depth
+        static const char* names[22] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "SQUARE", "DOUBLE", "FOLD", "MUL_CONST", "ADD_CONST", "TEE_TMP", "PUSH_TMP", "?", "?",
+                                        "ADD_COL", "SUB_COL", "RSUB_COL", "MUL_COL", "FOLD_COL", "NOP"};
+        uint32_t hist[22] = {0}, settles = 0;
+        for (const LowInstr& in : low) { const uint32_t o = in.w0 & 0xffu; if (o < 22) ++hist[o]; settles += ((in.w0 & K_SETTLE0) ? 1 : 0) + ((in.w0 & K_SETTLE1) ? 1 : 0); }
+        fprintf(stderr, "[zk quotient] 2^%u rows, %u lowered instructions, depth %d, %u settles:", ext_k, low_len, depth, settles);
+        for (int o = 0; o < 22; ++o) if (hist[o]) fprintf(stderr, " %s %u", names[o], hist[o]);
+        fprintf(stderr, "\n");
+    }
     std::vector<Fr> tev;
     if (divide_by_vanishing) vanishing_inverses(k, ext_k, &tev);
     // constants that multiply (MUL_CONST, FOLD) and the vanishing inverses go to the device in R' = 2^261 form too: x 32
