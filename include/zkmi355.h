@@ -250,8 +250,12 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
  * Pippenger windows empty; such a column takes the per-window MSM path, which skips empty windows,
  * instead of the merged-window path, which always pays for its 2^(c-1) shared buckets.
  * narrow[i] = 2: dense values in long runs of equal scalars (running products / sums that stay
- * constant over stretches of rows): merged-window path with the sliced bucket sort, whose four
- * workgroups per partition stream a run-filled partition faster than the one-launch sort does.
+ * constant over stretches of rows: permutation products of a circuit with few copy constraints).  A
+ * column of at least 4096 rows with at most n / 16 runs is committed by its run ends -- Abel
+ * summation against a prefix-sum table of the basis built on first use (64 B per SRS point,
+ * csrc/runs.hip; ZK_MSM_RUNS=0 turns that off); otherwise the merged-window path with the sliced
+ * bucket sort, whose four workgroups per partition stream a run-filled partition faster than the
+ * one-launch sort does.
  * 0: dense.  The hint affects speed only.  zk_commit_batch_h2d and zk_proof_advice_phase derive
  * 0 / 1 themselves from a sample of the host column.                                              */
 int zk_commit_batch_hint(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, void* h_out_affine);

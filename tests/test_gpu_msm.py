@@ -1,5 +1,6 @@
 """GPU parity: G1 group law, SRS generation and MSM (halo2 best_multiexp / ParamsKZG) vs the
 oracle.  Bit-exact on the affine result."""
+import os
 import random
 
 import numpy as np
@@ -371,8 +372,6 @@ def test_groups_of_small_valued_columns(ctx, cref, group):
         os.environ.pop("ZK_MSM_NARROW_GROUP", None)
     bad = [i for i in range(len(cols)) if not np.array_equal(got[i], want[i])]
     assert not bad, f"group size {group}: columns {bad} differ from best_multiexp"
-    for b_ in bufs:
-        b_.free()
     srs.destroy()
 
 
@@ -400,6 +399,52 @@ def test_mixed_columns_without_hints(ctx, cref, k):
     assert np.array_equal(got, want)
     for hint in ([1, 1, 1], [0, 0, 0]):                                                      # and both paths when forced
         assert np.array_equal(ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=True, narrow=hint), want)
-    for b_ in bufs:
-        b_.free()
+    srs.destroy()
+
+
+@pytest.mark.parametrize("k", [12, 14])
+def test_run_structured_columns_commit_by_their_run_ends(ctx, cref, k):
+    """Columns hinted as run-structured (hint 2: permutation products) with few runs are committed by Abel summation over their
+    run ends against the prefix-sum table of the basis (csrc/runs.hip); one with too many runs for that, one all zero, one a single
+    run of a field-sized value over every row, and dense / small-valued neighbours in the same batch take the ordinary paths.
+    Every result = best_multiexp of the same column over the same basis; both bases; and with the feature off."""
+    n, s = 1 << k, 0xC0DE
+    rng = np.random.default_rng(70 + k)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(s))
+    uni = cref.rand_fr_stream(31 + k, n)
+
+    def runs(cuts, with_zero_run=False):
+        col = np.zeros((n, 4), dtype=np.uint64)
+        edges = [0] + sorted(int(c) for c in cuts) + [n]
+        for j in range(len(edges) - 1):
+            if edges[j] < edges[j + 1] and not (with_zero_run and j % 5 == 2):
+                col[edges[j]:edges[j + 1]] = uni[j % n]
+        return col
+    cols = {
+        "few_runs": runs(rng.choice(np.arange(1, n), size=40, replace=False)),
+        "zero_runs_and_tail": runs(rng.choice(np.arange(1, n - 7), size=25, replace=False), with_zero_run=True),
+        "one_run": np.repeat(uni[3:4], n, axis=0),
+        "all_zero": np.zeros((n, 4), dtype=np.uint64),
+        "every_row_differs": uni.copy(),                         # hinted 2 but not run-structured: n runs > n / 16
+        "dense_neighbour": cref.rand_fr_stream(77, n),
+        "small_neighbour": cref.to_mont([int(v) for v in rng.integers(0, 1 << 16, size=n)]),
+    }
+    cols["zero_runs_and_tail"][n - 6:] = uni[100:106]              # blinding rows: a few single-row runs at the end
+    names = list(cols)
+    hints = [2, 2, 2, 2, 2, 0, 1]
+    bufs = [ctx.to_device(cols[nm]) for nm in names]
+    for lagrange in (True, False):
+        bases = srs.download_g_lagrange() if lagrange else srs.download_g()
+        want = [cref.best_multiexp(cols[nm], bases) for nm in names]
+        for env in (None, "0"):
+            if env is None:
+                os.environ.pop("ZK_MSM_RUNS", None)
+            else:
+                os.environ["ZK_MSM_RUNS"] = env
+            try:
+                got = ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=lagrange, narrow=hints)
+            finally:
+                os.environ.pop("ZK_MSM_RUNS", None)
+            bad = [nm for nm, g_, w_ in zip(names, got, want) if not np.array_equal(g_, w_)]
+            assert not bad, f"lagrange {lagrange}, ZK_MSM_RUNS={env}: {bad} differ from best_multiexp"
     srs.destroy()

@@ -184,6 +184,7 @@ struct zk_srs {
     // lazily built fixed-base window tables [W][2^k] (R' form) and the window size they were built for
     zk::G1Affine* tab[2] = {nullptr, nullptr};
     zk::G1Affine* tabn[2] = {nullptr, nullptr};   // per-window tables (c <= 16) for the columns that fill few windows
+    zk::G1Affine* pfx[2] = {nullptr, nullptr};    // prefix sums of a basis (R' form), for run-structured columns (runs.hip)
     int tab_c[2] = {0, 0};
 };
 
@@ -234,6 +235,8 @@ int msm_batch_tab(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, con
                   size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr);
 int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage = nullptr, void* stage_user = nullptr,
                   const uint8_t* narrow = nullptr /*per column: scalars fill few windows*/);
+// runs.hip: commits the columns hinted as run-structured that do have few runs (done[i] = 1), leaves the others to the caller
+int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done);
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow = nullptr);
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = at most a quarter of the sampled values are >= 2^64
 int sample_narrow_dev(zk_ctx* ctx, const void* const* d_cols, size_t count, size_t n, uint8_t* narrow);   // the same for columns resident on the device

@@ -2164,6 +2164,29 @@ static int srs_window_table_narrow(zk_ctx* ctx, const zk_srs* srs, int basis, si
 // table -- columns flagged `narrow` take the per-window path over their own table --, the plain
 // per-window path otherwise.  ZK_MSM_NARROW=0 / 1 overrides the flags (measurement knob).
 int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
+    // columns hinted as run-structured and resident on the device: by their run ends (runs.hip); what is left takes the paths below
+    if (narrow && !stage && count) {
+        bool any2 = false;
+        for (size_t i = 0; i < count; ++i) any2 |= narrow[i] == 2;
+        if (any2) {
+            std::vector<uint8_t> done(count);
+            int rc = msm_runs_try(ctx, srs, basis, d_scalar_ptrs, count, n, narrow, h_out, done.data());
+            if (rc) return rc;
+            std::vector<size_t> rest;
+            for (size_t i = 0; i < count; ++i) if (!done[i]) rest.push_back(i);
+            if (rest.size() < count) {
+                if (rest.empty()) return ZK_OK;
+                std::vector<const Fr*> ptrs(rest.size());
+                std::vector<uint8_t> hints(rest.size());
+                std::vector<G1Affine> outs(rest.size());
+                for (size_t j = 0; j < rest.size(); ++j) { ptrs[j] = d_scalar_ptrs[rest[j]]; hints[j] = narrow[rest[j]]; }
+                rc = msm_batch_srs(ctx, srs, basis, ptrs.data(), rest.size(), n, outs.data(), nullptr, nullptr, hints.data());
+                if (rc) return rc;
+                for (size_t j = 0; j < rest.size(); ++j) h_out[rest[j]] = outs[j];
+                return ZK_OK;
+            }
+        }
+    }
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     const G1Affine* brp = nullptr;
     int rc = srs_bases_rp(ctx, srs, basis, &brp);

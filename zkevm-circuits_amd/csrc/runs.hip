@@ -1,0 +1,253 @@
+// Commitments to run-structured columns: halo2_proofs' commit_lagrange applied to permutation grand products and other
+// piecewise-constant columns (reference call sites A1-A4 reach it through create_proof's
+// permutation::Argument::commit, external crate).
+//
+// A permutation product Z stays constant over every row whose cells take part in no copy constraint; in a zkEVM-style circuit
+// that is nearly every row (the SuperCircuit wires its sub-circuits with lookups, copies are few), so Z is a few hundred runs of
+// equal values over 2^20 rows.  The bucket method is at its worst there -- every row of a run lands in the same bucket of every
+// window -- while the sum itself collapses by Abel summation over the run ends e_0 < e_1 < ... (z constant on (e_{r-1}, e_r]):
+//
+//      sum_i z_i L_i  =  sum_r (z_{e_r} - z_{e_r + 1}) * P_{e_r},        P_e = sum_{i <= e} L_i,   z_n := 0.
+//
+// P is a prefix-sum table of the basis (64 B per point, built once per SRS and basis on first use, R' form like every base the
+// MSM kernels read); a column then costs one sweep that compares neighbouring rows and collects (difference, P_e) pairs, and an
+// MSM over as many points as the column has runs.  A column with more than n / 16 runs is not run-structured: it takes the
+// ordinary path.  Results are the same group elements either way (exact arithmetic; the affine output is unique).
+#include "ctx.hpp"
+#include "ec29.hip.hpp"
+#include "host_fq.hpp"
+
+namespace zk {
+
+constexpr int PFX_SEG = 64;               // points a thread sums one after the other
+constexpr int RUN_COLS = 32;              // columns per launch of the collection kernel
+struct RunCols { const Fr* p[RUN_COLS]; };
+
+// ---- prefix-sum table of a basis -----------------------------------------------------------------------------------------
+// three levels of segments of PFX_SEG points: segment totals, totals of PFX_SEG segments, a serial scan of those (n / 4096
+// values), then the offsets come back down and every thread re-adds its segment, converting each prefix to affine form
+__global__ void __launch_bounds__(256) k_pfx_totals_affine(const G1Affine* __restrict__ pts, uint64_t n, G1Xyzz29* __restrict__ totals) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = s * PFX_SEG;
+    if (i0 >= n) return;
+    G1Xyzz29 acc = identity29();
+    const uint64_t i1 = min(n, i0 + PFX_SEG);
+    for (uint64_t i = i0; i < i1; ++i) acc = madd29(acc, load_affine29(pts + i));
+    stg29(totals + s, acc);
+}
+__global__ void __launch_bounds__(256) k_pfx_totals_xyzz(const G1Xyzz29* __restrict__ in, uint64_t n, G1Xyzz29* __restrict__ totals) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = s * PFX_SEG;
+    if (i0 >= n) return;
+    G1Xyzz29 acc = identity29();
+    const uint64_t i1 = min(n, i0 + PFX_SEG);
+    for (uint64_t i = i0; i < i1; ++i) acc = add29pt(acc, ldg29(in + i));
+    stg29(totals + s, acc);
+}
+// in place: totals[i] <- sum of totals[j], j < i (one thread; n / 4096 values)
+__global__ void k_pfx_serial_exclusive(G1Xyzz29* __restrict__ v, uint64_t n) {
+    if (blockIdx.x || threadIdx.x) return;
+    G1Xyzz29 acc = identity29();
+    for (uint64_t i = 0; i < n; ++i) {
+        const G1Xyzz29 cur = ldg29(v + i);
+        stg29(v + i, acc);
+        acc = add29pt(acc, cur);
+    }
+}
+// in place: every segment of `child` becomes its exclusive prefix inside the parent, lifted by the parent's offset
+__global__ void __launch_bounds__(256) k_pfx_down(G1Xyzz29* __restrict__ child, uint64_t n_child, const G1Xyzz29* __restrict__ parent_off) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = s * PFX_SEG;
+    if (i0 >= n_child) return;
+    G1Xyzz29 acc = ldg29(parent_off + s);
+    const uint64_t i1 = min(n_child, i0 + PFX_SEG);
+    for (uint64_t i = i0; i < i1; ++i) {
+        const G1Xyzz29 cur = ldg29(child + i);
+        stg29(child + i, acc);
+        acc = add29pt(acc, cur);
+    }
+}
+__global__ void __launch_bounds__(256) k_pfx_finish(const G1Affine* __restrict__ pts, uint64_t n, const G1Xyzz29* __restrict__ seg_off, G1Affine* __restrict__ out) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = s * PFX_SEG;
+    if (i0 >= n) return;
+    G1Xyzz29 acc = ldg29(seg_off + s);
+    const uint64_t i1 = min(n, i0 + PFX_SEG);
+    for (uint64_t i = i0; i < i1; ++i) {
+        acc = madd29(acc, load_affine29(pts + i));
+        stg(out + i, to_affine_rp(acc));
+    }
+}
+
+static int srs_prefix_table(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out) {
+    *out = nullptr;
+    zk_srs* s = const_cast<zk_srs*>(srs);
+    if (s->pfx[basis]) { *out = s->pfx[basis]; return ZK_OK; }
+    const uint64_t n = 1ull << s->k;
+    const G1Affine* rp = nullptr;
+    int rc = srs_bases_rp(ctx, srs, basis, &rp);
+    if (rc) return rc;
+    const uint64_t n1 = (n + PFX_SEG - 1) / PFX_SEG, n2 = (n1 + PFX_SEG - 1) / PFX_SEG;
+    G1Xyzz29* t1 = (G1Xyzz29*)ctx->pool_get((n1 + n2) * sizeof(G1Xyzz29));
+    if (!t1) return ZK_OK;                                                                    // no memory: the ordinary path
+    G1Xyzz29* t2 = t1 + n1;
+    G1Affine* tab = nullptr;
+    if (hipMalloc(&tab, sizeof(G1Affine) * n) != hipSuccess) { (void)hipGetLastError(); ctx->pool_put(t1, (n1 + n2) * sizeof(G1Xyzz29)); return ZK_OK; }
+    auto grid = [](uint64_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    hipLaunchKernelGGL(k_pfx_totals_affine, grid(n1), dim3(256), 0, ctx->stream, rp, n, t1);
+    hipLaunchKernelGGL(k_pfx_totals_xyzz, grid(n2), dim3(256), 0, ctx->stream, (const G1Xyzz29*)t1, n1, t2);
+    hipLaunchKernelGGL(k_pfx_serial_exclusive, dim3(1), dim3(64), 0, ctx->stream, t2, n2);
+    hipLaunchKernelGGL(k_pfx_down, grid(n2), dim3(256), 0, ctx->stream, t1, n1, (const G1Xyzz29*)t2);
+    hipLaunchKernelGGL(k_pfx_finish, grid(n1), dim3(256), 0, ctx->stream, rp, n, (const G1Xyzz29*)t1, tab);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx->pool_put(t1, (n1 + n2) * sizeof(G1Xyzz29));
+    if (e != hipSuccess) { (void)hipFree(tab); return ctx->fail(ZK_ERR_HIP, "prefix table of the basis: %s", hipGetErrorString(e)); }
+    s->pfx[basis] = tab;
+    *out = tab;
+    return ZK_OK;
+}
+
+// ---- run ends of a column ------------------------------------------------------------------------------------------------
+// row i is a run end when z_i != z_{i+1} (z_n = 0): (z_i - z_{i+1}, P_i) goes to the column's list, in no particular order;
+// a workgroup reserves room for its ends with one atomic.  counts[col] may pass `cap`: nothing is written beyond it.
+__global__ void __launch_bounds__(256) k_runs_collect(RunCols cols, uint64_t n, const G1Affine* __restrict__ pfx, Fr* __restrict__ scal, G1Affine* __restrict__ base, uint32_t cap,
+                                                      uint32_t* __restrict__ counts) {
+    __shared__ uint32_t wcnt[4], wbase[4];
+    const Fr* __restrict__ z = cols.p[blockIdx.y];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    Fr cur = Fr::zero(), nxt = Fr::zero();
+    if (i < n) cur = ldg(z + i);
+    if (i + 1 < n) nxt = ldg(z + i + 1);
+    bool end = false;
+    if (i < n) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) end |= cur.l[q] != nxt.l[q];
+    }
+    const uint64_t bal = __ballot(end);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        const uint32_t start = total ? atomicAdd(&counts[blockIdx.y], total) : 0u;
+        wbase[0] = start; wbase[1] = start + wcnt[0]; wbase[2] = wbase[1] + wcnt[1]; wbase[3] = wbase[2] + wcnt[2];
+    }
+    __syncthreads();
+    if (end) {
+        const uint32_t pos = wbase[wave] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < cap) {
+            stg(scal + (uint64_t)blockIdx.y * cap + pos, cur - nxt);
+            stg(base + (uint64_t)blockIdx.y * cap + pos, ldg(pfx + i));
+        }
+    }
+}
+
+// ---- the sum over the run ends, directly -----------------------------------------------------------------------------------
+// A few hundred (difference, P_e) pairs per column are too few for the bucket method (a chain of some twenty-five launches per
+// column, 0.4 ms each): one lane per pair multiplies by double-and-add (254 doublings + ~127 mixed additions, 1.3 ms of latency
+// whatever the count), all columns of the launch side by side, then a tree sum per workgroup and one per column.
+constexpr uint32_t RUNS_DIRECT_MAX = 4096;       // run ends per column up to which the direct form is used
+__global__ void __launch_bounds__(256) k_runs_mul(const Fr* __restrict__ scal, const G1Affine* __restrict__ base, uint32_t cap, const uint32_t* __restrict__ counts, G1Xyzz29* __restrict__ partial) {
+    __shared__ G1Xyzz29 sh[256];
+    const uint32_t col = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cnt = counts[col];             // beyond cap the list is incomplete: such a column is not summed here
+    G1Xyzz29 acc = identity29();
+    if (cnt <= cap && cnt <= RUNS_DIRECT_MAX && j < cnt) {
+        const Fr k = from_mont(ldg(scal + (uint64_t)col * cap + j));
+        const G1Affine29 p = load_affine29(base + (uint64_t)col * cap + j);
+        int top = 255;
+        while (top >= 0 && !((k.l[top >> 5] >> (top & 31)) & 1u)) --top;
+#pragma unroll 1
+        for (int bit = top; bit >= 0; --bit) {
+            acc = dbl29pt(acc);
+            if ((k.l[bit >> 5] >> (bit & 31)) & 1u) acc = madd29(acc, p);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stg29(partial + (uint64_t)col * gridDim.x + blockIdx.x, sh[0]);
+}
+__global__ void __launch_bounds__(64) k_runs_sum(const G1Xyzz29* __restrict__ partial, uint32_t per_col, G1Xyzz* __restrict__ out) {
+    const uint32_t col = blockIdx.x;
+    if (threadIdx.x) return;
+    G1Xyzz29 acc = identity29();
+    for (uint32_t i = 0; i < per_col; ++i) acc = add29pt(acc, ldg29(partial + (uint64_t)col * per_col + i));
+    stg(out + col, to_std_xyzz(acc));
+}
+
+// Commits the columns hinted as run-structured (narrow[i] == 2) that do have few runs; done[i] = 1 for those, the others are left
+// to the caller's ordinary path.  No-op (all zero) when the feature is off, the columns are small, or memory is short.
+int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done) {
+    memset(done, 0, count);
+    if (!narrow || n < 4096) return ZK_OK;
+    if (const char* e = getenv("ZK_MSM_RUNS")) if (atoi(e) == 0) return ZK_OK;
+    std::vector<size_t> sel;
+    for (size_t i = 0; i < count; ++i) if (narrow[i] == 2) sel.push_back(i);
+    if (sel.empty()) return ZK_OK;
+    const G1Affine* pfx = nullptr;
+    int rc = srs_prefix_table(ctx, srs, basis, &pfx);
+    if (rc) return rc;
+    if (!pfx) return ZK_OK;
+    const uint32_t cap = (uint32_t)std::min<size_t>(n / 16, (size_t)1 << 16);
+    for (size_t first = 0; first < sel.size(); first += RUN_COLS) {
+        const size_t cnt = std::min<size_t>(RUN_COLS, sel.size() - first);
+        const size_t bytes = cnt * cap * (sizeof(Fr) + sizeof(G1Affine)) + 256;
+        char* buf = (char*)ctx->pool_get(bytes);
+        if (!buf) return ZK_OK;
+        uint32_t* d_counts = (uint32_t*)buf;
+        Fr* d_scal = (Fr*)(buf + 256);
+        G1Affine* d_base = (G1Affine*)(buf + 256 + cnt * cap * sizeof(Fr));
+        auto release = [&](int code) { ctx->pool_put(buf, bytes); return code; };
+        RunCols rcols{};
+        for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
+        hipError_t e = hipMemsetAsync(d_counts, 0, 256, ctx->stream);
+        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "run collection: %s", hipGetErrorString(e)));
+        hipLaunchKernelGGL(k_runs_collect, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, rcols, (uint64_t)n, pfx, d_scal, d_base, cap, d_counts);
+        uint32_t h_counts[RUN_COLS];
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h_counts, d_counts, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "run collection: %s", hipGetErrorString(e)));
+        // columns with at most RUNS_DIRECT_MAX run ends: one launch for all of them
+        uint32_t direct_max = 0;
+        auto direct = [&](size_t j) { return h_counts[j] <= cap && h_counts[j] <= RUNS_DIRECT_MAX; };
+        for (size_t j = 0; j < cnt; ++j) if (direct(j)) direct_max = std::max(direct_max, h_counts[j]);
+        if (direct_max) {
+            const uint32_t blocks = (direct_max + 255) / 256;
+            const size_t pbytes = (size_t)cnt * blocks * sizeof(G1Xyzz29) + cnt * sizeof(G1Xyzz);
+            char* pb = (char*)ctx->pool_get(pbytes);
+            if (pb) {
+                G1Xyzz29* d_part = (G1Xyzz29*)pb;
+                G1Xyzz* d_res = (G1Xyzz*)(pb + (size_t)cnt * blocks * sizeof(G1Xyzz29));
+                hipLaunchKernelGGL(k_runs_mul, dim3(blocks, (unsigned)cnt), dim3(256), 0, ctx->stream, (const Fr*)d_scal, (const G1Affine*)d_base, cap, (const uint32_t*)d_counts, d_part);
+                hipLaunchKernelGGL(k_runs_sum, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_part, blocks, d_res);
+                std::vector<G1Xyzz> hres(cnt);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(hres.data(), d_res, cnt * sizeof(G1Xyzz), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                ctx->pool_put(pb, pbytes);
+                if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "run sums: %s", hipGetErrorString(e)));
+                for (size_t j = 0; j < cnt; ++j) {
+                    if (!direct(j)) continue;
+                    host::msm_tail(hres.data() + j, 1, 1, h_out + sel[first + j]);
+                    done[sel[first + j]] = 1;
+                }
+            }
+        }
+        for (size_t j = 0; j < cnt; ++j) {
+            const size_t col = sel[first + j];
+            if (done[col] || h_counts[j] > cap) continue;              // done above / not run-structured after all: the ordinary path
+            if (h_counts[j] == 0) { memset(h_out + col, 0, sizeof(G1Affine)); done[col] = 1; continue; }      // the zero column
+            const Fr* sp = d_scal + j * cap;
+            const G1Affine* bp = d_base + j * cap;
+            rc = msm_batch_tab(ctx, &sp, 1, bp, bp, nullptr, 0, h_counts[j], h_out + col);
+            if (rc) return release(rc);
+            done[col] = 1;
+        }
+        ctx->pool_put(buf, bytes);
+    }
+    return ZK_OK;
+}
+
+}  // namespace zk

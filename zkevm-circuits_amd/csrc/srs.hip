@@ -199,6 +199,7 @@ void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs) {
     if (srs->g_lagrange_rp) (void)hipFree(srs->g_lagrange_rp);
     for (auto t : srs->tab) if (t) (void)hipFree(t);
     for (auto t : srs->tabn) if (t) (void)hipFree(t);
+    for (auto t : srs->pfx) if (t) (void)hipFree(t);
     delete srs;
 }
 uint32_t zk_srs_k(const zk_srs* srs) { return srs ? srs->k : 0; }
