@@ -107,6 +107,7 @@ static int srs_prefix_table(zk_ctx* ctx, const zk_srs* srs, int basis, const G1A
 // ---- run ends of a column ------------------------------------------------------------------------------------------------
 // row i is a run end when z_i != z_{i+1} (z_n = 0): (z_i - z_{i+1}, P_i) goes to the column's list, in no particular order;
 // a workgroup reserves room for its ends with one atomic.  counts[col] may pass `cap`: nothing is written beyond it.
+// pfx == nullptr: count only (the table does not exist yet: it is built once a column shows that it will be used).
 __global__ void __launch_bounds__(256) k_runs_collect(RunCols cols, uint64_t n, const G1Affine* __restrict__ pfx, Fr* __restrict__ scal, G1Affine* __restrict__ base, uint32_t cap,
                                                       uint32_t* __restrict__ counts) {
     __shared__ uint32_t wcnt[4], wbase[4];
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) k_runs_collect(RunCols cols, uint64_t n, 
     __syncthreads();
     if (end) {
         const uint32_t pos = wbase[wave] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < cap) {
+        if (pos < cap && pfx) {
             stg(scal + (uint64_t)blockIdx.y * cap + pos, cur - nxt);
             stg(base + (uint64_t)blockIdx.y * cap + pos, ldg(pfx + i));
         }
@@ -185,11 +186,37 @@ int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
     std::vector<size_t> sel;
     for (size_t i = 0; i < count; ++i) if (narrow[i] == 2) sel.push_back(i);
     if (sel.empty()) return ZK_OK;
+    const uint32_t cap = (uint32_t)std::min<size_t>(n / 16, (size_t)1 << 16);
+    int rc = ZK_OK;
+    if (!srs->pfx[basis]) {
+        // The prefix table costs 64 B per SRS point and an affine conversion per point: before it exists, one counting sweep
+        // decides whether any of these columns will use it (an aggregation circuit's permutation products have a run per row)
+        uint32_t* d_counts = (uint32_t*)ctx->pool_get(256);
+        if (!d_counts) return ZK_OK;
+        std::vector<size_t> keep;
+        for (size_t first = 0; first < sel.size(); first += RUN_COLS) {
+            const size_t cnt = std::min<size_t>(RUN_COLS, sel.size() - first);
+            RunCols rcols{};
+            for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
+            uint32_t h_counts[RUN_COLS];
+            hipError_t e = hipMemsetAsync(d_counts, 0, 256, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_runs_collect, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, rcols, (uint64_t)n, (const G1Affine*)nullptr, (Fr*)nullptr, (G1Affine*)nullptr, cap, d_counts);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(h_counts, d_counts, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->pool_put(d_counts, 256); return ctx->fail(ZK_ERR_HIP, "run count: %s", hipGetErrorString(e)); }
+            for (size_t j = 0; j < cnt; ++j) if (h_counts[j] <= cap) keep.push_back(sel[first + j]);
+        }
+        ctx->pool_put(d_counts, 256);
+        if (keep.empty()) return ZK_OK;
+        sel.swap(keep);
+    }
     const G1Affine* pfx = nullptr;
-    int rc = srs_prefix_table(ctx, srs, basis, &pfx);
+    rc = srs_prefix_table(ctx, srs, basis, &pfx);
     if (rc) return rc;
     if (!pfx) return ZK_OK;
-    const uint32_t cap = (uint32_t)std::min<size_t>(n / 16, (size_t)1 << 16);
     for (size_t first = 0; first < sel.size(); first += RUN_COLS) {
         const size_t cnt = std::min<size_t>(RUN_COLS, sel.size() - first);
         const size_t bytes = cnt * cap * (sizeof(Fr) + sizeof(G1Affine)) + 256;
