@@ -256,6 +256,12 @@ int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const
  * csrc/runs.hip; ZK_MSM_RUNS=0 turns that off); otherwise the merged-window path with the sliced
  * bucket sort, whose four workgroups per partition stream a run-filled partition faster than the
  * one-launch sort does.
+ * narrow[i] = 3: a running sum whose increments are mostly equal (a lookup's phi: the increment is
+ * the same on every row where the lookup is switched off and the table row unused).  A full-length
+ * column over the Lagrange basis is committed as an MSM of s_j = c - (z_{j+1} - z_j) -- zero wherever
+ * the increment is the common value c -- over the prefix sums of the basis, plus c times a fixed
+ * point (csrc/runs.hip; ZK_MSM_DIFF=0 turns that off); a column whose increments are not mostly
+ * equal costs what a dense column costs.
  * 0: dense.  The hint affects speed only.  zk_commit_batch_h2d and zk_proof_advice_phase derive
  * 0 / 1 themselves from a sample of the host column.                                              */
 int zk_commit_batch_hint(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, void* h_out_affine);

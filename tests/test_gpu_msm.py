@@ -448,3 +448,52 @@ def test_run_structured_columns_commit_by_their_run_ends(ctx, cref, k):
             bad = [nm for nm, g_, w_ in zip(names, got, want) if not np.array_equal(g_, w_)]
             assert not bad, f"lagrange {lagrange}, ZK_MSM_RUNS={env}: {bad} differ from best_multiexp"
     srs.destroy()
+
+
+@pytest.mark.parametrize("k", [12, 14])
+def test_columns_committed_through_their_first_differences(ctx, cref, k):
+    """Columns hinted as running sums with mostly equal increments (hint 3: a lookup's phi) are committed as an MSM of
+    s_j = c - (z_{j+1} - z_j) over the prefix basis plus c times a fixed point (csrc/runs.hip); a sum whose increments are all
+    different, a constant column, the zero column and a column whose common increment is zero take the same entry point.
+    Every result = best_multiexp of the column itself over the Lagrange basis; also with the feature off and in a mixed batch."""
+    n, s = 1 << k, 0xD1FF
+    rng = np.random.default_rng(90 + k)
+    srs = ctx.srs_setup_with_s(k, cref.fr_const(s))
+    uni = cref.from_mont(cref.rand_fr_stream(41 + k, n))          # canonical integers
+
+    def running_sum(incs, start=0):
+        out, acc = [], start
+        for d in incs:
+            out.append(acc)
+            acc = (acc + int(d)) % R
+        return out
+    c = int(uni[0])
+    active = set(int(i) for i in rng.choice(n - 1, size=n // 12, replace=False))
+    cols = {
+        "lookup_like": running_sum([int(uni[j]) if j in active else c for j in range(n)]),
+        "starts_elsewhere": running_sum([int(uni[j]) if j in active else c for j in range(n)], start=int(uni[5])),
+        "all_increments_differ": running_sum([int(uni[j]) for j in range(n)]),
+        "constant": [int(uni[9])] * n,
+        "zero": [0] * n,
+        "flat_with_steps": running_sum([int(uni[j]) if j % 97 == 0 else 0 for j in range(n)]),
+    }
+    for nm in ("lookup_like", "starts_elsewhere"):                  # blinding rows at the end
+        for t in range(1, 7):
+            cols[nm][n - t] = int(uni[100 + t])
+    names = list(cols)
+    mont = {nm: cref.to_mont(cols[nm]) for nm in names}
+    bufs = [ctx.to_device(mont[nm]) for nm in names]
+    basis = srs.download_g_lagrange()
+    want = [cref.best_multiexp(mont[nm], basis) for nm in names]
+    for hints, env in (([3] * len(names), None), ([3] * len(names), "0"), ([3, 0, 3, 1, 2, 3], None)):
+        if env is None:
+            os.environ.pop("ZK_MSM_DIFF", None)
+        else:
+            os.environ["ZK_MSM_DIFF"] = env
+        try:
+            got = ctx.commit_batch(srs, [b_.ptr for b_ in bufs], n, lagrange=True, narrow=hints)
+        finally:
+            os.environ.pop("ZK_MSM_DIFF", None)
+        bad = [nm for nm, g_, w_ in zip(names, got, want) if not np.array_equal(g_, w_)]
+        assert not bad, f"hints {hints}, ZK_MSM_DIFF={env}: {bad} differ from best_multiexp"
+    srs.destroy()

@@ -182,10 +182,13 @@ struct zk_srs {
     zk::G1Affine* g_rp = nullptr;
     zk::G1Affine* g_lagrange_rp = nullptr;
     // lazily built fixed-base window tables [W][2^k] (R' form) and the window size they were built for
-    zk::G1Affine* tab[2] = {nullptr, nullptr};
-    zk::G1Affine* tabn[2] = {nullptr, nullptr};   // per-window tables (c <= 16) for the columns that fill few windows
+    // basis index 2 = the prefix sums of the Lagrange basis (pfx[1]) used as a basis of its own: columns committed through
+    // their first differences (runs.hip)
+    zk::G1Affine* tab[3] = {nullptr, nullptr, nullptr};
+    zk::G1Affine* tabn[3] = {nullptr, nullptr, nullptr};   // per-window tables (c <= 16) for the columns that fill few windows
     zk::G1Affine* pfx[2] = {nullptr, nullptr};    // prefix sums of a basis (R' form), for run-structured columns (runs.hip)
-    int tab_c[2] = {0, 0};
+    int tab_c[3] = {0, 0, 0};
+    zk::G1Affine* pfx_negtot[2] = {nullptr, nullptr};   // one point on the device: -(sum of pfx[b][j], j <= 2^k - 2), R' form
 };
 
 #define ZK_HIP(ctx, call)                                                                          \
@@ -237,6 +240,7 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
                   const uint8_t* narrow = nullptr /*per column: scalars fill few windows*/);
 // runs.hip: commits the columns hinted as run-structured that do have few runs (done[i] = 1), leaves the others to the caller
 int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done);
+int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done);
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow = nullptr);
 void sample_narrow(const void* const* h_cols, size_t count, size_t n, uint8_t* narrow);   // host sampling of Montgomery-form columns: 1 = at most a quarter of the sampled values are >= 2^64
 int sample_narrow_dev(zk_ctx* ctx, const void* const* d_cols, size_t count, size_t n, uint8_t* narrow);   // the same for columns resident on the device

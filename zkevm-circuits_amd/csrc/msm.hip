@@ -2211,7 +2211,29 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
             }
         }
     }
-    const G1Affine* b = basis ? srs->g_lagrange : srs->g;
+    // columns hinted as sums with mostly equal increments (hint 3: a lookup's running sum): through their first differences
+    // against the prefix basis (runs.hip); what is left takes the paths below as dense columns
+    if (narrow && !stage && count && basis == 1) {
+        bool any3 = false;
+        for (size_t i = 0; i < count; ++i) any3 |= narrow[i] == 3;
+        if (any3) {
+            std::vector<uint8_t> done(count);
+            int rc3 = msm_diff_try(ctx, srs, basis, d_scalar_ptrs, count, n, narrow, h_out, done.data());
+            if (rc3) return rc3;
+            std::vector<size_t> rest;
+            for (size_t i = 0; i < count; ++i) if (!done[i]) rest.push_back(i);
+            if (rest.empty()) return ZK_OK;
+            std::vector<const Fr*> ptrs(rest.size());
+            std::vector<uint8_t> hints(rest.size());
+            std::vector<G1Affine> outs(rest.size());
+            for (size_t j = 0; j < rest.size(); ++j) { ptrs[j] = d_scalar_ptrs[rest[j]]; hints[j] = narrow[rest[j]] == 3 ? 0 : narrow[rest[j]]; }
+            rc3 = msm_batch_srs(ctx, srs, basis, ptrs.data(), rest.size(), n, outs.data(), nullptr, nullptr, hints.data());
+            if (rc3) return rc3;
+            for (size_t j = 0; j < rest.size(); ++j) h_out[rest[j]] = outs[j];
+            return ZK_OK;
+        }
+    }
+    const G1Affine* b = basis == 2 ? srs->pfx[1] : (basis ? srs->g_lagrange : srs->g);
     const G1Affine* brp = nullptr;
     int rc = srs_bases_rp(ctx, srs, basis, &brp);
     if (rc) return rc;
@@ -2270,6 +2292,11 @@ int msm_run(zk_ctx* ctx, const Fr* d_scalars, const G1Affine* d_bases, size_t n,
 // R'-form copy of an SRS basis, built on first use and cached on the zk_srs
 int srs_bases_rp(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out) {
     zk_srs* s = const_cast<zk_srs*>(srs);
+    if (basis == 2) {                   // the prefix basis is kept in R' form (runs.hip builds it)
+        if (!s->pfx[1]) return ctx->fail(ZK_ERR_INVALID_ARG, "the prefix basis has not been built");
+        *out = s->pfx[1];
+        return ZK_OK;
+    }
     G1Affine** slot = basis ? &s->g_lagrange_rp : &s->g_rp;
     const G1Affine* src = basis ? s->g_lagrange : s->g;
     if (!*slot) {

@@ -396,7 +396,7 @@ void push_perm_col(PB& b, const std::pair<uint32_t, uint32_t>& c) { b.col(c.firs
 // `count` commitments over one basis, split over the ranks of a sharded session: rank r commits
 // columns i = r, r + world, ... (pipelined batch) and the 64-byte points are all-gathered, so every
 // rank ends up with all of them in order and the transcripts stay identical.
-int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out, uint8_t kind = 0 /* zk_commit_batch_hint: 0 dense, 1 small values, 2 runs of equal values */) {
+int sharded_commit(zk_ctx* ctx, const zk_proof* pr, const zk_srs* srs, int basis, const void* const* ptrs, size_t count, size_t n, G1Affine* out, uint8_t kind = 0 /* zk_commit_batch_hint: 0 dense, 1 small values, 2 runs of equal values, 3 sums with mostly equal increments */) {
     const std::vector<uint8_t> hint(count, kind);
     if (pr->world <= 1 || !pr->gather) return commit_batch_staged(ctx, srs, basis, ptrs, count, n, out, nullptr, nullptr, hint.data());
     if (count < pr->world && n >= ((size_t)pr->world << 10)) {
@@ -1571,7 +1571,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             if (!host::fr_is_zero(closing[l])) return ctx->fail(ZK_ERR_INVALID_ARG, "lookup %u: grand sum does not close", l);
         trace.mark("  lookup: phi (all lookups)");
         std::vector<G1Affine> coms(pk->L);
-        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, pptrs.data(), pk->L, n, coms.data()));
+        PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, pptrs.data(), pk->L, n, coms.data(), 3));      // running sums: mostly equal increments (runs.hip)
         for (const G1Affine& com : coms) tr.write_point(com);
     }
     trace.mark("lookup phi");

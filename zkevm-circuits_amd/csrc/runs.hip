@@ -75,6 +75,15 @@ __global__ void __launch_bounds__(256) k_pfx_finish(const G1Affine* __restrict__
     }
 }
 
+// -(sum of v[0 .. n)) as one affine point in R' form (one thread; n / 4096 values)
+__global__ void k_pfx_neg_total(const G1Xyzz29* __restrict__ v, uint64_t n, G1Affine* __restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    G1Xyzz29 acc = identity29();
+    for (uint64_t i = 0; i < n; ++i) acc = add29pt(acc, ldg29(v + i));
+    G1Affine a = to_affine_rp(acc);
+    if (!a.is_identity()) a.y = neg(a.y);
+    stg(out, a);
+}
 static int srs_prefix_table(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out) {
     *out = nullptr;
     zk_srs* s = const_cast<zk_srs*>(srs);
@@ -95,11 +104,20 @@ static int srs_prefix_table(zk_ctx* ctx, const zk_srs* srs, int basis, const G1A
     hipLaunchKernelGGL(k_pfx_serial_exclusive, dim3(1), dim3(64), 0, ctx->stream, t2, n2);
     hipLaunchKernelGGL(k_pfx_down, grid(n2), dim3(256), 0, ctx->stream, t1, n1, (const G1Xyzz29*)t2);
     hipLaunchKernelGGL(k_pfx_finish, grid(n1), dim3(256), 0, ctx->stream, rp, n, (const G1Xyzz29*)t1, tab);
+    // -(P_0 + ... + P_{n-2}): what a column committed through its first differences owes for the constant part of its increments
+    G1Affine* negtot = nullptr;
+    if (hipMalloc(&negtot, sizeof(G1Affine)) != hipSuccess) { (void)hipGetLastError(); negtot = nullptr; }
+    if (negtot) {
+        hipLaunchKernelGGL(k_pfx_totals_affine, grid(n1), dim3(256), 0, ctx->stream, (const G1Affine*)tab, n - 1, t1);
+        hipLaunchKernelGGL(k_pfx_totals_xyzz, grid(n2), dim3(256), 0, ctx->stream, (const G1Xyzz29*)t1, (n - 1 + PFX_SEG - 1) / PFX_SEG, t2);
+        hipLaunchKernelGGL(k_pfx_neg_total, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)t2, ((n - 1 + PFX_SEG - 1) / PFX_SEG + PFX_SEG - 1) / PFX_SEG, negtot);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     ctx->pool_put(t1, (n1 + n2) * sizeof(G1Xyzz29));
-    if (e != hipSuccess) { (void)hipFree(tab); return ctx->fail(ZK_ERR_HIP, "prefix table of the basis: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(tab); if (negtot) (void)hipFree(negtot); return ctx->fail(ZK_ERR_HIP, "prefix table of the basis: %s", hipGetErrorString(e)); }
     s->pfx[basis] = tab;
+    s->pfx_negtot[basis] = negtot;
     *out = tab;
     return ZK_OK;
 }
@@ -273,6 +291,114 @@ int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
             done[col] = 1;
         }
         ctx->pool_put(buf, bytes);
+    }
+    return ZK_OK;
+}
+
+// ---- columns committed through their first differences ------------------------------------------------------------------------
+// A lookup's running sum phi (logUp: phi_{i+1} = phi_i + 1 / (f_i + beta) - m_i / (t_i + beta)) grows by the SAME amount on every
+// row where the lookup is switched off and the table row is unused -- in a circuit whose lookups are conditional, most rows.
+// With d_j = phi_{j+1} - phi_j and c the most frequent increment,
+//
+//      sum_i phi_i L_i  =  phi_{n-1} P_{n-1} - sum_{j <= n-2} d_j P_j  =  MSM_P(s) - c * (P_0 + ... + P_{n-2}),
+//      s_j = c - d_j (j <= n - 2),  s_{n-1} = phi_{n-1}:
+//
+// s is zero wherever the increment is the common one, so the commitment becomes an MSM of a mostly-zero column over the prefix
+// basis P (window tables of its own, built on first use: basis index 2 of msm_batch_srs, where the column is judged like any
+// other -- a column whose increments are not mostly equal simply takes the dense path there) plus one scalar multiplication of a
+// fixed point.  Only full-length columns (n = 2^k) of at least 4096 rows; ZK_MSM_DIFF=0 turns it off.
+constexpr int DIFF_SAMPLES = 256;
+__global__ void __launch_bounds__(DIFF_SAMPLES) k_diff_mode(RunCols cols, uint64_t n, Fr* __restrict__ c_out) {
+    __shared__ Fr d[DIFF_SAMPLES];
+    __shared__ uint32_t votes[DIFF_SAMPLES];
+    const Fr* __restrict__ z = cols.p[blockIdx.x];
+    const uint64_t j = (uint64_t)threadIdx.x * ((n - 1) / DIFF_SAMPLES) + (threadIdx.x * 7 + blockIdx.x) % ((n - 1) / DIFF_SAMPLES);      // n >= 4096: j <= n - 2
+    const Fr mine = ldg(z + j + 1) - ldg(z + j);
+    d[threadIdx.x] = mine;
+    __syncthreads();
+    uint32_t v = 0;
+    for (int t = 0; t < DIFF_SAMPLES; ++t) {
+        bool eq = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) eq &= d[t].l[q] == mine.l[q];
+        v += eq;
+    }
+    votes[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int t = 1; t < DIFF_SAMPLES; ++t) if (votes[t] > votes[best]) best = t;
+        stg(c_out + blockIdx.x, votes[best] * 2 >= DIFF_SAMPLES ? d[best] : Fr::zero());      // no majority: c = 0 (s = -d, a dense column)
+    }
+}
+__global__ void __launch_bounds__(256) k_diff_sparse(RunCols cols, uint64_t n, const Fr* __restrict__ c_in, Fr* __restrict__ s_out) {
+    const Fr* __restrict__ z = cols.p[blockIdx.y];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr cur = ldg(z + i);
+    Fr r = cur;                                      // s_{n-1} = phi_{n-1}
+    if (i + 1 < n) r = ldg(c_in + blockIdx.y) - (ldg(z + i + 1) - cur);
+    stg(s_out + (uint64_t)blockIdx.y * n + i, r);
+}
+
+int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done) {
+    memset(done, 0, count);
+    if (!narrow || basis != 1 || n < 4096 || n != ((size_t)1 << srs->k)) return ZK_OK;
+    if (const char* e = getenv("ZK_MSM_DIFF")) if (atoi(e) == 0) return ZK_OK;
+    std::vector<size_t> sel;
+    for (size_t i = 0; i < count; ++i) if (narrow[i] == 3) sel.push_back(i);
+    if (sel.empty()) return ZK_OK;
+    const G1Affine* pfx = nullptr;
+    int rc = srs_prefix_table(ctx, srs, basis, &pfx);
+    if (rc) return rc;
+    if (!pfx || !srs->pfx_negtot[basis]) return ZK_OK;
+    constexpr size_t CHUNK = 16;                       // columns whose difference images exist at a time (16 x n x 32 B)
+    for (size_t first = 0; first < sel.size(); first += CHUNK) {
+        const size_t cnt = std::min(CHUNK, sel.size() - first);
+        const size_t s_bytes = cnt * n * sizeof(Fr), aux_bytes = 256 + CHUNK * (sizeof(Fr) + sizeof(G1Affine) + sizeof(G1Xyzz29) + sizeof(G1Xyzz)) + 256;
+        Fr* d_s = (Fr*)ctx->pool_get(s_bytes);
+        char* aux = (char*)ctx->pool_get(aux_bytes);
+        if (!d_s || !aux) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return ZK_OK; }
+        auto release = [&](int code) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return code; };
+        uint32_t* d_ones = (uint32_t*)aux;                                   // counts[col] = 1 for k_runs_mul
+        Fr* d_c = (Fr*)(aux + 256);
+        G1Affine* d_pt = (G1Affine*)(d_c + CHUNK);
+        G1Xyzz29* d_part = (G1Xyzz29*)(d_pt + CHUNK);
+        G1Xyzz* d_res = (G1Xyzz*)(d_part + CHUNK);
+        RunCols rcols{};
+        for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
+        uint32_t ones[CHUNK];
+        for (size_t j = 0; j < CHUNK; ++j) ones[j] = 1u;
+        hipError_t e = hipMemcpyAsync(d_ones, ones, sizeof ones, hipMemcpyHostToDevice, ctx->stream);
+        for (size_t j = 0; j < cnt && e == hipSuccess; ++j) e = hipMemcpyAsync(d_pt + j, srs->pfx_negtot[basis], sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
+        hipLaunchKernelGGL(k_diff_mode, dim3((unsigned)cnt), dim3(DIFF_SAMPLES), 0, ctx->stream, rcols, (uint64_t)n, d_c);
+        hipLaunchKernelGGL(k_diff_sparse, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, rcols, (uint64_t)n, (const Fr*)d_c, d_s);
+        // c * (-(P_0 + ... + P_{n-2})) for every column of the chunk: one pair each for the direct sum of runs.hip
+        hipLaunchKernelGGL(k_runs_mul, dim3(1, (unsigned)cnt), dim3(256), 0, ctx->stream, (const Fr*)d_c, (const G1Affine*)d_pt, 1u, (const uint32_t*)d_ones, d_part);
+        hipLaunchKernelGGL(k_runs_sum, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_part, 1u, d_res);
+        e = hipGetLastError();
+        std::vector<G1Xyzz> hres(cnt);
+        if (e == hipSuccess) e = hipMemcpyAsync(hres.data(), d_res, cnt * sizeof(G1Xyzz), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
+        // the mostly-zero images over the prefix basis, judged and committed like any batch of columns
+        std::vector<const void*> sp(cnt);
+        for (size_t j = 0; j < cnt; ++j) sp[j] = d_s + j * n;
+        std::vector<uint8_t> kind(cnt);
+        rc = sample_narrow_dev(ctx, sp.data(), cnt, n, kind.data());
+        if (rc) return release(rc);
+        std::vector<G1Affine> part(cnt);
+        rc = msm_batch_srs(ctx, srs, 2, (const Fr* const*)sp.data(), cnt, n, part.data(), nullptr, nullptr, kind.data());
+        if (rc) return release(rc);
+        for (size_t j = 0; j < cnt; ++j) {
+            G1Xyzz a = G1Xyzz::identity();
+            if (!part[j].is_identity()) { a.x = part[j].x; a.y = part[j].y; a.zz = Fq::one(); a.zzz = Fq::one(); }
+            host::msm_tail2(&a, hres.data() + j, h_out + sel[first + j]);
+            done[sel[first + j]] = 1;
+        }
+        ctx->pool_put(d_s, s_bytes);
+        ctx->pool_put(aux, aux_bytes);
     }
     return ZK_OK;
 }
