@@ -186,7 +186,28 @@ def headline_single(args, torch):
     prof_bytes = {name: ctx.prof_get_bytes(name) for name in prof}
     per_proof = elapsed / args.steps
 
-    # ---- outside the timed region: the proof is checked, the same proof is made from page-locked host memory
+    # ---- outside the timed region: the same proof with the two commitment paths that read structure out of the data turned off
+    # (permutation products by their run ends, lookup sums through their first differences: csrc/runs.hip) -- what a circuit
+    # with a copy constraint on most rows and every lookup switched on everywhere would pay
+    blind = None
+    try:
+        os.environ["ZK_MSM_RUNS"], os.environ["ZK_MSM_DIFF"] = "0", "0"
+        proof_with = state["proof"]
+        tb = []
+        for _ in range(2):
+            device_sync(ctx, torch)
+            t1 = time.perf_counter()
+            step()
+            device_sync(ctx, torch)
+            tb.append(time.perf_counter() - t1)
+        blind = {"value": round(tb[-1], 4), "unit": "s", "same_proof_bytes": state["proof"] == proof_with,
+                 "note": "ZK_MSM_RUNS=0 ZK_MSM_DIFF=0: every permutation product and lookup sum committed as a dense column"}
+    except Exception as e:
+        blind = {"error": repr(e)}
+    finally:
+        os.environ.pop("ZK_MSM_RUNS", None)
+        os.environ.pop("ZK_MSM_DIFF", None)
+    # ---- the proof is checked, the same proof is made from page-locked host memory
     verified = None
     if not args.no_verify:
         from oracle import cref, pairing as pr, plonk_verifier as pv
@@ -273,7 +294,10 @@ def headline_single(args, torch):
         "config": {"workload": WORKLOAD, "k": circ.k, "advice": circ.A, "fixed": circ.F, "permutation_columns": len(circ.perm_cols), "lookups": len(circ.lookups),
                    "degree": circ.degree(), "extended_k": circ.extended_k(), "advice_phases": circ.num_phases(), "advice_columns_per_phase": [circ.advice_phase.count(p) for p in range(circ.num_phases())],
                    "challenges": len(circ.challenge_phase), "advice_queries": len(circ.advice_queries), "fixed_queries": len(circ.fixed_queries),
-                   "witness_cell_distribution": dist, "witness_residency": "HBM (device buffers handed to zk_proof_advice_phase_dev, in place: the session writes its blinding rows into them)", "multiopen": "shplonk", "transcript": "blake2b",
+                   "witness_cell_distribution": dist,
+                   "rows_with_an_active_lookup": round(float(np.asarray(rlc["q_lk"]).reshape(-1, 4).any(axis=1).mean()), 4),
+                   "rows_with_a_copy_constraint_per_column": round(len(set(r for pair in circ.copies for (_, _, r) in pair)) / circ.n, 5),
+                   "witness_residency": "HBM (device buffers handed to zk_proof_advice_phase_dev, in place: the session writes its blinding rows into them)", "multiopen": "shplonk", "transcript": "blake2b",
                    "vanishing_random_polynomial": "constant 1 (as the reference's own proofs)", "parallelism": "single GPU"},
         "roofline": roof_ntt,
         "rooflines": [r for r in (roof_ntt, roof_msm, roof_q) if r],
@@ -284,7 +308,7 @@ def headline_single(args, torch):
                   "witness_upload_s_outside_timing": round(t_upload, 2), "host_circuit_build_s": round(t_build, 2),
                   "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + circ.degree() - 3) // (circ.degree() - 2) + (circ.degree() - 1) + 2,
                   "kernel_class_device_ms_per_proof": {k_: round(v[0] / args.steps, 2) for k_, v in prof.items() if v[1]},
-                  "pcie_inclusive": pcie},
+                  "pcie_inclusive": pcie, "structure_blind": blind},
     }
     driver.free()
     for b_ in adv_dev:
