@@ -308,7 +308,7 @@ int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
 // other -- a column whose increments are not mostly equal simply takes the dense path there) plus one scalar multiplication of a
 // fixed point.  Only full-length columns (n = 2^k) of at least 4096 rows; ZK_MSM_DIFF=0 turns it off.
 constexpr int DIFF_SAMPLES = 256;
-__global__ void __launch_bounds__(DIFF_SAMPLES) k_diff_mode(RunCols cols, uint64_t n, Fr* __restrict__ c_out) {
+__global__ void __launch_bounds__(DIFF_SAMPLES) k_diff_mode(RunCols cols, uint64_t n, Fr* __restrict__ c_out, uint32_t* __restrict__ votes_out) {
     __shared__ Fr d[DIFF_SAMPLES];
     __shared__ uint32_t votes[DIFF_SAMPLES];
     const Fr* __restrict__ z = cols.p[blockIdx.x];
@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(DIFF_SAMPLES) k_diff_mode(RunCols cols, uint64
         int best = 0;
         for (int t = 1; t < DIFF_SAMPLES; ++t) if (votes[t] > votes[best]) best = t;
         stg(c_out + blockIdx.x, votes[best] * 2 >= DIFF_SAMPLES ? d[best] : Fr::zero());      // no majority: c = 0 (s = -d, a dense column)
+        votes_out[blockIdx.x] = votes[best];
     }
 }
 __global__ void __launch_bounds__(256) k_diff_sparse(RunCols cols, uint64_t n, const Fr* __restrict__ c_in, Fr* __restrict__ s_out) {
@@ -348,14 +349,38 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
     std::vector<size_t> sel;
     for (size_t i = 0; i < count; ++i) if (narrow[i] == 3) sel.push_back(i);
     if (sel.empty()) return ZK_OK;
+    constexpr size_t CHUNK = 16;                       // columns whose difference images exist at a time (16 x n x 32 B)
+    int rc = ZK_OK;
+    {   // Only sums whose increments ARE mostly equal go this way (three quarters of the sampled increments agree): the others would
+        // be dense columns over the prefix basis too -- same cost, but the basis' window tables would be built for nothing.
+        char* vb = (char*)ctx->pool_get(RUN_COLS * (sizeof(Fr) + 4));
+        if (!vb) return ZK_OK;
+        Fr* d_c0 = (Fr*)vb;
+        uint32_t* d_votes = (uint32_t*)(vb + RUN_COLS * sizeof(Fr));
+        std::vector<size_t> keep;
+        for (size_t first = 0; first < sel.size(); first += RUN_COLS) {
+            const size_t cnt = std::min<size_t>(RUN_COLS, sel.size() - first);
+            RunCols rcols{};
+            for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
+            uint32_t h_votes[RUN_COLS];
+            hipLaunchKernelGGL(k_diff_mode, dim3((unsigned)cnt), dim3(DIFF_SAMPLES), 0, ctx->stream, rcols, (uint64_t)n, d_c0, d_votes);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h_votes, d_votes, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->pool_put(vb, RUN_COLS * (sizeof(Fr) + 4)); return ctx->fail(ZK_ERR_HIP, "increment sampling: %s", hipGetErrorString(e)); }
+            for (size_t j = 0; j < cnt; ++j) if (h_votes[j] * 4 >= (uint32_t)DIFF_SAMPLES * 3) keep.push_back(sel[first + j]);
+        }
+        ctx->pool_put(vb, RUN_COLS * (sizeof(Fr) + 4));
+        if (keep.empty()) return ZK_OK;
+        sel.swap(keep);
+    }
     const G1Affine* pfx = nullptr;
-    int rc = srs_prefix_table(ctx, srs, basis, &pfx);
+    rc = srs_prefix_table(ctx, srs, basis, &pfx);
     if (rc) return rc;
     if (!pfx || !srs->pfx_negtot[basis]) return ZK_OK;
-    constexpr size_t CHUNK = 16;                       // columns whose difference images exist at a time (16 x n x 32 B)
     for (size_t first = 0; first < sel.size(); first += CHUNK) {
         const size_t cnt = std::min(CHUNK, sel.size() - first);
-        const size_t s_bytes = cnt * n * sizeof(Fr), aux_bytes = 256 + CHUNK * (sizeof(Fr) + sizeof(G1Affine) + sizeof(G1Xyzz29) + sizeof(G1Xyzz)) + 256;
+        const size_t s_bytes = cnt * n * sizeof(Fr), aux_bytes = 256 + CHUNK * (sizeof(Fr) + sizeof(G1Affine) + sizeof(G1Xyzz29) + sizeof(G1Xyzz) + 4) + 256;
         Fr* d_s = (Fr*)ctx->pool_get(s_bytes);
         char* aux = (char*)ctx->pool_get(aux_bytes);
         if (!d_s || !aux) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return ZK_OK; }
@@ -365,6 +390,7 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
         G1Affine* d_pt = (G1Affine*)(d_c + CHUNK);
         G1Xyzz29* d_part = (G1Xyzz29*)(d_pt + CHUNK);
         G1Xyzz* d_res = (G1Xyzz*)(d_part + CHUNK);
+        uint32_t* d_votes = (uint32_t*)(d_res + CHUNK);
         RunCols rcols{};
         for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
         uint32_t ones[CHUNK];
@@ -372,7 +398,7 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
         hipError_t e = hipMemcpyAsync(d_ones, ones, sizeof ones, hipMemcpyHostToDevice, ctx->stream);
         for (size_t j = 0; j < cnt && e == hipSuccess; ++j) e = hipMemcpyAsync(d_pt + j, srs->pfx_negtot[basis], sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream);
         if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
-        hipLaunchKernelGGL(k_diff_mode, dim3((unsigned)cnt), dim3(DIFF_SAMPLES), 0, ctx->stream, rcols, (uint64_t)n, d_c);
+        hipLaunchKernelGGL(k_diff_mode, dim3((unsigned)cnt), dim3(DIFF_SAMPLES), 0, ctx->stream, rcols, (uint64_t)n, d_c, d_votes);
         hipLaunchKernelGGL(k_diff_sparse, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, rcols, (uint64_t)n, (const Fr*)d_c, d_s);
         // c * (-(P_0 + ... + P_{n-2})) for every column of the chunk: one pair each for the direct sum of runs.hip
         hipLaunchKernelGGL(k_runs_mul, dim3(1, (unsigned)cnt), dim3(256), 0, ctx->stream, (const Fr*)d_c, (const G1Affine*)d_pt, 1u, (const uint32_t*)d_ones, d_part);
