@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) k_msm_m_partition(const Fr* __restrict__ 
 }
 // The same pass over the columns of a GM group in ONE launch (blockIdx.y = column of the group): a column's 512 workgroups of 256
 // threads leave three quarters of the device's wave slots empty; eight columns fill them.
-constexpr int GM_MAX_COLS = 8;
+constexpr int GM_MAX_COLS = 16;
 struct GmCols { const Fr* p[GM_MAX_COLS]; };
 template <int C, bool SCATTER>
 __global__ void __launch_bounds__(256) k_msm_gm_partition(GmCols cols, uint64_t n, int range_bits, uint32_t* __restrict__ hist, const uint32_t* __restrict__ hist_off,
@@ -1461,8 +1461,9 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     // 30-bit values: 0.68 / 0.51 / 0.43 / 0.38 ms per column, tools/gpu_r3u.sh).
     uint32_t NG = 1;
     if (any_narrow) {
-        NG = std::min<uint32_t>(8u, MSM_WFLAGS / (uint32_t)pn.W);
-        if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) NG = std::min<uint32_t>((uint32_t)v, MSM_WFLAGS / (uint32_t)pn.W); }
+        NG = std::min<uint32_t>((uint32_t)GM_MAX_COLS, MSM_WFLAGS / (uint32_t)pn.W);       // sixteen at c = 16: a group's dozen short launches (scans, size bins, task split) cost the same for eight
+                                                                                            // columns or sixteen -- 60/30/10 columns 0.265 -> 0.255 ms each in a batch, the sort 0.81 ms per eight -> 1.45 per sixteen
+        if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= GM_MAX_COLS) NG = std::min<uint32_t>((uint32_t)v, MSM_WFLAGS / (uint32_t)pn.W); }
         if (const char* e = getenv("ZK_MSM_SORT_AHEAD")) if (atoi(e) == 1) NG = 1;
         while (NG > 1 && (uint64_t)n * pn.W * NG >= (1ull << 32)) --NG;
         if (NG < 1) NG = 1;
