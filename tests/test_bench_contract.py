@@ -86,6 +86,15 @@ def test_every_proof_in_the_line_was_verified(line):
     assert proofs["supercircuit_shape_k20_dense"]["value"] > proofs["supercircuit_shape_k20_small"]["value"]
 
 
+def test_the_structure_reading_paths_are_reported_beside_the_headline(line):
+    """The headline's permutation and lookup commitments read structure out of the witness (csrc/runs.hip): the line says how much
+    structure there was, and what the same proof (same bytes) costs with those paths off -- never less than the headline."""
+    cfg, blind = line["config"], line["extra"]["structure_blind"]
+    assert 0.0 < cfg["rows_with_an_active_lookup"] < 1.0 and 0.0 <= cfg["rows_with_a_copy_constraint_per_column"] < 1.0
+    assert blind["same_proof_bytes"] is True and blind["unit"] == "s"
+    assert blind["value"] >= line["value"]
+
+
 def test_gpus_flag_without_a_launcher_starts_one_rank_per_gpu(monkeypatch):
     """`python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run on 127.0.0.1 with N ranks and
     hands its own flags through; under a launcher (WORLD_SIZE set) it must not."""
