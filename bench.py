@@ -21,8 +21,9 @@ the reference's own witness needs its Rust + Go toolchain, so every number here 
   * `proof`      -- the other shapes and witness distributions, one prover process each.
 
 `python bench.py --gpus N` launches itself as N ranks (torch.distributed.run, 127.0.0.1) when not started under a launcher.
-N > 1: ONE proof sharded over the ranks -- commitments by column, quotient by (class, coset), witness uploaded by
-its owner and all-gathered device to device over the library's RCCL communicator; strong scaling, value = seconds per proof.
+N > 1: the SAME workload -- one proof of the same three-phase circuit, witness resident and handed over in place --
+sharded over the ranks: a rank holds the columns it owns, commits them and all-gathers them device to device over the library's RCCL
+communicator; quotient by (degree class, coset); strong scaling, value = seconds per proof, same `roofline` record from rank 0.
 """
 import argparse
 import json
@@ -39,7 +40,10 @@ sys.path.insert(0, ROOT)
 K = 20
 N = 1 << K
 NCOL = 32                  # msm_ntt section: 32 x 32 MiB committed + 32 x 32 MiB transformed (2 GiB, eight times the Infinity Cache)
-SC_SHAPE = (20, 1000, 150, 150, 100, 9)      # k, advice, fixed, permutation columns, lookups, degree
+# ZK_BENCH_K: test switch (tests/test_gpu_bench_sharded.py) -- the SAME code path over the same column counts at a small k, so that
+# `bench.py --gpus 2` can run end to end with two ranks sharing the test box's one GPU.  The driver never sets it.
+HEADLINE_K = int(os.environ.get("ZK_BENCH_K", "20"))
+SC_SHAPE = (HEADLINE_K, 1000, 150, 150, 100, 9)      # k, advice, fixed, permutation columns, lookups, degree
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MULPEAK_G = 169.0          # measured 9x29-bit Montgomery products/s (G) of the library's own product routine (tools/ubench.hip)
 MAD_PEAK_T = 30.4          # measured v_mad_u64_u32 lane-ops/s (T), tools/ubench.hip: the hardware-side bound
@@ -47,8 +51,8 @@ MADS_PER_PRODUCT = 162     # v_mad_u64_u32 per 9 x 29-bit Montgomery product (81
 MADS_PER_MIXED_ADD = 1476  # per XYZZ mixed addition (csrc/ec29.hip.hpp madd29)
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 DTYPE = "u32x8 limbs (254-bit modular integer, Montgomery)"
-METRIC = "SuperCircuit-shape proof-gen wall-clock (s) at k = 20"
-WORKLOAD = ("BASELINE configs[3] stand-in: SuperCircuit shape k = 20 (1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9), "
+METRIC = f"SuperCircuit-shape proof-gen wall-clock (s) at k = {HEADLINE_K}"
+WORKLOAD = (f"BASELINE configs[3] stand-in: SuperCircuit shape k = {HEADLINE_K} (1000 advice / 150 fixed / 150 permutation columns, 100 lookups, degree 9), "
             "three advice phases, witness 60/30/10 per cell (SURVEY 8d), SHPLONK, Blake2b; one full proof per step")
 
 
@@ -59,10 +63,9 @@ def relaunch_under_launcher(args) -> int:
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch)]
-    if args.no_cpu_baseline:
-        cmd.append("--no-cpu-baseline")
-    if args.no_proof:
-        cmd.append("--no-proof")
+    for flag in ("no_cpu_baseline", "no_proof", "no_verify", "no_msm_ntt"):
+        if getattr(args, flag, False):
+            cmd.append("--" + flag.replace("_", "-"))
     return subprocess.call(cmd)
 
 
@@ -91,7 +94,7 @@ def hbm_roof(kernel, alg_bytes, ms, note, products=None, launches=None):
 
 def committed_traffic(key):
     """PMC traffic (FETCH_SIZE + WRITE_SIZE per launch) from the newest committed rocprofv3 --pmc passes under profiles/"""
-    for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
+    for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             try:
@@ -135,18 +138,32 @@ def device_sync(ctx, torch):
     torch.cuda.synchronize()
 
 
-# ------------------------------------------------------------------------------------ N = 1: the headline
-def headline_single(args, torch):
+# ------------------------------------------------------------------------------------ the headline, N = 1 and N > 1 alike
+def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=False):
+    """One full proof per step, the same circuit / witness / phases / hand-over for every N.  N > 1: ONE proof sharded
+    over the ranks -- a rank keeps only the witness columns it OWNS resident (position j of a phase's columns, j % N == rank), commits
+    them and sends them to the others device to device; the 64-byte commitments are all-gathered per transcript round; the quotient is
+    split by (degree class, coset).  Exchanges: the library's own RCCL communicator (csrc/comm.hip; its 128-byte id travels over the
+    launcher's process group, which otherwise carries only the barriers), or torch.distributed gloo callbacks when the ranks share one
+    GPU (test boxes: RCCL ranks cannot share a device).  Timing: W warm-up proofs, then K proofs between barrier + synchronize on both
+    sides, MAX over the ranks."""
     import numpy as np
 
     import bench_proof as bp
     import zkevm_circuits_amd as z
 
-    ctx = z.Context(0)
+    ctx = z.Context(local_rank)
+    shard = None
+    if world > 1:
+        from zkevm_circuits_amd import sharding as shard
+        if not shared_gpu:
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node, rendezvous over loopback: RCCL's bootstrap must not go looking for another interface
+            shard.comm_init_from_torch(ctx)
     t0 = time.perf_counter()
     circ, blob, adv_m, inst_m, inst, rlc = bp.build_shape(ctx, *SC_SHAPE, dist="survey", phases=True)
     t_build = time.perf_counter() - t0
-    dist = bp.cell_distribution(adv_m[:SC_SHAPE[1] - 2])
+    dist_cells = bp.cell_distribution(adv_m[:SC_SHAPE[1] - 2])
     npub = [int(np.flatnonzero(np.asarray(a).reshape(-1, 4).any(axis=1))[-1]) + 1 if np.asarray(a).any() else 0 for a in inst_m]
     inst = [list(col[:m]) for col, m in zip(inst, npub)]
     inst_m = [np.ascontiguousarray(a[:m]) for a, m in zip(inst_m, npub)]
@@ -157,31 +174,46 @@ def headline_single(args, torch):
     ctx.sync()
     t_keygen = time.perf_counter() - t0
     del blob
-    # the witness, resident in HBM: one device buffer per advice column (aliased host arrays become distinct device columns)
+    # the witness, resident in HBM: one device buffer per advice column this rank owns (aliased host arrays become distinct device
+    # columns); a rank that does not own a_0 / b_0 keeps private copies of them for the two challenge-dependent columns
     t0 = time.perf_counter()
-    adv_dev = [ctx.to_device(a) for a in adv_m]
+    owned = bp.owned_columns(circ, rank, world)
+    adv_dev = {c: ctx.to_device(adv_m[c]) for c in sorted(owned | {0, 1, rlc["w"], rlc["t"]})}
     ctx.sync()
     t_upload = time.perf_counter() - t0
-    driver = bp.PhaseDriver(ctx, circ, adv_dev, rlc)
+    driver = bp.PhaseDriver(ctx, circ, adv_dev, rlc, owned=owned if world > 1 else None)
     state = {}
 
     def step():
         sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
         sess.set_multiopen(1)
+        keep = None
+        if world > 1:
+            keep = shard.shard_session_device(sess) if shared_gpu else sess.set_sharding_comm()
         state["challenges"] = driver.run(sess)
         state["proof"] = sess.finish()
+        del keep
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        device_sync(ctx, torch)
 
     for _ in range(args.warmup):
         step()
-    device_sync(ctx, torch)
+    fence()
     ctx.prof_reset()
     ctx.prof_enable(2)           # HIP events around the roofline kernels only (NTT passes, bucket accumulation, quotient evaluator)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    device_sync(ctx, torch)
+    fence()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
+    if dist is not None:         # the slowest rank's clock
+        box = [None] * world
+        dist.all_gather_object(box, elapsed)
+        elapsed = max(box)
     prof = {name: ctx.prof_get(name) for name in ctx.prof_names()}
     prof_bytes = {name: ctx.prof_get_bytes(name) for name in prof}
     per_proof = elapsed / args.steps
@@ -195,10 +227,10 @@ def headline_single(args, torch):
         proof_with = state["proof"]
         tb = []
         for _ in range(2):
-            device_sync(ctx, torch)
+            fence()
             t1 = time.perf_counter()
             step()
-            device_sync(ctx, torch)
+            fence()
             tb.append(time.perf_counter() - t1)
         blind = {"value": round(tb[-1], 4), "unit": "s", "same_proof_bytes": state["proof"] == proof_with,
                  "note": "ZK_MSM_RUNS=0 ZK_MSM_DIFF=0: every permutation product and lookup sum committed as a dense column"}
@@ -207,82 +239,96 @@ def headline_single(args, torch):
     finally:
         os.environ.pop("ZK_MSM_RUNS", None)
         os.environ.pop("ZK_MSM_DIFF", None)
-    # ---- the proof is checked, the same proof is made from page-locked host memory
+    # ---- the proof is checked (rank 0), the same proof is made from page-locked host memory (N = 1)
     verified = None
-    if not args.no_verify:
+    if not args.no_verify and rank == 0:
         from oracle import cref, pairing as pr, plonk_verifier as pv
         com, rep = pk.vk(circ.F + len(circ.perm_cols))
         verified = bool(pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst, state["proof"], pr.ec_mul(pr.G2_GEN, S), multiopen="shplonk"))
     pcie = None
-    try:
-        pinned = {}
-        for a in adv_m[:SC_SHAPE[1] - 2]:
-            if id(a) not in pinned:
-                pinned[id(a)] = ctx.host_alloc(a.shape)
-                pinned[id(a)][:] = a
-        host_cols = [pinned[id(a)] for a in adv_m[:SC_SHAPE[1] - 2]]
-        w_h, t_h = ctx.host_alloc((circ.n, 4)), ctx.host_alloc((circ.n, 4))
-        times = []
-        for _ in range(2):
-            t1 = time.perf_counter()
-            sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
-            sess.set_multiopen(1)
-            ph = circ.advice_phase
-            ch0 = sess.advice_phase({i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 0})
-            driver._rlc(0, ch0[0], rlc["w"])
-            w_h[:] = adv_dev[rlc["w"]].download((circ.n, 4))          # a host caller synthesises the RLC column on the host; here it comes back from the device
-            ch1 = sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 1}, rlc["w"]: w_h})
-            driver._rlc(rlc["w"], ch1[0], rlc["t"])
-            t_h[:] = adv_dev[rlc["t"]].download((circ.n, 4))
-            sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 2}, rlc["t"]: t_h})
-            host_proof = sess.finish()
-            times.append(time.perf_counter() - t1)
-        pcie = {"value": round(min(times), 4), "unit": "s", "same_proof_bytes": host_proof == state["proof"],
-                "note": "the same proof with the witness in page-locked HOST memory (zk_proof_advice_phase): 33.5 GB cross PCIe inside the proof; what a Rust caller of "
-                        "create_proof pays today.  Never `value` (inputs resident in HBM)."}
-        for a in list(pinned.values()) + [w_h, t_h]:
-            ctx.host_free(a)
-    except Exception as e:       # the headline must survive this side measurement
-        pcie = {"error": repr(e)}
+    if world == 1:
+        try:
+            pinned = {}
+            for a in adv_m[:SC_SHAPE[1] - 2]:
+                if id(a) not in pinned:
+                    pinned[id(a)] = ctx.host_alloc(a.shape)
+                    pinned[id(a)][:] = a
+            host_cols = [pinned[id(a)] for a in adv_m[:SC_SHAPE[1] - 2]]
+            w_h, t_h = ctx.host_alloc((circ.n, 4)), ctx.host_alloc((circ.n, 4))
+            times = []
+            for _ in range(2):
+                t1 = time.perf_counter()
+                sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+                sess.set_multiopen(1)
+                ph = circ.advice_phase
+                ch0 = sess.advice_phase({i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 0})
+                driver._rlc(0, ch0[0], rlc["w"])
+                w_h[:] = adv_dev[rlc["w"]].download((circ.n, 4))          # a host caller synthesises the RLC column on the host; here it comes back from the device
+                ch1 = sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 1}, rlc["w"]: w_h})
+                driver._rlc(rlc["w"], ch1[0], rlc["t"])
+                t_h[:] = adv_dev[rlc["t"]].download((circ.n, 4))
+                sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 2}, rlc["t"]: t_h})
+                host_proof = sess.finish()
+                times.append(time.perf_counter() - t1)
+            pcie = {"value": round(min(times), 4), "unit": "s", "same_proof_bytes": host_proof == state["proof"],
+                    "note": "the same proof with the witness in page-locked HOST memory (zk_proof_advice_phase): 33.5 GB cross PCIe inside the proof; what a Rust caller of "
+                            "create_proof pays today.  Never `value` (inputs resident in HBM)."}
+            for a in list(pinned.values()) + [w_h, t_h]:
+                ctx.host_free(a)
+        except Exception as e:       # the headline must survive this side measurement
+            pcie = {"error": repr(e)}
 
-    # ---- rooflines of the proof's kernel classes, from the events of the timed region
+    # ---- rooflines of the proof's kernel classes, from this rank's events of the timed region
     n = circ.n
     ntt_ms = prof.get("ntt_pass", (0.0, 0))[0] + prof.get("ntt_last", (0.0, 0))[0]
     ntt_bytes = prof_bytes.get("ntt_pass", 0) + prof_bytes.get("ntt_last", 0)
     transforms = ntt_bytes / (64.0 * n) if ntt_bytes else 0
-    traffic_ntt, tsrc_ntt = committed_traffic("ntt_bytes_per_transform")
+    traffic_ntt, tsrc_ntt = committed_traffic("ntt_bytes_per_transform") if circ.k == 20 else (None, None)
     roof_ntt = None
     if transforms:
-        roof_ntt = hbm_roof("k_ntt_pass + k_ntt_last (one size-2^20 transform: lagrange_to_coeff / coset forms)", 64.0 * n, ntt_ms / transforms,
-                            "dominant kernel class of the proof by device time; algorithmic bytes = 64 B x 2^20 per transform (read once, write once; SURVEY 8d); `avg_launch_ms` is per TRANSFORM "
-                            "(both launches, up to four columns share a launch); VALU-issue bound: 10.5 M Montgomery products per transform", products=n * circ.k / 2.0,
-                            launches=prof.get("ntt_pass", (0, 0))[1] + prof.get("ntt_last", (0, 0))[1])
+        roof_ntt = hbm_roof(f"k_ntt_pass + k_ntt_last (one size-2^{circ.k} transform: lagrange_to_coeff / coset forms)", 64.0 * n, ntt_ms / transforms,
+                            f"dominant kernel class of the proof by device time; algorithmic bytes = 64 B x 2^{circ.k} per transform (read once, write once; SURVEY 8d); `avg_launch_ms` is per TRANSFORM "
+                            "(both launches; the columns of a launch share it).  VALU-issue bound: k/2 x 2^k Montgomery products per transform; `alu.frac_own_routine` here is the IN-PROOF fraction of the "
+                            "product peak (transforms share the device with the commitments running on the other stream) -- the same kernels alone reach the fraction in `msm_ntt.rooflines[1]`",
+                            products=n * circ.k / 2.0, launches=prof.get("ntt_pass", (0, 0))[1] + prof.get("ntt_last", (0, 0))[1])
         roof_ntt["transforms_per_proof"] = round(transforms / args.steps, 1)
         roof_ntt["device_ms_per_proof"] = round(ntt_ms / args.steps, 2)
         roof_ntt["traffic"] = traffic_ntt
         roof_ntt["traffic_source"] = f"profiles/{tsrc_ntt}" if traffic_ntt else None
+        if world > 1:
+            roof_ntt["rank"] = 0
     bk = prof.get("msm_buckets", (0.0, 0))
     traffic_msm, tsrc_msm = committed_traffic("msm_buckets_bytes_per_launch")
     roof_msm = hbm_roof("k_msm_buckets (merged-window launches of the proof: dense and mixed columns)", 96.0 * n, bk[0] / bk[1] if bk[1] else 0,
-                        "algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^20 per commitment (SURVEY 8d)", launches=bk[1])
+                        f"algorithmic bytes = 96 B (32 B scalar + 64 B affine base) x 2^{circ.k} per commitment (SURVEY 8d)", launches=bk[1])
     if roof_msm:
         roof_msm["device_ms_per_proof"] = round(bk[0] / args.steps, 2)
-        roof_msm["traffic_dense_column"] = traffic_msm
+        roof_msm["traffic_dense_column"] = traffic_msm if circ.k == 20 else None
     q = prof.get("quotient_coset", (0.0, 0))
     roof_q = None
+    qb = prof_bytes.get("quotient_coset", 0)
     if q[1]:
-        qb = prof_bytes.get("quotient_coset", 0)
         roof_q = {"kernel": "k_quotient_eval (degree-class launches)", "bound": "hbm", "achieved": round(qb / (q[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(qb / (q[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "device_ms_per_proof": round(q[0] / args.steps, 2), "launches_timed": q[1],
                   "algorithmic_bytes_per_proof": int(qb / args.steps), "traffic": None,
                   "note": "bytes = what the launches stream: 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result), counted by the library"}
     alg = proof_algorithmic_bytes(circ)
     alg_total = sum(alg.values())
+    # the same sum with the two stages the degree classes shrink replaced by what this implementation executes: the transforms the
+    # library launched (64 B x n each: one per committed column, one per (column, coset) a class reads) and the bytes its class
+    # programs stream -- halo2's algorithm books every column on all 2^(extended_k - k) cosets
+    executed = dict(alg)
+    k_l2c, k_cos, k_q = (next(k_ for k_ in alg if k_.startswith(p_)) for p_ in ("lagrange_to_coeff", "coset transforms", "quotient evaluation"))
+    if transforms and world == 1:
+        executed[k_l2c], executed[k_cos] = 0, int(64 * n * transforms / args.steps)
+        executed[k_q] = int(qb / args.steps)
+    executed_total = sum(executed.values()) if transforms and world == 1 else None
+    proof_traffic, tsrc_proof = committed_traffic("proof_traffic_bytes") if circ.k == 20 and world == 1 else (None, None)
     out = {
         "metric": METRIC,
         "value": round(per_proof, 4),
         "unit": "s",
-        "n_gpus": 1,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(per_proof * 1e3, 2),
@@ -294,27 +340,41 @@ def headline_single(args, torch):
         "config": {"workload": WORKLOAD, "k": circ.k, "advice": circ.A, "fixed": circ.F, "permutation_columns": len(circ.perm_cols), "lookups": len(circ.lookups),
                    "degree": circ.degree(), "extended_k": circ.extended_k(), "advice_phases": circ.num_phases(), "advice_columns_per_phase": [circ.advice_phase.count(p) for p in range(circ.num_phases())],
                    "challenges": len(circ.challenge_phase), "advice_queries": len(circ.advice_queries), "fixed_queries": len(circ.fixed_queries),
-                   "witness_cell_distribution": dist,
+                   "witness_cell_distribution": dist_cells,
                    "rows_with_an_active_lookup": round(float(np.asarray(rlc["q_lk"]).reshape(-1, 4).any(axis=1).mean()), 4),
                    "rows_with_a_copy_constraint_per_column": round(len(set(r for pair in circ.copies for (_, _, r) in pair)) / circ.n, 5),
-                   "witness_residency": "HBM (device buffers handed to zk_proof_advice_phase_dev, in place: the session writes its blinding rows into them)", "multiopen": "shplonk", "transcript": "blake2b",
-                   "vanishing_random_polynomial": "constant 1 (as the reference's own proofs)", "parallelism": "single GPU"},
+                   "witness_residency": "HBM (device buffers handed to zk_proof_advice_phase_dev, in place: the session writes its blinding rows into them)"
+                                        + ("; every rank holds the columns it owns, the others reach it device to device" if world > 1 else ""),
+                   "multiopen": "shplonk", "transcript": "blake2b",
+                   "vanishing_random_polynomial": "constant 1 (as the reference's own proofs)",
+                   "parallelism": "single GPU" if world == 1 else
+                                  f"one proof sharded x{world}: commitments by column, quotient by (degree class, coset), 64-byte commitments and witness columns all-gathered "
+                                  + ("over torch.distributed gloo callbacks (the ranks share one GPU: test box)" if shared_gpu else "over the library's RCCL communicator (xGMI)")},
         "roofline": roof_ntt,
         "rooflines": [r for r in (roof_ntt, roof_msm, roof_q) if r],
         "proof_roofline": {"algorithmic_bytes": int(alg_total), "achieved": round(alg_total / per_proof / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(alg_total / per_proof / 1e9 / HBM_PEAK_GBS, 4), "by_stage_bytes": {k_: int(v) for k_, v in alg.items()},
-                           "note": "sum over the stages of one create_proof of SURVEY 8d's algorithmic bytes (every operand once per stage) / wall-clock / 8 TB/s"},
-        "extra": {"proof_bytes": len(state["proof"]), "verified_by_oracle": verified, "create_proof_s_mean": round(per_proof, 4), "keygen_pk_s": round(t_keygen, 3),
+                           "executed_algorithmic_bytes": executed_total,
+                           "executed_frac": round(executed_total / per_proof / 1e9 / HBM_PEAK_GBS, 4) if executed_total else None,
+                           "traffic": proof_traffic, "traffic_source": f"profiles/{tsrc_proof}" if proof_traffic else None,
+                           "note": "`algorithmic_bytes` = sum over the stages of one create_proof of SURVEY 8d's algorithmic bytes as HALO2'S algorithm incurs them (every committed column "
+                                   "transformed to all 2^(extended_k - k) cosets, every operand once per stage) / wall-clock / 8 TB/s: a work-equivalent throughput, NOT bytes this "
+                                   "implementation moves -- its degree classes transform a column to 2 / 4 / 8 cosets only; `executed_algorithmic_bytes` counts the transforms and class "
+                                   "programs actually launched; `traffic` = what the PMC counters saw per proof (FETCH_SIZE raw, x 2 as the guide corrects 64-byte requests, WRITE_SIZE)"},
+        "extra": {"proof_bytes": len(state["proof"]), "proof_sha256": __import__("hashlib").sha256(state["proof"]).hexdigest(), "verified_by_oracle": verified,
+                  "create_proof_s_mean": round(per_proof, 4), "keygen_pk_s": round(t_keygen, 3),
                   "witness_upload_s_outside_timing": round(t_upload, 2), "host_circuit_build_s": round(t_build, 2),
                   "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + circ.degree() - 3) // (circ.degree() - 2) + (circ.degree() - 1) + 2,
                   "kernel_class_device_ms_per_proof": {k_: round(v[0] / args.steps, 2) for k_, v in prof.items() if v[1]},
                   "pcie_inclusive": pcie, "structure_blind": blind},
     }
     driver.free()
-    for b_ in adv_dev:
+    for b_ in adv_dev.values():
         b_.free()
     pk.destroy()
     srs.destroy()
+    if world > 1 and not shared_gpu:
+        ctx.comm_destroy()
     ctx.close()
     return out
 
@@ -541,8 +601,7 @@ def mock_worker(name):
 
 
 def proof_worker(name):
-    """One proof shape, measured in this (fresh) process; witness resident in HBM (single-GPU shapes) or page-locked on the host
-    (sharded sessions: the owner rank uploads, the ranks all-gather device to device)."""
+    """One proof shape, measured in this (fresh) process; witness resident in HBM."""
     import bench_proof as bp
     import zkevm_circuits_amd as z
 
@@ -551,15 +610,7 @@ def proof_worker(name):
     if name in MOCK_SHAPES:
         return mock_worker(name)
 
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    ctx = z.Context(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
-    hook = barrier = None
-    if world > 1:
-        from zkevm_circuits_amd import rendezvous
-
-        rendezvous.comm_init_from_env(ctx)
-        hook = lambda sess: sess.set_sharding_comm()
-        barrier = lambda: rendezvous.comm_barrier(ctx, rank, world)
+    ctx = z.Context(0)
     repeat_env = int(os.environ.get("ZK_BENCH_STEPS", "0"))
     # (builder, proofs per key, transcript).  bundle_shape_k21: the recursion / bundle layer (BASELINE configs[4] stand-in) -- halo2-base
     # layout sized by [REF aggregator/configs/bundle_circuit.config] (degree 21, 5 + 1 advice, 1 fixed), FOUR sequential proofs sharing
@@ -574,24 +625,17 @@ def proof_worker(name):
     t0 = time.perf_counter()
     circ, blob, adv_m, inst_m, inst = build()
     t_build = time.perf_counter() - t0
-    rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, pinned=world > 1, resident=world == 1, t_build=t_build,
-                         transcript_kind=tkind, session_hook=hook, barrier=barrier, report=rank == 0, world=world)
+    rec = bp.proof_bench(ctx, circ.k, circ, blob, adv_m, inst_m, inst, shplonk=True, repeat=repeat, verify=True, resident=True, t_build=t_build, transcript_kind=tkind)
     if rec is not None and tkind == 1:
         rec["transcript"] = "poseidon"
         rec["chain_of_4_proofs_s"] = round(sum(rec["create_proof_s"]), 4)
-    if rec is not None and world > 1:
-        rec["metric"] = f"synthetic-shape full proof wall-clock (s), sharded session on {world} x MI355X (in-library RCCL)"
     ctx.close()
     return rec
 
 
-# ------------------------------------------------------------------------------------ N > 1: one proof sharded over the ranks
-def sharded_headline(args, torch, dist, rank, world, local_rank):
-    """One prover process per rank (`--proof-worker supercircuit_shape_k20` with the launcher's RANK / WORLD_SIZE / LOCAL_RANK in its
-    environment): the ranks join the library's own RCCL communicator through a file (zkevm-circuits_amd/rendezvous.py) and run the
-    sharded session -- commitments split by column (by points when there are fewer columns than ranks), quotient split by
-    (class, coset), witness columns uploaded by their owner and all-gathered device to device.  Every proof is bracketed by the
-    communicator's barrier on all ranks; rank 0 reports."""
+# ------------------------------------------------------------------------------------ N > 1: can this box hold it?
+def sharded_preflight(torch, dist, rank, world, shared_gpu):
+    """None when the sharded headline can run here, else the reason (the same on every rank)"""
     def host_bytes_free():
         free = None
         try:
@@ -608,36 +652,17 @@ def sharded_headline(args, torch, dist, rank, world, local_rank):
             pass
         return free
 
-    need = 24 << 30                                               # host bytes per rank (blob + witness + builder temporaries)
+    need = (24 << 30) >> max(0, 2 * (20 - HEADLINE_K))             # host bytes per rank at k = 20 (blob + witness + builder temporaries)
     verdict = [None]
     if rank == 0:
         free = host_bytes_free()
-        if torch.cuda.device_count() < world:
-            verdict[0] = f"{world} ranks on {torch.cuda.device_count()} GPU(s): the sharded proof needs one GPU per rank (RCCL ranks cannot share a device; 150 GB of session state each)"
+        if shared_gpu and HEADLINE_K > 14:
+            verdict[0] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s): the sharded proof at k = {HEADLINE_K} needs one GPU per rank (RCCL ranks cannot share a device; "
+                          "150 GB of session state each); ranks may share a device only under the test switch ZK_BENCH_K <= 14")
         elif free is not None and free < world * need:
             verdict[0] = f"host memory: {free >> 30} GiB free, {world} ranks x {need >> 30} GiB needed"
     dist.broadcast_object_list(verdict, src=0)
-    if verdict[0]:
-        return {"error": verdict[0]} if rank == 0 else None
-    env = dict(os.environ)
-    env["ZK_COMM_ID_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"zkmi355_comm_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}_sc")
-    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
-    env["ZK_BENCH_STEPS"] = str(args.steps)
-    rec = None
-    try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--proof-worker", "supercircuit_shape_k20"], capture_output=True, text=True, timeout=600, env=env)
-        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-        if rank == 0:
-            rec = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": f"rank 0 worker exited with {res.returncode}: {res.stderr[-400:]}"}
-    except Exception as e:           # a time-out here usually means another rank failed and the collectives never completed
-        if rank == 0:
-            rec = {"error": repr(e)}
-    if rank == 0:
-        try:
-            os.remove(env["ZK_COMM_ID_FILE"])
-        except OSError:
-            pass
-    return rec
+    return verdict[0]
 
 
 def main():
@@ -678,7 +703,7 @@ def main():
         print(json.dumps(msm_ntt_section(args, torch)), flush=True)
         return
     if world == 1:
-        out = headline_single(args, torch)
+        out = headline(args, torch)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_proof(18)
         else:
@@ -693,32 +718,24 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    import datetime
+
     import torch.distributed as dist
 
-    if shared_gpu:
-        dist.init_process_group("gloo")
-    else:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rec = sharded_headline(args, torch, dist, rank, world, local_rank)
-    dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    # the launcher's process group carries the barriers, the library communicator's 128-byte id and the per-rank clocks; the proof's
+    # data moves over the library's own RCCL communicator (gloo callbacks when the ranks share a GPU)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))
+    why_not = sharded_preflight(torch, dist, rank, world, shared_gpu)
+    if why_not:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": False, "scaling": "strong",
+                              "vs_baseline": None, "dtype": DTYPE, "data": "synthetic-shape", "config": {"workload": WORKLOAD}, "roofline": None, "cpu_baseline": None, "error": why_not}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    out = headline(args, torch, rank, world, dist, local_rank, shared_gpu)
     if rank == 0:
-        ok = rec is not None and not rec.get("error") and rec.get("create_proof_s")
-        times = rec["create_proof_s"][1:] if ok and len(rec["create_proof_s"]) > 1 else (rec["create_proof_s"] if ok else [])
-        per_proof = sum(times) / len(times) if times else None
-        out = {
-            "metric": METRIC, "value": round(per_proof, 4) if per_proof else None, "unit": "s", "n_gpus": world, "steps": len(times), "warmup": 1 if ok and len(rec["create_proof_s"]) > 1 else 0,
-            "ms_per_step": round(per_proof * 1e3, 2) if per_proof else None, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic-shape",
-            "config": {"workload": WORKLOAD.replace("three advice phases, ", "one advice phase, "), "witness_residency": "page-locked host memory: every column uploaded by its owner rank, all-gathered device to device",
-                       "parallelism": f"one proof sharded x{world}: commitments by column, quotient by (class, coset), 64-byte commitments and witness columns all-gathered over the library's RCCL communicator"
-                                      + (" (ranks share a GPU: gloo-free in-library path on one device)" if shared_gpu else "")},
-            "roofline": None, "cpu_baseline": None,
-            "proof_sharded": rec, "section_wall_s": round(wall, 1),
-        }
+        out["cpu_baseline"] = None          # timed on rank 0 at N = 1 only (the N = 1 line carries it)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -567,13 +567,26 @@ def cell_distribution(adv_m, sample_cols: int = 24):
     return {"zero": round(zero / total, 3), "below_2^16": round(small / total, 3), "larger": round(1 - (zero + small) / total, 3), "cells_sampled": total}
 
 
+def owned_columns(circ, rank: int, world: int) -> set:
+    """advice columns rank `rank` of a `world`-rank sharded session owns: position j of each phase's columns (ascending column
+    index), j % world == rank -- the rule of zk_proof_advice_phase_dev (include/zkmi355.h)"""
+    out = set()
+    for ph in range(circ.num_phases()):
+        cols = [i for i in range(circ.A) if circ.advice_phase[i] == ph]
+        out.update(cols[rank::world])
+    return out
+
+
 class PhaseDriver:
     """The host side of a three-phase proof over device-resident witness columns: what the Rust shim does by calling
     `Circuit::synthesize` once per phase [REF zkevm-circuits/src/super_circuit.rs:728-736], here with the two challenge-dependent
-    columns computed on the device between the phases (w = q_lk (a_0 + evm_word b_0), t = q_lk (w + lookup_input b_0))."""
+    columns computed on the device between the phases (w = q_lk (a_0 + evm_word b_0), t = q_lk (w + lookup_input b_0)).
+    adv_dev: list or {column: DeviceBuffer}.  owned (sharded sessions): the columns this rank hands over; the others go in as None
+    and arrive from their owner (a_0, b_0, w, t are held by every rank: the two RLC columns are recomputed everywhere)."""
 
-    def __init__(self, ctx, circ, adv_dev, rlc, in_place=True):
-        self.ctx, self.circ, self.adv, self.rlc, self.in_place = ctx, circ, adv_dev, rlc, in_place
+    def __init__(self, ctx, circ, adv_dev, rlc, in_place=True, owned=None):
+        self.ctx, self.circ, self.rlc, self.in_place, self.owned = ctx, circ, rlc, in_place, owned
+        self.adv = adv_dev if isinstance(adv_dev, dict) else dict(enumerate(adv_dev))
         self.n = circ.n
         self.q = ctx.to_device(rlc["q_lk"])
         self.tmp = ctx.alloc(self.n * 32)
@@ -595,7 +608,8 @@ class PhaseDriver:
     def run(self, sess):
         """three advice phases of `sess`; returns the challenges"""
         phase_of = self.circ.advice_phase
-        cols = lambda ph: {i: self.adv[i] for i in range(self.circ.A) if phase_of[i] == ph}
+        mine = lambda i: self.owned is None or i in self.owned
+        cols = lambda ph: {i: (self.adv[i] if mine(i) else None) for i in range(self.circ.A) if phase_of[i] == ph}
         ch0 = sess.advice_phase_dev(cols(0), in_place=self.in_place)      # evm_word, keccak_input
         self._rlc(0, ch0[0], self.rlc["w"])
         ch1 = sess.advice_phase_dev(cols(1), in_place=self.in_place)      # lookup_input

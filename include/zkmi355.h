@@ -461,7 +461,11 @@ int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_inde
  * session copies the columns device to device into its own buffers (the caller's stay untouched).  ZK_ADVICE_DEV_IN_PLACE: the
  * session works in the caller's buffers -- it overwrites their last blinding_factors + 1 rows (halo2 puts blinding values there; a
  * witness holds nothing in them) and reads them until zk_proof_finish / zk_proof_abort returns; no copy, n x 32 B less device
- * memory per column.                                                                                                              */
+ * memory per column.
+ * Sharded session with a device all-gather (zk_proof_set_sharding_comm, or zk_proof_set_sharding + zk_proof_set_device_gather):
+ * a rank needs only the columns it OWNS -- position j of the phase's columns in ascending column index, j % world == rank; those
+ * it commits and sends to the other ranks over the fabric.  d_cols[j] of a column the rank does not own may be NULL (col_index
+ * still lists every column of the phase on every rank).                                                                           */
 #define ZK_ADVICE_DEV_IN_PLACE 1u
 int zk_proof_advice_phase_dev(zk_ctx* ctx, zk_proof* proof, const uint32_t* col_index, const void* const* d_cols, uint32_t ncols, uint32_t flags,
                               void* h_challenges, uint32_t* num_challenges);

@@ -54,13 +54,19 @@ def test_stale_id_of_a_finished_launch_is_refused(tmp_path):
         f.write(bytes(128) + struct.pack("<QQ", dead.pid, rendezvous._host_tag()) + bytes(16))           # left behind by a rank 0 of this host that has exited
     with pytest.raises(TimeoutError):
         rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
-    # written on ANOTHER host (shared file system): its pid cannot be looked up here -- accepted on the nonce alone ...
+    # written on ANOTHER host (shared file system): its pid cannot be looked up here.  Without a launch nonce (all zeros) it could be
+    # the leftover of any earlier launch: refused ...
     with open(path, "wb") as f:
         f.write(bytes(range(128)) + struct.pack("<QQ", dead.pid, rendezvous._host_tag() ^ 1) + bytes(16))
-    assert rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3) == bytes(range(128))
-    # ... and refused when the launcher's nonce differs (ZK_COMM_NONCE), whoever wrote it
-    os.environ["ZK_COMM_NONCE"] = "launch-2"
+    with pytest.raises(TimeoutError):
+        rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
+    # ... accepted on the nonce alone when the launch has one, and refused when the nonce is another launch's, whoever wrote it
+    os.environ["ZK_COMM_NONCE"] = "launch-1"
     try:
+        with open(path, "wb") as f:
+            f.write(bytes(range(128)) + struct.pack("<QQ", dead.pid, rendezvous._host_tag() ^ 1) + rendezvous._launch_nonce())
+        assert rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3) == bytes(range(128))
+        os.environ["ZK_COMM_NONCE"] = "launch-2"
         with pytest.raises(TimeoutError):
             rendezvous.exchange_unique_id(lambda: b"", 1, 2, path, timeout=0.3)
     finally:

@@ -331,10 +331,12 @@ class ProofSession:
 
     def advice_phase_dev(self, columns: dict, in_place: bool = False) -> np.ndarray:
         """{advice column index: DeviceBuffer (n x 32 B, Montgomery)}: the phase's witness columns resident on the device.
-        in_place: the session works in these buffers (it overwrites their blinding rows) until finish() / abort() returns."""
+        in_place: the session works in these buffers (it overwrites their blinding rows) until finish() / abort() returns.
+        Sharded session with a device all-gather: a column this rank does not own (position j of the phase's columns in ascending
+        index order, j % world != rank) may be None -- it arrives over the fabric from its owner."""
         idx = sorted(columns)
         ci = (ctypes.c_uint32 * max(len(idx), 1))(*idx)
-        ptrs = (ctypes.c_void_p * max(len(idx), 1))(*[columns[i].ptr for i in idx])
+        ptrs = (ctypes.c_void_p * max(len(idx), 1))(*[None if columns[i] is None else columns[i].ptr for i in idx])
         cap = getattr(self, "_challenge_cap", None)
         if cap is None:
             cap = self._challenge_cap = max(1, self.pk.shape()["challenges"])

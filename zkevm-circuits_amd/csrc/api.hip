@@ -398,7 +398,8 @@ int zk_msm_g1(zk_ctx* ctx, const void* d_scalars, const void* d_bases, size_t n,
 }
 int zk_commit(zk_ctx* ctx, const zk_srs* srs, int basis, const void* d_scalars, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, srs && h_out_affine, "null pointer");
+    ZK_REQUIRE(ctx, srs && h_out_affine && (d_scalars || !n), "null pointer");
+    ZK_REQUIRE(ctx, basis == 0 || basis == 1, "basis must be 0 (monomial) or 1 (Lagrange)");
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
@@ -431,7 +432,11 @@ int zk_g1_sum_host(const void* h_points_affine, size_t n, void* h_out_affine) {
 // bucket reduction of column i runs on a side stream under the sort + accumulation of column i+1).
 int zk_commit_batch(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, d_scalar_ptrs || !count, "null pointer");
+    ZK_REQUIRE(ctx, (d_scalar_ptrs && srs && h_out_affine) || !count, "null pointer");
+    if (count == 0) return ZK_OK;
+    ZK_REQUIRE(ctx, basis == 0 || basis == 1, "basis must be 0 (monomial) or 1 (Lagrange)");
+    ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
+    for (size_t i = 0; i < count; ++i) ZK_REQUIRE(ctx, d_scalar_ptrs[i] || !n, "null column pointer");
     // no hints from the caller: the columns are judged on the device (4096 sampled cells each, one launch per batch) and those with
     // at most a quarter of field-sized cells take the per-window path
     std::vector<uint8_t> narrow(count);
@@ -549,7 +554,9 @@ int sample_narrow_dev(zk_ctx* ctx, const void* const* d_cols, size_t count, size
 int commit_batch_staged(zk_ctx* ctx, const zk_srs* srs, int basis, const void* const* d_scalar_ptrs, size_t count, size_t n, void* h_out_affine, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
     if (count == 0) return ZK_OK;            // an empty batch (a circuit without permutation columns or lookups) commits nothing
     ZK_REQUIRE(ctx, srs && h_out_affine && d_scalar_ptrs, "null pointer");
+    ZK_REQUIRE(ctx, basis == 0 || basis == 1, "basis must be 0 (monomial) or 1 (Lagrange)");      // index 2 (the prefix basis) is internal: msm_diff_try only
     ZK_REQUIRE(ctx, n <= ((size_t)1 << srs->k), "polynomial longer than the SRS");
+    for (size_t i = 0; i < count; ++i) ZK_REQUIRE(ctx, d_scalar_ptrs[i] || !n, "null column pointer");
     const G1Affine* b = basis ? srs->g_lagrange : srs->g;
     ZK_REQUIRE(ctx, b, "SRS has no Lagrange basis");
     return msm_batch_srs(ctx, srs, basis, (const Fr* const*)d_scalar_ptrs, count, n, (G1Affine*)h_out_affine, stage, stage_user, narrow);

@@ -189,6 +189,7 @@ struct zk_srs {
     zk::G1Affine* pfx[2] = {nullptr, nullptr};    // prefix sums of a basis (R' form), for run-structured columns (runs.hip)
     int tab_c[3] = {0, 0, 0};
     zk::G1Affine* pfx_negtot[2] = {nullptr, nullptr};   // one point on the device: -(sum of pfx[b][j], j <= 2^k - 2), R' form
+    zk::G1Affine* pfx_negtot_tab[2] = {nullptr, nullptr};   // its fixed-base table: [32 byte windows][256 digits] = digit * 2^(8 w) * point, R' form (runs.hip: k_fixed_mul)
 };
 
 #define ZK_HIP(ctx, call)                                                                          \

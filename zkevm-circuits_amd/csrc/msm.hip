@@ -1438,6 +1438,7 @@ static int launch_scatter_staged(zk_ctx* ctx, int c, int W, dim3 grid, const Fr*
 // only a few windows (witness columns of small values, selectors, lookup multiplicities) and takes the
 // per-window path -- bucket sets of empty windows are never touched there, whereas the merged path
 // always pays for its 2^(c-1) shared buckets.  The two paths alternate freely inside one pipelined batch.
+static thread_local uint32_t tl_gm_group_cap = 0;       // upper bound on the columns of a GM group while a batch is retried with smaller groups (0 = none)
 int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, const G1Affine* d_table, size_t tab_stride, const MsmPlan& pl,
                      size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const G1Affine* d_table_n = nullptr, const MsmPlan* pl_n = nullptr, const uint8_t* narrow = nullptr) {
     if (count == 0) return ZK_OK;
@@ -1465,6 +1466,7 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
                                                                                             // columns or sixteen -- 60/30/10 columns 0.265 -> 0.255 ms each in a batch, the sort 0.81 ms per eight -> 1.45 per sixteen
         if (const char* e = getenv("ZK_MSM_NARROW_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= GM_MAX_COLS) NG = std::min<uint32_t>((uint32_t)v, MSM_WFLAGS / (uint32_t)pn.W); }
         if (const char* e = getenv("ZK_MSM_SORT_AHEAD")) if (atoi(e) == 1) NG = 1;
+        if (tl_gm_group_cap && NG > tl_gm_group_cap) NG = tl_gm_group_cap;            // a retry after the group's sort workspace did not fit (below)
         while (NG > 1 && (uint64_t)n * pn.W * NG >= (1ull << 32)) --NG;
         if (NG < 1) NG = 1;
     }
@@ -1554,6 +1556,13 @@ int msm_batch_merged(zk_ctx* ctx, const Fr* const* d_scalar_ptrs, size_t count, 
     const char* env_sa = getenv("ZK_MSM_SORT_AHEAD");
     const int ws_copies = want_graph ? GP : ((npipe == 2 || (count >= 2 && env_sa && atoi(env_sa) == 1)) ? 2 : 1);
     uint32_t* ws = (uint32_t*)ctx->get_scratch(SC_MSM_KEYS, words * 4 * ws_copies);
+    if (!ws && any_narrow && NG > 1 && words_N > head_words + 4 + 2 * max_entries) {
+        // the group sort's workspace is sized for the worst case (every digit of all NG columns non-zero: 3 GiB per copy at 2^20 rows and
+        // sixteen columns): with memory short, smaller groups are tried before the batch is given up
+        struct Cap { uint32_t prev; explicit Cap(uint32_t v) : prev(tl_gm_group_cap) { tl_gm_group_cap = v; } ~Cap() { tl_gm_group_cap = prev; } } cap(NG / 2);
+        (void)hipGetLastError();
+        return msm_batch_merged(ctx, d_scalar_ptrs, count, d_table, tab_stride, pl, n, h_out, stage, stage_user, d_table_n, pl_n, narrow);
+    }
     if (!ws) return ZK_ERR_OOM;
     uint32_t* slice_counts = ws;
     uint32_t* slice_off = slice_counts + (size_t)nb * MSM_SLICES;
@@ -2190,7 +2199,8 @@ static int srs_window_table_narrow(zk_ctx* ctx, const zk_srs* srs, int basis, si
 // per-window path otherwise.  ZK_MSM_NARROW=0 / 1 overrides the flags (measurement knob).
 int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, G1Affine* h_out, MsmStageFn stage, void* stage_user, const uint8_t* narrow) {
     // columns hinted as run-structured and resident on the device: by their run ends (runs.hip); what is left takes the paths below
-    if (narrow && !stage && count) {
+    static thread_local bool runs_tried = false;     // set while the columns msm_runs_try left undone are re-submitted: hint 2 then only selects the sliced sort
+    if (narrow && !stage && count && !runs_tried) {
         bool any2 = false;
         for (size_t i = 0; i < count; ++i) any2 |= narrow[i] == 2;
         if (any2) {
@@ -2205,7 +2215,10 @@ int msm_batch_srs(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_
                 std::vector<uint8_t> hints(rest.size());
                 std::vector<G1Affine> outs(rest.size());
                 for (size_t j = 0; j < rest.size(); ++j) { ptrs[j] = d_scalar_ptrs[rest[j]]; hints[j] = narrow[rest[j]]; }
-                rc = msm_batch_srs(ctx, srs, basis, ptrs.data(), rest.size(), n, outs.data(), nullptr, nullptr, hints.data());
+                {
+                    struct Tried { Tried() { runs_tried = true; } ~Tried() { runs_tried = false; } } tried;
+                    rc = msm_batch_srs(ctx, srs, basis, ptrs.data(), rest.size(), n, outs.data(), nullptr, nullptr, hints.data());
+                }
                 if (rc) return rc;
                 for (size_t j = 0; j < rest.size(); ++j) h_out[rest[j]] = outs[j];
                 return ZK_OK;

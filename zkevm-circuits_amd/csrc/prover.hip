@@ -793,15 +793,29 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
     if (h_challenges && (!num_challenges || *num_challenges < phase_challenges))
         return ctx->fail(ZK_ERR_INVALID_ARG, "phase %u yields %u challenges: pass a buffer for at least that many and its capacity in *num_challenges", pr->phase, phase_challenges);
     if (ncols != expected) return ctx->fail(ZK_ERR_INVALID_ARG, "phase %u has %u advice columns, %u were passed", pr->phase, expected, ncols);
+    // Sharded session with a device all-gather and a device-resident witness: a rank holds only the columns it OWNS (position j of
+    // the phase's columns in ascending column order, j % world == rank); the others arrive over the fabric and may be passed as NULL.
+    const bool owner_only = dev_src && pr->world > 1 && pr->gather && pr->gather_dev;
     std::vector<const void*> by_col(pk->A, nullptr);
+    std::vector<uint8_t> seen(pk->A, 0);
     for (uint32_t j = 0; j < ncols; ++j) {
         const uint32_t c = col_index[j];
-        if (c >= pk->A || pk->adv_phase[c] != pr->phase || by_col[c] || !h_cols[j]) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u does not belong to phase %u (or is repeated)", c, pr->phase);
+        if (c >= pk->A || pk->adv_phase[c] != pr->phase || seen[c] || (!h_cols[j] && !owner_only)) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u does not belong to phase %u (or is repeated)", c, pr->phase);
         by_col[c] = h_cols[j];
+        seen[c] = 1;
+    }
+    if (owner_only) {
+        uint32_t pos = 0;
+        for (uint32_t c = 0; c < pk->A; ++c) {
+            if (!seen[c]) continue;
+            if (pos % pr->world == pr->rank && !by_col[c]) return ctx->fail(ZK_ERR_INVALID_ARG, "advice column %u is owned by this rank (position %u of the phase, rank %u of %u) and was passed as NULL", c, pos, pr->rank, pr->world);
+            ++pos;
+        }
     }
     if (dev_src) pr->advice_on_device = true;
     if (in_place) {
-        std::vector<const void*> sorted_ptrs(h_cols, h_cols + ncols);
+        std::vector<const void*> sorted_ptrs;
+        for (uint32_t j = 0; j < ncols; ++j) if (h_cols[j]) sorted_ptrs.push_back(h_cols[j]);
         std::sort(sorted_ptrs.begin(), sorted_ptrs.end());
         if (std::adjacent_find(sorted_ptrs.begin(), sorted_ptrs.end()) != sorted_ptrs.end()) return ctx->fail(ZK_ERR_INVALID_ARG, "in-place witness columns must be distinct buffers (each gets its own blinding rows)");
         pr->advice_in_place = true;
@@ -858,8 +872,8 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
     sg.pr = pr;
     sg.kind = dev_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     for (uint32_t c = 0; c < pk->A; ++c) {        // column-index order = transcript order
-        if (!by_col[c]) continue;
-        if (in_place) pr->adv_lag[c].borrow(const_cast<void*>(by_col[c]));
+        if (!seen[c]) continue;
+        if (in_place && by_col[c] && (!owner_only || sg.dst.size() % pr->world == pr->rank)) pr->adv_lag[c].borrow(const_cast<void*>(by_col[c]));
         else if (!pr->adv_lag[c].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc of %zu bytes failed", n * 32);
         sg.src.push_back(by_col[c]);
         sg.dst.push_back(pr->adv_lag[c].p);
@@ -919,7 +933,13 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
     };
     std::vector<G1Affine> coms(sg.dst.size());
     std::vector<uint8_t> narrow(sg.src.size());
-    if (dev_src) PK_TRY(sample_narrow_dev(ctx, sg.src.data(), sg.src.size(), n, narrow.data()));
+    if (owner_only) {                             // only this rank's own columns are on this device (and only they are committed here)
+        std::vector<const void*> own_src;
+        for (size_t c_ = pr->rank; c_ < sg.src.size(); c_ += pr->world) own_src.push_back(sg.src[c_]);
+        std::vector<uint8_t> own_narrow(own_src.size());
+        PK_TRY(sample_narrow_dev(ctx, own_src.data(), own_src.size(), n, own_narrow.data()));
+        for (size_t j = 0; j < own_src.size(); ++j) narrow[pr->rank + j * pr->world] = own_narrow[j];
+    } else if (dev_src) PK_TRY(sample_narrow_dev(ctx, sg.src.data(), sg.src.size(), n, narrow.data()));
     else sample_narrow(sg.src.data(), sg.src.size(), n, narrow.data());       // witness columns of (mostly) small values take the per-window MSM path
     trace.mark("  advice: columns sampled");
     // ... and their blinding rows (the last blinding_factors + 1, field-sized) are committed apart, so that they do not occupy every window

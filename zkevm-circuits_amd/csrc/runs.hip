@@ -195,6 +195,60 @@ __global__ void __launch_bounds__(64) k_runs_sum(const G1Xyzz29* __restrict__ pa
     stg(out + col, to_std_xyzz(acc));
 }
 
+// ---- a scalar times ONE fixed point -------------------------------------------------------------------------------------------
+// c * Q for the fixed point Q = -(P_0 + ... + P_{n-2}) of a basis (msm_diff_try below): a table of digit * 2^(8 w) * Q over the 32
+// byte windows of a scalar (512 KiB, built once per SRS and basis: one lane per entry, double-and-add) turns the 254-step chain of a
+// single lane into 32 table reads and a five-level sum inside one wave.
+constexpr int FIXED_WINDOWS = 32, FIXED_DIGITS = 256;
+__global__ void __launch_bounds__(256) k_fixed_table(const G1Affine* __restrict__ q, G1Affine* __restrict__ tab) {
+    const uint32_t w = blockIdx.x, d = threadIdx.x;           // entry [w][d] = (d << 8 w) * Q
+    const G1Affine29 p = load_affine29(q);
+    G1Xyzz29 acc = identity29();
+    if (d) {
+#pragma unroll 1
+        for (int bit = 7; bit >= 0; --bit) {
+            acc = dbl29pt(acc);
+            if ((d >> bit) & 1u) acc = madd29(acc, p);
+        }
+#pragma unroll 1
+        for (uint32_t t = 0; t < 8 * w; ++t) acc = dbl29pt(acc);
+    }
+    stg(tab + (size_t)w * FIXED_DIGITS + d, to_affine_rp(acc));
+}
+// out[col] = c[col] * Q from the table; one wave per column, lane w < 32 holds window w
+__global__ void __launch_bounds__(64) k_fixed_mul(const Fr* __restrict__ c, const G1Affine* __restrict__ tab, G1Xyzz* __restrict__ out) {
+    __shared__ G1Xyzz29 sh[64];
+    const uint32_t col = blockIdx.x, w = threadIdx.x;
+    G1Xyzz29 acc = identity29();
+    if (w < (uint32_t)FIXED_WINDOWS) {
+        const Fr k = from_mont(ldg(c + col));
+        const uint32_t digit = (k.l[w >> 2] >> (8 * (w & 3))) & 0xFFu;
+        if (digit) acc = madd29(acc, load_affine29(tab + (size_t)w * FIXED_DIGITS + digit));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 16; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add29pt(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stg(out + col, to_std_xyzz(sh[0]));
+}
+static int srs_fixed_table(zk_ctx* ctx, const zk_srs* srs, int basis, const G1Affine** out) {
+    *out = nullptr;
+    zk_srs* s = const_cast<zk_srs*>(srs);
+    if (s->pfx_negtot_tab[basis]) { *out = s->pfx_negtot_tab[basis]; return ZK_OK; }
+    if (!s->pfx_negtot[basis]) return ZK_OK;
+    G1Affine* tab = nullptr;
+    if (hipMalloc(&tab, sizeof(G1Affine) * FIXED_WINDOWS * FIXED_DIGITS) != hipSuccess) { (void)hipGetLastError(); return ZK_OK; }
+    hipLaunchKernelGGL(k_fixed_table, dim3(FIXED_WINDOWS), dim3(FIXED_DIGITS), 0, ctx->stream, (const G1Affine*)s->pfx_negtot[basis], tab);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(tab); return ctx->fail(ZK_ERR_HIP, "fixed-base table: %s", hipGetErrorString(e)); }
+    s->pfx_negtot_tab[basis] = tab;
+    *out = tab;
+    return ZK_OK;
+}
+
 // Commits the columns hinted as run-structured (narrow[i] == 2) that do have few runs; done[i] = 1 for those, the others are left
 // to the caller's ordinary path.  No-op (all zero) when the feature is off, the columns are small, or memory is short.
 int msm_runs_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_scalar_ptrs, size_t count, size_t n, const uint8_t* narrow, G1Affine* h_out, uint8_t* done) {
@@ -378,35 +432,28 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
     rc = srs_prefix_table(ctx, srs, basis, &pfx);
     if (rc) return rc;
     if (!pfx || !srs->pfx_negtot[basis]) return ZK_OK;
+    const G1Affine* fixed_tab = nullptr;
+    rc = srs_fixed_table(ctx, srs, basis, &fixed_tab);
+    if (rc) return rc;
+    if (!fixed_tab) return ZK_OK;
     for (size_t first = 0; first < sel.size(); first += CHUNK) {
         const size_t cnt = std::min(CHUNK, sel.size() - first);
-        const size_t s_bytes = cnt * n * sizeof(Fr), aux_bytes = 256 + CHUNK * (sizeof(Fr) + sizeof(G1Affine) + sizeof(G1Xyzz29) + sizeof(G1Xyzz) + 4) + 256;
+        const size_t s_bytes = cnt * n * sizeof(Fr), aux_bytes = CHUNK * (sizeof(Fr) + sizeof(G1Xyzz) + 4) + 256;
         Fr* d_s = (Fr*)ctx->pool_get(s_bytes);
         char* aux = (char*)ctx->pool_get(aux_bytes);
         if (!d_s || !aux) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return ZK_OK; }
         auto release = [&](int code) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return code; };
-        uint32_t* d_ones = (uint32_t*)aux;                                   // counts[col] = 1 for k_runs_mul
-        Fr* d_c = (Fr*)(aux + 256);
-        G1Affine* d_pt = (G1Affine*)(d_c + CHUNK);
-        G1Xyzz29* d_part = (G1Xyzz29*)(d_pt + CHUNK);
-        G1Xyzz* d_res = (G1Xyzz*)(d_part + CHUNK);
+        Fr* d_c = (Fr*)aux;
+        G1Xyzz* d_res = (G1Xyzz*)(d_c + CHUNK);
         uint32_t* d_votes = (uint32_t*)(d_res + CHUNK);
         RunCols rcols{};
         for (size_t j = 0; j < cnt; ++j) rcols.p[j] = d_scalar_ptrs[sel[first + j]];
-        uint32_t ones[CHUNK];
-        for (size_t j = 0; j < CHUNK; ++j) ones[j] = 1u;
-        hipError_t e = hipMemcpyAsync(d_ones, ones, sizeof ones, hipMemcpyHostToDevice, ctx->stream);
-        for (size_t j = 0; j < cnt && e == hipSuccess; ++j) e = hipMemcpyAsync(d_pt + j, srs->pfx_negtot[basis], sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
         hipLaunchKernelGGL(k_diff_mode, dim3((unsigned)cnt), dim3(DIFF_SAMPLES), 0, ctx->stream, rcols, (uint64_t)n, d_c, d_votes);
         hipLaunchKernelGGL(k_diff_sparse, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, rcols, (uint64_t)n, (const Fr*)d_c, d_s);
-        // c * (-(P_0 + ... + P_{n-2})) for every column of the chunk: one pair each for the direct sum of runs.hip
-        hipLaunchKernelGGL(k_runs_mul, dim3(1, (unsigned)cnt), dim3(256), 0, ctx->stream, (const Fr*)d_c, (const G1Affine*)d_pt, 1u, (const uint32_t*)d_ones, d_part);
-        hipLaunchKernelGGL(k_runs_sum, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_part, 1u, d_res);
-        e = hipGetLastError();
-        std::vector<G1Xyzz> hres(cnt);
-        if (e == hipSuccess) e = hipMemcpyAsync(hres.data(), d_res, cnt * sizeof(G1Xyzz), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        // c * (-(P_0 + ... + P_{n-2})) for every column of the chunk, out of the point's fixed-base table; the results are fetched
+        // after the batch below has drained the stream (no synchronisation of their own)
+        hipLaunchKernelGGL(k_fixed_mul, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, (const Fr*)d_c, fixed_tab, d_res);
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
         // the mostly-zero images over the prefix basis, judged and committed like any batch of columns
         std::vector<const void*> sp(cnt);
@@ -417,6 +464,10 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
         std::vector<G1Affine> part(cnt);
         rc = msm_batch_srs(ctx, srs, 2, (const Fr* const*)sp.data(), cnt, n, part.data(), nullptr, nullptr, kind.data());
         if (rc) return release(rc);
+        std::vector<G1Xyzz> hres(cnt);
+        e = hipMemcpyAsync(hres.data(), d_res, cnt * sizeof(G1Xyzz), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return release(ctx->fail(ZK_ERR_HIP, "difference commitments: %s", hipGetErrorString(e)));
         for (size_t j = 0; j < cnt; ++j) {
             G1Xyzz a = G1Xyzz::identity();
             if (!part[j].is_identity()) { a.x = part[j].x; a.y = part[j].y; a.zz = Fq::one(); a.zzz = Fq::one(); }

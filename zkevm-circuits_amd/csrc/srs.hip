@@ -201,6 +201,7 @@ void zk_srs_destroy(zk_ctx* ctx, zk_srs* srs) {
     for (auto t : srs->tabn) if (t) (void)hipFree(t);
     for (auto t : srs->pfx) if (t) (void)hipFree(t);
     for (auto t : srs->pfx_negtot) if (t) (void)hipFree(t);
+    for (auto t : srs->pfx_negtot_tab) if (t) (void)hipFree(t);
     delete srs;
 }
 uint32_t zk_srs_k(const zk_srs* srs) { return srs ? srs->k : 0; }

@@ -38,7 +38,8 @@ def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float
     and carries the id followed by rank 0's pid, a tag of its host name and the launch nonce.  A file whose nonce
     differs is another launch's; with equal nonces, a reader ON RANK 0's HOST also requires the writer to be alive (a
     leftover of an earlier launch from the same shell / port / fixed ZK_COMM_ID_FILE is never accepted), while a reader
-    on ANOTHER host (a path on a shared file system) cannot see that pid and relies on the nonce.  Rank 0 removes
+    on ANOTHER host (a path on a shared file system) cannot see that pid and relies on the nonce: there ZK_COMM_NONCE is
+    REQUIRED -- a file from a foreign host with the all-zero nonce is refused.  Rank 0 removes
     whatever is at `path` before it even creates its id, and `retire_unique_id` removes the file once every rank has joined."""
     import struct
     import time
@@ -57,14 +58,24 @@ def exchange_unique_id(make_id, rank: int, world: int, path: str, timeout: float
             os.replace(tmp, path)
         return uid
     deadline = time.monotonic() + timeout
+    warned = False
     while True:
         try:
             with open(path, "rb") as f:
                 blob = f.read()
             if len(blob) == ID_FILE_LEN and blob[144:] == _launch_nonce():
                 pid, host = struct.unpack("<QQ", blob[128:144])
-                if host != _host_tag() or _alive(pid):
+                if host == _host_tag():
+                    if _alive(pid):
+                        return blob[:128]
+                elif blob[144:] != bytes(16):
                     return blob[:128]
+                elif not warned:
+                    # a writer on another host cannot be checked for liveness: without a launch nonce a leftover file of an
+                    # earlier launch would be joined (and hang until the timeout) -- refused, and said so once
+                    warned = True
+                    print(f"[zkmi355 rendezvous] rank {rank}: the id file at {path} was written on another host and carries no launch nonce: "
+                          "export ZK_COMM_NONCE (any string, the same on every rank of this launch) for ranks spread over hosts", flush=True)
         except FileNotFoundError:
             pass
         if time.monotonic() > deadline:
