@@ -181,6 +181,14 @@ int zk_host_quotient_lower(const uint32_t* program, uint32_t num_instr, uint32_t
  * marker {FOLD (9), i, 0}.  *conflict = 1 for slot reuse across constraints (the prover then evaluates a single class). */
 int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const uint32_t* cls, uint32_t count, uint32_t classes,
                            uint32_t* out_words, size_t out_cap_words, uint32_t* out_lens, int* conflict);
+/* Host only, for tests: the additive split of ONE constraint program over the degree classes 0 .. E as the prover applies it: a
+ * constraint that is a sum of terms of different degrees (q (a b - c): degree 3 and degree 2) hands each term to the class of its
+ * own degree -- h is linear in the constraints -- so that columns occurring only in low-degree terms are transformed to fewer cosets
+ * (halo2's evaluate_h, external crate, evaluates every constraint on the whole extended domain; same h).  Output: the pieces back to
+ * back, out_lens[j] instructions of class out_cls[j]; one piece (the program itself) when it is not split.  out_words may be NULL
+ * (count only). */
+int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E, uint32_t* out_words, size_t out_cap_words, uint32_t* out_cls, uint32_t* out_lens,
+                           uint32_t cap_pieces, uint32_t* num_pieces);
 
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);

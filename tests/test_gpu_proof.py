@@ -769,8 +769,12 @@ def test_degree_classes_leave_the_proof_unchanged(ctx, cref, srs8):
     assert circ.degree() == 9 and pv.check_witness(circ, adv, []) is None
     from oracle import plonk_prover as pp
     proofs = {}
-    for mode in ("1", "0"):
-        os.environ["ZK_QUOTIENT_SPLIT"] = mode
+    # "1": classes + the additive split of sums over the classes of their terms (q (a b - c): q c is evaluated on one coset and c is
+    # transformed to one coset only -- the factored form); "1-whole": classes, every constraint whole; "0": a single domain
+    for mode in ("1", "1-whole", "0"):
+        os.environ["ZK_QUOTIENT_SPLIT"] = mode[0]
+        if mode == "1-whole":
+            os.environ["ZK_QUOTIENT_ADDSPLIT"] = "0"
         try:
             pk = ctx.pk_create(srs8[k], circ.blob())
             _, rep = pk.vk(circ.F + len(circ.perm_cols))
@@ -778,7 +782,8 @@ def test_degree_classes_leave_the_proof_unchanged(ctx, cref, srs8):
             pk.destroy()
         finally:
             os.environ.pop("ZK_QUOTIENT_SPLIT", None)
-    assert proofs["1"] == proofs["0"]
+            os.environ.pop("ZK_QUOTIENT_ADDSPLIT", None)
+    assert proofs["1"] == proofs["0"] and proofs["1-whole"] == proofs["0"]
     want = pp.create_proof(circ, pp.Srs(k, S_SECRET), adv, [], cref.from_mont(rep.reshape(1, 4))[0], bytes(range(16)), "shplonk")
     assert proofs["1"] == want
 

@@ -122,3 +122,132 @@ def test_slot_reuse_across_constraints_is_reported(zk):
     # a read before any definition is malformed
     _, conflict = split(zk, [[(PUSH_TMP, 3, 0)]], [0], 1)
     assert conflict == 1
+
+
+# ------------------------------------------------------------------------------------------------- additive split over classes
+def additive_split(zk, prog, E):
+    lib = zk.lib()
+    words = np.array([w & 0xFFFFFFFF for ins in prog for w in ins], dtype=np.uint32)       # rotations travel as the u32 image of an i32
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    cnt = ctypes.c_uint32()
+    assert lib.zk_host_additive_split(ptr(words), ctypes.c_uint32(len(prog)), ctypes.c_uint32(E), None, ctypes.c_size_t(0), None, None, ctypes.c_uint32(0), ctypes.byref(cnt)) == 0
+    out = np.zeros(3 * (len(prog) + 8) * max(cnt.value, 1), dtype=np.uint32)
+    cls, lens = np.zeros(cnt.value, dtype=np.uint32), np.zeros(cnt.value, dtype=np.uint32)
+    assert lib.zk_host_additive_split(ptr(words), ctypes.c_uint32(len(prog)), ctypes.c_uint32(E), ptr(out), ctypes.c_size_t(out.size), ptr(cls), ptr(lens), ctypes.c_uint32(cnt.value), ctypes.byref(cnt)) == 0
+    pieces, at = [], 0
+    for j in range(cnt.value):
+        signed = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+        pieces.append((int(cls[j]), [(int(out[3 * (at + i)]), int(out[3 * (at + i) + 1]), signed(int(out[3 * (at + i) + 2]))) for i in range(int(lens[j]))]))
+        at += int(lens[j])
+    return pieces
+
+
+def degree(prog):
+    st = []
+    for op, a, b in prog:
+        if op == PUSH_COL: st.append(1)
+        elif op == PUSH_CONST: st.append(0)
+        elif op in (ADD, SUB): y, x = st.pop(), st.pop(); st.append(max(x, y))
+        elif op == MUL: y, x = st.pop(), st.pop(); st.append(x + y)
+        elif op == SQUARE: st.append(2 * st.pop())
+        elif op in (NEG, DOUBLE, MUL_CONST, ADD_CONST): pass
+        else: raise AssertionError(op)
+    assert len(st) == 1
+    return st[0]
+
+
+def class_of(deg, E):
+    e = 0
+    while e < E and (1 << e) < max(deg - 1, 1):
+        e += 1
+    return e
+
+
+def test_a_gate_is_split_into_the_classes_of_its_terms(zk):
+    """q (a b - c): the product is of degree 3 (two cosets), q c of degree 2 (one coset) -- the shape of the multiplication gates of
+    the SuperCircuit stand-in (bench_proof.build_shape); the output column c is then read on one coset only"""
+    E = 3
+    q, a, b_, c = (PUSH_COL, 0, 0), (PUSH_COL, 1, 0), (PUSH_COL, 2, 0), (PUSH_COL, 3, 0)
+    gate = [q, a, b_, (MUL, 0, 0), c, (SUB, 0, 0), (MUL, 0, 0)]
+    pieces = additive_split(zk, gate, E)
+    assert sorted(cl for cl, _ in pieces) == [0, 1]
+    by = dict(pieces)
+    assert 3 not in [ins[1] for ins in by[1] if ins[0] == PUSH_COL]         # the class of the product does not read c
+    assert [ins[1] for ins in by[0] if ins[0] == PUSH_COL] == [0, 3]         # the low class reads q and c only
+    # the selector on the other side, a sum without a factor, a linear gate (not split: one class), a product (not a sum: whole)
+    assert sorted(cl for cl, _ in additive_split(zk, [a, b_, (MUL, 0, 0), c, (SUB, 0, 0), q, (MUL, 0, 0)], E)) == [0, 1]
+    assert sorted(cl for cl, _ in additive_split(zk, [a, b_, (MUL, 0, 0), a, (MUL, 0, 0), a, (MUL, 0, 0), c, (ADD, 0, 0)], E)) == [0, 2]
+    assert [cl for cl, _ in additive_split(zk, [q, a, b_, (ADD, 0, 0), c, (SUB, 0, 0), (MUL, 0, 0)], E)] == [0]
+    assert [cl for cl, _ in additive_split(zk, [q, a, (MUL, 0, 0), b_, (MUL, 0, 0), c, (MUL, 0, 0)], E)] == [2]
+    # parked intermediates: left whole
+    assert len(additive_split(zk, [q, a, b_, (MUL, 0, 0), (TEE, 0, 0), c, (SUB, 0, 0), (MUL, 0, 0)], E)) == 1
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_the_pieces_of_a_constraint_sum_to_it(zk, seed):
+    rng = random.Random(1000 + seed)
+    ncols, nconsts, E = 6, 3, rng.randrange(1, 4)
+
+    def term(depth, prog):
+        if depth <= 0 or rng.random() < 0.3:
+            prog.append((PUSH_COL, rng.randrange(ncols), rng.randrange(-1, 2)) if rng.random() < 0.8 else (PUSH_CONST, rng.randrange(nconsts), 0))
+            return
+        pick = rng.random()
+        if pick < 0.2:
+            term(depth - 1, prog)
+            prog.append((rng.choice([NEG, SQUARE, DOUBLE, MUL_CONST, ADD_CONST]), rng.randrange(nconsts), 0))
+        else:
+            term(depth - 1, prog)
+            term(depth - 1, prog)
+            prog.append((rng.choice([ADD, SUB, MUL, MUL, MUL]), 0, 0))
+
+    def build_sum(count, prog):
+        term(rng.randrange(0, 3), prog)
+        if rng.random() < 0.3:
+            prog.append((NEG, 0, 0))
+        for _ in range(count - 1):
+            term(rng.randrange(0, 3), prog)
+            prog.append((rng.choice([ADD, SUB]), 0, 0))
+
+    for _ in range(20):
+        prog = []
+        shape = rng.randrange(3)
+        if shape == 0:
+            build_sum(rng.randrange(2, 6), prog)
+        elif shape == 1:
+            prog.append((PUSH_COL, 0, 0))
+            build_sum(rng.randrange(2, 6), prog)
+            prog.append((MUL, 0, 0))
+        else:
+            build_sum(rng.randrange(2, 6), prog)
+            prog.append((PUSH_COL, 0, 0))
+            prog.append((MUL, 0, 0))
+        if degree(prog) > (1 << E) + 1:
+            continue
+        pieces = additive_split(zk, prog, E)
+        classes = [cl for cl, _ in pieces]
+        assert classes == sorted(set(classes))                    # ascending, one piece per class
+        assert max(classes) == class_of(degree(prog), E)            # the highest class is the constraint's own
+        for cl, pg in pieces:
+            assert class_of(degree(pg), E) == cl or len(pieces) == 1
+
+        def run(pg, cols, consts):
+            st = []
+            for op, a, b in pg:
+                if op == PUSH_COL: st.append(cols[(a, b)])
+                elif op == PUSH_CONST: st.append(consts[a])
+                elif op == ADD: y, x = st.pop(), st.pop(); st.append((x + y) % R)
+                elif op == SUB: y, x = st.pop(), st.pop(); st.append((x - y) % R)
+                elif op == MUL: y, x = st.pop(), st.pop(); st.append(x * y % R)
+                elif op == NEG: st.append(-st.pop() % R)
+                elif op == SQUARE: x = st.pop(); st.append(x * x % R)
+                elif op == DOUBLE: st.append(2 * st.pop() % R)
+                elif op == MUL_CONST: st.append(st.pop() * consts[a] % R)
+                elif op == ADD_CONST: st.append((st.pop() + consts[a]) % R)
+                else: raise AssertionError(op)
+            assert len(st) == 1
+            return st[0]
+        for _ in range(3):
+            cols = {(c_, r_): rng.randrange(R) for c_ in range(ncols) for r_ in (-1, 0, 1)}
+            consts = [rng.randrange(R) for _ in range(nconsts)]
+            assert sum(run(pg, cols, consts) for _, pg in pieces) % R == run(prog, cols, consts)

@@ -205,16 +205,23 @@ __device__ __forceinline__ void dit_first_step(Fr29 (&e)[4], const Tw29* __restr
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(NttIo io, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
            const Fr* __restrict__ hi, int h, int log_np, int log_t, int log_m, int tw_shift, const Fr* __restrict__ pre,
-           const Fr* __restrict__ out_tw) {
+           const Fr* __restrict__ out_tw, uint32_t ncols, int xcd_cols) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const Fr* __restrict__ src = io.src[blockIdx.y];
-    Fr* __restrict__ dst = io.dst[blockIdx.y];
+    // One-dimensional grid over (tile, column).  The per-element tables (inter-pass twiddles, coset shifts: 32 B per element of the
+    // TILE, the same for every column) are read by every column's workgroup of a tile: those workgroups are numbered so that they
+    // are consecutive workgroups of ONE XCD (workgroups go to the eight XCDs round-robin, each XCD has its own L2) -- the table
+    // lines are fetched from HBM once per tile instead of once per (tile, column).
+    uint32_t tile_id, col;
+    if (xcd_cols) { const uint32_t slot = blockIdx.x >> 3; col = slot % ncols; tile_id = (slot / ncols) * 8u + (blockIdx.x & 7u); }
+    else { col = blockIdx.x % ncols; tile_id = blockIdx.x / ncols; }
+    const Fr* __restrict__ src = io.src[col];
+    Fr* __restrict__ dst = io.dst[col];
     const int tile = 1 << (log_np + log_t);
     Lds29 L{smem, tile};
     const int T = 1 << log_t;
     const uint64_t m = 1ull << log_m;
     const uint32_t tiles_per_hi = (uint32_t)(m >> log_t);
-    const uint32_t hi_idx = blockIdx.x / tiles_per_hi, blk = blockIdx.x % tiles_per_hi;
+    const uint32_t hi_idx = tile_id / tiles_per_hi, blk = tile_id % tiles_per_hi;
     const uint64_t base = ((uint64_t)hi_idx << (log_np + log_m)) + ((uint64_t)blk << log_t);
 
     for (int s = 0; s < log_np;) {
@@ -538,6 +545,7 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
     if (count > 1) {
         const uint64_t tiles = std::max<uint64_t>(1, n >> 12);
         per_launch = (size_t)std::min<uint64_t>(NTT_BATCH, std::max<uint64_t>(1, 1024 / tiles));
+        if (const char* e = getenv("ZK_NTT_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= NTT_BATCH) per_launch = (size_t)v; }      // measurement knob
     }
     Fr* scratch = nullptr;
     if (P > 1) {
@@ -577,8 +585,10 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             const int tw_shift = (int)log_n - ps.log_np - ps.log_m;
             ZkProfScope pscope(ctx, "ntt_pass");
             pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;      // a transform's algorithmic 64 B per element (read once, write once), spread over its P launches
-            hipLaunchKernelGGL(k_ntt_pass, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
-                               dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw);
+            static const bool xcd_off = getenv("ZK_NTT_XCD_COLS") && atoi(getenv("ZK_NTT_XCD_COLS")) == 0;       // measurement knob
+            hipLaunchKernelGGL(k_ntt_pass, dim3(blocks * (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
+                               dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw,
+                               (uint32_t)nb, (nb > 1 && blocks % 8 == 0 && !xcd_off) ? 1 : 0);
             ZK_CHECK_LAUNCH(ctx);
             for (size_t j = 0; j < nb; ++j) cur_io.src[j] = io.dst[j];
         }

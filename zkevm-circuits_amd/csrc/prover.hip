@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <random>
 #include <tuple>
+#include <functional>
 #include "ctx.hpp"
 #include "host_hash.hpp"
 
@@ -1102,6 +1103,115 @@ static int classify_constraints(zk_ctx* ctx, const zk_pk* pk, const std::vector<
     }
     return ZK_OK;
 }
+// Additive split of a constraint over degree classes.  h is linear in the constraints, so a constraint that is a SUM of terms of
+// different degrees -- q (a b - c): the product is of degree 3, q c of degree 2 -- may put each term into the class of ITS degree,
+// all with the constraint's own power of y: the term q c is then evaluated on one coset instead of two, and a column that occurs
+// only in such low-degree terms (the outputs of multiplication gates, every linearly constrained cell) is transformed to fewer
+// cosets.  Recognised shapes (the program's top): SUM, F * SUM and SUM * F with SUM a tree of + / - / negations; the factor F (a
+// selector, as a rule) multiplies every group.  Exact field arithmetic: the sum of the groups is the constraint, h and every proof
+// byte stay what they were.  Programs that park or read shared intermediates are left whole.  ZK_QUOTIENT_ADDSPLIT=0 turns it off.
+struct ClassPiece { uint32_t cons, cls; Prog prog; };
+static int TmpSplitArity(uint32_t op) {
+    switch (op) {
+        case Q_PUSH_COL: case Q_PUSH_CONST: case Q_PUSH_TMP: return 0;
+        case Q_ADD: case Q_SUB: case Q_MUL: return 2;
+        default: return 1;                        // NEG, DOUBLE, SQUARE, ADD_CONST, MUL_CONST, TEE_TMP
+    }
+}
+static uint32_t class_of_degree(int dg, uint32_t E) {
+    uint32_t e = 0;
+    while (e < E && ((uint32_t)1 << e) < (uint32_t)std::max(dg - 1, 1)) ++e;
+    return e;
+}
+static bool additive_split(const Prog& g, uint32_t E, uint32_t whole_cls, std::vector<std::pair<uint32_t, Prog>>& out) {
+    struct Node { Instr in; int l, r; };
+    std::vector<Node> nd;
+    std::vector<int> st;
+    for (const Instr& in : g) {
+        if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP || in.op == Q_FOLD || in.op == Q_END) return false;
+        const int ar = TmpSplitArity(in.op);
+        Node n_{in, -1, -1};
+        if (ar == 2) { if (st.size() < 2) return false; n_.r = st.back(); st.pop_back(); n_.l = st.back(); st.pop_back(); }
+        else if (ar == 1) { if (st.empty()) return false; n_.l = st.back(); st.pop_back(); }
+        nd.push_back(n_);
+        st.push_back((int)nd.size() - 1);
+    }
+    if (st.size() != 1) return false;
+    const int root = st[0];
+    std::function<void(int, Prog&)> emit = [&](int v, Prog& o) {
+        if (nd[v].l >= 0) emit(nd[v].l, o);
+        if (nd[v].r >= 0) emit(nd[v].r, o);
+        o.push_back(nd[v].in);
+    };
+    auto is_sum = [&](int v) { return nd[v].in.op == Q_ADD || nd[v].in.op == Q_SUB || nd[v].in.op == Q_NEG; };
+    int factor = -1, sum = root;
+    if (nd[root].in.op == Q_MUL) {
+        if (is_sum(nd[root].r)) { factor = nd[root].l; sum = nd[root].r; }
+        else if (is_sum(nd[root].l)) { factor = nd[root].r; sum = nd[root].l; }
+        else return false;
+    } else if (!is_sum(root)) return false;
+    std::vector<std::pair<int, bool>> terms;            // (node, negative)
+    std::function<void(int, bool)> collect = [&](int v, bool neg_) {
+        const uint32_t op = nd[v].in.op;
+        if (op == Q_ADD) { collect(nd[v].l, neg_); collect(nd[v].r, neg_); }
+        else if (op == Q_SUB) { collect(nd[v].l, neg_); collect(nd[v].r, !neg_); }
+        else if (op == Q_NEG) collect(nd[v].l, !neg_);
+        else terms.push_back({v, neg_});
+    };
+    collect(sum, false);
+    if (terms.size() < 2 || terms.size() > 4096) return false;
+    std::vector<int> no_tmps;
+    Prog fprog;
+    int fdeg = 0;
+    if (factor >= 0) { emit(factor, fprog); fdeg = program_degree(fprog, &no_tmps); if (fdeg < 0) return false; }
+    std::vector<Prog> tprog(terms.size());
+    std::vector<uint32_t> tcls(terms.size());
+    for (size_t t = 0; t < terms.size(); ++t) {
+        emit(terms[t].first, tprog[t]);
+        const int tdeg = program_degree(tprog[t], &no_tmps);
+        if (tdeg < 0) return false;
+        tcls[t] = class_of_degree(fdeg + tdeg, E);
+    }
+    std::vector<Prog> group(E + 1);
+    std::vector<uint8_t> started(E + 1, 0);
+    for (uint32_t e = 0; e <= E; ++e) {
+        int lead = -1;                                   // a positive term first (no negation to spend), else the first term negated
+        for (size_t t = 0; t < terms.size() && lead < 0; ++t) if (tcls[t] == e && !terms[t].second) lead = (int)t;
+        for (size_t t = 0; t < terms.size() && lead < 0; ++t) if (tcls[t] == e) lead = (int)t;
+        if (lead < 0) continue;
+        started[e] = 1;
+        group[e] = tprog[lead];
+        if (terms[lead].second) group[e].push_back({Q_NEG, 0, 0});
+        for (size_t t = 0; t < terms.size(); ++t) {
+            if (tcls[t] != e || (int)t == lead) continue;
+            group[e].insert(group[e].end(), tprog[t].begin(), tprog[t].end());
+            group[e].push_back({terms[t].second ? Q_SUB : Q_ADD, 0, 0});
+        }
+    }
+    uint32_t used = 0;
+    for (uint32_t e = 0; e <= E; ++e) used += started[e] != 0;
+    if (used < 2) return false;
+    (void)whole_cls;
+    for (uint32_t e = 0; e <= E; ++e) {
+        if (!started[e]) continue;
+        Prog pg = fprog;
+        pg.insert(pg.end(), group[e].begin(), group[e].end());
+        if (factor >= 0) pg.push_back({Q_MUL, 0, 0});
+        out.push_back({e, std::move(pg)});
+    }
+    return true;
+}
+// the pieces the classes evaluate, in constraint order (a constraint's pieces by ascending class)
+static void class_pieces(const std::vector<Prog>& cons, const std::vector<uint32_t>& cls, bool split, uint32_t E, std::vector<ClassPiece>& out) {
+    const char* env = getenv("ZK_QUOTIENT_ADDSPLIT");
+    const bool on = split && !(env && atoi(env) == 0);
+    for (uint32_t i = 0; i < cons.size(); ++i) {
+        std::vector<std::pair<uint32_t, Prog>> parts;
+        if (on && cls[i] > 0 && additive_split(cons[i], E, cls[i], parts)) {
+            for (auto& pt : parts) out.push_back({i, pt.first, std::move(pt.second)});
+        } else out.push_back({i, cls[i], cons[i]});
+    }
+}
 // Intermediates shared between constraints (TEE_TMP in one gate, PUSH_TMP in a later one: the common-subexpression
 // elimination of halo2's GraphEvaluator as it survives the export) and degree classes: a class evaluates only ITS constraints,
 // so a class that reads an intermediate another class parked must compute it itself.  `TmpSplit` re-materialises: walking the
@@ -1196,7 +1306,9 @@ static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::ve
     // columns through an intermediate that another class's constraint defined)
     std::vector<Prog> progs(E + 1);
     TmpSplit tmps(E + 1);
-    for (uint32_t i = 0; i < cons.size(); ++i) tmps.append(cons[i], cls[i], progs[cls[i]]);
+    std::vector<ClassPiece> pieces;
+    class_pieces(cons, cls, quotient_split_enabled(sharded, share) && !tmp_slots_conflict(cons), E, pieces);
+    for (const ClassPiece& pc : pieces) tmps.append(pc.prog, pc.cls, progs[pc.cls]);
     for (uint32_t e = 0; e <= E; ++e) {
         uint32_t cosets = 0;
         for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - e)) - 1u)) == 0) cosets |= 1u << r;
@@ -1317,6 +1429,33 @@ int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const ui
     if (3 * total > out_cap_words) return ZK_ERR_INVALID_ARG;
     size_t w = 0;
     for (const Prog& pg : progs) for (const Instr& in : pg) { out_words[w++] = in.op; out_words[w++] = in.a; out_words[w++] = in.b; }
+    return ZK_OK;
+}
+
+// Host only (no device), for tests: the additive split of ONE constraint program over the degree classes 0 .. E exactly as
+// zk_proof_finish applies it (additive_split above).  Output: the pieces back to back (out_lens[j] instructions of class
+// out_cls[j] each), *num_pieces of them -- one piece, the program itself in the class of its degree, when it is not split.
+int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E, uint32_t* out_words, size_t out_cap_words, uint32_t* out_cls, uint32_t* out_lens,
+                           uint32_t cap_pieces, uint32_t* num_pieces) {
+    if (!words || !num_pieces || E > 8) return ZK_ERR_INVALID_ARG;
+    Prog g(num_instr);
+    for (uint32_t j = 0; j < num_instr; ++j) g[j] = {words[3 * j], words[3 * j + 1], words[3 * j + 2]};
+    std::vector<int> tmp_deg;
+    const int dg = program_degree(g, &tmp_deg);
+    if (dg < 0) return ZK_ERR_INVALID_ARG;
+    std::vector<std::pair<uint32_t, Prog>> parts;
+    const uint32_t whole = class_of_degree(dg, E);
+    if (!(whole > 0 && additive_split(g, E, whole, parts))) { parts.clear(); parts.push_back({whole, g}); }
+    *num_pieces = (uint32_t)parts.size();
+    if (!out_words) return ZK_OK;
+    if (!out_cls || !out_lens || parts.size() > cap_pieces) return ZK_ERR_INVALID_ARG;
+    size_t w = 0;
+    for (size_t j = 0; j < parts.size(); ++j) {
+        out_cls[j] = parts[j].first;
+        out_lens[j] = (uint32_t)parts[j].second.size();
+        if (w + 3 * parts[j].second.size() > out_cap_words) return ZK_ERR_INVALID_ARG;
+        for (const Instr& in : parts[j].second) { out_words[w++] = in.op; out_words[w++] = in.a; out_words[w++] = in.b; }
+    }
     return ZK_OK;
 }
 
@@ -1667,9 +1806,12 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     struct QClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; DevBuf h; };
     std::vector<QClass> qc(E + 1);
     TmpSplit tmps(E + 1);
-    for (uint32_t i = 0; i < K; ++i) {
-        QClass& c = qc[cls[i]];
-        tmps.append(cons[i], cls[i], c.prog);                                        // the constraint, its shared intermediates resolved for this class
+    std::vector<ClassPiece> cpieces;
+    class_pieces(cons, cls, split, E, cpieces);
+    for (const ClassPiece& pc : cpieces) {
+        const uint32_t i = pc.cons;
+        QClass& c = qc[pc.cls];
+        tmps.append(pc.prog, pc.cls, c.prog);                                        // the constraint (or its terms of this class), shared intermediates resolved for this class
         c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
         c.last = i;
         c.used = true;
