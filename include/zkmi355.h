@@ -184,7 +184,8 @@ int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const ui
 /* Host only, for tests: the additive split of ONE constraint program over the degree classes 0 .. E as the prover applies it: a
  * constraint that is a sum of terms of different degrees (q (a b - c): degree 3 and degree 2) hands each term to the class of its
  * own degree -- h is linear in the constraints -- so that columns occurring only in low-degree terms are transformed to fewer cosets
- * (halo2's evaluate_h, external crate, evaluates every constraint on the whole extended domain; same h).  Output: the pieces back to
+ * (halo2's evaluate_h, external crate, evaluates every constraint on the whole extended domain; same h: the prover carries what a
+ * moved term is on H along as a remainder polynomial, so that every class stays divisible by X^n - 1).  Output: the pieces back to
  * back, out_lens[j] instructions of class out_cls[j]; one piece (the program itself) when it is not split.  out_words may be NULL
  * (count only). */
 int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E, uint32_t* out_words, size_t out_cap_words, uint32_t* out_cls, uint32_t* out_lens,

@@ -37,7 +37,7 @@ def test_kit_round_trip_from_files_only(tmp_path):
     res = run("make", kit)
     assert res.returncode == 0, res.stdout + res.stderr
     res = run("check", kit)
-    assert res.returncode == 0 and res.stdout.count("accepted") == 14 and "REJECTED" not in res.stdout, res.stdout + res.stderr
+    assert res.returncode == 0 and res.stdout.count("accepted") == 24 and "REJECTED" not in res.stdout, res.stdout + res.stderr     # 8 cases x (SHPLONK, GWC, Poseidon + SHPLONK)
     assert run("prove", kit).returncode == 1              # no vk_repr.hex yet: the Rust `repr` step has not run
     # stand in for the Rust step: any field element will do as "upstream's vk.transcript_repr" for the mechanics
     for case in os.listdir(kit):
@@ -45,7 +45,7 @@ def test_kit_round_trip_from_files_only(tmp_path):
     res = run("prove", kit)
     assert res.returncode == 0, res.stdout + res.stderr
     res = run("check", kit)
-    assert res.returncode == 0 and res.stdout.count("accepted") == 28, res.stdout + res.stderr
+    assert res.returncode == 0 and res.stdout.count("accepted") == 40, res.stdout + res.stderr
     # a proof made under one repr must not verify under another (the repr is absorbed first)
     d = os.path.join(kit, "plain_k6")
     os.replace(os.path.join(d, "selfcheck_shplonk.bin"), os.path.join(d, "proof_shplonk.bin"))
@@ -64,3 +64,20 @@ def test_rust_program_and_python_tool_agree_on_the_files():
     for kind in kinds:
         assert f'"{kind}" =>' in rust, kind
     assert 'rev = "e5ddf67e5ae16be38d6368ed355c7c41906272ab"' in open(os.path.join(ROOT, "shim", "t1_standalone", "Cargo.toml")).read()
+
+
+def test_the_kit_covers_what_the_headline_proof_is_made_of():
+    """the kit's cases must hold what the reference-held proof cannot pin -- three phases with the SuperCircuit's
+    challenges, a multi-chunk permutation, a two-input lookup, GWC, and the Poseidon transcript next to Blake2b."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import t1_kit
+    cs = t1_kit.cases()
+    three = cs["three_phase_k6"][0]
+    assert three.num_phases() == 3 and [three.advice_phase.count(p) for p in range(3)] == [3, 1, 1] and len(three.challenge_phase) == 3
+    assert sorted(three.challenge_phase) == [0, 0, 1] and len(three.lookups) == 1 and len(three.lookups[0].inputs[0]) == 2
+    wide = cs["wide_k7"][0]
+    d = wide.degree()
+    assert (len(wide.perm_cols) + d - 3) // (d - 2) >= 3                     # three chunks of the grand product: Z chaining at omega^last
+    assert any(len(lk.inputs) == 2 for lk in cs["lookup_2x_k6"][0].lookups)    # two input tuples into one table
+    tool = open(os.path.join(ROOT, "tools", "t1_kit.py")).read()
+    assert '("shplonk", "gwc")' in tool and "selfcheck_poseidon_shplonk.bin" in tool

@@ -56,6 +56,55 @@ def two_phase_case(k=6):
     return circ, phase_witness, []
 
 
+def three_phase_case(k=6):
+    """The SuperCircuit's challenge structure [REF zkevm-circuits/src/util.rs:120-133] as the headline bench builds it
+    (bench_proof.build_shape, phases=True): `evm_word` and `keccak_input` usable after the first phase, `lookup_input` after the
+    second; w = q (a + evm_word b) is a second-phase column, t = q (w + lookup_input b) a third-phase one, next to a first-phase
+    multiplication gate, a lookup of (a, b) and copy constraints."""
+    import random
+    from zkevm_circuits_amd import plonk
+    circ = plonk.Circuit(k, num_fixed=4, num_advice=5, num_instance=0, blinding_factors=5)
+    q, q_lk, t_a, t_b = (circ.fixed_col(i) for i in range(4))
+    a, b_, c_, w_, t_ = (circ.advice_col(i) for i in range(5))
+    circ.advice_phase = [0, 0, 0, 1, 2]
+    evm_word, keccak_input = circ.challenge_usable_after(0), circ.challenge_usable_after(0)
+    lookup_input = circ.challenge_usable_after(1)
+    circ.add_gate(q * (a * b_ - c_))
+    circ.add_gate(q_lk * (a + evm_word * b_ - w_))
+    circ.add_gate(q_lk * (w_ + lookup_input * b_ + keccak_input * 0 - t_))
+    circ.add_lookup([q_lk * a, q_lk * b_], [t_a, t_b])
+    for col in range(3):
+        circ.enable_equality(plonk.ADVICE, col)
+    rng = random.Random(7)
+    n, u = circ.n, circ.u
+    av, bv, cv = [0] * n, [0] * n, [0] * n
+    for row in range(u):
+        if 0 < row < 16:
+            circ.fixed[2][row], circ.fixed[3][row] = row, (row * row + 3) % R
+    for row in range(1, u - 1):
+        if row % 2:
+            circ.fixed[0][row] = 1
+            av[row], bv[row] = rng.randrange(R), rng.randrange(R)
+            cv[row] = av[row] * bv[row] % R
+        else:
+            circ.fixed[1][row] = 1
+            i = rng.randrange(1, 16)
+            av[row], bv[row] = i, (i * i + 3) % R
+    av[3] = cv[1]                                           # the product of row 1 feeds row 3
+    cv[3] = av[3] * bv[3] % R
+    circ.copy((plonk.ADVICE, 2, 1), (plonk.ADVICE, 0, 3))
+
+    def phase_witness(phase, challenges):
+        if phase == 0:
+            return {0: av, 1: bv, 2: cv}
+        sel = circ.fixed[1]
+        if phase == 1:
+            return {3: [(av[i] + challenges[0] * bv[i]) % R if sel[i] else 0 for i in range(n)]}
+        wv = [(av[i] + challenges[0] * bv[i]) % R if sel[i] else 0 for i in range(n)]
+        return {4: [(wv[i] + challenges[2] * bv[i]) % R if sel[i] else 0 for i in range(n)]}
+    return circ, phase_witness, []
+
+
 def cases():
     from plonk_fixtures import build_circuit, build_multi_lookup_circuit, build_rotation_circuit
 
@@ -70,6 +119,7 @@ def cases():
         "lookup_2x_k6": static(build_multi_lookup_circuit(6, 1, 2, 1, 3)),        # two tuples merged into one argument
         "lookup_5x_k7": static(build_multi_lookup_circuit(7, 1, 5, 1, 9)),        # five tuples, degree 9: chunk_lookups splits and packs
         "two_phase_k6": two_phase_case(6),                                        # second-phase columns behind two challenges
+        "three_phase_k6": three_phase_case(6),                                    # the SuperCircuit's three phases and three challenges, with a two-column lookup and a copy constraint
     }
 
 
@@ -98,11 +148,11 @@ def read_instances(d):
     return [[int(x, 16) for x in ln.split()] for ln in open(os.path.join(d, "instances.txt")).read().splitlines()]
 
 
-def prove(circ, phase_witness, inst, vk_repr, multiopen, gpu):
+def prove(circ, phase_witness, inst, vk_repr, multiopen, gpu, transcript="blake2b"):
     from oracle import plonk_prover as pp
     inst_cols = [list(c) for c in inst]
     if not gpu:
-        return pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), [[0] * circ.n for _ in range(circ.A)], inst_cols, vk_repr, SEED, multiopen, phase_witness=phase_witness)
+        return pp.create_proof(circ, pp.Srs(circ.k, S_SECRET), [[0] * circ.n for _ in range(circ.A)], inst_cols, vk_repr, SEED, multiopen, transcript=transcript, phase_witness=phase_witness)
     import numpy as np
     import zkevm_circuits_amd as z
     from zkevm_circuits_amd import plonk
@@ -113,6 +163,8 @@ def prove(circ, phase_witness, inst, vk_repr, multiopen, gpu):
     pk.set_transcript_repr(cref.to_mont([vk_repr])[0])
     sess = ctx.proof_session(pk, [plonk.column_to_mont(c) for c in inst_cols], SEED, instance_slices=True)
     sess.set_multiopen(1 if multiopen == "shplonk" else 0)
+    if transcript != "blake2b":
+        sess.set_transcript_kind({"poseidon": 1, "evm": 2}[transcript])
     challenges = []
     for phase in range(circ.num_phases()):
         cols = phase_witness(phase, challenges)
@@ -134,6 +186,9 @@ def cmd_make(args):
         repr_ = pv.default_vk_repr(circ, vk)
         for mo in ("shplonk", "gwc"):
             open(os.path.join(d, f"selfcheck_{mo}.bin"), "wb").write(prove(circ, phase_witness, inst_vals, repr_, mo, args.gpu))
+        # the same proof under the Poseidon transcript of gen_snark_shplonk [REF prover/src/common/prover/utils.rs:31]: not read by the Rust
+        # program (upstream halo2 alone has no Poseidon transcript; snark-verifier's verify_snark_shplonk is its consumer), checked by `check`
+        open(os.path.join(d, "selfcheck_poseidon_shplonk.bin"), "wb").write(prove(circ, phase_witness, inst_vals, repr_, "shplonk", args.gpu, transcript="poseidon"))
         open(os.path.join(d, "selfcheck_vk_repr.hex"), "w").write(hexfr(repr_) + "\n")
         print(f"{name}: k = {circ.k}, degree {circ.degree()}, {circ.A} advice / {circ.F} fixed / {len(circ.perm_cols)} permutation columns, {len(circ.lookups)} lookup arguments")
     print(f"kit inputs written to {args.dir}; next: (cd shim/t1_standalone && cargo run --release -- repr {os.path.abspath(args.dir)})")
@@ -182,6 +237,11 @@ def cmd_check(args):
                     continue
                 good = pv.verify(circ, vk, repr_, inst, open(pf, "rb").read(), s_g2, multiopen=mo)
                 print(f"{name}: {tag}_{mo}.bin ({os.path.getsize(pf)} B) {'accepted' if good else 'REJECTED'} by the oracle verifier")
+                ok &= good
+            pf = os.path.join(d, f"{tag}_poseidon_shplonk.bin")
+            if os.path.exists(pf):
+                good = pv.verify(circ, vk, repr_, inst, open(pf, "rb").read(), s_g2, multiopen="shplonk", transcript="poseidon")
+                print(f"{name}: {tag}_poseidon_shplonk.bin ({os.path.getsize(pf)} B) {'accepted' if good else 'REJECTED'} by the oracle verifier (Poseidon transcript)")
                 ok &= good
     if not ok:
         raise SystemExit(1)

@@ -59,7 +59,7 @@ extern "C" int zk_poly_eval_pairs(zk_ctx*, const void* const*, const uint32_t*, 
 
 namespace {
 
-enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECIAL = 3, CT_PERM_Z = 4, CT_SIGMA = 5, CT_LK_M = 6, CT_LK_PHI = 7, CT_RANDOM = 8, CT_H = 9 };
+enum ColType : uint32_t { CT_FIXED = 0, CT_ADVICE = 1, CT_INSTANCE = 2, CT_SPECIAL = 3, CT_PERM_Z = 4, CT_SIGMA = 5, CT_LK_M = 6, CT_LK_PHI = 7, CT_RANDOM = 8, CT_H = 9, CT_SPLIT_R = 10 /* remainder polynomials of the additive split (zk_proof_finish) */ };
 enum Special : uint32_t { SP_X = 0, SP_L0 = 1, SP_LLAST = 2, SP_LACTIVE = 3 };
 enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_SUB = 4, Q_MUL = 5, Q_NEG = 6, Q_SQUARE = 7, Q_DOUBLE = 8, Q_FOLD = 9, Q_MUL_CONST = 10, Q_ADD_CONST = 11, Q_TEE_TMP = 12, Q_PUSH_TMP = 13 };
 // abstract constant operands: user constants are [0, num_consts); challenges live above
@@ -918,7 +918,7 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
         // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
         if (it > 0 && s_->world == 1) {
             s_->pending.push_back(it - 1);
-            if (s_->pending.size() >= 4) PK_TRY(s_->flush());        // four columns share a launch of each transform (zk_ntt_batch granularity at k = 20)
+            if (s_->pending.size() >= 8) PK_TRY(s_->flush());        // eight columns share a launch of each transform (ntt_run_many's granularity at k = 20)
         } else if (it > 0)
             for (size_t c_ = (it - 1) * s_->world; c_ < std::min(it * (size_t)s_->world, s_->dst.size()); ++c_)
                 PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
@@ -1108,8 +1108,10 @@ static int classify_constraints(zk_ctx* ctx, const zk_pk* pk, const std::vector<
 // all with the constraint's own power of y: the term q c is then evaluated on one coset instead of two, and a column that occurs
 // only in such low-degree terms (the outputs of multiplication gates, every linearly constrained cell) is transformed to fewer
 // cosets.  Recognised shapes (the program's top): SUM, F * SUM and SUM * F with SUM a tree of + / - / negations; the factor F (a
-// selector, as a rule) multiplies every group.  Exact field arithmetic: the sum of the groups is the constraint, h and every proof
-// byte stay what they were.  Programs that park or read shared intermediates are left whole.  ZK_QUOTIENT_ADDSPLIT=0 turns it off.
+// selector, as a rule) multiplies every group.  The groups sum to the constraint, but only the constraint vanishes on H: what a group
+// that moves to a lower class is on H travels with it as a remainder polynomial (zk_proof_finish, CT_SPLIT_R), so that every class
+// still divides by X^n - 1 exactly.  Exact field arithmetic: h and every proof byte stay what they were.  Programs that park or
+// read shared intermediates are left whole.  ZK_QUOTIENT_ADDSPLIT=0 turns it off.
 struct ClassPiece { uint32_t cons, cls; Prog prog; };
 static int TmpSplitArity(uint32_t op) {
     switch (op) {
@@ -1808,13 +1810,62 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     TmpSplit tmps(E + 1);
     std::vector<ClassPiece> cpieces;
     class_pieces(cons, cls, split, E, cpieces);
-    for (const ClassPiece& pc : cpieces) {
-        const uint32_t i = pc.cons;
-        QClass& c = qc[pc.cls];
-        tmps.append(pc.prog, pc.cls, c.prog);                                        // the constraint (or its terms of this class), shared intermediates resolved for this class
-        c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
-        c.last = i;
-        c.used = true;
+    // A constraint vanishes on H; a PART of it does not, and only multiples of X^n - 1 may be divided class by class.  So the
+    // parts that leave their constraint's class t for a lower class e take their values on H along: R_(t,e) = the polynomial of
+    // degree < n that agrees on H with the y-weighted sum of those parts (evaluated over the Lagrange forms, one pass, one
+    // inverse transform).  Class e evaluates (its parts - R), class t (its parts + R): both vanish on H again, the total is
+    // unchanged.  R is read like a column (CT_SPLIT_R) on the cosets of the two classes.
+    struct Remainder { uint32_t t, e; Prog prog; uint32_t last = 0; bool used = false; DevBuf coeff; };
+    std::vector<Remainder> rems;
+    {
+        std::vector<uint32_t> top(K, 0);
+        for (const ClassPiece& pc : cpieces) top[pc.cons] = std::max(top[pc.cons], pc.cls);
+        for (const ClassPiece& pc : cpieces) {
+            const uint32_t i = pc.cons;
+            QClass& c = qc[pc.cls];
+            tmps.append(pc.prog, pc.cls, c.prog);                                        // the constraint (or its terms of this class), shared intermediates resolved for this class
+            c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
+            c.last = i;
+            c.used = true;
+            if (pc.cls < top[i]) {
+                size_t at = 0;
+                while (at < rems.size() && !(rems[at].t == top[i] && rems[at].e == pc.cls)) ++at;
+                if (at == rems.size()) { rems.emplace_back(); rems.back().t = top[i]; rems.back().e = pc.cls; }
+                Remainder& rm = rems[at];
+                rm.prog.insert(rm.prog.end(), pc.prog.begin(), pc.prog.end());
+                rm.prog.push_back({Q_FOLD, rm.used ? C_YPOW0 + (i - rm.last) : C_Y, 0});
+                rm.last = i;
+                rm.used = true;
+            }
+        }
+    }
+    if (!rems.empty()) {
+        lag.perm_z = &pz_lag;
+        lag.lk_m = &lk_m;
+        lag.lk_phi = &lk_phi;
+        std::vector<Fr*> dsts;
+        for (size_t j = 0; j < rems.size(); ++j) {
+            Remainder& rm = rems[j];
+            if (!rm.coeff.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            PK_TRY(run_program(ctx, lag, rm.prog, rm.coeff.p));                         // the parts on H, folded with y
+            const F4 yp = host::fr_pow(lag.y, K - 1 - rm.last);                         // ... and weighted like the constraints they belong to
+            PK_TRY(zk_fr_scale(ctx, rm.coeff.p, &yp, n));
+            dsts.push_back(rm.coeff.fr());
+            // both classes take R in as one more term at the very end of the constraint list (weight y^0)
+            const uint32_t ref = colref(CT_SPLIT_R, (uint32_t)j);
+            QClass& lo_c = qc[rm.e];
+            lo_c.prog.push_back({Q_PUSH_COL, ref, 0});
+            lo_c.prog.push_back({Q_NEG, 0, 0});
+            lo_c.prog.push_back({Q_FOLD, C_YPOW0 + (K - 1 - lo_c.last), 0});
+            lo_c.last = K - 1;
+            QClass& hi_c = qc[rm.t];
+            hi_c.prog.push_back({Q_PUSH_COL, ref, 0});
+            hi_c.prog.push_back({Q_FOLD, C_YPOW0 + (K - 1 - hi_c.last), 0});
+            hi_c.last = K - 1;
+        }
+        const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
+        PK_TRY(ntt_run_many(ctx, dsts.data(), nullptr, dsts.size(), pk->k, omega_inv, &ninv, nullptr, nullptr, false));
+        trace.mark("  quotient: remainders of the split constraints");
     }
     std::vector<uint32_t> refs;          // every column any class reads
     for (QClass& c : qc)
@@ -1947,7 +1998,8 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 part_of[refs[i]] = dst;
                 if (refs[i] == colref(CT_SPECIAL, SP_X)) PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n));   // X on the coset: g * omega^i
                 else {
-                    const Fr* cf = coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
+                    const Fr* cf = (refs[i] >> 24) == CT_SPLIT_R ? ((refs[i] & 0xFFFFFFu) < rems.size() ? rems[refs[i] & 0xFFFFFFu].coeff.fr() : nullptr)
+                                                                 : coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
                     if (!cf) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: unresolved column reference 0x%08x", refs[i]);
                     bat_src.push_back(cf);
                     bat_dst.push_back(dst);
