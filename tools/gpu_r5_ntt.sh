@@ -1,10 +1,13 @@
 #!/bin/bash
-# round 5: parity tests of what changed, then the headline proof under measurement knobs (one line per variant)
+# round 5: the fixed-structure NTT passes (ZK_NTT_FIXED) -- parity tests, standalone batch timings, headline proof with the knob off / on
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); O=$ROOT/gpurun_out/${1:-r5ab}; mkdir -p $O
+ROOT=$(pwd); O=$ROOT/gpurun_out/${1:-r5ntt}; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_proof.py tests/test_gpu_ntt.py tests/test_gpu_msm.py tests/test_gpu_quotient.py tests/test_gpu_headline_config.py -q -m gpu -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
-run() {  # name, env...
+timeout 600 python -m pytest tests/test_gpu_ntt.py tests/test_gpu_field.py -q -m gpu -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+for f in 0 1; do
+  for kk in 20 18 21; do ZK_NTT_FIXED=$f timeout 120 python tools/ntt_batch_time.py $kk 32 10 2>&1 | grep "us per" | sed "s/^/fixed=$f /"; done
+done | tee $O/batch_time.txt
+run() {
   local name=$1; shift
   env "$@" timeout 600 python bench.py --no-cpu-baseline --no-proof --no-msm-ntt --no-verify --steps 3 --warmup 1 > $O/$name.json 2> $O/$name.err
   python - "$O/$name.json" "$name" <<'PY'
@@ -21,11 +24,7 @@ PY
 shift
 for v in "$@"; do
   case $v in
-    base) run base ZK_X=0 ;;
-    nosplit) run nosplit ZK_QUOTIENT_ADDSPLIT=0 ;;
-    noxcd) run noxcd ZK_NTT_XCD_COLS=0 ;;
-    batch8) run batch8 ZK_NTT_BATCH=8 ;;
-    batch16) run batch16 ZK_NTT_BATCH=16 ;;
-    trace) run trace ZK_PROVER_TRACE=1 ZK_QUOTIENT_TRACE=1 ;;
+    fixed0) run fixed0 ZK_NTT_FIXED=0 ;;
+    fixed1) run fixed1 ZK_NTT_FIXED=1 ;;
   esac
 done

@@ -9,6 +9,9 @@
 #include <vector>
 #include "../zkevm-circuits_amd/csrc/ff.hip.hpp"
 #include "../zkevm-circuits_amd/csrc/ff29.hip.hpp"
+namespace zk {
+#include "mul29_asm.hip.hpp"      // python tools/gen_mul29_asm.py > tools/mul29_asm.hip.hpp (an experiment of round 5: profiles/r05_ubench.md)
+}
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -42,6 +45,71 @@ __global__ void k_mad64_addc(uint64_t* out, uint32_t a, uint32_t b) {
     }
     uint64_t s = 0;
     for (int i = 0; i < CH; ++i) s += acc[i] + cnt[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// mixes: one v_mad_u64_u32 and one other instruction per pair, on independent registers -- does the other instruction cost issue time beside the multiply-add?
+#define KMIX(NAME, ASMSTR, TY)                                                          \
+    __global__ void NAME(uint64_t* out, uint32_t a, uint32_t b) {                      \
+        uint64_t acc[CH];                                                              \
+        TY z[CH];                                                                      \
+        uint32_t x = a + threadIdx.x, y = b + blockIdx.x;                              \
+        for (int i = 0; i < CH; ++i) { acc[i] = i + threadIdx.x; z[i] = (TY)(i * 77 + threadIdx.x + b); } \
+        for (int it = 0; it < ITERS; ++it) {                                           \
+            _Pragma("unroll") for (int r = 0; r < 2; ++r) {                            \
+                _Pragma("unroll") for (int i = 0; i < CH; ++i)                         \
+                    asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t" ASMSTR : "+v"(acc[i]), "+v"(z[i]) : "v"(x), "v"(y) : "vcc"); \
+            }                                                                          \
+        }                                                                              \
+        uint64_t s = 0;                                                                \
+        for (int i = 0; i < CH; ++i) s += acc[i] + (uint64_t)z[i];                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                \
+    }
+KMIX(k_mix_xor, "v_xor_b32 %1, %1, %2", uint32_t)
+KMIX(k_mix_2xor, "v_xor_b32 %1, %1, %2\n\tv_add_u32 %1, %1, %3", uint32_t)
+KMIX(k_mix_and, "v_and_b32 %1, 0x1fffffff, %1", uint32_t)
+KMIX(k_mix_mullo, "v_mul_lo_u32 %1, %1, %2", uint32_t)
+KMIX(k_mix_alignbit, "v_alignbit_b32 %1, %1, %2, 7", uint32_t)
+KMIX(k_mix_lshr64, "v_lshrrev_b64 %1, 1, %1", uint64_t)
+KMIX(k_mix_lshladd64, "v_lshl_add_u64 %1, %1, 0, %0", uint64_t)
+
+// v_mad_u64_u32 with one factor in a scalar register / both factors the same vector register / a zero addend: what bounds the instruction's rate?
+#define KMAD(NAME, ASMSTR, YC)                                                          \
+    __global__ void NAME(uint64_t* out, uint32_t a, uint32_t b) {                      \
+        uint64_t acc[CH];                                                              \
+        uint32_t x = a + threadIdx.x, y = b + blockIdx.x;                              \
+        for (int i = 0; i < CH; ++i) acc[i] = i + threadIdx.x;                         \
+        for (int it = 0; it < ITERS; ++it) {                                           \
+            _Pragma("unroll") for (int r = 0; r < 2; ++r) {                            \
+                _Pragma("unroll") for (int i = 0; i < CH; ++i)                         \
+                    asm volatile(ASMSTR : "+v"(acc[i]) : "v"(x), YC(y), "s"(b) : "vcc", "s20", "s21"); \
+            }                                                                          \
+        }                                                                              \
+        uint64_t s = 0;                                                                \
+        for (int i = 0; i < CH; ++i) s += acc[i];                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                \
+    }
+KMAD(k_mad64_vs, "v_mad_u64_u32 %0, vcc, %1, %3, %0", "v")
+KMAD(k_mad64_xx, "v_mad_u64_u32 %0, vcc, %1, %1, %0", "v")
+KMAD(k_mad64_vc, "v_mad_u64_u32 %0, vcc, %1, 17, %0", "v")
+KMAD(k_mad64_sgprcarry, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0", "v")
+
+// the same multiply-add as ONE dependent chain per thread (every instruction accumulates into the register pair the one before it wrote),
+// as two and as four chains: the column sums of the Montgomery product are chains of this kind
+template <int NCH>
+__global__ void k_mad64_chain(uint64_t* out, uint32_t a, uint32_t b) {
+    uint64_t acc[NCH];
+    uint32_t x = a + threadIdx.x, y = b + blockIdx.x;
+    for (int i = 0; i < NCH; ++i) acc[i] = i + threadIdx.x;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16 / NCH; ++r) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < NCH; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 #define K32(NAME, ASMSTR)                                                              \
@@ -139,12 +207,80 @@ __global__ void k_field29(uint64_t* out, const zk::Fp<typename P::P32>* in) {
         for (int i = 0; i < 4; ++i) {
             if (OP == 0) a[i] = zk::mul29(a[i], b);
             if (OP == 1) { a[i] = zk::add29(a[i], b); zk::normalize29(a[i]); a[i].l[8] &= 0xffff; }
-            if (OP == 2) { a[i] = zk::sub29(a[i], b); zk::normalize29(a[i]); a[i].l[8] &= 0xffff; }
+            if (OP == 2) { a[i] = zk::sub29k<4>(a[i], b); zk::normalize29(a[i]); a[i].l[8] &= 0xffff; }
             if (OP == 3) a[i] = zk::mul29(a[i], a[i]);
         }
     }
     uint64_t s = 0;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 9; ++j) s += a[i].l[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---- the asm products (csrc/mul29_asm.hip.hpp) against the C forms they replace: results on pseudo-random operands at the documented
+// limb bounds (mismatches counted on the device), and the rate of each
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <class P>
+__global__ void k_cmp29(uint32_t* bad, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    zk::F29<P> a, b, c, d, u;
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t top = i == 8;
+        a.l[i] = hash32(seed + tid * 41 + i) & (top ? 0x3ffffffu : 0x3fffffffu);          // limbs < 2^30, value < 2^258
+        b.l[i] = hash32(seed + tid * 43 + i + 100) & (top ? 0xffffffu : 0x1fffffffu);     // normalised, < 2^256
+        c.l[i] = hash32(seed + tid * 47 + i + 200) & (top ? 0xffffffu : 0x1fffffffu);
+        d.l[i] = hash32(seed + tid * 53 + i + 300) & (top ? 0xffffffu : 0x3fffffffu);     // limbs < 2^30
+        u.l[i] = hash32(seed + blockIdx.x * 59 + i + 400) & (top ? 0xffffffu : 0x1fffffffu);   // wave-uniform second factor
+        if ((tid & 15) == 3 && i < 8) { a.l[i] = 0x3fffffffu; b.l[i] = 0x1fffffffu; c.l[i] = 0x1fffffffu; d.l[i] = 0x3fffffffu; }     // everything at its bound
+    }
+    zk::F29<P> an = a;
+    for (int i = 0; i < 8; ++i) an.l[i] &= 0x1fffffffu;
+    uint32_t diff = 0;
+    auto cmp = [&](const zk::F29<P>& x, const zk::F29<P>& y, uint32_t bit) { for (int i = 0; i < 9; ++i) if (x.l[i] != y.l[i]) diff |= bit; };
+    cmp(zk::mul29_asm<P>(a, b), zk::mul29(a, b), 1u);
+    cmp(zk::mul29_ub_asm<P>(a, u), zk::mul29_ub(a, u), 2u);
+    cmp(zk::sqr29_asm<P>(an), zk::sqr29(an), 4u);
+    cmp(zk::mul2add29_asm<P>(an, b, c, d), zk::mul2add29(an, b, c, d), 8u);
+    if (diff) { atomicAdd(bad, 1u); atomicOr(bad + 1, diff); }
+}
+template <class P, int OP>
+__global__ void k_field29c(uint64_t* out, const zk::Fp<typename P::P32>* in) {
+    zk::F29<P> a[4], b = zk::unpack29<P>(zk::ldg(in + 4));
+    for (int i = 0; i < 4; ++i) { auto x = zk::ldg(in + i); x.l[0] ^= threadIdx.x; x.l[7] &= 0x0fffffffu; a[i] = zk::unpack29<P>(x); }
+    for (int it = 0; it < ITERS / 8; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (OP == 0) a[i] = zk::mul29_asm<P>(a[i], b);
+            if (OP == 3) a[i] = zk::sqr29(a[i]);
+            if (OP == 4) a[i] = zk::sqr29_asm<P>(a[i]);
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 9; ++j) s += a[i].l[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// The radix-4 register step of csrc/ntt.hip (dit_step<2>: four products, lazy butterfly sums, one carry propagation per element) on registers
+// only -- no LDS, no barriers, no twiddle loads: what the arithmetic of an NTT step costs by itself, in products per second.
+template <int WITH_SUMS>
+__global__ void k_ntt_step_alu(uint64_t* out, const zk::Fr* in) {
+    using F = zk::Fr29;
+    F e[4], w[3];
+    for (int i = 0; i < 4; ++i) { auto x = zk::ldg(in + i); x.l[0] ^= threadIdx.x; x.l[7] &= 0x0fffffffu; e[i] = zk::unpack29<zk::Fr29P>(x); }
+    for (int i = 0; i < 3; ++i) { auto x = zk::ldg(in + 1 + i); x.l[1] ^= threadIdx.x * 3; x.l[7] &= 0x0fffffffu; w[i] = zk::unpack29<zk::Fr29P>(x); }
+    auto bfly = [&](F& u, F& x, const F& tw) {
+        const F v = zk::mul29(x, tw);
+        if (WITH_SUMS) { const F a0 = zk::add29(u, v), a1 = zk::sub29k<2>(u, v); u = a0; x = a1; }
+        else { x = v; }
+    };
+    for (int it = 0; it < ITERS / 8; ++it) {
+        bfly(e[0], e[1], w[0]);
+        bfly(e[2], e[3], w[0]);
+        bfly(e[0], e[2], w[1]);
+        bfly(e[1], e[3], w[2]);
+        if (WITH_SUMS) { zk::normalize29(e[0]); zk::normalize29(e[1]); zk::normalize29(e[2]); zk::normalize29(e[3]); for (int i = 0; i < 4; ++i) e[i].l[8] &= 0xffffff; }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 9; ++j) s += e[i].l[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 // correctness dump: o32[i] = a*b (R=2^256 Montgomery), o29[i] = pack(mul29(unpack a, unpack b))
@@ -154,7 +290,7 @@ __global__ void k_check29(const zk::Fq* a, const zk::Fq* b, zk::Fq* o32, zk::Fq*
     zk::Fq x = zk::ldg(a + i), y = zk::ldg(b + i);
     zk::stg(o32 + i, x * y);
     zk::Fq29 r = zk::mul29(zk::unpack29<zk::Fq29P>(x), zk::unpack29<zk::Fq29P>(y));
-    zk::Fq29 d = zk::sub29(zk::add29(r, r), r);     // exercises add/sub: r + r - r + 4p
+    zk::Fq29 d = zk::sub29k<4>(zk::add29(r, r), r);     // exercises add/sub: r + r - r + 4p
     zk::normalize29(d);
     zk::stg(o29 + i, zk::pack29(d));
 }
@@ -195,6 +331,14 @@ int main() {
     RUN(k_fma32); RUN(k_add); RUN(k_xor); RUN(k_addco); RUN(k_addc); RUN(k_alignbit);
     RUN(k_mul_lo); RUN(k_mul_hi); RUN(k_mad24); RUN(k_mulhi24);
     RUN(k_mad64); RUN(k_lshladd64); RUN(k_lshr64); RUN(k_fma64);
+    RUN(k_mad64_vs); RUN(k_mad64_xx); RUN(k_mad64_vc); RUN(k_mad64_sgprcarry);
+    RUN(k_mad64_chain<1>); RUN(k_mad64_chain<2>); RUN(k_mad64_chain<4>);
+    RUN(k_mix_xor); RUN(k_mix_2xor); RUN(k_mix_and); RUN(k_mix_mullo); RUN(k_mix_alignbit); RUN(k_mix_lshr64); RUN(k_mix_lshladd64);
+    for (int wps = 1; wps <= 8; wps *= 2) {      // occupancy: waves per SIMD
+        const int bl = prop.multiProcessorCount * wps;
+        double secs = time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fr29P, 0>), dim3(bl), dim3(threads), 0, 0, out, (const zk::Fr*)out); });
+        printf("Fr29 mul at %d waves/SIMD: %.1f G products/s\n", wps, (double)bl * threads * (double)(ITERS / 8) * 4 / secs * 1e-9);
+    }
     report("k_mad64_addc(pair)", time_kernel([&] { hipLaunchKernelGGL(k_mad64_addc, dim3(blocks), dim3(threads), 0, 0, out, 12345u, 678u); }), n16);
 
     // field ops
@@ -212,6 +356,26 @@ int main() {
     report("Fq29 add+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 1>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
     report("Fq29 sub+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 2>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
     report("Fr29 mul", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
+    report("Fr29 mul (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
+    report("Fq29 mul (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sqr (library)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 3>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sqr (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 4>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    {
+        uint32_t* dbad; CK(hipMalloc(&dbad, 8)); CK(hipMemset(dbad, 0, 8));
+        for (uint32_t seed = 1; seed <= 8; ++seed) {
+            hipLaunchKernelGGL((k_cmp29<zk::Fr29P>), dim3(1024), dim3(256), 0, 0, dbad, seed * 7919u);
+            hipLaunchKernelGGL((k_cmp29<zk::Fq29P>), dim3(1024), dim3(256), 0, 0, dbad, seed * 104729u);
+        }
+        uint32_t hbad[2]; CK(hipMemcpy(hbad, dbad, 8, hipMemcpyDeviceToHost));
+        printf("asm products against the library's: %u mismatching lanes of %u (mask 0x%x: 1 mul29, 2 mul29_ub, 4 sqr29, 8 mul2add29)\n", hbad[0], 16u * 1024u * 256u, hbad[1]);
+    }
+    for (int wps = 2; wps <= 8; wps *= 2) {
+        const int bl = prop.multiProcessorCount * wps;
+        const double np = (double)bl * threads * (double)(ITERS / 8) * 4;
+        double s1 = time_kernel([&] { hipLaunchKernelGGL((k_ntt_step_alu<1>), dim3(bl), dim3(threads), 0, 0, out, (const zk::Fr*)din); });
+        double s0 = time_kernel([&] { hipLaunchKernelGGL((k_ntt_step_alu<0>), dim3(bl), dim3(threads), 0, 0, out, (const zk::Fr*)din); });
+        printf("NTT radix-4 step on registers at %d waves/SIMD: %.1f G products/s with the butterfly sums and carry propagation, %.1f G/s products alone\n", wps, np / s1 * 1e-9, np / s0 * 1e-9);
+    }
     {   // correctness dump for offline verification (tools/check29.py)
         const int n = 4096;
         std::vector<zk::Fq> ha(n), hb(n), h32(n), h29(n);

@@ -344,6 +344,128 @@ k_ntt_last(NttIo io, const Tw29* __restrict__ tw, int log_np, int log_t,
     }
 }
 
+
+// ------------------------------------------------------------------ the two passes with their step structure fixed at compile time
+// k_ntt_pass / k_ntt_last above take the digit size at run time: which step is the first, which the last, whether a step is radix 2
+// or 4, whether element k of it exists -- all of it is decided by branches around every element, and the compiler neither moves a load
+// across a branch nor joins the loads of different elements: the first step waited for global memory once per element and table
+// (eight dependent round trips to HBM per thread on a coset transform), the last step once per inter-pass twiddle.  The same passes
+// with LOG_NP as a template parameter are straight-line code per step: all operands of a step (the 2^R elements, their coset shifts,
+// the twiddles of the butterflies, the inter-pass twiddles of the outputs) are requested before the first of them is used.
+// Same arithmetic in the same order: results are bit-identical to the generic kernels (which remain for every other shape; ZK_NTT_FIXED=0
+// selects them everywhere).
+template <int LOG_NP, int S, bool HAS_PRE>
+__device__ __forceinline__ void ntt_pass_steps(const Lds29& L, const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw,
+                                               const Fr* __restrict__ pre, const Fr* __restrict__ out_tw, const int log_t, const uint64_t m, const uint64_t base) {
+    constexpr int R = ((LOG_NP - S) & 1) ? 1 : 2, NE = 1 << R, hgt = 1 << S;
+    constexpr bool FIRST = S == 0, LAST = S + R == LOG_NP;
+    const int T = 1 << log_t, items = (1 << (LOG_NP + log_t)) >> R;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int c = it & (T - 1), b = it >> log_t;      // c fastest: T-element contiguous runs in global memory
+        const int j = b & (hgt - 1);
+        const int lo_d = ((b >> S) << (S + R)) | j;
+        Fr otw[NE];
+        if (LAST) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) otw[k] = ldg(out_tw + base + (uint64_t)(lo_d + k * hgt) * m + c);
+        }
+        Fr29 e[4];
+        if (FIRST) {
+            Fr raw[NE], praw[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const uint64_t gi = base + (uint64_t)bitrev(lo_d + k * hgt, LOG_NP) * m + c;
+                raw[k] = ldg(src + gi);
+                if (HAS_PRE) praw[k] = ldg(pre + gi);
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                e[k] = unpack29<Fr29P>(raw[k]);
+                if (HAS_PRE) e[k] = mul29(e[k], unpack29<Fr29P>(praw[k]));     // coset shift a[i] * g^i (table in R' form)
+            }
+            dit_first_step<R>(e, tw, LOG_NP);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) e[k] = L.load(((lo_d + k * hgt) << log_t) | c);
+            dit_step<R>(e, tw, LOG_NP, S, j);
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int dl = lo_d + k * hgt;
+            if (LAST) stg(dst + base + (uint64_t)dl * m + c, pack29_lt2p(mul29(e[k], unpack29<Fr29P>(otw[k]))));
+            else L.store((dl << log_t) | c, e[k]);
+        }
+    }
+    if constexpr (!LAST) {
+        __syncthreads();
+        ntt_pass_steps<LOG_NP, S + R, HAS_PRE>(L, src, dst, tw, pre, out_tw, log_t, m, base);
+    }
+}
+template <int LOG_NP, bool HAS_PRE>
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass_f(NttIo io, const Tw29* __restrict__ tw, int log_t, int log_m, const Fr* __restrict__ pre, const Fr* __restrict__ out_tw, uint32_t ncols, int xcd_cols) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t tile_id, col;          // (tile, column) numbering: k_ntt_pass
+    if (xcd_cols) { const uint32_t slot = blockIdx.x >> 3; col = slot % ncols; tile_id = (slot / ncols) * 8u + (blockIdx.x & 7u); }
+    else { col = blockIdx.x % ncols; tile_id = blockIdx.x / ncols; }
+    Lds29 L{smem, 1 << (LOG_NP + log_t)};
+    const uint64_t m = 1ull << log_m;
+    const uint32_t tiles_per_hi = (uint32_t)(m >> log_t);
+    const uint32_t hi_idx = tile_id / tiles_per_hi, blk = tile_id % tiles_per_hi;
+    const uint64_t base = ((uint64_t)hi_idx << (LOG_NP + log_m)) + ((uint64_t)blk << log_t);
+    ntt_pass_steps<LOG_NP, 0, HAS_PRE>(L, io.src[col], io.dst[col], tw, pre, out_tw, log_t, m, base);
+}
+
+template <int LOG_NP, int S>
+__device__ __forceinline__ void ntt_last_steps(const Lds29& L, const Fr* __restrict__ src, Fr* __restrict__ dst, const Tw29* __restrict__ tw,
+                                               const int log_t, const int row, const uint32_t blk, const uint32_t mid, const int log_mid, const int log_n1) {
+    constexpr int R = ((LOG_NP - S) & 1) ? 1 : 2, NE = 1 << R, hgt = 1 << S;
+    constexpr bool FIRST = S == 0, LAST = S + R == LOG_NP;
+    const int T = 1 << log_t, items = (1 << (LOG_NP + log_t)) >> R;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        int c, b;
+        if (LAST) { c = it & (T - 1); b = it >> log_t; }                              // c fastest: coalesced output
+        else { b = it & ((1 << (LOG_NP - R)) - 1); c = it >> (LOG_NP - R); }          // d fastest: conflict-free LDS
+        const int j = b & (hgt - 1);
+        const int lo_d = ((b >> S) << (S + R)) | j;
+        const uint64_t i1 = ((uint64_t)blk << log_t) + c;
+        Fr29 e[4];
+        if (FIRST) {
+            Fr raw[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) raw[k] = ldg(src + ((((i1 << log_mid) + mid) << LOG_NP) + bitrev(lo_d + k * hgt, LOG_NP)));
+#pragma unroll
+            for (int k = 0; k < NE; ++k) e[k] = unpack29<Fr29P>(raw[k]);
+            dit_first_step<R>(e, tw, LOG_NP);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) e[k] = L.load(c * row + lo_d + k * hgt);
+            dit_step<R>(e, tw, LOG_NP, S, j);
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int dl = lo_d + k * hgt;
+            if (LAST) stg(dst + (i1 + (((uint64_t)mid + ((uint64_t)dl << log_mid)) << log_n1)), reduce_lazy29(e[k]));      // the output scale rode on the last inter-pass twiddle
+            else L.store(c * row + dl, e[k]);
+        }
+    }
+    if constexpr (!LAST) {
+        __syncthreads();
+        ntt_last_steps<LOG_NP, S + R>(L, src, dst, tw, log_t, row, blk, mid, log_mid, log_n1);
+    }
+}
+template <int LOG_NP>
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_last_f(NttIo io, const Tw29* __restrict__ tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int row = (1 << LOG_NP) + ntt_row_pad(LOG_NP);
+    Lds29 L{smem, (1 << log_t) * row};
+    uint32_t bx = blockIdx.x;
+    if (xcd_remap) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const uint32_t mid = bx & ((1u << log_mid) - 1), blk = bx >> log_mid;
+    ntt_last_steps<LOG_NP, 0>(L, io.src[blockIdx.y], io.dst[blockIdx.y], tw, log_t, row, blk, mid, log_mid, log_n1);
+}
+
 __global__ void k_scale(Fr* a, Fr s, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) stg(a + i, ldg(a + i) * s);
@@ -445,6 +567,35 @@ static int set_lds_attr(zk_ctx* ctx) {
     ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_last, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT));
     ctx->ntt_attr_set = true;
     return ZK_OK;
+}
+
+
+// launchers of the fixed-structure passes: false = this digit size has no instance (the caller takes the generic kernel)
+template <int LOG_NP, bool HAS_PRE>
+static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols) {
+    static bool attr_set = false;          // setting it twice is harmless
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); attr_set = true; }
+    hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols);
+}
+static bool ntt_fixed_on() { static const bool on = !(getenv("ZK_NTT_FIXED") && atoi(getenv("ZK_NTT_FIXED")) == 0); return on; }      // measurement knob
+static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols) {
+    if (!ntt_fixed_on() || !out_tw) return false;
+#define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols); \
+                                else launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols); return true;
+    switch (log_np) { ZK_PASS_CASE(8) ZK_PASS_CASE(9) ZK_PASS_CASE(10) ZK_PASS_CASE(11) default: return false; }
+#undef ZK_PASS_CASE
+}
+template <int LOG_NP>
+static void launch_last_f(zk_ctx* ctx, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ntt_last_f<LOG_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT); attr_set = true; }
+    hipLaunchKernelGGL((k_ntt_last_f<LOG_NP>), grid, dim3(threads), lds, ctx->stream, io, tw, log_t, log_n1, log_mid, xcd_remap);
+}
+static bool launch_last_fixed(zk_ctx* ctx, int log_np, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
+    if (!ntt_fixed_on()) return false;
+#define ZK_LAST_CASE(N) case N: launch_last_f<N>(ctx, grid, threads, lds, io, tw, log_t, log_n1, log_mid, xcd_remap); return true;
+    switch (log_np) { ZK_LAST_CASE(7) ZK_LAST_CASE(8) ZK_LAST_CASE(9) ZK_LAST_CASE(10) ZK_LAST_CASE(11) default: return false; }
+#undef ZK_LAST_CASE
 }
 
 static int pick_threads(int tile) { return tile >= 4096 ? 1024 : (tile >= 1024 ? 512 : (tile >= 256 ? 128 : 64)); }
@@ -586,9 +737,12 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             ZkProfScope pscope(ctx, "ntt_pass");
             pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;      // a transform's algorithmic 64 B per element (read once, write once), spread over its P launches
             static const bool xcd_off = getenv("ZK_NTT_XCD_COLS") && atoi(getenv("ZK_NTT_XCD_COLS")) == 0;       // measurement knob
-            hipLaunchKernelGGL(k_ntt_pass, dim3(blocks * (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
-                               dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw,
-                               (uint32_t)nb, (nb > 1 && blocks % 8 == 0 && !xcd_off) ? 1 : 0);
+            const int xcd_cols = (nb > 1 && blocks % 8 == 0 && !xcd_off) ? 1 : 0;
+            if (!launch_pass_fixed(ctx, ps.log_np, blocks * (unsigned)nb, (unsigned)pick_threads(tile), (size_t)tile * NTT_LDS_BYTES_PER_ELT, io, ps.tw, log_t, ps.log_m,
+                                   p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw, (uint32_t)nb, xcd_cols))
+                hipLaunchKernelGGL(k_ntt_pass, dim3(blocks * (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
+                                   dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw,
+                                   (uint32_t)nb, xcd_cols);
             ZK_CHECK_LAUNCH(ctx);
             for (size_t j = 0; j < nb; ++j) cur_io.src[j] = io.dst[j];
         }
@@ -609,9 +763,11 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             for (size_t j = 0; j < nb; ++j) { io.src[j] = cur_io.src[j]; io.dst[j] = d_datas[first + j]; }
             ZkProfScope pscope(ctx, "ntt_last");
             pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;
-            hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
-                               ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0,
-                               (log_mid == 0 && blocks % 8 == 0 && blocks >= 16 && ntt_xcd_remap()) ? 1 : 0);
+            const int xcd_last = (log_mid == 0 && blocks % 8 == 0 && blocks >= 16 && ntt_xcd_remap()) ? 1 : 0;
+            const size_t lds_last = (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT;
+            if (!(P > 1 && dom->fin_folded && launch_last_fixed(ctx, ps.log_np, dim3(blocks, (unsigned)nb), (unsigned)pick_threads(tile), lds_last, io, ps.tw, log_t, log_n1, log_mid, xcd_last)))
+                hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), lds_last, ctx->stream, io, ps.tw,
+                                   ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0, xcd_last);
             ZK_CHECK_LAUNCH(ctx);
         }
     }
