@@ -190,6 +190,15 @@ int zk_host_split_programs(const uint32_t* words, const uint32_t* lens, const ui
  * (count only). */
 int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E, uint32_t* out_words, size_t out_cap_words, uint32_t* out_cls, uint32_t* out_lens,
                            uint32_t cap_pieces, uint32_t* num_pieces);
+/* Host only, for tests: the program of ONE degree class as the prover assembles it from the class's terms (term t belongs to
+ * constraint cons[t] < K of the K constraints halo2's evaluate_h folds with y, external crate): the weighted sum
+ * sum_t y^(K-1-cons[t]) term_t with the terms that share a single-column factor -- a selector, l_active -- collected under ONE product by
+ * that factor, instead of folding the terms one by one (a product per term for the folding, another for its selector).  Same
+ * polynomial, same h.  A weight is the constant 0xFFFC0000 + (K-1-cons[t]) (= that power of y).  Terms that park or read
+ * intermediates keep their definitions ahead of their readers.  ZK_ERR_UNSUPPORTED when the prover would keep the folded form (a
+ * stack deeper than the evaluator's).  out_words may be NULL (count only). */
+int zk_host_group_terms(const uint32_t* words, const uint32_t* lens, const uint32_t* cons, uint32_t count, uint32_t K, uint32_t* out_words, size_t out_cap_words,
+                        uint32_t* out_instr);
 
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);

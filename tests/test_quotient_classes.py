@@ -251,3 +251,157 @@ def test_the_pieces_of_a_constraint_sum_to_it(zk, seed):
             cols = {(c_, r_): rng.randrange(R) for c_ in range(ncols) for r_ in (-1, 0, 1)}
             consts = [rng.randrange(R) for _ in range(nconsts)]
             assert sum(run(pg, cols, consts) for _, pg in pieces) % R == run(prog, cols, consts)
+
+
+# ------------------------------------------------------------------------------------------------- one weighted sum per class
+YPOW0 = 0xFFFC0000
+
+
+def group_terms(zk, terms, cons, K):
+    lib = zk.lib()
+    words = np.array([w & 0xFFFFFFFF for p in terms for ins in p for w in ins], dtype=np.uint32)
+    lens = np.array([len(p) for p in terms], dtype=np.uint32)
+    cons_a = np.array(cons, dtype=np.uint32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    cnt = ctypes.c_uint32()
+    rc = lib.zk_host_group_terms(ptr(words), ptr(lens), ptr(cons_a), ctypes.c_uint32(len(terms)), ctypes.c_uint32(K), None, ctypes.c_size_t(0), ctypes.byref(cnt))
+    if rc != 0:
+        return None
+    out = np.zeros(3 * cnt.value, dtype=np.uint32)
+    assert lib.zk_host_group_terms(ptr(words), ptr(lens), ptr(cons_a), ctypes.c_uint32(len(terms)), ctypes.c_uint32(K), ptr(out), ctypes.c_size_t(out.size), ctypes.byref(cnt)) == 0
+    return [tuple(int(x) for x in out[3 * j:3 * j + 3]) for j in range(cnt.value)]
+
+
+def evaluate_weighted(prog, cols, consts, y, tmp):
+    """the evaluator of the grouped form: MUL_CONST by a power of y (0xFFFC0000 + g) or by a circuit constant, one closing FOLD"""
+    st = []
+    for op, a, b in prog:
+        if op == PUSH_COL: st.append(cols[a])
+        elif op == PUSH_CONST: st.append(consts[a])
+        elif op == PUSH_TMP: st.append(tmp[a])
+        elif op == TEE: tmp[a] = st[-1]
+        elif op == ADD: y_, x_ = st.pop(), st.pop(); st.append((x_ + y_) % R)
+        elif op == SUB: y_, x_ = st.pop(), st.pop(); st.append((x_ - y_) % R)
+        elif op == MUL: y_, x_ = st.pop(), st.pop(); st.append(x_ * y_ % R)
+        elif op == NEG: st.append(-st.pop() % R)
+        elif op == SQUARE: x_ = st.pop(); st.append(x_ * x_ % R)
+        elif op == DOUBLE: st.append(2 * st.pop() % R)
+        elif op == MUL_CONST: st.append(st.pop() * (pow(y, a - YPOW0, R) if a >= YPOW0 else consts[a]) % R)
+        elif op == ADD_CONST: st.append((st.pop() + consts[a]) % R)
+        elif op == FOLD: assert len(st) == 1; return st.pop()
+        else: raise AssertionError(op)
+    raise AssertionError("no closing FOLD")
+
+
+def weighted_reference(terms, cons, K, cols, consts, y):
+    tmp, total = {}, 0
+    for p, i in zip(terms, cons):
+        st = evaluate(p_plain(p, consts), cols, consts, tmp, {})
+        assert len(st) == 1
+        total = (total + pow(y, K - 1 - i, R) * st[0]) % R
+    return total
+
+
+def p_plain(p, consts):
+    """MUL_CONST / ADD_CONST rewritten as PUSH_CONST + MUL / ADD for the plain evaluator"""
+    out = []
+    for op, a, b in p:
+        if op == MUL_CONST: out += [(PUSH_CONST, a, 0), (MUL, 0, 0)]
+        elif op == ADD_CONST: out += [(PUSH_CONST, a, 0), (ADD, 0, 0)]
+        else: out.append((op, a, b))
+    return out
+
+
+def test_terms_under_a_shared_selector_are_collected(zk):
+    """the terms of the SuperCircuit stand-in's gate classes: q_s (a b) and q_s c under a handful of selectors, a term nobody shares a
+    factor with, and the remainder columns at weight one"""
+    rng = random.Random(5)
+    S, G = 3, 11
+    col = lambda i: (PUSH_COL, i, 0)
+    terms, cons = [], []
+    for g in range(G):
+        q, a, b_ = col(g % S), col(S + 2 * g), col(S + 2 * g + 1)
+        terms.append([q, a, b_, (MUL, 0, 0), (MUL, 0, 0)] if g % 2 else [a, b_, (MUL, 0, 0), q, (MUL, 0, 0)])     # factor first / factor last
+        cons.append(2 * g)
+    lone = [col(S), (SQUARE, 0, 0), col(S + 1), (ADD, 0, 0), (MUL_CONST, 1, 0)]
+    terms.append(lone); cons.append(2 * G)
+    terms.append([col(S + 3), (NEG, 0, 0)]); cons.append(2 * G + 4)           # a remainder: weight y^0 when it is the last constraint
+    K = 2 * G + 5
+    prog = group_terms(zk, terms, cons, K)
+    assert prog is not None
+    # one product per selector, none for the folding: G products a*b, G + 1 weights (the lone term's too), S selector products
+    assert sum(1 for ins in prog if ins[0] == MUL) == G + S
+    assert sum(1 for ins in prog if ins[0] == MUL_CONST and ins[1] >= YPOW0) == G + 1
+    assert sum(1 for ins in prog if ins[0] == FOLD) == 1 and prog[-1][0] == FOLD
+    ncols = S + 2 * G + 2
+    for _ in range(4):
+        cols = [rng.randrange(R) for _ in range(ncols)]
+        consts = [rng.randrange(R) for _ in range(3)]
+        y = rng.randrange(R)
+        assert evaluate_weighted(prog, cols, consts, y, {}) == weighted_reference(terms, cons, K, cols, consts, y)
+
+
+def test_parked_intermediates_stay_ahead_of_their_readers(zk):
+    """the lookup identities: l_active * (phi_f ((phi' - phi) tau + m) - tau) with tau parked by the first lookup into a table and read
+    back by the others; a second table parks its own; a term that re-parks a slot it alone reads (the multi-tuple form) is left where it
+    stands"""
+    rng = random.Random(9)
+    col = lambda i, rot=0: (PUSH_COL, i, rot)
+    lact, ta, tb = col(0), col(1), col(2)
+    terms, cons = [], []
+    nl = 7
+    for l in range(nl):
+        table = l % 2                               # two tables, slots 4 and 5
+        slot = 4 + table
+        first = l < 2
+        tau = [ta if table == 0 else tb, (ADD_CONST, 0, 0), (TEE, slot, 0)] if first else [(PUSH_TMP, slot, 0)]
+        phi, m, f = 3 + 3 * l, 4 + 3 * l, 5 + 3 * l
+        t = [lact, col(phi, 1), col(phi), (SUB, 0, 0)] + tau + [(MUL, 0, 0), col(m), (ADD, 0, 0), col(f), (ADD_CONST, 0, 0), (MUL, 0, 0), (PUSH_TMP, slot, 0), (SUB, 0, 0), (MUL, 0, 0)]
+        terms.append(t); cons.append(3 * l + 2)
+    # a multi-tuple style term in between: parks slot 0 twice over the list, reads it itself
+    for pos in (2, 5):
+        t = [lact, col(3 + pos), (ADD_CONST, 1, 0), (TEE, 0, 0), (PUSH_TMP, 0, 0), (MUL, 0, 0), (MUL, 0, 0)]
+        terms.insert(pos, t); cons.insert(pos, cons[pos - 1] + 1)
+    K = max(cons) + 2
+    prog = group_terms(zk, terms, cons, K)
+    assert prog is not None
+    # every read of a slot comes after a definition of it
+    seen = set()
+    for op, a, b in prog:
+        if op == TEE: seen.add(a)
+        if op == PUSH_TMP: assert a in seen
+    ncols = 3 + 3 * nl + 3
+    for _ in range(4):
+        cols = [rng.randrange(R) for _ in range(ncols)]
+        consts = [rng.randrange(R) for _ in range(2)]
+        y = rng.randrange(R)
+        assert evaluate_weighted(prog, cols, consts, y, {}) == weighted_reference(terms, cons, K, cols, consts, y)
+    # the seven single-tuple lookups share ONE product by l_active
+    assert sum(1 for i, ins in enumerate(prog) if ins[0] == MUL and prog[i - 1] == lact) <= 3
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_terms_keep_their_weighted_sum(zk, seed):
+    rng = random.Random(100 + seed)
+    ncols, nconsts, count = 5, 3, rng.randrange(3, 16)
+    progs = random_constraints(rng, count, ncols, nconsts, reuse_slots=(seed % 3 == 0))
+    # give some of them a shared single-column factor, in front or behind
+    terms = []
+    for p in progs:
+        r = rng.random()
+        f = (PUSH_COL, rng.randrange(2), 0)
+        terms.append([f] + p + [(MUL, 0, 0)] if r < 0.35 else (p + [f, (MUL, 0, 0)] if r < 0.7 else p))
+    cons = sorted(rng.sample(range(3 * count), count))
+    K = 3 * count + 1
+    prog = group_terms(zk, terms, cons, K)
+    if prog is None:
+        pytest.skip("kept folded (stack depth)")
+    for _ in range(3):
+        cols = [rng.randrange(R) for _ in range(ncols)]
+        consts = [rng.randrange(R) for _ in range(nconsts)]
+        y = rng.randrange(R)
+        try:
+            want = weighted_reference(terms, cons, K, cols, consts, y)
+        except KeyError:
+            pytest.skip("a term reads a slot nobody parked before it (malformed input)")
+        assert evaluate_weighted(prog, cols, consts, y, {}) == want

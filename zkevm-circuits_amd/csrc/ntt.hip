@@ -403,11 +403,17 @@ __device__ __forceinline__ void ntt_pass_steps(const Lds29& L, const Fr* __restr
 }
 template <int LOG_NP, bool HAS_PRE>
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass_f(NttIo io, const Tw29* __restrict__ tw, int log_t, int log_m, const Fr* __restrict__ pre, const Fr* __restrict__ out_tw, uint32_t ncols, int xcd_cols) {
+k_ntt_pass_f(NttIo io, const Tw29* __restrict__ tw, int log_t, int log_m, const Fr* __restrict__ pre, const Fr* __restrict__ out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t tile_id, col;          // (tile, column) numbering: k_ntt_pass
-    if (xcd_cols) { const uint32_t slot = blockIdx.x >> 3; col = slot % ncols; tile_id = (slot / ncols) * 8u + (blockIdx.x & 7u); }
-    else { col = blockIdx.x % ncols; tile_id = blockIdx.x / ncols; }
+    // (tile, column) numbering as in k_ntt_pass, with one more level: a tile of T < 4 columns reads and writes runs shorter than a
+    // 128-byte line, and the 2^log_grp = 4 / T tiles that share those lines are consecutive workgroups of ONE XCD as well (same L2:
+    // the line is fetched once and its parts are written back together), ahead of the columns of the launch
+    uint32_t tile_id, col;
+    if (xcd_cols) {
+        const uint32_t slot = blockIdx.x >> 3, sub = slot & ((1u << log_grp) - 1u), s2 = slot >> log_grp;
+        col = s2 % ncols;
+        tile_id = ((((s2 / ncols) << 3) + (blockIdx.x & 7u)) << log_grp) + sub;
+    } else { col = blockIdx.x % ncols; tile_id = blockIdx.x / ncols; }
     Lds29 L{smem, 1 << (LOG_NP + log_t)};
     const uint64_t m = 1ull << log_m;
     const uint32_t tiles_per_hi = (uint32_t)(m >> log_t);
@@ -572,16 +578,16 @@ static int set_lds_attr(zk_ctx* ctx) {
 
 // launchers of the fixed-structure passes: false = this digit size has no instance (the caller takes the generic kernel)
 template <int LOG_NP, bool HAS_PRE>
-static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols) {
+static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     static bool attr_set = false;          // setting it twice is harmless
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); attr_set = true; }
-    hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols);
+    hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp);
 }
 static bool ntt_fixed_on() { static const bool on = !(getenv("ZK_NTT_FIXED") && atoi(getenv("ZK_NTT_FIXED")) == 0); return on; }      // measurement knob
-static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols) {
+static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     if (!ntt_fixed_on() || !out_tw) return false;
-#define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols); \
-                                else launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols); return true;
+#define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); \
+                                else launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); return true;
     switch (log_np) { ZK_PASS_CASE(8) ZK_PASS_CASE(9) ZK_PASS_CASE(10) ZK_PASS_CASE(11) default: return false; }
 #undef ZK_PASS_CASE
 }
@@ -738,8 +744,10 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;      // a transform's algorithmic 64 B per element (read once, write once), spread over its P launches
             static const bool xcd_off = getenv("ZK_NTT_XCD_COLS") && atoi(getenv("ZK_NTT_XCD_COLS")) == 0;       // measurement knob
             const int xcd_cols = (nb > 1 && blocks % 8 == 0 && !xcd_off) ? 1 : 0;
-            if (!launch_pass_fixed(ctx, ps.log_np, blocks * (unsigned)nb, (unsigned)pick_threads(tile), (size_t)tile * NTT_LDS_BYTES_PER_ELT, io, ps.tw, log_t, ps.log_m,
-                                   p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw, (uint32_t)nb, xcd_cols))
+            const int log_grp = log_t < 2 ? 2 - log_t : 0;           // tiles per 128-byte line of a run
+            const int xcd_fixed = (!xcd_off && blocks % (8u << log_grp) == 0 && (nb > 1 || log_grp > 0)) ? 1 : 0;
+            if (!launch_pass_fixed(ctx, ps.log_np, blocks * (unsigned)nb, (unsigned)std::max(64, std::min(1024, tile >> 2)) /* one radix-4 item per thread and step */, (size_t)tile * NTT_LDS_BYTES_PER_ELT, io, ps.tw, log_t, ps.log_m,
+                                   p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw, (uint32_t)nb, xcd_fixed, xcd_fixed ? log_grp : 0))
                 hipLaunchKernelGGL(k_ntt_pass, dim3(blocks * (unsigned)nb), dim3(pick_threads(tile)), (size_t)tile * NTT_LDS_BYTES_PER_ELT, ctx->stream, io, ps.tw,
                                    dom->d_lo, dom->d_hi, dom->h, ps.log_np, log_t, ps.log_m, tw_shift, p == 0 ? pre_table : (const Fr*)nullptr, ps.out_tw,
                                    (uint32_t)nb, xcd_cols);
@@ -765,7 +773,7 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
             pscope.bytes = (uint64_t)nb * n * 64 / (uint64_t)P;
             const int xcd_last = (log_mid == 0 && blocks % 8 == 0 && blocks >= 16 && ntt_xcd_remap()) ? 1 : 0;
             const size_t lds_last = (size_t)(tile + (ntt_row_pad(ps.log_np) << log_t)) * NTT_LDS_BYTES_PER_ELT;
-            if (!(P > 1 && dom->fin_folded && launch_last_fixed(ctx, ps.log_np, dim3(blocks, (unsigned)nb), (unsigned)pick_threads(tile), lds_last, io, ps.tw, log_t, log_n1, log_mid, xcd_last)))
+            if (!(P > 1 && dom->fin_folded && launch_last_fixed(ctx, ps.log_np, dim3(blocks, (unsigned)nb), (unsigned)std::max(64, std::min(1024, tile >> 2)), lds_last, io, ps.tw, log_t, log_n1, log_mid, xcd_last)))
                 hipLaunchKernelGGL(k_ntt_last, dim3(blocks, (unsigned)nb), dim3(pick_threads(tile)), lds_last, ctx->stream, io, ps.tw,
                                    ps.log_np, log_t, log_n1, log_mid, dom->final_mul, P == 1 ? pre_table : (const Fr*)nullptr, dom->fin_folded ? 1 : 0, xcd_last);
             ZK_CHECK_LAUNCH(ctx);

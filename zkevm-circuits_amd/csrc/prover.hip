@@ -281,6 +281,7 @@ struct Env {   // where an abstract column lives in the form being read (Lagrang
     F4 theta, beta, gamma, y;
     std::vector<F4> beta_delta;   // beta * delta^j
     std::vector<F4> challenges;   // user challenges (halo2 `Challenge`), by index
+    std::vector<F4> ypow;         // y^g, g < size (optional: the weights of a grouped class program, assemble_grouped)
 };
 
 const void* resolve_col(const Env& e, uint32_t ref) {
@@ -317,7 +318,7 @@ bool resolve_const(const Env& e, uint32_t ref, F4* out) {
     }
     if (ref >= C_DELTA0 && ref - C_DELTA0 < e.beta_delta.size()) { *out = e.beta_delta[ref - C_DELTA0]; return true; }
     if (ref >= C_CHAL0 && ref - C_CHAL0 < e.challenges.size()) { *out = e.challenges[ref - C_CHAL0]; return true; }
-    if (ref >= C_YPOW0 && ref < C_CHAL0) { *out = host::fr_pow(e.y, ref - C_YPOW0); return true; }
+    if (ref >= C_YPOW0 && ref < C_CHAL0) { *out = ref - C_YPOW0 < e.ypow.size() ? e.ypow[ref - C_YPOW0] : host::fr_pow(e.y, ref - C_YPOW0); return true; }
     return false;
 }
 int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
@@ -384,7 +385,54 @@ struct PB {
     PB& append(const Prog& o) { g.insert(g.end(), o.begin(), o.end()); return *this; }
 };
 // theta-compression of a list of expressions: ((e0 * theta + e1) * theta + e2) ...
+// An expression of the form F * X or X * F with F a single column read: X (postfix) and F; false for any other shape.
+// (The inputs of a zkEVM lookup are `q_enable * value`, all of a tuple under the same q_enable.)
+static bool split_leaf_factor(const Prog& g, bool factor_first, Prog* rest, Instr* factor) {
+    if (g.size() < 3 || g.back().op != Q_MUL) return false;
+    if (factor_first) {
+        if (g[0].op != Q_PUSH_COL) return false;
+        *factor = g[0];
+        rest->assign(g.begin() + 1, g.end() - 1);
+    } else {
+        if (g[g.size() - 2].op != Q_PUSH_COL) return false;
+        *factor = g[g.size() - 2];
+        rest->assign(g.begin(), g.end() - 2);
+    }
+    // `rest` must be ONE complete expression (the other operand of the product at the root)
+    int sp = 0;
+    for (const Instr& in : *rest) {
+        switch (in.op) {
+            case Q_PUSH_COL: case Q_PUSH_CONST: case Q_PUSH_TMP: ++sp; break;
+            case Q_ADD: case Q_SUB: case Q_MUL: if (sp < 2) return false; --sp; break;
+            case Q_TEE_TMP: return false;
+            default: if (sp < 1) return false; break;
+        }
+    }
+    return sp == 1;
+}
 void push_compressed(PB& b, const std::vector<Prog>& exprs) {
+    // sum_i theta^(N-1-i) (F x_i) = F * sum_i theta^(N-1-i) x_i: one product by F instead of N (exact: same polynomial)
+    if (exprs.size() >= 2) {
+        for (int first = 1; first >= 0; --first) {
+            std::vector<Prog> rest(exprs.size());
+            Instr f0{0, 0, 0};
+            bool all = true;
+            for (size_t i = 0; i < exprs.size() && all; ++i) {
+                Instr f{0, 0, 0};
+                all = split_leaf_factor(exprs[i], first != 0, &rest[i], &f) && (i == 0 || (f.a == f0.a && f.b == f0.b));
+                if (i == 0) f0 = f;
+            }
+            if (!all) continue;
+            for (size_t i = 0; i < rest.size(); ++i) {
+                if (i) b.mulc(C_THETA);
+                b.append(rest[i]);
+                if (i) b.op(Q_ADD);
+            }
+            b.g.push_back(f0);
+            b.op(Q_MUL);
+            return;
+        }
+    }
     for (size_t i = 0; i < exprs.size(); ++i) {
         if (i) b.mulc(C_THETA);
         b.append(exprs[i]);
@@ -1041,13 +1089,28 @@ static void build_constraints(const zk_pk* pk, std::vector<Prog>& cons, bool& ga
     uint32_t tmp_base = 0;
     for (const Prog& g : pk->gates) for (const Instr& in : g) if (in.op == Q_TEE_TMP || in.op == Q_PUSH_TMP) tmp_base = std::max(tmp_base, in.a + 1);
     const bool gates_share_tmps = tmp_base != 0;
+    // Single-tuple lookups share the table side: tau = t + beta of a table is parked by the first lookup into it and read back by the
+    // others (slots above the ones the multi-tuple form reuses; defined once each, so degree classes re-materialise them, TmpSplit).
+    uint32_t max_tuples = 0;
+    for (uint32_t l = 0; l < pk->L; ++l) if (pk->lookups[l].inputs.size() > 1) max_tuples = std::max<uint32_t>(max_tuples, (uint32_t)pk->lookups[l].inputs.size());
+    const uint32_t table_slot0 = tmp_base + (max_tuples ? max_tuples + 2 : 0);
+    std::vector<const std::vector<Prog>*> parked_tables;               // table of slot table_slot0 + i
+    static const bool lk_plain = getenv("ZK_LOOKUP_PLAIN") && atoi(getenv("ZK_LOOKUP_PLAIN")) == 1;      // measurement knob: the identity as halo2 writes it
+    auto same_tables = [](const std::vector<Prog>& x, const std::vector<Prog>& y) {
+        if (x.size() != y.size()) return false;
+        for (size_t i = 0; i < x.size(); ++i) {
+            if (x[i].size() != y[i].size()) return false;
+            for (size_t j = 0; j < x[i].size(); ++j) if (x[i][j].op != y[i][j].op || x[i][j].a != y[i][j].a || x[i][j].b != y[i][j].b) return false;
+        }
+        return true;
+    };
     for (uint32_t l = 0; l < pk->L; ++l) {
         const auto& lk = pk->lookups[l];
         const uint32_t N = (uint32_t)lk.inputs.size();
         q.col(CT_SPECIAL, SP_L0).col(CT_LK_PHI, l).op(Q_MUL); end_c();
         q.col(CT_SPECIAL, SP_LLAST).col(CT_LK_PHI, l).op(Q_MUL); end_c();
         q.col(CT_SPECIAL, SP_LACTIVE);
-        if (N == 1) {
+        if (N == 1 && lk_plain) {
             // (phi(wX) - phi(X)) (f+beta)(t+beta) - ((t+beta) - m (f+beta))
             q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
             push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
@@ -1055,6 +1118,25 @@ static void build_constraints(const zk_pk* pk, std::vector<Prog>& cons, bool& ga
             push_compressed(q, lk.tables); q.addc(C_BETA);
             q.col(CT_LK_M, l); push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
             q.op(Q_SUB).op(Q_SUB).op(Q_MUL); end_c();
+            continue;
+        }
+        if (N == 1) {
+            // the same polynomial with phi_f = f + beta and tau = t + beta each computed once:
+            //   (phi(wX) - phi(X)) phi_f tau - (tau - m phi_f)  =  phi_f ((phi(wX) - phi(X)) tau + m) - tau
+            // four products instead of twelve on a two-column tuple under one selector (push_compressed takes the selector out)
+            size_t ti = 0;
+            while (ti < parked_tables.size() && !same_tables(*parked_tables[ti], lk.tables)) ++ti;
+            const bool first_use = ti == parked_tables.size();
+            if (first_use) parked_tables.push_back(&lk.tables);
+            const uint32_t slot = table_slot0 + (uint32_t)ti;
+            q.col(CT_LK_PHI, l, 1).col(CT_LK_PHI, l, 0).op(Q_SUB);
+            if (first_use) { push_compressed(q, lk.tables); q.addc(C_BETA); q.g.push_back({Q_TEE_TMP, slot, 0}); }
+            else q.g.push_back({Q_PUSH_TMP, slot, 0});
+            q.op(Q_MUL);
+            q.col(CT_LK_M, l).op(Q_ADD);
+            push_compressed(q, lk.inputs[0]); q.addc(C_BETA).op(Q_MUL);
+            q.g.push_back({Q_PUSH_TMP, slot, 0});
+            q.op(Q_SUB).op(Q_MUL); end_c();
             continue;
         }
         const uint32_t t_tau = tmp_base, t_phi = tmp_base + 1;          // reused by every multi-input lookup: a row's values are consumed right away
@@ -1213,6 +1295,108 @@ static void class_pieces(const std::vector<Prog>& cons, const std::vector<uint32
             for (auto& pt : parts) out.push_back({i, pt.first, std::move(pt.second)});
         } else out.push_back({i, cls[i], cons[i]});
     }
+}
+// A class program as ONE weighted sum (round 5).  The class's accumulator used to fold its terms one by one, acc = acc * y^gap + term:
+// a product per term, and every term carried its selector -- q (a b), q' c, l_active (...) -- as a product of its own.  The sum
+//      sum_i y^(K-1-i) t_i      (t_i = the terms of this class, i = the constraint a term belongs to)
+// is the same polynomial when the terms that share a single-column factor F are collected first:
+//      sum_F F * (sum_{i in F} y^(K-1-i) r_i) + sum_{others} y^(K-1-i) t_i,        t_i = F r_i
+// -- one product by F per group instead of one per term, and no product for the folding.  Exact field arithmetic: h and every proof
+// byte are unchanged (tests/test_quotient_classes.py evaluates both forms; the GPU proof tests compare bytes with the oracle prover).
+// A term may use parked intermediates: it joins a group only if everything it reads was parked before the group's first term, and a
+// term that parks something only ever opens a group, so definitions stay ahead of their readers when later terms move up.
+// ZK_QUOTIENT_GROUP=0 keeps the folded form.
+struct ClassTerm { uint32_t cons; Prog prog; };
+static bool assemble_grouped(const std::vector<ClassTerm>& terms, uint32_t K, Prog& out) {
+    if (terms.empty() || K >= 0xFFFFu) return false;
+    struct Info { bool has_factor[2] = {false, false}; Instr factor[2]; Prog rest[2]; std::vector<uint32_t> reads, defs; int pick = -1; };
+    std::vector<Info> info(terms.size());
+    auto key = [](const Instr& f) { return ((uint64_t)f.a << 32) | f.b; };
+    std::unordered_map<uint64_t, uint32_t> count;
+    for (size_t t = 0; t < terms.size(); ++t) {
+        const Prog& g = terms[t].prog;
+        for (const Instr& in : g) {
+            if (in.op == Q_PUSH_TMP) info[t].reads.push_back(in.a);
+            else if (in.op == Q_TEE_TMP) info[t].defs.push_back(in.a);
+            else if (in.op == Q_FOLD || in.op == Q_END) return false;
+        }
+        for (int first = 0; first < 2; ++first) {
+            info[t].has_factor[first] = split_leaf_factor(g, first != 0, &info[t].rest[first], &info[t].factor[first]);
+            if (info[t].has_factor[first] && !(first == 1 && info[t].has_factor[0] && key(info[t].factor[0]) == key(info[t].factor[1]))) ++count[key(info[t].factor[first])];
+        }
+    }
+    for (size_t t = 0; t < terms.size(); ++t) {
+        uint32_t best = 1;          // a factor no other term shares is left where it is
+        for (int first = 1; first >= 0; --first)
+            if (info[t].has_factor[first] && count[key(info[t].factor[first])] > best) { best = count[key(info[t].factor[first])]; info[t].pick = first; }
+    }
+    // groups in the order of their first terms
+    struct Group { std::vector<uint32_t> members; bool factored; std::vector<uint32_t> known; };       // known: what was parked before (and by) the first term
+    std::vector<Group> groups;
+    std::unordered_map<uint64_t, uint32_t> open;
+    std::vector<uint32_t> parked;                      // slots parked by the terms seen so far (original order)
+    std::unordered_map<uint32_t, uint32_t> ndefs;      // a slot that is parked more than once (reused) is only read where it stands
+    for (const Info& ti : info) for (uint32_t d : ti.defs) ++ndefs[d];
+    auto stable = [&](const std::vector<uint32_t>& reads) { for (uint32_t v : reads) { auto it = ndefs.find(v); if (it == ndefs.end() || it->second != 1) return false; } return true; };
+    auto subset = [](const std::vector<uint32_t>& x, const std::vector<uint32_t>& of) { for (uint32_t v : x) if (std::find(of.begin(), of.end(), v) == of.end()) return false; return true; };
+    for (size_t t = 0; t < terms.size(); ++t) {
+        const Info& ti = info[t];
+        bool joined = false;
+        if (ti.pick >= 0 && ti.defs.empty() && stable(ti.reads)) {
+            auto it = open.find(key(ti.factor[ti.pick]));
+            if (it != open.end() && subset(ti.reads, groups[it->second].known)) { groups[it->second].members.push_back((uint32_t)t); joined = true; }
+        }
+        if (!joined) {
+            Group gnew;
+            gnew.members.push_back((uint32_t)t);
+            gnew.factored = ti.pick >= 0;
+            gnew.known = parked;
+            // what the first term parks inside its OWN co-factor is computed before any other member's co-factor is
+            if (ti.pick >= 0) for (const Instr& in : ti.rest[ti.pick]) if (in.op == Q_TEE_TMP) gnew.known.push_back(in.a);
+            groups.push_back(std::move(gnew));
+            if (ti.pick >= 0) open[key(ti.factor[ti.pick])] = (uint32_t)groups.size() - 1;
+        }
+        for (uint32_t d : ti.defs) parked.push_back(d);
+    }
+    out.clear();
+    auto weight = [&](uint32_t cons) { if (K - 1 - cons) out.push_back({Q_MUL_CONST, C_YPOW0 + (K - 1 - cons), 0}); };
+    bool first_item = true;
+    for (const Group& gr : groups) {
+        if (gr.factored && gr.members.size() >= 2) {
+            const Info& lead = info[gr.members[0]];
+            for (size_t j = 0; j < gr.members.size(); ++j) {
+                const uint32_t t = gr.members[j];
+                const Prog& r = info[t].rest[info[t].pick];
+                out.insert(out.end(), r.begin(), r.end());
+                weight(terms[t].cons);
+                if (j) out.push_back({Q_ADD, 0, 0});
+            }
+            out.push_back(lead.factor[lead.pick]);
+            out.push_back({Q_MUL, 0, 0});
+        } else {
+            for (size_t j = 0; j < gr.members.size(); ++j) {          // a lone term (a group nobody joined)
+                const uint32_t t = gr.members[j];
+                out.insert(out.end(), terms[t].prog.begin(), terms[t].prog.end());
+                weight(terms[t].cons);
+                if (j) out.push_back({Q_ADD, 0, 0});
+            }
+        }
+        if (!first_item) out.push_back({Q_ADD, 0, 0});
+        first_item = false;
+    }
+    out.push_back({Q_FOLD, C_ONE, 0});                  // acc = 0 * 1 + the sum
+    // depth of the caller's stack machine (Q_MAX_STACK in quotient.hip is 16): beyond it the folded form is kept
+    int sp = 0, mx = 0;
+    for (const Instr& in : out) {
+        if (in.op == Q_PUSH_COL || in.op == Q_PUSH_CONST || in.op == Q_PUSH_TMP) ++sp;
+        else if (in.op == Q_ADD || in.op == Q_SUB || in.op == Q_MUL || in.op == Q_FOLD) --sp;
+        mx = std::max(mx, sp);
+    }
+    return sp == 0 && mx <= 14;
+}
+static bool quotient_group_enabled() {
+    const char* env = getenv("ZK_QUOTIENT_GROUP");
+    return !(env && atoi(env) == 0);
 }
 // Intermediates shared between constraints (TEE_TMP in one gate, PUSH_TMP in a later one: the common-subexpression
 // elimination of halo2's GraphEvaluator as it survives the export) and degree classes: a class evaluates only ITS constraints,
@@ -1458,6 +1642,25 @@ int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E
         if (w + 3 * parts[j].second.size() > out_cap_words) return ZK_ERR_INVALID_ARG;
         for (const Instr& in : parts[j].second) { out_words[w++] = in.op; out_words[w++] = in.a; out_words[w++] = in.b; }
     }
+    return ZK_OK;
+}
+
+int zk_host_group_terms(const uint32_t* words, const uint32_t* lens, const uint32_t* cons, uint32_t count, uint32_t K, uint32_t* out_words, size_t out_cap_words, uint32_t* out_instr) {
+    if (!words || !lens || !cons || !out_instr) return ZK_ERR_INVALID_ARG;
+    std::vector<ClassTerm> terms(count);
+    size_t at = 0;
+    for (uint32_t t = 0; t < count; ++t) {
+        if (cons[t] >= K) return ZK_ERR_INVALID_ARG;
+        terms[t].cons = cons[t];
+        terms[t].prog.resize(lens[t]);
+        for (uint32_t j = 0; j < lens[t]; ++j, ++at) terms[t].prog[j] = {words[3 * at], words[3 * at + 1], words[3 * at + 2]};
+    }
+    Prog out;
+    if (!assemble_grouped(terms, K, out)) return ZK_ERR_UNSUPPORTED;
+    *out_instr = (uint32_t)out.size();
+    if (!out_words) return ZK_OK;
+    if (out_cap_words < 3 * out.size()) return ZK_ERR_INVALID_ARG;
+    for (size_t j = 0; j < out.size(); ++j) { out_words[3 * j] = out[j].op; out_words[3 * j + 1] = out[j].a; out_words[3 * j + 2] = out[j].b; }
     return ZK_OK;
 }
 
@@ -1817,16 +2020,15 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // unchanged.  R is read like a column (CT_SPLIT_R) on the cosets of the two classes.
     struct Remainder { uint32_t t, e; Prog prog; uint32_t last = 0; bool used = false; DevBuf coeff; };
     std::vector<Remainder> rems;
+    std::vector<std::vector<ClassTerm>> cterms(E + 1);       // the terms of every class in constraint order: (constraint, program)
     {
         std::vector<uint32_t> top(K, 0);
         for (const ClassPiece& pc : cpieces) top[pc.cons] = std::max(top[pc.cons], pc.cls);
         for (const ClassPiece& pc : cpieces) {
             const uint32_t i = pc.cons;
-            QClass& c = qc[pc.cls];
-            tmps.append(pc.prog, pc.cls, c.prog);                                        // the constraint (or its terms of this class), shared intermediates resolved for this class
-            c.prog.push_back({Q_FOLD, c.used ? C_YPOW0 + (i - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
-            c.last = i;
-            c.used = true;
+            cterms[pc.cls].emplace_back();
+            cterms[pc.cls].back().cons = i;
+            tmps.append(pc.prog, pc.cls, cterms[pc.cls].back().prog);                   // the constraint (or its terms of this class), shared intermediates resolved for this class
             if (pc.cls < top[i]) {
                 size_t at = 0;
                 while (at < rems.size() && !(rems[at].t == top[i] && rems[at].e == pc.cls)) ++at;
@@ -1853,19 +2055,34 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             dsts.push_back(rm.coeff.fr());
             // both classes take R in as one more term at the very end of the constraint list (weight y^0)
             const uint32_t ref = colref(CT_SPLIT_R, (uint32_t)j);
-            QClass& lo_c = qc[rm.e];
-            lo_c.prog.push_back({Q_PUSH_COL, ref, 0});
-            lo_c.prog.push_back({Q_NEG, 0, 0});
-            lo_c.prog.push_back({Q_FOLD, C_YPOW0 + (K - 1 - lo_c.last), 0});
-            lo_c.last = K - 1;
-            QClass& hi_c = qc[rm.t];
-            hi_c.prog.push_back({Q_PUSH_COL, ref, 0});
-            hi_c.prog.push_back({Q_FOLD, C_YPOW0 + (K - 1 - hi_c.last), 0});
-            hi_c.last = K - 1;
+            cterms[rm.e].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}, {Q_NEG, 0, 0}}});
+            cterms[rm.t].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}}});
         }
         const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
         PK_TRY(ntt_run_many(ctx, dsts.data(), nullptr, dsts.size(), pk->k, omega_inv, &ninv, nullptr, nullptr, false));
         trace.mark("  quotient: remainders of the split constraints");
+    }
+    // the class programs: one weighted sum each (assemble_grouped), or -- knob off, a program too deep for the evaluator's stack, keys whose
+    // intermediates reuse slots across constraints -- the terms folded one by one, acc = acc * y^gap + term
+    {
+        const bool grouped = quotient_group_enabled() && !tmp_slots_conflict(cons);
+        for (uint32_t e = 0; e <= E; ++e) {
+            QClass& c = qc[e];
+            if (cterms[e].empty()) continue;
+            c.used = true;
+            if (grouped && assemble_grouped(cterms[e], K, c.prog)) { c.last = K - 1; continue; }
+            c.prog.clear();
+            bool any = false;
+            for (const ClassTerm& t : cterms[e]) {
+                c.prog.insert(c.prog.end(), t.prog.begin(), t.prog.end());
+                c.prog.push_back({Q_FOLD, any ? C_YPOW0 + (t.cons - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
+                c.last = t.cons;
+                any = true;
+            }
+        }
+        lag.ypow.resize(K + 1);
+        lag.ypow[0] = host::fr_one();
+        for (uint32_t g_ = 1; g_ <= K; ++g_) lag.ypow[g_] = host::fr_mul(lag.ypow[g_ - 1], lag.y);
     }
     std::vector<uint32_t> refs;          // every column any class reads
     for (QClass& c : qc)
