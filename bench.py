@@ -222,7 +222,10 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
     # (permutation products by their run ends, lookup sums through their first differences: csrc/runs.hip) -- what a circuit
     # with a copy constraint on most rows and every lookup switched on everywhere would pay
     blind = None
+    quick = os.environ.get("ZK_BENCH_QUICK") == "1"          # A/B runs (tools/gpu_ab.sh): the timed proofs only, no side measurements
     try:
+        if quick:
+            raise RuntimeError("skipped (ZK_BENCH_QUICK)")
         os.environ["ZK_MSM_RUNS"], os.environ["ZK_MSM_DIFF"] = "0", "0"
         proof_with = state["proof"]
         tb = []
@@ -246,7 +249,7 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
         com, rep = pk.vk(circ.F + len(circ.perm_cols))
         verified = bool(pv.verify(circ, cref.affine_from_mont(com), cref.from_mont(rep.reshape(1, 4))[0], inst, state["proof"], pr.ec_mul(pr.G2_GEN, S), multiopen="shplonk"))
     pcie = None
-    if world == 1:
+    if world == 1 and not quick:
         try:
             pinned = {}
             for a in adv_m[:SC_SHAPE[1] - 2]:

@@ -588,7 +588,7 @@ static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned t
     if (!ntt_fixed_on() || !out_tw) return false;
 #define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); \
                                 else launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); return true;
-    switch (log_np) { ZK_PASS_CASE(8) ZK_PASS_CASE(9) ZK_PASS_CASE(10) ZK_PASS_CASE(11) default: return false; }
+    switch (log_np) { ZK_PASS_CASE(7) ZK_PASS_CASE(8) ZK_PASS_CASE(9) ZK_PASS_CASE(10) ZK_PASS_CASE(11) default: return false; }      // 7, 8: the three-pass sizes (2^21 .. 2^24)
 #undef ZK_PASS_CASE
 }
 template <int LOG_NP>
