@@ -328,3 +328,46 @@ def test_malformed_programs_are_refused_not_executed():
         rc = lib.zk_host_quotient_lower(words.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(prog)), ctypes.c_uint32(4), ctypes.c_int(1),
                                         None, ctypes.c_size_t(0), ctypes.byref(n_out), ctypes.byref(depth))
         assert rc != 0, prog
+
+
+# ---- the class programs of round 5: one weighted sum (csrc/prover.hip assemble_grouped) -----------------------------------
+def test_grouped_class_programs_keep_every_bound():
+    """a class program as the prover assembles it since round 5 -- terms under a shared single-column factor collected, weights
+    y^(K-1-i) as constants, one closing FOLD -- lowered and executed limb by limb with every column at p - 1, 0, 1 and random:
+    long chains of added products are what the settle bits of lower_bounds have to keep inside the limits"""
+    import test_quotient_classes as tqc
+    rng = random.Random(77)
+    lib_mod = type("Z", (), {"lib": staticmethod(binding.lib)})
+    S, G = 3, 40
+    col = lambda i, rot=0: (Q_PUSH_COL, i, rot)
+    terms, cons = [], []
+    for g in range(G):                                           # q_s (a b), q_s c, q'_s (a + b - c(+1)): the gate classes of the headline circuit
+        q, a, b_, c = col(g % S), col(S + 3 * g), col(S + 3 * g + 1), col(S + 3 * g + 2)
+        terms.append([q, a, b_, (Q_MUL, 0, 0), (Q_MUL, 0, 0)]); cons.append(3 * g)
+        terms.append([q, c, (Q_NEG, 0, 0), (Q_MUL, 0, 0)]); cons.append(3 * g)
+        terms.append([col((g + 1) % S), a, b_, (Q_ADD, 0, 0), (Q_PUSH_COL, S + 3 * g + 2, 1), (Q_SUB, 0, 0), (Q_MUL, 0, 0)]); cons.append(3 * g + 1)
+    terms.append([col(S + 1), (Q_NEG, 0, 0)]); cons.append(3 * G + 1)         # a remainder column, weight one
+    K = 3 * G + 2
+    ncols = S + 3 * G
+    prog = tqc.group_terms(lib_mod, terms, cons, K)
+    assert prog is not None
+    # constant references (0xFFFC0000 + g = y^g, 0xFFFF0004 = one) -> indices, as the prover's concretise does
+    y = rng.randrange(P)
+    refs = sorted({a for op, a, b in prog if op in (Q_MUL_CONST, Q_ADD_CONST, Q_FOLD, Q_PUSH_CONST)})
+    index = {r: i for i, r in enumerate(refs)}
+    rinv = pow(R, -1, P)
+    def const_of(r):
+        if r >= 0xFFFC0000 and r < 0xFFFD0000:
+            v = R % P                                            # y^g in R form: (y R)^g / R^(g-1)
+            for _ in range(r - 0xFFFC0000):
+                v = v * y * rinv % P
+            return v
+        assert r == 0xFFFF0004
+        return R % P
+    consts = [const_of(r) for r in refs]
+    conc = [(op, index[a] if op in (Q_MUL_CONST, Q_ADD_CONST, Q_FOLD, Q_PUSH_CONST) else a, b) for op, a, b in prog]
+    words, depth = lower(conc, ncols)
+    assert depth <= 16
+    for kind in ("max", "mixed", "mixed", "zero", "one"):
+        cols = col_values(rng, conc, kind)
+        assert run_lowered(words, cols, consts, ncols) == run_plain(conc, cols, consts), kind

@@ -112,6 +112,26 @@ __global__ void k_mad64_chain(uint64_t* out, uint32_t a, uint32_t b) {
     for (int i = 0; i < NCH; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// Rate of the int8 matrix instruction the round-4 review asked about (tools/ only: the product path keeps MFMA unused, north_star): the
+// reduction half of a Montgomery product as a contraction against a constant Toeplitz matrix of the modulus' bytes would be, per 32
+// field elements, one 64 x 32 x 32 tile product for m p (two v_mfma_i32_32x32x32_i8) + one 32 x 32 x 32 for m = t (-1/p) mod 2^256 (one).
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+__global__ void k_mfma_i8(uint64_t* out, uint32_t a, uint32_t b) {
+    mfma_v4i x = {(int)(a + threadIdx.x), (int)(b ^ threadIdx.x), (int)(a * 3u + blockIdx.x), (int)(b + 7u)}, y = {(int)b, (int)a, (int)(a ^ b), (int)threadIdx.x};
+    mfma_v16i c[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) c[i][j] = i + j;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, y, c[i], 0, 0, 0);
+    }
+    uint64_t s_ = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s_ += (uint32_t)c[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s_;
+}
 #define K32(NAME, ASMSTR)                                                              \
     __global__ void NAME(uint64_t* out, uint32_t a, uint32_t b) {                      \
         uint32_t acc[CH];                                                              \
@@ -375,6 +395,13 @@ int main() {
         double s1 = time_kernel([&] { hipLaunchKernelGGL((k_ntt_step_alu<1>), dim3(bl), dim3(threads), 0, 0, out, (const zk::Fr*)din); });
         double s0 = time_kernel([&] { hipLaunchKernelGGL((k_ntt_step_alu<0>), dim3(bl), dim3(threads), 0, 0, out, (const zk::Fr*)din); });
         printf("NTT radix-4 step on registers at %d waves/SIMD: %.1f G products/s with the butterfly sums and carry propagation, %.1f G/s products alone\n", wps, np / s1 * 1e-9, np / s0 * 1e-9);
+    }
+    {
+        const double secs = time_kernel([&] { hipLaunchKernelGGL(k_mfma_i8, dim3(blocks), dim3(threads), 0, 0, out, 12345u, 678u); });
+        const double insts = (double)blocks * threads / 64.0 * (double)ITERS * 16.0;          // wave-level instructions
+        printf("v_mfma_i32_32x32x32_i8: %.2f G wave-instructions/s (%.1f T int8 multiply-adds/s), %.2f ns per instruction and SIMD; three of them per 32 field elements = %.3f ns per element and SIMD\n",
+               insts / secs * 1e-9, insts * 32768.0 / secs * 1e-12, secs * nsimd / insts * 1e9, 3.0 / 32.0 * secs * nsimd / insts * 1e9);
+        printf("   against the reduction half on the VALU: 81 v_mad_u64_u32 per element = %.3f ns per element and SIMD (64 elements per wave-instruction)\n", 81.0 * 2.07 / 64.0);
     }
     {   // correctness dump for offline verification (tools/check29.py)
         const int n = 4096;
