@@ -8,10 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../zkevm-circuits_amd/csrc/ff.hip.hpp"
-#include "../zkevm-circuits_amd/csrc/ff29.hip.hpp"
-namespace zk {
-#include "mul29_asm.hip.hpp"      // python tools/gen_mul29_asm.py > tools/mul29_asm.hip.hpp (an experiment of round 5: profiles/r05_ubench.md)
-}
+#include "../zkevm-circuits_amd/csrc/ff29.hip.hpp"      // the products: one asm statement each (mul29 = mul29_asm on the device), the C forms as mul29_c ...
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -256,10 +253,10 @@ __global__ void k_cmp29(uint32_t* bad, uint32_t seed) {
     for (int i = 0; i < 8; ++i) an.l[i] &= 0x1fffffffu;
     uint32_t diff = 0;
     auto cmp = [&](const zk::F29<P>& x, const zk::F29<P>& y, uint32_t bit) { for (int i = 0; i < 9; ++i) if (x.l[i] != y.l[i]) diff |= bit; };
-    cmp(zk::mul29_asm<P>(a, b), zk::mul29(a, b), 1u);
-    cmp(zk::mul29_ub_asm<P>(a, u), zk::mul29_ub(a, u), 2u);
-    cmp(zk::sqr29_asm<P>(an), zk::sqr29(an), 4u);
-    cmp(zk::mul2add29_asm<P>(an, b, c, d), zk::mul2add29(an, b, c, d), 8u);
+    cmp(zk::mul29(a, b), zk::mul29_c(a, b), 1u);
+    cmp(zk::mul29_ub(a, u), zk::mul29_ub_c(a, u), 2u);
+    cmp(zk::sqr29(an), zk::sqr29_c(an), 4u);
+    cmp(zk::mul2add29(an, b, c, d), zk::mul2add29_c(an, b, c, d), 8u);
     if (diff) { atomicAdd(bad, 1u); atomicOr(bad + 1, diff); }
 }
 template <class P, int OP>
@@ -269,9 +266,9 @@ __global__ void k_field29c(uint64_t* out, const zk::Fp<typename P::P32>* in) {
     for (int it = 0; it < ITERS / 8; ++it) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (OP == 0) a[i] = zk::mul29_asm<P>(a[i], b);
-            if (OP == 3) a[i] = zk::sqr29(a[i]);
-            if (OP == 4) a[i] = zk::sqr29_asm<P>(a[i]);
+            if (OP == 0) a[i] = zk::mul29_c(a[i], b);
+            if (OP == 3) a[i] = zk::sqr29_c(a[i]);
+            if (OP == 4) a[i] = zk::sqr29(a[i]);
         }
     }
     uint64_t s = 0;
@@ -376,10 +373,10 @@ int main() {
     report("Fq29 add+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 1>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
     report("Fq29 sub+norm", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fq29P, 2>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
     report("Fr29 mul", time_kernel([&] { hipLaunchKernelGGL((k_field29<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
-    report("Fr29 mul (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
-    report("Fq29 mul (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
-    report("Fq29 sqr (library)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 3>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
-    report("Fq29 sqr (one asm statement)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 4>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fr29 mul (C form)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fr29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, din); }), nf);
+    report("Fq29 mul (C form)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sqr (C form)", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 3>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
+    report("Fq29 sqr", time_kernel([&] { hipLaunchKernelGGL((k_field29c<zk::Fq29P, 4>), dim3(blocks), dim3(threads), 0, 0, out, (const zk::Fq*)din); }), nf);
     {
         uint32_t* dbad; CK(hipMalloc(&dbad, 8)); CK(hipMemset(dbad, 0, 8));
         for (uint32_t seed = 1; seed <= 8; ++seed) {
@@ -387,7 +384,7 @@ int main() {
             hipLaunchKernelGGL((k_cmp29<zk::Fq29P>), dim3(1024), dim3(256), 0, 0, dbad, seed * 104729u);
         }
         uint32_t hbad[2]; CK(hipMemcpy(hbad, dbad, 8, hipMemcpyDeviceToHost));
-        printf("asm products against the library's: %u mismatching lanes of %u (mask 0x%x: 1 mul29, 2 mul29_ub, 4 sqr29, 8 mul2add29)\n", hbad[0], 16u * 1024u * 256u, hbad[1]);
+        printf("asm products against the C forms: %u mismatching lanes of %u (mask 0x%x: 1 mul29, 2 mul29_ub, 4 sqr29, 8 mul2add29)\n", hbad[0], 16u * 1024u * 256u, hbad[1]);
     }
     for (int wps = 2; wps <= 8; wps *= 2) {
         const int bl = prop.multiProcessorCount * wps;

@@ -342,7 +342,7 @@ __host__ __device__ __forceinline__ uint64_t dotk(const uint32_t* x, const uint3
 
 // Montgomery product, product-scanning (FIPS) form, 64-bit column accumulator, no carries.
 template <class P>
-__host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& b) {
+__host__ __device__ __forceinline__ F29<P> mul29_c(const F29<P>& a, const F29<P>& b) {
     uint32_t m[9];
     F29<P> t;
     uint64_t acc = 0;
@@ -370,7 +370,7 @@ __host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& 
 // The same product with a wave-uniform second factor (a constant of a program, a challenge): its limbs stay in scalar
 // registers and enter the multiply-adds as the scalar operand, like the modulus -- no vector copies of b.
 template <class P>
-__host__ __device__ __forceinline__ F29<P> mul29_ub(const F29<P>& a, const F29<P>& b) {
+__host__ __device__ __forceinline__ F29<P> mul29_ub_c(const F29<P>& a, const F29<P>& b) {
     uint32_t m[9];
     F29<P> t;
     uint64_t acc = 0;
@@ -399,7 +399,7 @@ __host__ __device__ __forceinline__ F29<P> mul29_ub(const F29<P>& a, const F29<P
 // a, b, c normalised (limbs < 2^29), d with limbs < 2^30 (e.g. K*p - x taken limb-wise, see neg29k), a*b + c*d < 2^261 * p:
 // a column holds at most 9*2^58 + 9*2^59 + 9*2^58 < 2^64.  Result normalised, < (a*b + c*d) / 2^261 + p.
 template <class P>
-__host__ __device__ __forceinline__ F29<P> mul2add29(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+__host__ __device__ __forceinline__ F29<P> mul2add29_c(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
     uint32_t m[9];
     F29<P> t;
     uint64_t acc = 0;
@@ -456,7 +456,7 @@ __host__ __device__ __forceinline__ Fp<typename P::P32> reduce_lazy29(const F29<
 // 45 products instead of 81 in the operand part (the reduction part is unchanged): 126 vs 162.
 // Same operand and result bounds as mul29(a, a).
 template <class P>
-__host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) {
+__host__ __device__ __forceinline__ F29<P> sqr29_c(const F29<P>& a) {
     uint32_t m[9], a2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
@@ -486,6 +486,34 @@ __host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) {
     t.l[8] = (uint32_t)acc;
     return t;
 }
+
+
+// The products as the rest of the library calls them.  On the device (ZK_MUL_ASM, default 1) each is ONE asm statement generated by
+// tools/gen_mul29_asm.py (csrc/mul29_asm.hip.hpp) -- the same column sums in the same order as the C forms above, which stay the
+// definition (host compilation, tests/test_host_arith.py) and what the device forms are compared with on the GPU (tools/ubench.hip:
+// 4 M operand sets at the documented bounds, bit-identical).  With one statement per column part (ZK_MAD_CHAIN = 2, the C forms) a
+// product carries its 162 multiply-adds in ~260 instructions; written out whole it is 162 + 9 v_mul_lo + 26 v_and + 17 v_lshrrev_b64 + 1.
+// The bare product chain does not gain from that (179 vs 176 G/s: its other instructions hide behind the multiply-adds), the kernels
+// do: NTT class of the headline proof 718 -> 700 ms, proof 1.033 -> 1.014 s on one box (alternating A/B, profiles/r05_experiments.md).
+// `make VARIANT=c EXTRA=-DZK_MUL_ASM=0` builds the C forms for A/B runs.
+#ifndef ZK_MUL_ASM
+#define ZK_MUL_ASM 1
+#endif
+#if ZK_MUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+#include "mul29_asm.hip.hpp"
+#define ZK_MUL29_DISPATCH(NAME, ...) return NAME##_asm<P>(__VA_ARGS__)
+#else
+#define ZK_MUL29_DISPATCH(NAME, ...) return NAME##_c<P>(__VA_ARGS__)
+#endif
+template <class P>
+__host__ __device__ __forceinline__ F29<P> mul29(const F29<P>& a, const F29<P>& b) { ZK_MUL29_DISPATCH(mul29, a, b); }
+template <class P>
+__host__ __device__ __forceinline__ F29<P> mul29_ub(const F29<P>& a, const F29<P>& b) { ZK_MUL29_DISPATCH(mul29_ub, a, b); }
+template <class P>
+__host__ __device__ __forceinline__ F29<P> mul2add29(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) { ZK_MUL29_DISPATCH(mul2add29, a, b, c, d); }
+template <class P>
+__host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) { ZK_MUL29_DISPATCH(sqr29, a); }
+#undef ZK_MUL29_DISPATCH
 
 // a^(m-2) for a canonical 8 x 32 element in R = 2^256 Montgomery form; result in the same form.
 // The 254-step exponentiation runs on 29-bit limbs (R' domain): its dependent chain is what a
