@@ -59,9 +59,9 @@ def sums(run):
 bench = json.loads(open(f"{src}/bench_full.json").read().strip().splitlines()[-1])
 json.dump(bench, open(f"profiles/bench_{tag}.json", "w"))
 steps, warm = bench["steps"], bench["warmup"]
-proofs_in_trace = steps + warm + 2          # + the two host-memory proofs of the pcie_inclusive side measurement
+proofs_in_trace = steps + warm + 4          # + the two structure-blind proofs and the two host-memory proofs of the side measurements
 kp = kernel_table("prof_proof", "proof", f"Kernel statistics of the headline run, round 5 (`bench.py --no-cpu-baseline --no-proof --no-msm-ntt --no-verify`)",
-                  f"{proofs_in_trace} proofs of the SuperCircuit shape (k = 20, 60/30/10 witness, three phases: {warm} warm-up + {steps} timed with the witness resident in HBM, 2 with the witness in "
+                  f"{proofs_in_trace} proofs of the SuperCircuit shape (k = 20, 60/30/10 witness, three phases: {warm} warm-up + {steps} timed with the witness resident in HBM, 2 with the structure-reading commitments off, 2 with the witness in "
                   "page-locked host memory) + one keygen + the benchmark's own circuit construction (`k_powers`, `k_scale`: data generation, not proving).  Kernel time sums over concurrent streams.")
 km = kernel_table("prof_msmntt", "msmntt", "Kernel statistics of the MSM / NTT section, round 5 (`bench.py --only-msm-ntt --no-cpu-baseline`: BASELINE configs[1])",
                   "16 warm-up + 32 timed steps (one 2^20 commitment + one 2^20 transform each, batches of 32 columns) + 6 lone commitments; `k_build_window_tables` / `k_fb_mul` build the SRS and its tables once.")
@@ -86,9 +86,9 @@ for k in ("k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_scatter_stag
     lines.append(f"| `{k}` | {n} | {f_:.1f} | {2 * f_:.1f} | {w_:.1f} | {f_ + w_:.1f} | {2 * f_ + w_:.1f} | {alg.get(k, '')} |")
 lines += ["", "The NTT kernels carry EIGHT columns per launch (zk_ntt_batch; `k_ntt_pass` / `k_ntt_last` here = all compile-time instances `k_ntt_pass_f<..>` / `k_ntt_last_f<..>` together); a transform's algorithmic 64 MiB (read once, write once) are split over its two launches: 32 MiB per column and launch.",
           "`k_ntt_pass` reads the column and the 32 MiB inter-pass twiddle table (FETCH x2 = 2 x algorithmic), `k_ntt_last` reads the intermediate once.", "",
-          f"## Headline proof (`bench.py --no-msm-ntt --steps 1 --warmup 0`: 3 proofs in the pass, figures per proof)", "",
+          f"## Headline proof (`bench.py --no-msm-ntt --steps 1 --warmup 0`: 5 proofs in the pass -- the timed one, two with the structure-reading commitments off, two from host memory --, figures per proof)", "",
           "| kernel | launches per proof | FETCH GiB | FETCH x2 GiB | WRITE GiB |", "|---|---|---|---|---|"]
-proofs_pmc = 3.0
+proofs_pmc = 5.0
 tot_f = tot_w = 0.0
 for k, v in sorted(fetch_p.items(), key=lambda kv: -kv[1]["sum"])[:18]:
     f_ = v["sum"] / proofs_pmc / KB / KB
@@ -112,6 +112,8 @@ traffic = {
     "ntt_bytes_per_transform_note": "FETCH x 2 (gfx950 streaming-read correction) + WRITE of k_ntt_pass and k_ntt_last, per column",
     "quotient_proof": {"launches": q["launches"] / proofs_pmc, "fetch_bytes_raw": int(q["sum"] / proofs_pmc * KB), "write_bytes": int(write_p.get("k_quotient_eval<true>", {"sum": 0})["sum"] / proofs_pmc * KB)},
     "proof_total": {"fetch_bytes_raw": int(tot_f / proofs_pmc * KB), "write_bytes": int(tot_w / proofs_pmc * KB)},
+    "proof_traffic_bytes": {"fetch_raw": int(tot_f / proofs_pmc * KB), "fetch_x2": int(2 * tot_f / proofs_pmc * KB), "write": int(tot_w / proofs_pmc * KB),
+                            "note": "all proving kernels of one headline proof (circuit construction excluded), mean over the five proofs of the counter passes; FETCH_SIZE raw and doubled (the guide's correction for wide streaming reads), WRITE_SIZE"},
 }
 json.dump(traffic, open(f"profiles/traffic_{tag}.json", "w"), indent=1)
 print("bench value", bench["value"], "| msm buckets", round(mb[0] + mb[1], 1), "MiB per launch | ntt", round(nt, 1), "MiB per transform")
