@@ -157,7 +157,8 @@ def test_two_product_pass(h, which):
 def test_lazy_reduction_and_inverse(h, which):
     rng = random.Random(11 + which)
     mod = MOD[which]
-    for v in edge_values(mod, rng, 64):          # reduce_lazy29: normalised lazy value < 64 m
+    around_multiples = [k_ * mod + d for k_ in range(1, 64) for d in (-1, 0, 1)] + [64 * mod - 1]      # the quotient estimate may be one short, never over
+    for v in edge_values(mod, rng, 64) + around_multiples + [rng.randrange(64 * mod) for _ in range(300)]:          # reduce_lazy29: normalised lazy value < 64 m
         o8 = U8()
         h.h_reduce_lazy29(which, U9(*limbs(v)), o8)
         assert sum(int(x) << (32 * i) for i, x in enumerate(o8)) == v % mod

@@ -433,14 +433,17 @@ __host__ __device__ __forceinline__ F29<P> neg29k(const F29<P>& b) {
     return r;
 }
 
-// canonical representative of a normalised lazy value < 64 m (sums of a few dozen reduced terms):
-// quotient estimate from the bits above 2^254 (both BN254 moduli are 0.756 * 2^254, so
-// floor(t * 1354 / 1024) never exceeds floor(x / m) and misses it by at most 2), one multiple of m
-// subtracted with signed carries, then conditional subtractions.  ~half the work of multiplying
-// by one just to reduce.
+// canonical representative of a normalised lazy value < 64 m (sums of a few dozen reduced terms): quotient estimate from the bits
+// above 2^232 -- t = x >> 232 is the top limb, q = floor(t C / 2^52) with C = floor(2^92 / ((m >> 192) + 1)) <= 2^284 / m (31 bits; both
+// BN254 moduli share their top 128 bits) -- never exceeds x / m and misses it by less than 1 + 2^-20, so x - q m lies in
+// [0, (1 + 2^-20) m): one multiple of m subtracted with signed carries, then ONE conditional subtraction (round 5; the estimate from
+// six bits that this replaces missed by up to 2 and paid three conditional subtractions -- 50 instructions per output of the NTT's
+// last pass).  ~half the work of multiplying by one just to reduce.
 template <class P>
 __host__ __device__ __forceinline__ Fp<typename P::P32> reduce_lazy29(const F29<P>& x) {
-    const uint32_t q = ((x.l[8] >> 22) * 1354u) >> 10;
+    constexpr uint64_t mhi = ((uint64_t)P::P32::M(7) << 32) | P::P32::M(6);
+    constexpr uint32_t C = (uint32_t)((((unsigned __int128)1) << 92) / ((unsigned __int128)mhi + 1));
+    const uint32_t q = (uint32_t)(((uint64_t)x.l[8] * C) >> 52);
     F29<P> r;
     int64_t c = 0;
 #pragma unroll
@@ -449,7 +452,7 @@ __host__ __device__ __forceinline__ Fp<typename P::P32> reduce_lazy29(const F29<
         r.l[i] = i < 8 ? (uint32_t)(s_ & MASK29) : (uint32_t)s_;
         c = s_ >> 29;
     }
-    return pack29(r);          // r < 4m: up to three conditional subtractions
+    return pack29_lt2p(r);          // r < (1 + 2^-20) m
 }
 
 // Montgomery square: the cross products a_i a_j (i < j) are taken once against the doubled limb,

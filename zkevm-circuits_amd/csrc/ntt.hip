@@ -258,7 +258,7 @@ k_ntt_pass(NttIo io, const Tw29* __restrict__ tw, const Fr* __restrict__ lo,
                     // inter-pass twiddle: one load from the per-domain table in output order (one product),
                     // or two table entries and two products when the table was not built
                     const Fr29 v = mul29(e[k], out_tw ? unpack29<Fr29P>(ldg(out_tw + go)) : two_level29(lo, hi, h, (jpp * (uint32_t)dl) << tw_shift));
-                    stg(dst + go, pack29_lt2p(v));
+                    stg(dst + go, pack29_raw(v));           // an intermediate: below 2p, not canonical (the next pass does not need it to be)
                 } else {
                     L.store((dl << log_t) | c, e[k]);
                 }
@@ -392,7 +392,7 @@ __device__ __forceinline__ void ntt_pass_steps(const Lds29& L, const Fr* __restr
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int dl = lo_d + k * hgt;
-            if (LAST) stg(dst + base + (uint64_t)dl * m + c, pack29_lt2p(mul29(e[k], unpack29<Fr29P>(otw[k]))));
+            if (LAST) stg(dst + base + (uint64_t)dl * m + c, pack29_raw(mul29(e[k], unpack29<Fr29P>(otw[k]))));      // an intermediate (the next pass reads it): any representative below 2p will do, no conditional subtraction
             else L.store((dl << log_t) | c, e[k]);
         }
     }
