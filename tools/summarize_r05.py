@@ -74,7 +74,7 @@ lines = [f"# PMC traffic, round 5 (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SI
          "bound for the 64-byte gathers of `k_msm_buckets` (uncalibrated access width: both figures are given).", "",
          "## MSM / NTT section (`bench.py --only-msm-ntt`): per launch", "",
          "| kernel | launches | FETCH MiB | FETCH x2 MiB | WRITE MiB | FETCH + WRITE MiB | FETCH x2 + WRITE MiB | algorithmic MiB |", "|---|---|---|---|---|---|---|---|"]
-NTT_COLS = 8          # columns per launch of a 2^20 batch (csrc/ntt.hip: per_launch)
+NTT_COLS = 16         # columns per launch of a 2^20 batch (csrc/ntt.hip: per_launch)
 alg = {"k_msm_buckets": 96.0, "k_ntt_pass": NTT_COLS * 32.0, "k_ntt_last": NTT_COLS * 32.0}
 per = {}
 for k in ("k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_scatter_staged<20>", "k_msm_m_binsort", "k_ntt_pass", "k_ntt_last", "k_wsum_level<false>", "k_wsum_level<true>", "k_wsum_final"):
@@ -84,7 +84,7 @@ for k in ("k_msm_buckets", "k_msm_m_partition<20, false>", "k_msm_m_scatter_stag
     f_, w_ = fetch[k]["sum"] / n / KB, write.get(k, {"sum": 0, "launches": 1})["sum"] / max(write.get(k, {"launches": 1})["launches"], 1) / KB
     per[k] = (f_, w_, n)
     lines.append(f"| `{k}` | {n} | {f_:.1f} | {2 * f_:.1f} | {w_:.1f} | {f_ + w_:.1f} | {2 * f_ + w_:.1f} | {alg.get(k, '')} |")
-lines += ["", "The NTT kernels carry EIGHT columns per launch (zk_ntt_batch; `k_ntt_pass` / `k_ntt_last` here = all compile-time instances `k_ntt_pass_f<..>` / `k_ntt_last_f<..>` together); a transform's algorithmic 64 MiB (read once, write once) are split over its two launches: 32 MiB per column and launch.",
+lines += ["", "The NTT kernels carry SIXTEEN columns per launch (zk_ntt_batch; `k_ntt_pass` / `k_ntt_last` here = all compile-time instances `k_ntt_pass_f<..>` / `k_ntt_last_f<..>` together); a transform's algorithmic 64 MiB (read once, write once) are split over its two launches: 32 MiB per column and launch.",
           "`k_ntt_pass` reads the column and the 32 MiB inter-pass twiddle table (FETCH x2 = 2 x algorithmic), `k_ntt_last` reads the intermediate once.", "",
           f"## Headline proof (`bench.py --no-msm-ntt --steps 1 --warmup 0`: 5 proofs in the pass -- the timed one, two with the structure-reading commitments off, two from host memory --, figures per proof)", "",
           "| kernel | launches per proof | FETCH GiB | FETCH x2 GiB | WRITE GiB |", "|---|---|---|---|---|"]

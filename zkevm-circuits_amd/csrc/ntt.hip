@@ -701,7 +701,7 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
     size_t per_launch = 1;
     if (count > 1) {
         const uint64_t tiles = std::max<uint64_t>(1, n >> 12);
-        per_launch = (size_t)std::min<uint64_t>(NTT_BATCH, std::max<uint64_t>(1, 2048 / tiles));       // eight columns at 2^20: a launch is eight rounds of workgroups (one per CU), its last round's tail is paid once per eight columns (headline proof 1.108 -> 1.091 s against four)
+        per_launch = (size_t)std::min<uint64_t>(NTT_BATCH, std::max<uint64_t>(1, 4096 / tiles));       // sixteen columns at 2^20: a launch's last round of workgroups and the 10-20 us between dependent launches are paid once per sixteen columns (headline proof, alternating A/B on one box: 1.006 s with four, 0.9855 with eight, 0.9793 with sixteen; alone the transform does not care: 94.8 / 94.6 us)
         if (const char* e = getenv("ZK_NTT_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= NTT_BATCH) per_launch = (size_t)v; }      // measurement knob
     }
     Fr* scratch = nullptr;
