@@ -966,7 +966,8 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
         // its lagrange_to_coeff runs now, on a main stream that is otherwise waiting for PCIe
         if (it > 0 && s_->world == 1) {
             s_->pending.push_back(it - 1);
-            if (s_->pending.size() >= 8) PK_TRY(s_->flush());        // eight columns share a launch of each transform (ntt_run_many's granularity at k = 20)
+            static const size_t flush_at = [] { const char* e = getenv("ZK_ADVICE_NTT_GROUP"); const int v = e ? atoi(e) : 32; return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();      // measurement knob
+            if (s_->pending.size() >= flush_at) PK_TRY(s_->flush());        // two launch pairs of sixteen columns (ntt_run_many's granularity at k = 20) per hand-over to the auxiliary stream: headline 0.9785 / 0.9882 s with 16, 0.9738 / 0.9851 with 32, 0.9812 with 64, 0.9788 with 8 (two alternating A/B runs)
         } else if (it > 0)
             for (size_t c_ = (it - 1) * s_->world; c_ < std::min(it * (size_t)s_->world, s_->dst.size()); ++c_)
                 PK_TRY(to_coeff_aux(s_->ctx, s_->pk, *s_->lag[c_], s_->coeff[c_]));
