@@ -110,6 +110,7 @@ struct zk_ctx {
     // per-kernel HIP-event profiling (zk_prof_*): off by default
     uint32_t msm_attr_set = 0;            // bit C: k_msm_m_scatter_staged<C> has its dynamic-LDS attribute on this device
     bool ntt_attr_set = false, quotient_attr_set = false;   // hipFuncSetAttribute (large dynamic LDS) is per device: remembered per context, not per process
+    uint32_t ntt_fixed_attr = 0;                             // the same for the compile-time instances of the NTT passes: bit 2 (LOG_NP - 7) + HAS_PRE for the strided pass, bit 24 + LOG_NP - 7 for the last pass
     bool prof_on = false;
     bool prof_main_only = false;         // zk_prof_enable(ctx, 2): only the scopes of the roofline kernels (accumulation, transforms, evaluator) record events
     const char* prof_tag = nullptr;      // when set, zk_quotient_eval books its launch under this name (the prover tags the big coset programs)

@@ -579,8 +579,8 @@ static int set_lds_attr(zk_ctx* ctx) {
 // launchers of the fixed-structure passes: false = this digit size has no instance (the caller takes the generic kernel)
 template <int LOG_NP, bool HAS_PRE>
 static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
-    static bool attr_set = false;          // setting it twice is harmless
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); attr_set = true; }
+    const uint32_t bit = 1u << (2 * (LOG_NP - 7) + (HAS_PRE ? 1 : 0));          // the attribute is per device: remembered per context
+    if (!(ctx->ntt_fixed_attr & bit)) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); ctx->ntt_fixed_attr |= bit; }
     hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp);
 }
 static bool ntt_fixed_on() { static const bool on = !(getenv("ZK_NTT_FIXED") && atoi(getenv("ZK_NTT_FIXED")) == 0); return on; }      // measurement knob
@@ -593,8 +593,8 @@ static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned t
 }
 template <int LOG_NP>
 static void launch_last_f(zk_ctx* ctx, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ntt_last_f<LOG_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT); attr_set = true; }
+    const uint32_t bit = 1u << (24 + LOG_NP - 7);
+    if (!(ctx->ntt_fixed_attr & bit)) { (void)hipFuncSetAttribute((const void*)k_ntt_last_f<LOG_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT); ctx->ntt_fixed_attr |= bit; }
     hipLaunchKernelGGL((k_ntt_last_f<LOG_NP>), grid, dim3(threads), lds, ctx->stream, io, tw, log_t, log_n1, log_mid, xcd_remap);
 }
 static bool launch_last_fixed(zk_ctx* ctx, int log_np, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
