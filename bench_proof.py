@@ -422,7 +422,150 @@ def build_halo2_base_shape(ctx, k: int, num_advice: int, num_lookup_advice: int 
     return c, blob, adv_m, [inst_m_full], inst_int
 
 
-def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: int = 8, seed: int = 1, dist: str = None, phases: bool = False):
+# ---------------------------------------------------------------------------------------------------------------- EVM-style block
+EVM_DEFAULT = {"states": 80, "per_state": 64, "cond_cols": 8, "input_cols": 77, "seed": 7}
+
+
+def evm_step_columns(p: dict) -> int:
+    """advice columns an EVM-style block with these parameters occupies: q_step | pair bits | odd | condition bits | inputs |
+    outputs | rw_counter"""
+    pairs = (p["states"] + 1) // 2
+    return 1 + pairs + 1 + p["cond_cols"] + p["input_cols"] + (p["per_state"] + 1) // 2 + 1
+
+
+def evm_block(c, first_col: int, q_usable, p: dict):
+    """The constraint system of an EVM-circuit-like state machine over S = evm_step_columns(p) advice columns starting at `first_col`
+    (what the reference's ExecutionConfig emits, restated as a generator -- the circuit itself needs the Rust workspace):
+
+      * a step is 2 rows high; `q_step` (an ADVICE column, as in [REF zkevm-circuits/src/evm_circuit/execution.rs:265,410]) marks
+        its first row; a step's cells are its columns at rotations 0 and 1, the next step's at rotation 2;
+      * the execution state is a DynamicSelectorHalf [REF zkevm-circuits/src/evm_circuit/step.rs:624-631]: ceil(states/2) pair bits
+        and one `odd` bit, state_selector_s = pair[s/2] * (odd or 1 - odd): degree 2;
+      * every constraint of state s is the polynomial  q_usable * q_step * state_selector_s * (constraint * condition)
+        [REF execution.rs:839-851]: implicit degree 4 [REF util/constraint_builder.rs:33-34], constraint * condition of degree 1 .. 5
+        (the builder splits only above that [REF util/constraint_builder.rs:322-341]), so the polynomials have degree 5 .. 9;
+      * `per_state` constraints per state in gadget blocks of eight that share one condition (a product of up to two condition
+        cells: the builder's condition stack), eight constraint forms (multiply-add, byte composition, triple product, select,
+        ...), each defining one output cell of the step from its input cells; one state-transition constraint per state
+        (rw_counter(next) = rw_counter + delta_s); booleanity of every selector / condition bit and "exactly one pair bit" under
+        q_usable * q_step.
+    Adds the gates to `c` and returns the spec `evm_witness` fills the columns from."""
+    import random as _random
+    rng = _random.Random(p["seed"])
+    ns, per = p["states"], p["per_state"]
+    pairs = (ns + 1) // 2
+    col = first_col
+    q_step_c = col; col += 1
+    pair_c = list(range(col, col + pairs)); col += pairs
+    odd_c = col; col += 1
+    cond_c = list(range(col, col + p["cond_cols"])); col += p["cond_cols"]
+    in_c = list(range(col, col + p["input_cols"])); col += p["input_cols"]
+    out_c = list(range(col, col + (per + 1) // 2)); col += (per + 1) // 2
+    ctr_c = col; col += 1
+    assert col - first_col == evm_step_columns(p)
+    adv = c.advice_col
+    q_step = adv(q_step_c)
+    enable = q_usable * q_step
+    odd = adv(odd_c)
+    cond_cells = [(cc, r) for cc in cond_c for r in (0, 1)]
+    in_cells = [(ic, r) for ic in in_c for r in (0, 1)]
+    out_cells = [(oc, r) for oc in out_c for r in (0, 1)][:per]
+    cell = lambda cr: adv(cr[0], cr[1])
+    # booleanity and one-hot of the selector bits, booleanity of the condition bits
+    for b_ in [adv(pc) for pc in pair_c] + [odd] + [cell(cr) for cr in cond_cells]:
+        c.add_gate(enable * (b_ * (1 - b_)))
+    tot = adv(pair_c[0])
+    for pc in pair_c[1:]:
+        tot = tot + adv(pc)
+    c.add_gate(enable * (tot - 1))
+    spec = {"q_step": q_step_c, "pair": pair_c, "odd": odd_c, "cond": cond_cells, "in": in_cells, "out": out_cells, "ctr": ctr_c, "states": []}
+    for s_ in range(ns):
+        sel = adv(pair_c[s_ // 2]) * (odd if s_ % 2 else (1 - odd))
+        delta = 1 + s_ % 5
+        c.add_gate(enable * sel * (adv(ctr_c, 2) - adv(ctr_c) - delta))
+        cons = []
+        for j in range(per):
+            if j % 8 == 0:      # a new gadget block: its condition (shared by the block's constraints)
+                nc = (j // 8 + s_) % 3
+                cc_ = rng.sample(range(len(cond_cells)), nc)
+            a_, b_, c_, d_ = (rng.randrange(len(in_cells)) for _ in range(4))
+            if j % 8 == 3 and cons:                # reuses the product a*b of the block's first constraint (what a gadget's cached expressions look like)
+                a_, b_ = cons[j - 3]["in"][0], cons[j - 3]["in"][1]
+            form = j % 8
+            sel_bit = rng.randrange(len(cond_cells))
+            a, b, cx, dx, o = cell(in_cells[a_]), cell(in_cells[b_]), cell(in_cells[c_]), cell(in_cells[d_]), cell(out_cells[j])
+            if form == 0: e = a * b + cx - o
+            elif form == 1: e = a + b * 256 + cx * 65536 - o
+            elif form == 2: e = a * b * cx - o
+            elif form == 3: e = a * b * dx - o
+            elif form == 4: e = cell(cond_cells[sel_bit]) * a + (1 - cell(cond_cells[sel_bit])) * b - o
+            elif form == 5: e = a * (b + cx) - o
+            elif form == 6: e = a - b + 255 - o
+            else: e = a * a + b - o
+            if cc_:
+                cnd = cell(cond_cells[cc_[0]])
+                for x in cc_[1:]:
+                    cnd = cnd * cell(cond_cells[x])
+                e = e * cnd
+            c.add_gate(enable * sel * e)
+            cons.append({"form": form, "in": (a_, b_, c_, d_), "sel_bit": sel_bit, "cond": list(cc_)})
+        spec["states"].append({"delta": delta, "cons": cons})
+    return spec
+
+
+def evm_witness(spec: dict, n: int, u: int, seed: int = 3):
+    """a satisfying assignment of the block's columns: {column: uint64 array of n canonical values}, and the q_usable column.
+    Steps on the even rows below u - 4 with a random execution state each; inputs are bytes, outputs what the step's state defines
+    them to be where the gadget's condition holds and arbitrary bytes where it does not."""
+    rng = np.random.default_rng(seed)
+    rows = np.arange(0, u - 4, 2)
+    ns = len(spec["states"])
+    state = rng.integers(0, ns, size=rows.size)
+    cols = {}
+    z = lambda: np.zeros(n, dtype=np.uint64)
+    q_usable = z(); q_usable[:rows[-1] + 2] = 1
+    cols[spec["q_step"]] = z(); cols[spec["q_step"]][rows] = 1
+    for j, pc in enumerate(spec["pair"]):
+        cols[pc] = z(); cols[pc][rows[state // 2 == j]] = 1
+    cols[spec["odd"]] = z(); cols[spec["odd"]][rows] = (state % 2).astype(np.uint64)
+    getc = lambda cidx: cols.setdefault(cidx, z())
+    cval = {}
+    for (cc, r) in spec["cond"]:
+        v = rng.integers(0, 2, size=rows.size, dtype=np.uint64)
+        getc(cc)[rows + r] = v
+        cval[(cc, r)] = v
+    ival = {}
+    for (ic, r) in spec["in"]:
+        v = rng.integers(0, 256, size=rows.size, dtype=np.uint64)
+        getc(ic)[rows + r] = v
+        ival[(ic, r)] = v
+    delta = np.array([st["delta"] for st in spec["states"]], dtype=np.uint64)
+    ctr = np.concatenate([[0], np.cumsum(delta[state])]).astype(np.uint64)       # one more cell: the last step's "next"
+    getc(spec["ctr"])[np.concatenate([rows, [rows[-1] + 2]])] = ctr
+    garbage = rng.integers(0, 256, size=(len(spec["out"]), rows.size), dtype=np.uint64)
+    for s_, st in enumerate(spec["states"]):
+        m = state == s_
+        for j, cn in enumerate(st["cons"]):
+            a, b, cx, dx = (ival[spec["in"][i]][m] for i in cn["in"])
+            f = cn["form"]
+            if f == 0: o = a * b + cx
+            elif f == 1: o = a + b * np.uint64(256) + cx * np.uint64(65536)
+            elif f == 2: o = a * b * cx
+            elif f == 3: o = a * b * dx
+            elif f == 4: sb = cval[spec["cond"][cn["sel_bit"]]][m]; o = sb * a + (np.uint64(1) - sb) * b
+            elif f == 5: o = a * (b + cx)
+            elif f == 6: o = a + np.uint64(255) - b
+            else: o = a * a + b
+            holds = np.ones(o.size, dtype=bool)
+            for x in cn["cond"]:
+                holds &= cval[spec["cond"][x]][m] == 1
+            o = np.where(holds, o, garbage[j][m])
+            oc, r = spec["out"][j]
+            getc(oc)[rows[m] + r] = o
+    return cols, q_usable
+
+
+def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: int = 8, seed: int = 1, dist: str = None, phases: bool = False, evm: dict = None):
     """SURVEY 8d config 4 stand-in: a circuit with the SuperCircuit's *shape* (A advice, F fixed,
     P permutation columns, L lookups, max degree d).  Same ingredients as `build_large`; to keep
     the host side small only `distinct` advice triples hold distinct data (the other triples
@@ -438,16 +581,22 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
       the first phase, `lookup_input` after the second; as in the EVM circuit [REF zkevm-circuits/src/evm_circuit/execution.rs:418-431]
       ~8 % of the columns are third-phase and a handful second-phase.  The last two advice columns are RLCs that need the challenges:
       w = q_lk * (a_0 + evm_word * b_0) (second phase), t = q_lk * (w + lookup_input * b_0) (third phase); the caller computes them
-      between the phases (`phase_columns`).  With phases the function returns a sixth value: that callback's ingredients."""
+      between the phases (`phase_columns`).  With phases the function returns a sixth value: that callback's ingredients.
+    evm -- parameters of an EVM-style block (`evm_block`, EVM_DEFAULT): evm_step_columns(evm) of the A advice columns become the step
+      columns of an execution-state machine whose >= 5 000 constraints of degree 5 .. 9 read them at rotations 0 / 1 / 2 -- every one of
+      them on all 8 cosets --; the other columns keep the triple gates, and the lookups become 4- / 6- / 8-column tuples (three
+      neighbouring triples' a, b, c on a lookup row, into (t_a, t_b, t_c) repeated).  The adverse degree structure of the two shapes
+      (round-5 review: the plain shape has ONE degree-9 gate on three columns)."""
     import struct
     rng = np.random.default_rng(seed)
     if dist is None:
         dist = "dense" if os.environ.get("ZK_BENCH_DENSE") == "1" else "small"
     assert dist in ("small", "survey", "dense")
     vbits = 8 if dist == "survey" else 30            # operand size: products below 2^16 / 2^60
-    groups = (A - 2) // 3 if phases else A // 3
-    S = max(1, (F - 4) // 2)                       # selector classes: q_mul[j], q_add[j]
-    assert F >= 2 * S + 4 and groups >= 1 and d >= 5 and P >= 2
+    n_step = evm_step_columns(evm) if evm else 0
+    groups = (A - 2 - n_step) // 3 if phases else (A - n_step) // 3
+    S = max(1, (F - (6 if evm else 4)) // 2)       # selector classes: q_mul[j], q_add[j]
+    assert F >= 2 * S + (6 if evm else 4) and groups >= (3 if evm else 1) and d >= 5 and P >= 2
     c = plonk.Circuit(k, num_fixed=F, num_advice=A, num_instance=1, blinding_factors=5)
     c.fixed = None                                  # fixed columns live in the blob only (numpy), not as Python ints
     n, u = c.n, c.u
@@ -472,9 +621,18 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
         w_, t_ = c.advice_col(A - 2), c.advice_col(A - 1)
         c.add_gate(q_lk * (a0 + evm_word * b0 - w_))                       # selector-gated: the blinding rows of w and t are free
         c.add_gate(q_lk * (w_ + lookup_input * b0 + keccak_input * 0 - t_))
+    evm_spec = None
+    if evm:
+        q_usable, t_c = c.fixed_col(2 * S + 4), c.fixed_col(2 * S + 5)
+        evm_spec = evm_block(c, 3 * groups, q_usable, evm)
     for j in range(L):
         g = j % groups
-        c.add_lookup([q_lk * c.advice_col(3 * g), q_lk * c.advice_col(3 * g + 1)], [t_a, t_b])
+        if evm:      # tuples of 4 / 6 / 8 cells: a, b, c of this triple and of its neighbours, all holding (i, i^2 + 3, 7 i + 1) of ONE i on a lookup row
+            width = (4, 6, 8)[j % 3]
+            cells = [c.advice_col(3 * ((g + t) % groups) + i) for t in range(3) for i in range(3)][:width]
+            c.add_lookup([q_lk * x for x in cells], [(t_a, t_b, t_c)[i % 3] for i in range(width)])
+        else:
+            c.add_lookup([q_lk * c.advice_col(3 * g), q_lk * c.advice_col(3 * g + 1)], [t_a, t_b])
     for col in range(min(P - 1, A)):
         c.enable_equality(plonk.ADVICE, col)
     c.enable_equality(plonk.INSTANCE, 0)
@@ -496,8 +654,11 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
         x = rng.integers(0, 1 << vbits, size=r_add.size, dtype=np.uint64)
         y = rng.integers(0, 1 << vbits, size=r_add.size, dtype=np.uint64)
         data[t, 0, r_add], data[t, 1, r_add], data[t, 2, r_add + 1] = x, y, x + y
-        i = rng.integers(1, tab_n, size=r_lk.size, dtype=np.uint64)       # every triple may be a lookup input
+        if not (evm and t):
+            i = rng.integers(1, tab_n, size=r_lk.size, dtype=np.uint64)   # every triple may be a lookup input (evm: the SAME i in every triple of a row -- the tuples span triples)
         data[t, 0, r_lk], data[t, 1, r_lk] = i, i * i + 3
+        if evm:
+            data[t, 2, r_lk] = i * np.uint64(7) + np.uint64(1)
         # copy pairs (product of a mul row feeds `a` of the next one), same pattern in every triple
         data[t, 0, dst] = data[t, 2, src] % np.uint64(1 << vbits)
         data[t, 2, src] = data[t, 0, dst]
@@ -529,6 +690,14 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
                 data_m[t][i][pick] = limbs
     zero_col = np.zeros((n, 4), dtype=np.uint64)
     adv_m = [data_m[(col // 3) % D][col % 3] if col < 3 * groups else zero_col for col in range(A)]
+    f_usable = f_tc = zero_col
+    if evm:
+        step_cols, usable = evm_witness(evm_spec, n, u, seed + 2)
+        for col, v in step_cols.items():
+            adv_m[col] = to_mont_gpu(ctx, small_to_limbs(v))
+        f_usable = to_mont_gpu(ctx, small_to_limbs(usable))
+        tc = np.zeros(n, dtype=np.uint64); tc[1:tab_n] = ti[1:] * np.uint64(7) + np.uint64(1)
+        f_tc = to_mont_gpu(ctx, small_to_limbs(tc))
     inst_m = [to_mont_gpu(ctx, small_to_limbs(inst[0]))]
 
     def sel(rows_):
@@ -539,7 +708,7 @@ def build_shape(ctx, k: int, A: int, F: int, P: int, L: int, d: int, distinct: i
     ta = np.zeros(n, dtype=np.uint64); ta[1:tab_n] = ti[1:]
     tb = np.zeros(n, dtype=np.uint64); tb[1:tab_n] = ti[1:] * ti[1:] + 3
     f_ta, f_tb = to_mont_gpu(ctx, small_to_limbs(ta)), to_mont_gpu(ctx, small_to_limbs(tb))
-    fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb][i - 2 * S] if i < 2 * S + 4 else zero_col)
+    fixed_of = lambda i: (f_mul if i % 2 == 0 else f_add) if i < 2 * S else ([f_hi, f_lk, f_ta, f_tb, f_usable, f_tc][i - 2 * S] if i < 2 * S + 6 else zero_col)
     blob = assemble_blob(ctx, c, F, fixed_of, copies)
     inst_int = [[int(v) for v in inst[0]]]
     if phases:

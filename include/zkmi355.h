@@ -200,6 +200,24 @@ int zk_host_additive_split(const uint32_t* words, uint32_t num_instr, uint32_t E
 int zk_host_group_terms(const uint32_t* words, const uint32_t* lens, const uint32_t* cons, uint32_t count, uint32_t K, uint32_t* out_words, size_t out_cap_words,
                         uint32_t* out_instr);
 
+/* Host only, for tests: the program of ONE degree class as the prover COMPILES it (round 6; csrc/class_compile.hpp) -- what halo2's
+ * GraphEvaluator (plonk/evaluation.rs, external crate) does for a circuit whose gates share sub-expressions, done on this side of the
+ * boundary: the terms become one hash-consed expression graph (TEE_TMP / PUSH_TMP of the incoming programs resolved), the y-weighted
+ * sum is regrouped under common FACTORS of any shape (a selector product q_usable * q_step * state_selector, a gadget's condition
+ * [REF zkevm-circuits/src/evm_circuit/execution.rs:832-851]), sums run in Horner form over the constraint index, values still used
+ * twice are parked in slots assigned by liveness.  The program leaves acc = sum_t y^(*out_last - cons[t]) term_t.  out_stats[0..5] =
+ * graph nodes, values parked, slots alive at once, products, factor groups, stack depth.  ZK_ERR_UNSUPPORTED: stack too deep (the
+ * prover then keeps zk_host_group_terms' form). */
+int zk_host_compile_class(const uint32_t* words, const uint32_t* lens, const uint32_t* cons, uint32_t count, uint32_t K, uint32_t* out_words, size_t out_cap_words,
+                          uint32_t* out_instr, uint32_t* out_last, uint32_t* out_stats);
+/* Host only (no device, no SRS): the quotient plan of a constraint system -- degree classes, additive split, each class's compiled
+ * program -- exactly as zk_proof_finish will follow it; cs_blob = the constraint-system part of a zk_pk_create blob (column data
+ * not needed).  out_summary: [0] ext_k - k, [1] constraints, [2] classes on, [3] additive split on, [4] expression graph on,
+ * [5] remainder polynomials, [6] cost estimate, [7] columns read; then 8 words per class: used, instructions, products, columns,
+ * values parked, slots alive at once, factor groups, last.  class_index / out_words / out_instr: one class's program (optional). */
+int zk_host_quotient_plan(const void* cs_blob, size_t blob_len, uint32_t* out_summary, size_t cap_summary, uint32_t class_index, uint32_t* out_words, size_t out_cap_words,
+                          uint32_t* out_instr);
+
 /* out[i] = base^i * mul for i < n (Montgomery form): omega-power / delta-power "columns"          */
 int zk_fr_powers(zk_ctx* ctx, const void* h_base, const void* h_mul, void* d_out, size_t n);
 /* logUp multiplicities (halo2 Scroll fork, plonk/mv_lookup/prover.rs: m(X)): d_m[i] = number of rows
@@ -330,6 +348,10 @@ int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk* pk, const void* h_repr_fr32);
  * phases, challenges, blinding factors, advice queries, fixed queries, commitments per proof,
  * evaluations per proof                                                                            */
 int zk_pk_shape(zk_ctx* ctx, const zk_pk* pk, uint32_t* out16);
+/* The quotient plan of a key -- how its constraints are dealt to degree classes and what each class's program costs (halo2's
+ * `Evaluator::new` builds the corresponding GraphEvaluator at keygen, plonk/evaluation.rs, external crate): zk_host_quotient_plan's
+ * summary (8 + 8 x (extended_k - k + 1) words) for `pk` under the measurement knobs in force.  Made on first use, kept by the key. */
+int zk_pk_quotient_plan(zk_ctx* ctx, const zk_pk* pk, uint32_t* out_summary, size_t cap_summary);
 /* create_proof: h_advice / h_instance are arrays of host pointers to n x 32-byte Lagrange columns;
  * seed16 seeds the XorShift blinding RNG; the proof bytes (compressed points and canonical
  * scalars, halo2 encoding) are written to h_proof.  Fails with ZK_ERR_INVALID_ARG if the witness

@@ -190,3 +190,59 @@ def build_multi_lookup_circuit(k: int, seed: int = 1, n_inputs: int = 3, input_d
         adv[A - 2][row] = c.fixed[3][rng.randrange(u)]
         adv[A - 1][row] = pow(adv[0][row], gate_degree - 1, R) if on else rng.randrange(R)
     return c, adv, []
+
+
+def build_evm_circuit(k: int, seed: int = 1, states: int = 6, per_state: int = 16, input_cols: int = 5, cond_cols: int = 2):
+    """The EVM-style shape of the bench (bench_proof.evm_block: an execution-state machine whose constraints are
+    q_usable * q_step * state_selector_s * (constraint * condition), degree 5 .. 9, step cells at rotations 0 / 1 / 2
+    [REF zkevm-circuits/src/evm_circuit/execution.rs:832-851]) at a size the big-int prover handles, with the other ingredients of
+    bench_proof.build_shape(evm=...) beside it:
+
+    columns: fixed  0 q_usable | 1 q_mul | 2 q_lk | 3 t_a | 4 t_b | 5 t_c
+             advice 0 .. S-1 the step columns | S a | S+1 b | S+2 c | S+3 a' | S+4 b' | S+5 c'      instance 0
+    gates:   the block's (booleanity, one-hot, one transition and `per_state` gadget constraints per state),  q_mul (a b - c)
+    lookup:  (q_lk a, q_lk b, q_lk c, q_lk a') in (t_a, t_b, t_c, t_a)      -- a 4-column tuple spanning two triples
+    copies:  rw_counter cells of the block == instance cells; c of one mul row == a of another"""
+    import numpy as np
+    import bench_proof as bp
+    rng = random.Random(seed)
+    p = {"states": states, "per_state": per_state, "cond_cols": cond_cols, "input_cols": input_cols, "seed": seed + 4}
+    S = bp.evm_step_columns(p)
+    c = plonk.Circuit(k, num_fixed=6, num_advice=S + 6, num_instance=1, blinding_factors=5)
+    n, u = c.n, c.u
+    q_usable, q_mul, q_lk, t_a, t_b, t_c = (c.fixed_col(i) for i in range(6))
+    spec = bp.evm_block(c, 0, q_usable, p)
+    a, b_, cc, a2, b2, c2 = (c.advice_col(S + i) for i in range(6))
+    c.add_gate(q_mul * (a * b_ - cc))
+    c.add_gate(q_mul * (a2 * b2 - c2))
+    c.add_lookup([q_lk * a, q_lk * b_, q_lk * cc, q_lk * a2], [t_a, t_b, t_c, t_a])
+    cols, usable = bp.evm_witness(spec, n, u, seed + 2)
+    adv = [[0] * n for _ in range(S + 6)]
+    for col, v in cols.items():
+        adv[col] = [int(x) for x in v]
+    c.fixed[0] = [int(x) for x in usable]
+    tab_n = min(40, u)
+    for i in range(1, tab_n):
+        c.fixed[3][i], c.fixed[4][i], c.fixed[5][i] = i, i * i + 3, 7 * i + 1
+    mul_rows = []
+    for row in range(1, u - 1):
+        if row % 3 == 0:
+            c.fixed[1][row] = 1
+            x, y, x2, y2 = (rng.randrange(R) for _ in range(4))
+            adv[S][row], adv[S + 1][row], adv[S + 2][row] = x, y, x * y % R
+            adv[S + 3][row], adv[S + 4][row], adv[S + 5][row] = x2, y2, x2 * y2 % R
+            mul_rows.append(row)
+        elif row % 3 == 1:
+            c.fixed[2][row] = 1
+            i = rng.randrange(1, tab_n)
+            adv[S][row], adv[S + 1][row], adv[S + 2][row], adv[S + 3][row] = i, i * i + 3, 7 * i + 1, i
+    for r0, r1 in zip(mul_rows[:-1:2], mul_rows[1::2]):
+        adv[S][r1] = adv[S + 2][r0]
+        adv[S + 2][r1] = adv[S][r1] * adv[S + 1][r1] % R
+        c.copy((plonk.ADVICE, S + 2, r0), (plonk.ADVICE, S, r1))
+    inst = [[0] * n]
+    for j, row in enumerate((0, 2, 4, 6)):
+        inst[0][j] = adv[spec["ctr"]][row]
+        c.copy((plonk.ADVICE, spec["ctr"], row), (plonk.INSTANCE, 0, j))
+    c.evm_spec = spec
+    return c, adv, inst

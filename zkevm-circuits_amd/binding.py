@@ -167,10 +167,25 @@ class ProvingKey:
                  "advice_queries", "fixed_queries", "commitments", "evaluations"]
         return dict(zip(names, list(out)))
 
+    def quotient_plan(self) -> dict:
+        """how the key's constraints are dealt to degree classes and what each class's compiled program costs (zk_pk_quotient_plan)"""
+        out = (ctypes.c_uint32 * (8 + 8 * 16))()
+        self.ctx._ck(lib().zk_pk_quotient_plan(self.ctx.h, self.h, out, ctypes.c_size_t(len(out))))
+        return plan_summary(list(out))
+
     def destroy(self):
         if self.h:
             lib().zk_pk_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+def plan_summary(words) -> dict:
+    """the summary words of zk_host_quotient_plan / zk_pk_quotient_plan as a dict"""
+    E = int(words[0])
+    names = ("used", "instructions", "products", "columns", "values_parked", "slots_alive", "factor_groups", "last")
+    return {"classes_E": E, "constraints": int(words[1]), "degree_classes": int(words[2]), "additive_split": int(words[3]), "expression_graph": int(words[4]),
+            "remainders": int(words[5]), "cost_estimate": int(words[6]), "columns": int(words[7]),
+            "classes": [dict(zip(names, (int(v) for v in words[8 + 8 * e:16 + 8 * e]))) for e in range(E + 1)]}
 
 
 TRANSCRIPT_BLAKE2B, TRANSCRIPT_POSEIDON, TRANSCRIPT_EVM = 0, 1, 2

@@ -31,6 +31,9 @@
 #include <algorithm>
 #include <array>
 #include <unordered_map>
+#include <unordered_set>
+#include <memory>
+#include <string>
 
 #include <chrono>
 #include <cstdlib>
@@ -143,6 +146,7 @@ struct StageTrace {
 
 }  // namespace
 
+struct QuotientPlan;
 struct zk_pk {
     uint32_t k = 0, bf = 0, d = 0, ext_k = 0, F = 0, A = 0, I = 0, P = 0, L = 0;
     uint32_t chunk = 0, C = 0, u = 0;   // permutation chunk size, #chunks, last usable row index
@@ -169,6 +173,7 @@ struct zk_pk {
     F4 vk_repr;                              // vk.transcript_repr: the default, or what zk_pk_set_transcript_repr installed
     std::vector<Query> inst_q;               // instance queries (verifier side; carried for the vk)
     const zk_srs* srs = nullptr;
+    mutable std::shared_ptr<const QuotientPlan> qplan;      // the quotient's plan (degree classes, class programs), made on first use
 };
 
 struct zk_proof {
@@ -493,48 +498,44 @@ void zk_pk_destroy(zk_ctx* ctx, zk_pk* pk) {
     delete pk;
 }
 
-// keygen_pk: parse the blob, make the key material device resident, commit fixed / sigma columns.
-int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out) {
-    if (!ctx) return ZK_ERR_INVALID_ARG;
-    ZK_REQUIRE(ctx, srs && h_blob && out, "null pointer");
-    Reader r{(const uint8_t*)h_blob, blob_len};
-    if (r.u32() != 0x4B505A4Bu) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic");
+// The constraint-system part of a key blob (everything before the column data) into `pk`: shape, phases, query lists,
+// permutation columns, constants, gate and lookup programs -- with every count checked against what the blob can hold and the
+// declared degree against what the programs need.  No device, no SRS (zk_pk_create goes on from here; the host-only hooks stop here).
+static int parse_cs(Reader& r, zk_pk* pk, size_t blob_len, bool with_columns, std::string* err) {
+    char msg[256];
+    auto fail = [&](int code, const char* fmt, auto... args) { snprintf(msg, sizeof msg, fmt, args...); *err = msg; return code; };
+    if (r.u32() != 0x4B505A4Bu) return fail(ZK_ERR_INVALID_ARG, "pk blob: bad magic");
     const uint32_t version = r.u32();
-    if (version != 3u) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: unsupported version %u (this library reads version 3)", version);
-    std::unique_ptr<zk_pk> pk(new zk_pk());
-    pk->srs = srs;
+    if (version != 3u) return fail(ZK_ERR_INVALID_ARG, "pk blob: unsupported version %u (this library reads version 3)", version);
     pk->k = r.u32(); pk->bf = r.u32(); pk->d = r.u32(); pk->F = r.u32(); pk->A = r.u32(); pk->I = r.u32(); pk->P = r.u32(); pk->L = r.u32();
     const uint32_t ngates = r.u32(), nconsts = r.u32();
     // halo2: cs.degree() >= 3 (the permutation argument); the extended domain has at most 2^28 rows
-    if (!r.ok || pk->k < 2 || pk->k > 27 || pk->d < 3 || pk->d > 17) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad header (k=%u, degree=%u)", pk->k, pk->d);
-    // commit_lagrange needs the Lagrange basis of exactly this domain (halo2: ParamsKZG::downsize)
-    if (pk->k != srs->k) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS is for k=%u but the circuit has k=%u: downsize the SRS first", srs->k, pk->k);
+    if (!r.ok || pk->k < 2 || pk->k > 27 || pk->d < 3 || pk->d > 17) return fail(ZK_ERR_INVALID_ARG, "pk blob: bad header (k=%u, degree=%u)", pk->k, pk->d);
     const size_t n = (size_t)1 << pk->k;
-    if (pk->bf + 2 >= n) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many blinding rows");
-    if (!srs->g_lagrange) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS has no Lagrange basis");
+    if (pk->bf + 2 >= n) return fail(ZK_ERR_INVALID_ARG, "pk blob: too many blinding rows");
     // every count of the header is checked against what the blob can hold before anything is sized by it
     if ((size_t)pk->A * 4 > r.left || (size_t)pk->P * 8 > r.left || (size_t)nconsts * 32 > r.left || (size_t)ngates * 4 > r.left || (size_t)pk->L * 8 > r.left ||
-        ((size_t)pk->F + pk->P) > r.left / (n * 32) || pk->A > 0xFFFFFFu || pk->F > 0xFFFFFFu || pk->I > 0xFFFFFFu)
-        return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: header counts exceed the blob (%zu bytes)", blob_len);
+        (with_columns && ((size_t)pk->F + pk->P) > r.left / (n * 32)) || pk->A > 0xFFFFFFu || pk->F > 0xFFFFFFu || pk->I > 0xFFFFFFu)
+        return fail(ZK_ERR_INVALID_ARG, "pk blob: header counts exceed the blob (%zu bytes)", blob_len);
     pk->u = (uint32_t)n - pk->bf - 1;
     pk->chunk = pk->d - 2;
     pk->C = pk->P ? (pk->P + pk->chunk - 1) / pk->chunk : 0;
     pk->ext_k = pk->k;
     while (((size_t)1 << pk->ext_k) < n * (pk->d - 1)) ++pk->ext_k;
-    if (pk->ext_k > 28) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: extended domain 2^%u exceeds the two-adicity of Fr", pk->ext_k);
+    if (pk->ext_k > 28) return fail(ZK_ERR_INVALID_ARG, "pk blob: extended domain 2^%u exceeds the two-adicity of Fr", pk->ext_k);
     pk->adv_phase.assign(pk->A, 0);
     {   // phases: [num_challenges][A x advice phase][num_challenges x challenge phase]
         const uint32_t nch = r.count(4);
-        if (nch > 4096) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: too many challenges");
+        if (nch > 4096) return fail(ZK_ERR_INVALID_ARG, "pk blob: too many challenges");
         for (uint32_t i = 0; i < pk->A && r.ok; ++i) { pk->adv_phase[i] = r.u32(); if (pk->adv_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->adv_phase[i] + 1; }
         for (uint32_t i = 0; i < nch && r.ok; ++i) { pk->chal_phase.push_back(r.u32()); if (pk->chal_phase[i] + 1 > pk->num_phases) pk->num_phases = pk->chal_phase[i] + 1; }
-        if (!r.ok || pk->num_phases > 16) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad phase table");
+        if (!r.ok || pk->num_phases > 16) return fail(ZK_ERR_INVALID_ARG, "pk blob: bad phase table");
     }
     // cs.advice_queries / fixed_queries / instance_queries: (column, rotation) in registration order
     r.queries(&pk->adv_q, CT_ADVICE, pk->A);
     r.queries(&pk->fix_q, CT_FIXED, pk->F);
     r.queries(&pk->inst_q, CT_INSTANCE, pk->I);
-    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad query lists");
+    if (!r.ok) return fail(ZK_ERR_INVALID_ARG, "pk blob: bad query lists");
     for (uint32_t i = 0; i < pk->P && r.ok; ++i) { uint32_t t = r.u32(), x = r.u32(); pk->perm_cols.push_back({t, x}); }
     for (uint32_t i = 0; i < nconsts && r.ok; ++i) { const uint8_t* b = r.bytes(32); F4 v; if (b) memcpy(v.l, b, 32); pk->consts.push_back(v); }
     for (uint32_t i = 0; i < ngates && r.ok; ++i) pk->gates.push_back(r.prog());
@@ -549,8 +550,7 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         }
         pk->lookups.push_back(std::move(lk));
     }
-    if (!r.ok) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: truncated or malformed constraint system");
-    const size_t cs_len = blob_len - r.left;        // the constraint-system part: everything before the column data
+    if (!r.ok) return fail(ZK_ERR_INVALID_ARG, "pk blob: truncated or malformed constraint system");
     // The degree the blob declares must cover what its own programs need (halo2 ConstraintSystem::degree:
     // permutation argument 3, mv_lookup::Argument::required_degree, every gate polynomial): with a
     // smaller one the quotient would not fit its d - 1 pieces and the proof would be rejected.
@@ -559,30 +559,50 @@ int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob
         std::vector<int> tmp_deg;
         for (const Prog& g : pk->gates) {
             const int dg = program_degree(g, &tmp_deg);
-            if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed gate program");
+            if (dg < 0) return fail(ZK_ERR_INVALID_ARG, "pk blob: malformed gate program");
             need = std::max(need, (uint32_t)dg);
         }
         for (const auto& lk : pk->lookups) {
             std::vector<int> none;
             int table_degree = 0, inputs_degree = 0;
-            for (const Prog& g : lk.tables) { const int dg = program_degree(g, &none); if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup table program"); table_degree = std::max(table_degree, dg); }
+            for (const Prog& g : lk.tables) { const int dg = program_degree(g, &none); if (dg < 0) return fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup table program"); table_degree = std::max(table_degree, dg); }
             for (const auto& in : lk.inputs) {
                 int one = 0;
-                for (const Prog& g : in) { const int dg = program_degree(g, &none); if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup input program"); one = std::max(one, dg); }
+                for (const Prog& g : in) { const int dg = program_degree(g, &none); if (dg < 0) return fail(ZK_ERR_INVALID_ARG, "pk blob: malformed lookup input program"); one = std::max(one, dg); }
                 inputs_degree += one;
             }
             need = std::max(need, std::max((uint32_t)(3 + lk.inputs.size()), (uint32_t)(table_degree + inputs_degree + 2)));
         }
-        if (pk->d < need) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: declared degree %u is below the %u its gates and lookup arguments require", pk->d, need);
+        if (pk->d < need) return fail(ZK_ERR_INVALID_ARG, "pk blob: declared degree %u is below the %u its gates and lookup arguments require", pk->d, need);
     }
     for (const auto& pc : pk->perm_cols) {          // halo2: enable_equality queries the column at Rotation::cur()
-        if (pc.first > CT_INSTANCE) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: bad permutation column type %u", pc.first);
+        if (pc.first > CT_INSTANCE) return fail(ZK_ERR_INVALID_ARG, "pk blob: bad permutation column type %u", pc.first);
         if (pc.first == CT_INSTANCE) continue;
         const std::vector<Query>& qs = pc.first == CT_ADVICE ? pk->adv_q : pk->fix_q;
         bool seen = false;
         for (const Query& q : qs) if (q.idx == pc.second && q.rot == 0) { seen = true; break; }
-        if (!seen) return ctx->fail(ZK_ERR_INVALID_ARG, "pk blob: permutation column (%u, %u) is not queried at rotation 0", pc.first, pc.second);
+        if (!seen) return fail(ZK_ERR_INVALID_ARG, "pk blob: permutation column (%u, %u) is not queried at rotation 0", pc.first, pc.second);
     }
+    return ZK_OK;
+}
+
+// keygen_pk: parse the blob, make the key material device resident, commit fixed / sigma columns.
+int zk_pk_create(zk_ctx* ctx, const zk_srs* srs, const void* h_blob, size_t blob_len, zk_pk** out) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, srs && h_blob && out, "null pointer");
+    Reader r{(const uint8_t*)h_blob, blob_len};
+    std::unique_ptr<zk_pk> pk(new zk_pk());
+    pk->srs = srs;
+    {
+        std::string err;
+        const int rc = parse_cs(r, pk.get(), blob_len, true, &err);
+        if (rc) return ctx->fail(rc, "%s", err.c_str());
+    }
+    // commit_lagrange needs the Lagrange basis of exactly this domain (halo2: ParamsKZG::downsize)
+    if (pk->k != srs->k) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS is for k=%u but the circuit has k=%u: downsize the SRS first", srs->k, pk->k);
+    if (!srs->g_lagrange) return ctx->fail(ZK_ERR_INVALID_ARG, "SRS has no Lagrange basis");
+    const size_t n = (size_t)1 << pk->k;
+    const size_t cs_len = blob_len - r.left;        // the constraint-system part: everything before the column data
     // fixed + sigma columns
     pk->fixed_lag.resize(pk->F); pk->fixed_coeff.resize(pk->F);
     pk->sigma_lag.resize(pk->P); pk->sigma_coeff.resize(pk->P);
@@ -1173,13 +1193,14 @@ static void build_constraints(const zk_pk* pk, std::vector<Prog>& cons, bool& ga
     gates_share_tmps_out = gates_share_tmps;
 }
 // e = ceil(log2(degree - 1)) of every constraint (its degree class, see zk_proof_finish), or E for all when classes are off
-static int classify_constraints(zk_ctx* ctx, const zk_pk* pk, const std::vector<Prog>& cons, bool split, uint32_t E, std::vector<uint32_t>& cls) {
+static int classify_constraints(std::string* err, const zk_pk* pk, const std::vector<Prog>& cons, bool split, uint32_t E, std::vector<uint32_t>& cls) {
     cls.assign(cons.size(), E);
     std::vector<int> tmp_deg;
+    char msg[160];
     for (uint32_t i = 0; i < cons.size(); ++i) {
         const int dg = program_degree(cons[i], &tmp_deg);
-        if (dg < 0) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: malformed constraint program %u", i);
-        if ((uint32_t)dg > pk->d) return ctx->fail(ZK_ERR_INVALID_ARG, "prover: constraint %u has degree %d above the circuit degree %u", i, dg, pk->d);
+        if (dg < 0) { snprintf(msg, sizeof msg, "prover: malformed constraint program %u", i); *err = msg; return ZK_ERR_INVALID_ARG; }
+        if ((uint32_t)dg > pk->d) { snprintf(msg, sizeof msg, "prover: constraint %u has degree %d above the circuit degree %u", i, dg, pk->d); *err = msg; return ZK_ERR_INVALID_ARG; }
         uint32_t e = 0;
         while (e < E && ((uint32_t)1 << e) < (uint32_t)std::max(dg - 1, 1)) ++e;
         cls[i] = split ? e : E;
@@ -1287,9 +1308,12 @@ static bool additive_split(const Prog& g, uint32_t E, uint32_t whole_cls, std::v
     return true;
 }
 // the pieces the classes evaluate, in constraint order (a constraint's pieces by ascending class)
-static void class_pieces(const std::vector<Prog>& cons, const std::vector<uint32_t>& cls, bool split, uint32_t E, std::vector<ClassPiece>& out) {
+static bool quotient_addsplit_enabled() {
     const char* env = getenv("ZK_QUOTIENT_ADDSPLIT");
-    const bool on = split && !(env && atoi(env) == 0);
+    return !(env && atoi(env) == 0);
+}
+static void class_pieces(const std::vector<Prog>& cons, const std::vector<uint32_t>& cls, bool split, bool addsplit, uint32_t E, std::vector<ClassPiece>& out) {
+    const bool on = split && addsplit;
     for (uint32_t i = 0; i < cons.size(); ++i) {
         std::vector<std::pair<uint32_t, Prog>> parts;
         if (on && cls[i] > 0 && additive_split(cons[i], E, cls[i], parts)) {
@@ -1399,6 +1423,11 @@ static bool quotient_group_enabled() {
     const char* env = getenv("ZK_QUOTIENT_GROUP");
     return !(env && atoi(env) == 0);
 }
+#include "class_compile.hpp"
+static bool quotient_dag_enabled() {
+    const char* env = getenv("ZK_QUOTIENT_DAG");
+    return !(env && atoi(env) == 0);
+}
 // Intermediates shared between constraints (TEE_TMP in one gate, PUSH_TMP in a later one: the common-subexpression
 // elimination of halo2's GraphEvaluator as it survives the export) and degree classes: a class evaluates only ITS constraints,
 // so a class that reads an intermediate another class parked must compute it itself.  `TmpSplit` re-materialises: walking the
@@ -1479,39 +1508,178 @@ static bool quotient_split_enabled(bool sharded, bool gates_share_tmps) {
     (void)sharded;                            // sharded sessions distribute (class, coset) pairs over the ranks (zk_proof_finish)
     return !(split_env && atoi(split_env) == 0);
 }
+// ---- the quotient's plan: which constraint (or part of one) is evaluated in which degree class, and each class's program --------
+// A pure function of the key and of the measurement knobs, so it is made once per key (zk_pk::qplan) and shared by the advice
+// phases (which cosets read which column) and zk_proof_finish.  Candidates: degree classes with the additive split, degree
+// classes alone, one class -- the cheapest by a count of what each would execute (below) is taken; ZK_QUOTIENT_COSTGATE=0 takes
+// the most split one the knobs allow, as rounds 3-5 did.
+struct QPlanClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; uint32_t products = 0, parked = 0, max_live = 0, groups = 0; };
+struct QPlanRem { uint32_t t = 0, e = 0; Prog prog; uint32_t last = 0; bool used = false; uint32_t products = 0; };
+struct QuotientPlan {
+    std::string key;                 // the knob values the plan was made under
+    uint32_t K = 0, E = 0;
+    bool split = false, addsplit = false, dag = false;
+    std::vector<QPlanClass> cls;     // E + 1 classes
+    std::vector<QPlanRem> rems;      // remainder polynomials of the additive split: evaluated per proof over the Lagrange forms
+    std::vector<uint32_t> refs;      // every column any class reads
+    double cost = 0;                 // the estimate the candidates were compared by (units: one product over n rows)
+};
+static uint32_t count_products(const Prog& g) {
+    uint32_t c = 0;
+    for (const Instr& in : g) c += in.op == Q_MUL || in.op == Q_SQUARE || in.op == Q_MUL_CONST || in.op == Q_FOLD;
+    return c;
+}
+static int make_quotient_plan(const zk_pk* pk, bool split_req, bool addsplit_req, QuotientPlan& qp, std::string* err) {
+    std::vector<Prog> cons;
+    bool gates_share_tmps = false;
+    build_constraints(pk, cons, gates_share_tmps);
+    const uint32_t E = pk->ext_k - pk->k, K = (uint32_t)cons.size();
+    const bool conflict = tmp_slots_conflict(cons);
+    const bool split = split_req && !conflict;
+    qp.K = K; qp.E = E; qp.split = split; qp.addsplit = split && addsplit_req; qp.dag = quotient_dag_enabled();
+    qp.cls.assign(E + 1, QPlanClass());
+    qp.rems.clear();
+    qp.refs.clear();
+    std::vector<uint32_t> cls;
+    PK_TRY(classify_constraints(err, pk, cons, split, E, cls));
+    TmpSplit tmps(E + 1);
+    std::vector<ClassPiece> cpieces;
+    class_pieces(cons, cls, split, qp.addsplit, E, cpieces);
+    // A constraint vanishes on H; a PART of it does not, and only multiples of X^n - 1 may be divided class by class.  So the
+    // parts that leave their constraint's class t for a lower class e take their values on H along: R_(t,e) = the polynomial of
+    // degree < n that agrees on H with the y-weighted sum of those parts (evaluated over the Lagrange forms, one pass, one
+    // inverse transform).  Class e evaluates (its parts - R), class t (its parts + R): both vanish on H again, the total is
+    // unchanged.  R is read like a column (CT_SPLIT_R) on the cosets of the two classes.
+    std::vector<std::vector<ClassTerm>> cterms(E + 1);       // the terms of every class in constraint order: (constraint, program)
+    {
+        std::vector<uint32_t> top(K, 0);
+        for (const ClassPiece& pc : cpieces) top[pc.cons] = std::max(top[pc.cons], pc.cls);
+        for (const ClassPiece& pc : cpieces) {
+            const uint32_t i = pc.cons;
+            cterms[pc.cls].emplace_back();
+            cterms[pc.cls].back().cons = i;
+            tmps.append(pc.prog, pc.cls, cterms[pc.cls].back().prog);                   // the constraint (or its terms of this class), shared intermediates resolved for this class
+            if (pc.cls < top[i]) {
+                size_t at = 0;
+                while (at < qp.rems.size() && !(qp.rems[at].t == top[i] && qp.rems[at].e == pc.cls)) ++at;
+                if (at == qp.rems.size()) { qp.rems.emplace_back(); qp.rems.back().t = top[i]; qp.rems.back().e = pc.cls; }
+                QPlanRem& rm = qp.rems[at];
+                rm.prog.insert(rm.prog.end(), pc.prog.begin(), pc.prog.end());
+                rm.prog.push_back({Q_FOLD, rm.used ? C_YPOW0 + (i - rm.last) : C_Y, 0});
+                rm.last = i;
+                rm.used = true;
+            }
+        }
+    }
+    if (tmps.conflict) { *err = "prover: a constraint reads an intermediate before any constraint parked it"; return ZK_ERR_INVALID_ARG; }
+    for (size_t j = 0; j < qp.rems.size(); ++j) {
+        // both classes take R in as one more term at the very end of the constraint list (weight y^0)
+        const uint32_t ref = colref(CT_SPLIT_R, (uint32_t)j);
+        cterms[qp.rems[j].e].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}, {Q_NEG, 0, 0}}});
+        cterms[qp.rems[j].t].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}}});
+        qp.rems[j].products = count_products(qp.rems[j].prog);
+    }
+    // the class programs: compiled through the expression graph (class_compile.hpp); knob off or a program too deep for the evaluator's
+    // stack: one weighted sum (assemble_grouped, round 5) or the terms folded one by one, acc = acc * y^gap + term
+    const bool grouped = quotient_group_enabled() && !conflict;
+    for (uint32_t e = 0; e <= E; ++e) {
+        QPlanClass& c = qp.cls[e];
+        if (cterms[e].empty()) continue;
+        c.used = true;
+        ClassCompileStats st;
+        bool done = qp.dag && compile_class(cterms[e], K, c.prog, &c.last, &st);
+        if (done) { c.parked = st.parked; c.max_live = st.max_live; c.groups = st.groups; }
+        if (!done && grouped && assemble_grouped(cterms[e], K, c.prog)) { c.last = K - 1; done = true; }
+        if (!done) {
+            c.prog.clear();
+            bool any = false;
+            for (const ClassTerm& t : cterms[e]) {
+                c.prog.insert(c.prog.end(), t.prog.begin(), t.prog.end());
+                c.prog.push_back({Q_FOLD, any ? C_YPOW0 + (t.cons - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
+                c.last = t.cons;
+                any = true;
+            }
+        }
+        c.products = count_products(c.prog);
+    }
+    for (QPlanClass& c : qp.cls) {
+        std::unordered_set<uint32_t> seen;
+        for (const Instr& in : c.prog)
+            if (in.op == Q_PUSH_COL && seen.insert(in.a).second) {
+                c.refs.push_back(in.a);
+                if (std::find(qp.refs.begin(), qp.refs.end(), in.a) == qp.refs.end()) qp.refs.push_back(in.a);
+            }
+    }
+    // What the plan executes per proof, in units of one field product over n rows (~10 us at k = 20): a coset transform of a
+    // witness-side column ~ 10 of them (the key's own columns are transformed once per key and cached), a remainder its program
+    // over H, an inverse transform, and the transforms the two classes that read it already count.
+    auto of_key = [](uint32_t ref) { const uint32_t t = ref >> 24; return t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL; };
+    const double C_T = 10.0;
+    qp.cost = 0;
+    for (uint32_t e = 0; e <= E; ++e) {
+        if (!qp.cls[e].used) continue;
+        uint32_t moving = 0;
+        for (uint32_t ref : qp.cls[e].refs) moving += !of_key(ref);
+        qp.cost += (double)(1u << e) * (moving * C_T + (double)qp.cls[e].products + 2.0);
+    }
+    for (const QPlanRem& rm : qp.rems) qp.cost += (double)rm.products + C_T + 4.0;
+    return ZK_OK;
+}
+static std::string quotient_plan_key() {
+    std::string k;
+    for (const char* name : {"ZK_QUOTIENT_SPLIT", "ZK_QUOTIENT_ADDSPLIT", "ZK_QUOTIENT_GROUP", "ZK_QUOTIENT_DAG", "ZK_QUOTIENT_COSTGATE"}) { const char* v = getenv(name); k += v ? v : "-"; k += '|'; }
+    return k;
+}
+static int quotient_plan(const zk_pk* pk, std::shared_ptr<const QuotientPlan>* out, std::string* err) {
+    const std::string key = quotient_plan_key();
+    if (pk->qplan && pk->qplan->key == key) { *out = pk->qplan; return ZK_OK; }
+    const bool split_on = quotient_split_enabled(false, false), add_on = quotient_addsplit_enabled();
+    const char* gate_env = getenv("ZK_QUOTIENT_COSTGATE");
+    const bool gate = !(gate_env && atoi(gate_env) == 0);
+    std::shared_ptr<QuotientPlan> best;
+    std::vector<std::pair<bool, bool>> cand;
+    if (split_on && add_on) cand.push_back({true, true});
+    if (split_on && (gate || !add_on)) cand.push_back({true, false});
+    if (!split_on || gate) cand.push_back({false, false});
+    for (const auto& c : cand) {
+        auto qp = std::make_shared<QuotientPlan>();
+        PK_TRY(make_quotient_plan(pk, c.first, c.second, *qp, err));
+        if (getenv("ZK_QUOTIENT_TRACE")) {
+            fprintf(stderr, "[zk quotient] plan split=%d addsplit=%d dag=%d: cost %.0f, %zu remainders;", (int)qp->split, (int)qp->addsplit, (int)qp->dag, qp->cost, qp->rems.size());
+            for (uint32_t e = 0; e <= qp->E; ++e) if (qp->cls[e].used) fprintf(stderr, " class %u: %zu instr, %u products, %zu columns, %u parked (%u live), %u groups;", e, qp->cls[e].prog.size(), qp->cls[e].products, qp->cls[e].refs.size(), qp->cls[e].parked, qp->cls[e].max_live, qp->cls[e].groups);
+            fprintf(stderr, "\n");
+        }
+        if (!best || (gate && qp->cost < best->cost)) best = qp;
+        if (!gate) break;
+    }
+    best->key = key;
+    pk->qplan = best;
+    *out = best;
+    return ZK_OK;
+}
 // For every advice column: the set of cosets r (bit r) of the extended domain on which some constraint class active there reads it.
 static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::vector<uint32_t>& mask, size_t* key_slots = nullptr) {
-    std::vector<Prog> cons;
-    bool share = false;
-    build_constraints(pk, cons, share);
-    const uint32_t E = pk->ext_k - pk->k;
-    std::vector<uint32_t> cls;
-    PK_TRY(classify_constraints(ctx, pk, cons, quotient_split_enabled(sharded, share) && !tmp_slots_conflict(cons), E, cls));
+    (void)sharded;
+    std::shared_ptr<const QuotientPlan> qp;
+    {
+        std::string err;
+        const int rc = quotient_plan(pk, &qp, &err);
+        if (rc) return ctx->fail(rc, "%s", err.c_str());
+    }
+    const uint32_t E = qp->E;
     mask.assign(pk->A, 0u);
     if (E > 5) return ZK_OK;           // more than 32 cosets: no plan (the quotient transforms everything itself)
-    // the class programs as zk_proof_finish assembles them (shared intermediates re-materialised per class: a class may read
-    // columns through an intermediate that another class's constraint defined)
-    std::vector<Prog> progs(E + 1);
-    TmpSplit tmps(E + 1);
-    std::vector<ClassPiece> pieces;
-    class_pieces(cons, cls, quotient_split_enabled(sharded, share) && !tmp_slots_conflict(cons), E, pieces);
-    for (const ClassPiece& pc : pieces) tmps.append(pc.prog, pc.cls, progs[pc.cls]);
+    std::unordered_map<uint32_t, uint32_t> key_mask;
     for (uint32_t e = 0; e <= E; ++e) {
         uint32_t cosets = 0;
         for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - e)) - 1u)) == 0) cosets |= 1u << r;
-        for (const Instr& in : progs[e])
-            if (in.op == Q_PUSH_COL && (in.a >> 24) == CT_ADVICE && (in.a & 0xFFFFFFu) < pk->A) mask[in.a & 0xFFFFFFu] |= cosets;
-    }
-    if (key_slots) {          // (column of the key, coset) pairs the quotient reads: what the key's coset cache will hold
-        std::unordered_map<uint32_t, uint32_t> key_mask;
-        for (uint32_t e = 0; e <= E; ++e) {
-            uint32_t cosets = 0;
-            for (uint32_t r = 0; r < (1u << E); ++r) if ((r & ((1u << (E - e)) - 1u)) == 0) cosets |= 1u << r;
-            for (const Instr& in : progs[e]) {
-                const uint32_t t = in.a >> 24;
-                if (in.op == Q_PUSH_COL && (t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL)) key_mask[in.a] |= cosets;
-            }
+        for (uint32_t ref : qp->cls[e].refs) {
+            const uint32_t t = ref >> 24;
+            if (t == CT_ADVICE && (ref & 0xFFFFFFu) < pk->A) mask[ref & 0xFFFFFFu] |= cosets;
+            else if (t == CT_FIXED || t == CT_SIGMA || t == CT_SPECIAL) key_mask[ref] |= cosets;      // (column of the key, coset) pairs the quotient reads: what the key's coset cache will hold
         }
+    }
+    if (key_slots) {
         size_t cnt = 0;
         for (const auto& kv : key_mask) cnt += (size_t)__builtin_popcount(kv.second);
         *key_slots = cnt;
@@ -1662,6 +1830,80 @@ int zk_host_group_terms(const uint32_t* words, const uint32_t* lens, const uint3
     if (!out_words) return ZK_OK;
     if (out_cap_words < 3 * out.size()) return ZK_ERR_INVALID_ARG;
     for (size_t j = 0; j < out.size(); ++j) { out_words[3 * j] = out[j].op; out_words[3 * j + 1] = out[j].a; out_words[3 * j + 2] = out[j].b; }
+    return ZK_OK;
+}
+
+// Host only, for tests: compile_class (class_compile.hpp) over the terms of one class.  out_stats[0..5] = graph nodes, values parked,
+// parking slots alive at once, products, factor groups, stack depth; *out_last = the constraint index the program's sum is aligned to
+// (the caller scales by y^(K-1-last)).
+int zk_host_compile_class(const uint32_t* words, const uint32_t* lens, const uint32_t* cons, uint32_t count, uint32_t K, uint32_t* out_words, size_t out_cap_words, uint32_t* out_instr,
+                          uint32_t* out_last, uint32_t* out_stats) {
+    if (!words || !lens || !cons || !out_instr || !out_last) return ZK_ERR_INVALID_ARG;
+    std::vector<ClassTerm> terms(count);
+    size_t at = 0;
+    for (uint32_t t = 0; t < count; ++t) {
+        if (cons[t] >= K) return ZK_ERR_INVALID_ARG;
+        terms[t].cons = cons[t];
+        terms[t].prog.resize(lens[t]);
+        for (uint32_t j = 0; j < lens[t]; ++j, ++at) terms[t].prog[j] = {words[3 * at], words[3 * at + 1], words[3 * at + 2]};
+    }
+    Prog out;
+    ClassCompileStats st;
+    if (!compile_class(terms, K, out, out_last, &st)) return ZK_ERR_UNSUPPORTED;
+    *out_instr = (uint32_t)out.size();
+    if (out_stats) { out_stats[0] = st.nodes; out_stats[1] = st.parked; out_stats[2] = st.max_live; out_stats[3] = st.products; out_stats[4] = st.groups; out_stats[5] = (uint32_t)st.depth; }
+    if (!out_words) return ZK_OK;
+    if (out_cap_words < 3 * out.size()) return ZK_ERR_INVALID_ARG;
+    for (size_t j = 0; j < out.size(); ++j) { out_words[3 * j] = out[j].op; out_words[3 * j + 1] = out[j].a; out_words[3 * j + 2] = out[j].b; }
+    return ZK_OK;
+}
+
+// Host only (no device, no SRS): the quotient plan zk_proof_finish will follow for a constraint system -- `cs_blob` is the
+// constraint-system part of a key blob (the column data may be missing).  out_summary: [0] E = ext_k - k, [1] K constraints,
+// [2] degree classes on, [3] additive split on, [4] compiled through the expression graph, [5] remainder polynomials, [6] the cost
+// estimate the candidates were compared by, [7] columns read; then 8 words per class e <= E: used, instructions, products, columns
+// read, values parked, parking slots alive at once, factor groups, last.  class_index <= E with out_words: that class's program.
+static int write_plan_summary(const std::shared_ptr<const QuotientPlan>& qp, uint32_t* out_summary, size_t cap_summary, uint32_t class_index, uint32_t* out_words, size_t out_cap_words, uint32_t* out_instr);
+int zk_host_quotient_plan(const void* cs_blob, size_t blob_len, uint32_t* out_summary, size_t cap_summary, uint32_t class_index, uint32_t* out_words, size_t out_cap_words, uint32_t* out_instr) {
+    if (!cs_blob || !out_summary) return ZK_ERR_INVALID_ARG;
+    Reader r{(const uint8_t*)cs_blob, blob_len};
+    zk_pk pk;
+    std::string err;
+    int rc = parse_cs(r, &pk, blob_len, false, &err);
+    if (rc) { fprintf(stderr, "zk_host_quotient_plan: %s\n", err.c_str()); return rc; }
+    std::shared_ptr<const QuotientPlan> qp;
+    rc = quotient_plan(&pk, &qp, &err);
+    if (rc) { fprintf(stderr, "zk_host_quotient_plan: %s\n", err.c_str()); return rc; }
+    return write_plan_summary(qp, out_summary, cap_summary, class_index, out_words, out_cap_words, out_instr);
+}
+// The plan of a key (what zk_proof_finish follows for it under the knobs in force): same summary as zk_host_quotient_plan.
+int zk_pk_quotient_plan(zk_ctx* ctx, const zk_pk* pk, uint32_t* out_summary, size_t cap_summary) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, pk && out_summary, "null pointer");
+    std::shared_ptr<const QuotientPlan> qp;
+    std::string err;
+    const int rc = quotient_plan(pk, &qp, &err);
+    if (rc) return ctx->fail(rc, "%s", err.c_str());
+    if (write_plan_summary(qp, out_summary, cap_summary, 0xFFFFFFFFu, nullptr, 0, nullptr)) return ctx->fail(ZK_ERR_INVALID_ARG, "zk_pk_quotient_plan: the summary needs %u words", 8 + 8 * (qp->E + 1));
+    return ZK_OK;
+}
+static int write_plan_summary(const std::shared_ptr<const QuotientPlan>& qp, uint32_t* out_summary, size_t cap_summary, uint32_t class_index, uint32_t* out_words, size_t out_cap_words, uint32_t* out_instr) {
+    if (cap_summary < 8 + 8 * (size_t)(qp->E + 1)) return ZK_ERR_INVALID_ARG;
+    out_summary[0] = qp->E; out_summary[1] = qp->K; out_summary[2] = qp->split; out_summary[3] = qp->addsplit; out_summary[4] = qp->dag;
+    out_summary[5] = (uint32_t)qp->rems.size(); out_summary[6] = (uint32_t)std::min(qp->cost, 4.0e9); out_summary[7] = (uint32_t)qp->refs.size();
+    for (uint32_t e = 0; e <= qp->E; ++e) {
+        const QPlanClass& c = qp->cls[e];
+        uint32_t* o = out_summary + 8 + 8 * e;
+        o[0] = c.used; o[1] = (uint32_t)c.prog.size(); o[2] = c.products; o[3] = (uint32_t)c.refs.size(); o[4] = c.parked; o[5] = c.max_live; o[6] = c.groups; o[7] = c.last;
+    }
+    if (out_instr && class_index <= qp->E) {
+        const Prog& g = qp->cls[class_index].prog;
+        *out_instr = (uint32_t)g.size();
+        if (out_words) {
+            if (out_cap_words < 3 * g.size()) return ZK_ERR_INVALID_ARG;
+            for (size_t j = 0; j < g.size(); ++j) { out_words[3 * j] = g[j].op; out_words[3 * j + 1] = g[j].a; out_words[3 * j + 2] = g[j].b; }
+        }
+    }
     return ZK_OK;
 }
 
@@ -1984,9 +2226,6 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     }
     trace.mark("coefficient forms");
     // ---- the quotient's constraints in halo2's order: gates, permutation, lookups (folded with y below)
-    std::vector<Prog> cons;
-    bool gates_share_tmps = false;
-    build_constraints(pk, cons, gates_share_tmps);
     const int32_t rot_last = -(int32_t)(pk->bf + 1);
     // The extended domain is evaluated one coset at a time (g_r = zeta * omega_ext^r, r < 2^(ext_k-k)):
     // every column the program reads is taken to that coset with a size-n transform of its
@@ -2004,94 +2243,43 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // low-degree part of the program runs over 2^e n rows instead of 2^E n.  The polynomial h -- and with
     // it every proof byte -- is the same as when everything is evaluated on the full extended domain
     // (what halo2's evaluate_h does); how much is saved depends on the circuit's degree profile.
-    const uint32_t E = ext_k - k, K = (uint32_t)cons.size();
-    const bool sharded = pr->world > 1 && pr->gather;
-    const bool split = quotient_split_enabled(sharded, gates_share_tmps) && !tmp_slots_conflict(cons);
-    std::vector<uint32_t> cls;
-    PK_TRY(classify_constraints(ctx, pk, cons, split, E, cls));
-    struct QClass { Prog prog; std::vector<uint32_t> refs; uint32_t last = 0; bool used = false; DevBuf h; };
-    std::vector<QClass> qc(E + 1);
-    TmpSplit tmps(E + 1);
-    std::vector<ClassPiece> cpieces;
-    class_pieces(cons, cls, split, E, cpieces);
-    // A constraint vanishes on H; a PART of it does not, and only multiples of X^n - 1 may be divided class by class.  So the
-    // parts that leave their constraint's class t for a lower class e take their values on H along: R_(t,e) = the polynomial of
-    // degree < n that agrees on H with the y-weighted sum of those parts (evaluated over the Lagrange forms, one pass, one
-    // inverse transform).  Class e evaluates (its parts - R), class t (its parts + R): both vanish on H again, the total is
-    // unchanged.  R is read like a column (CT_SPLIT_R) on the cosets of the two classes.
-    struct Remainder { uint32_t t, e; Prog prog; uint32_t last = 0; bool used = false; DevBuf coeff; };
-    std::vector<Remainder> rems;
-    std::vector<std::vector<ClassTerm>> cterms(E + 1);       // the terms of every class in constraint order: (constraint, program)
+    // The plan (which class evaluates what, each class's program) is a function of the key: made once, make_quotient_plan.
+    std::shared_ptr<const QuotientPlan> qplan;
     {
-        std::vector<uint32_t> top(K, 0);
-        for (const ClassPiece& pc : cpieces) top[pc.cons] = std::max(top[pc.cons], pc.cls);
-        for (const ClassPiece& pc : cpieces) {
-            const uint32_t i = pc.cons;
-            cterms[pc.cls].emplace_back();
-            cterms[pc.cls].back().cons = i;
-            tmps.append(pc.prog, pc.cls, cterms[pc.cls].back().prog);                   // the constraint (or its terms of this class), shared intermediates resolved for this class
-            if (pc.cls < top[i]) {
-                size_t at = 0;
-                while (at < rems.size() && !(rems[at].t == top[i] && rems[at].e == pc.cls)) ++at;
-                if (at == rems.size()) { rems.emplace_back(); rems.back().t = top[i]; rems.back().e = pc.cls; }
-                Remainder& rm = rems[at];
-                rm.prog.insert(rm.prog.end(), pc.prog.begin(), pc.prog.end());
-                rm.prog.push_back({Q_FOLD, rm.used ? C_YPOW0 + (i - rm.last) : C_Y, 0});
-                rm.last = i;
-                rm.used = true;
-            }
-        }
+        std::string err;
+        const int rc_plan = quotient_plan(pk, &qplan, &err);
+        if (rc_plan) return ctx->fail(rc_plan, "%s", err.c_str());
     }
+    const uint32_t E = ext_k - k, K = qplan->K;
+    const bool sharded = pr->world > 1 && pr->gather;
+    struct QClass { const Prog& prog; const std::vector<uint32_t>& refs; uint32_t last; bool used; DevBuf h; };
+    std::vector<QClass> qc;
+    qc.reserve(E + 1);
+    for (uint32_t e = 0; e <= E; ++e) qc.push_back(QClass{qplan->cls[e].prog, qplan->cls[e].refs, qplan->cls[e].last, qplan->cls[e].used, DevBuf()});
+    struct Remainder { DevBuf coeff; };
+    std::vector<Remainder> rems(qplan->rems.size());
+    lag.ypow.resize(K + 1);
+    lag.ypow[0] = host::fr_one();
+    for (uint32_t g_ = 1; g_ <= K; ++g_) lag.ypow[g_] = host::fr_mul(lag.ypow[g_ - 1], lag.y);
     if (!rems.empty()) {
-        lag.perm_z = &pz_lag;
-        lag.lk_m = &lk_m;
-        lag.lk_phi = &lk_phi;
+        Env lag_r = lag;                       // the remainders read the Lagrange forms of Z, m and phi as well
+        lag_r.perm_z = &pz_lag;
+        lag_r.lk_m = &lk_m;
+        lag_r.lk_phi = &lk_phi;
         std::vector<Fr*> dsts;
         for (size_t j = 0; j < rems.size(); ++j) {
-            Remainder& rm = rems[j];
-            if (!rm.coeff.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            PK_TRY(run_program(ctx, lag, rm.prog, rm.coeff.p));                         // the parts on H, folded with y
-            const F4 yp = host::fr_pow(lag.y, K - 1 - rm.last);                         // ... and weighted like the constraints they belong to
-            PK_TRY(zk_fr_scale(ctx, rm.coeff.p, &yp, n));
-            dsts.push_back(rm.coeff.fr());
-            // both classes take R in as one more term at the very end of the constraint list (weight y^0)
-            const uint32_t ref = colref(CT_SPLIT_R, (uint32_t)j);
-            cterms[rm.e].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}, {Q_NEG, 0, 0}}});
-            cterms[rm.t].push_back({K - 1, Prog{{Q_PUSH_COL, ref, 0}}});
+            const QPlanRem& rp = qplan->rems[j];
+            if (!rems[j].coeff.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            PK_TRY(run_program(ctx, lag_r, rp.prog, rems[j].coeff.p));                  // the parts on H, folded with y
+            const F4 yp = host::fr_pow(lag.y, K - 1 - rp.last);                         // ... and weighted like the constraints they belong to
+            PK_TRY(zk_fr_scale(ctx, rems[j].coeff.p, &yp, n));
+            dsts.push_back(rems[j].coeff.fr());
         }
         const Fr omega_inv = fr_inv_host(fr_root_of_unity(pk->k)), ninv = fr_inv_host(fr_from_u64(1ull << pk->k));
         PK_TRY(ntt_run_many(ctx, dsts.data(), nullptr, dsts.size(), pk->k, omega_inv, &ninv, nullptr, nullptr, false));
         trace.mark("  quotient: remainders of the split constraints");
     }
-    // the class programs: one weighted sum each (assemble_grouped), or -- knob off, a program too deep for the evaluator's stack, keys whose
-    // intermediates reuse slots across constraints -- the terms folded one by one, acc = acc * y^gap + term
-    {
-        const bool grouped = quotient_group_enabled() && !tmp_slots_conflict(cons);
-        for (uint32_t e = 0; e <= E; ++e) {
-            QClass& c = qc[e];
-            if (cterms[e].empty()) continue;
-            c.used = true;
-            if (grouped && assemble_grouped(cterms[e], K, c.prog)) { c.last = K - 1; continue; }
-            c.prog.clear();
-            bool any = false;
-            for (const ClassTerm& t : cterms[e]) {
-                c.prog.insert(c.prog.end(), t.prog.begin(), t.prog.end());
-                c.prog.push_back({Q_FOLD, any ? C_YPOW0 + (t.cons - c.last) : C_Y, 0});       // acc = acc * y^(gap) + g_i
-                c.last = t.cons;
-                any = true;
-            }
-        }
-        lag.ypow.resize(K + 1);
-        lag.ypow[0] = host::fr_one();
-        for (uint32_t g_ = 1; g_ <= K; ++g_) lag.ypow[g_] = host::fr_mul(lag.ypow[g_ - 1], lag.y);
-    }
-    std::vector<uint32_t> refs;          // every column any class reads
-    for (QClass& c : qc)
-        for (const Instr& in : c.prog)
-            if (in.op == Q_PUSH_COL) {
-                if (std::find(c.refs.begin(), c.refs.end(), in.a) == c.refs.end()) c.refs.push_back(in.a);
-                if (std::find(refs.begin(), refs.end(), in.a) == refs.end()) refs.push_back(in.a);
-            }
+    const std::vector<uint32_t>& refs = qplan->refs;          // every column any class reads
     for (uint32_t e = 0; e <= E; ++e)
         if (qc[e].used || e == E) {
             if (!qc[e].h.alloc(((size_t)n << e) * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
