@@ -357,6 +357,10 @@ int concretise(zk_ctx* ctx, const Env& e, const Prog& g, Concrete* c) {
 int run_program(zk_ctx* ctx, const Env& e, const Prog& g, void* d_out) {
     Concrete c;
     PK_TRY(concretise(ctx, e, g, &c));
+    {   // measurement knob (results are WRONG): every operand read from ONE column -- the same instruction stream with its loads served by the caches
+        static const bool alias = getenv("ZK_QUOTIENT_ALIAS") && atoi(getenv("ZK_QUOTIENT_ALIAS")) == 1;
+        if (alias) for (auto& p : c.cols) p = c.cols[0];
+    }
     return zk_quotient_eval(ctx, c.words.data(), (uint32_t)(c.words.size() / 3), c.cols.data(), (uint32_t)c.cols.size(),
                             c.consts.empty() ? nullptr : c.consts.data(), (uint32_t)c.consts.size(), e.pk->k, e.pk->k, 0, d_out);
 }
