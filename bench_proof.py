@@ -422,6 +422,71 @@ def build_halo2_base_shape(ctx, k: int, num_advice: int, num_lookup_advice: int 
     return c, blob, adv_m, [inst_m_full], inst_int
 
 
+def build_reference_cs_shape(ctx, k: int, seed: int = 1, table_bits: int = 16):
+    """The constraint system of the reference-held ChunkProof (tests/golden/reference_chunk_proof.json: `protocol`; a halo2-base
+    circuit as [REF aggregator/data/batch-task.json] carries it) at any k, built with numpy: fixed 0 = lookup table, 1 = constants
+    (equality-enabled), 2 = q_gate, 3 = q_lookup; ONE advice column a under q_gate * (a + a.rot(1) * a.rot(2) - a.rot(3)); the lookup
+    (q_lookup * a) in the table; permutation over (fixed 1, advice 0, instance 0); blinding_factors = 6; queries registered in the order
+    of the fixture's evaluation list -- the same object tests/test_gpu_reference_protocol.build_reference_cs builds cell by cell at k = 8,
+    so that a proof at an aggregation layer's size (k = 21 .. 25) can be put in front of the verifier driven by the reference's own
+    protocol object."""
+    rng = np.random.default_rng(seed)
+    c = plonk.Circuit(k, num_fixed=4, num_advice=1, num_instance=1, blinding_factors=6)
+    c.fixed = None
+    table, consts, q_gate, q_lookup = (c.fixed_col(i) for i in range(4))
+    a = c.advice_col(0)
+    c.enable_equality(plonk.FIXED, 1)
+    c.add_gate(q_gate * (a + a.rot(1) * a.rot(2) - a.rot(3)))
+    c.lookup_any("range", [q_lookup * a], [table])
+    c.chunk_lookups()
+    c.enable_equality(plonk.ADVICE, 0)
+    c.enable_equality(plonk.INSTANCE, 0)
+    c.fixed_queries = [(1, 0), (0, 0), (2, 0), (3, 0)]
+    assert c.advice_queries == [(0, 0), (0, 1), (0, 2), (0, 3)] and c.degree() == 5 and c.halo2_blinding_factors() == 6
+    n, u = c.n, c.u
+    tab_n = min(1 << table_bits, u // 4)
+    n_lk = min(u // 4, 1 << 18) & ~3                 # range-checked cells below the gates
+    gates = np.arange(0, u - n_lk - 8, 4)
+    lk_rows = np.arange(u - n_lk - 4, u - 4)
+    mont = lambda limbs: to_mont_gpu(ctx, np.ascontiguousarray(limbs))
+
+    def rand_limbs(m, bits):
+        out = np.zeros((m, 4), dtype=np.uint64)
+        full, rest = divmod(bits, 64)
+        for w in range(full):
+            out[:, w] = rng.integers(0, 1 << 63, size=m, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=m, dtype=np.uint64)
+        if rest:
+            out[:, full] = rng.integers(0, 1 << rest, size=m, dtype=np.uint64)
+        return out
+    col = np.zeros((n, 4), dtype=np.uint64)
+    col[gates], col[gates + 1], col[gates + 2] = rand_limbs(gates.size, 250), rand_limbs(gates.size, 250), rand_limbs(gates.size, 250)
+    col[lk_rows, 0] = rng.integers(0, tab_n, size=lk_rows.size, dtype=np.uint64)
+    col[lk_rows[3]] = col[lk_rows[2]]
+    col_m = mont(col)
+    abuf, bbuf, cbuf = (ctx.to_device(np.ascontiguousarray(col_m[gates + o])) for o in (0, 1, 2))
+    ctx.field_vec_op(0, 2, bbuf, cbuf, bbuf, gates.size)          # d = a + b c on the device (Montgomery images)
+    ctx.field_vec_op(0, 0, bbuf, abuf, bbuf, gates.size)
+    col_m[gates + 3] = bbuf.download((gates.size, 4))
+    for b_ in (abuf, bbuf, cbuf):
+        b_.free()
+    ta = np.zeros((n, 4), dtype=np.uint64); ta[:tab_n, 0] = np.arange(tab_n, dtype=np.uint64)
+    kon = np.zeros((n, 4), dtype=np.uint64); kon[0], kon[1] = col[lk_rows[0]], col[lk_rows[1]]
+    qg = np.zeros((n, 4), dtype=np.uint64); qg[gates, 0] = 1
+    ql = np.zeros((n, 4), dtype=np.uint64); ql[lk_rows, 0] = 1
+    fixed_m = [mont(ta), mont(kon), mont(qg), mont(ql)]
+    copies = [((plonk.FIXED, 1, 0), (plonk.ADVICE, 0, int(lk_rows[0]))), ((plonk.FIXED, 1, 1), (plonk.ADVICE, 0, int(lk_rows[1]))),
+              ((plonk.ADVICE, 0, int(lk_rows[2])), (plonk.ADVICE, 0, int(lk_rows[3]))),
+              ((plonk.ADVICE, 0, int(gates[0] + 3)), (plonk.INSTANCE, 0, 0)), ((plonk.ADVICE, 0, int(gates[1] + 3)), (plonk.INSTANCE, 0, 1))]
+    c.copies = copies
+    blob = assemble_blob(ctx, c, 4, lambda i: fixed_m[i], copies)
+    inst_m_full = np.zeros((n, 4), dtype=np.uint64)
+    inst_m_full[0], inst_m_full[1] = col_m[gates[0] + 3], col_m[gates[1] + 3]
+    rinv = pow(1 << 256, -1, R)
+    to_int = lambda v: (int(v[0]) | int(v[1]) << 64 | int(v[2]) << 128 | int(v[3]) << 192) * rinv % R
+    inst_int = [[to_int(inst_m_full[0]), to_int(inst_m_full[1])] + [0] * (n - 2)]
+    return c, blob, [col_m], [inst_m_full], inst_int
+
+
 # ---------------------------------------------------------------------------------------------------------------- EVM-style block
 EVM_DEFAULT = {"states": 80, "per_state": 64, "cond_cols": 8, "input_cols": 77, "seed": 7}
 

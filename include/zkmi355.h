@@ -93,6 +93,12 @@ int zk_prof_get_bytes(zk_ctx* ctx, const char* name, uint64_t* bytes);
 /* writes a ';'-separated list of the names seen so far into buf */
 int zk_prof_names(zk_ctx* ctx, char* buf, size_t len);
 
+/* Self-test of the device's Montgomery products (no reference counterpart: halo2curves' `Fr::mul` has one form; here the device runs
+ * generated gfx950 asm -- csrc/mul29_asm.hip.hpp -- and the host / the definition the C forms of csrc/ff29.hip.hpp): `operand_sets`
+ * lanes each run mul29 / mul29_ub / sqr29 / mul2add29 in both forms on pseudo-random operands AT the documented lazy-reduction
+ * bounds and compare every limb.  out3 = {lanes with a difference, OR of the differing routines (1, 2, 4, 8), lanes run}. */
+int zk_selftest_products(zk_ctx* ctx, int field, uint32_t operand_sets, uint32_t seed, uint32_t* out3);
+
 /* ---- field vectors (halo2curves Fr/Fq Add/Sub/Mul, element-wise)  -- SURVEY 8a K4/K10 ---------- */
 int zk_field_vec_op(zk_ctx* ctx, int field, int op, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* out[i] = a[i] * s  (s: host pointer to one element) */

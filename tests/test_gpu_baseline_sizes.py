@@ -90,3 +90,43 @@ def test_supercircuit_shape_k20_proof_is_accepted(ctx, cref):
     bad = bytearray(proof)
     bad[40] ^= 1
     assert not _verify(circ, vk_points, vk_repr, inst, bytes(bad))
+
+
+def test_bundle_shape_k21_proof_is_accepted(ctx, cref):
+    """BASELINE configs[4] stand-in at the size `bench.py` times it (`proof.bundle_shape_k21`): the halo2-base layout of
+    [REF aggregator/configs/bundle_circuit.config] (degree 21, 5 + 1 advice, 1 fixed) under the Poseidon transcript of
+    gen_snark_shplonk [REF prover/src/common/prover/recursion.rs:60-77]: accepted by the circuit-driven oracle verifier, rejected with
+    one bit flipped -- so that the driver's own GPU run vouches for that line, not only the bench's `verified_by_oracle`."""
+    import bench_proof as bp
+    circ, blob, adv_m, inst_m, inst = bp.build_halo2_base_shape(ctx, 21, 5, 1, 20)
+    assert circ.k == 21 and circ.A == 6 and circ.degree() == 5
+    proof, vk_points, vk_repr, inst = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst, transcript_kind=1)
+    assert _verify(circ, vk_points, vk_repr, inst, proof, transcript="poseidon")
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    assert not _verify(circ, vk_points, vk_repr, inst, bytes(bad), transcript="poseidon")
+
+
+def test_reference_constraint_system_at_k21_under_the_references_protocol(ctx, cref):
+    """The constraint system of the reference-held ChunkProof at an aggregation layer's size (k = 21; the reference's own proof is
+    k = 25), proved on the device under Poseidon + SHPLONK and handed to oracle/snark_verifier.py -- snark-verifier's
+    PlonkSuccinctVerifier + decider restated -- DRIVEN BY THE REFERENCE'S OWN PROTOCOL OBJECT (quotient numerator, query and evaluation
+    lists as snark-verifier compiled them; only the domain, the seven key commitments, the initial state and the instance count are
+    ours).  The k = 8 twin is tests/test_gpu_reference_protocol.py."""
+    import json
+    import bench_proof as bp
+    from oracle import pairing as pr, snark_verifier as sv
+    from test_gpu_reference_protocol import protocol_for
+    fixture = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_chunk_proof.json")))
+    circ, blob, adv_m, inst_m, inst = bp.build_reference_cs_shape(ctx, 21)
+    proof, vk_points, vk_repr, inst = _prove(ctx, cref, circ, blob, adv_m, inst_m, inst, transcript_kind=1, seed=bytes(range(16)))
+    assert len(inst[0]) == 2
+    s_g2 = pr.ec_mul(pr.G2_GEN, S)
+    prot = sv.Protocol(protocol_for(fixture["protocol"], circ, vk_points, vk_repr, len(inst[0])))
+    assert len(proof) == 32 * (sum(prot.num_witness) + prot.quotient["num_chunk"] + len(prot.evaluations) + 2) == 896
+    assert sv.verify_snark(prot, inst, proof, pr.G2_GEN, s_g2)
+    for word in (0, 5, 13, 27):
+        bad = bytearray(proof)
+        bad[32 * word + 7] ^= 8
+        assert not sv.verify_snark(prot, inst, bytes(bad), pr.G2_GEN, s_g2), word
+    assert _verify(circ, vk_points, vk_repr, inst, proof, transcript="poseidon")

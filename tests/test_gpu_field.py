@@ -150,3 +150,19 @@ def test_lookup_multiplicities(ctx, cref, n, usable, distinct):
         assert inputs[r_] not in first
     dI = ctx.to_device(cref.to_mont(inputs))
     assert ctx.lookup_multiplicities(dI, dT, usable, dM, n) == bad_rows[0]
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_asm_products_equal_the_c_forms(zk, ctx, field):
+    """The device products are one generated asm statement each (csrc/mul29_asm.hip.hpp); tests/test_host_arith.py only ever sees the C
+    forms.  zk_selftest_products runs mul29 / mul29_ub / sqr29 / mul2add29 in both forms on 2^21 operand sets per seed at the
+    documented lazy-reduction bounds (every sixteenth lane with every limb AT its bound), Fr and Fq: not one limb may differ."""
+    import ctypes
+    out = (ctypes.c_uint32 * 3)()
+    total = 0
+    for seed in (1, 0x9E3779B9, 0xDEADBEEF):
+        ctx._ck(zk.lib().zk_selftest_products(ctx.h, ctypes.c_int(field), ctypes.c_uint32(1 << 21), ctypes.c_uint32(seed), out))
+        assert (out[0], out[1]) == (0, 0), f"{out[0]} lanes differ, routines mask {out[1]:#x}"
+        assert out[2] == 1 << 21
+        total += out[2]
+    assert total >= 10 ** 6

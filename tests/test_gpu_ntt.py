@@ -145,7 +145,7 @@ def test_extreme_inputs(ctx, cref, k, pattern):
     assert np.array_equal(d.download((n, 4)), A)
 
 
-@pytest.mark.parametrize("k,count", [(0, 3), (1, 2), (5, 20), (10, 33), (13, 17), (18, 9), (20, 5)])
+@pytest.mark.parametrize("k,count", [(0, 3), (1, 2), (5, 20), (10, 33), (13, 17), (18, 9), (20, 5), (20, 35)])
 def test_batched_transforms_equal_single_ones(ctx, cref, k, count):
     """zk_ntt_batch / zk_coeff_to_coset_batch put several columns into one launch (blockIdx.y = column): every column must
     come out exactly as from the single-column entry points, across group boundaries of the batch, forward and inverse."""
@@ -170,3 +170,40 @@ def test_batched_transforms_equal_single_ones(ctx, cref, k, count):
     ctx.coeff_to_coset_batch(bufs[:2], k, g, bufs[:2])
     assert np.array_equal(bufs[0].download((n, 4)), outs[0].download((n, 4)))
     ctx.ntt_batch([], k)
+
+
+@pytest.mark.parametrize("k", list(range(7, 23)))
+def test_fixed_structure_passes_equal_the_generic_kernels(ctx, cref, k):
+    """csrc/ntt.hip: the passes whose step structure is fixed at compile time (k_ntt_pass_f / k_ntt_last_f, the default wherever a
+    digit size has an instance) claim to be bit-identical to the run-time kernels (ZK_NTT_FIXED=0): forward, inverse and coset
+    transforms of the same columns under both, a batch that crosses a launch group, and the oracle on the first column."""
+    import os
+    n = 1 << k
+    count = 3 if k >= 20 else 5
+    cols = [cref.rand_fr_stream(7700 + 13 * k + i, n) for i in range(count)]
+    g = cref.fr_const(0xC05E7 + k)
+
+    def run():
+        bufs = [ctx.to_device(c) for c in cols]
+        outs = [ctx.alloc(n * 32) for _ in range(count)]
+        ctx.ntt_batch(bufs, k)
+        fwd = [b.download((n, 4)) for b in bufs]
+        ctx.ntt_batch(bufs, k, inverse=True)
+        inv = [b.download((n, 4)) for b in bufs]
+        ctx.coeff_to_coset_batch(bufs, k, g, outs)
+        cos = [o.download((n, 4)) for o in outs]
+        for b_ in bufs + outs:
+            b_.free()
+        return fwd, inv, cos
+    default = run()
+    os.environ["ZK_NTT_FIXED"] = "0"
+    try:
+        generic = run()
+    finally:
+        os.environ.pop("ZK_NTT_FIXED")
+    for a_, b_ in zip(default, generic):
+        for x_, y_ in zip(a_, b_):
+            assert np.array_equal(x_, y_)
+    assert np.array_equal(default[0][0], cref.best_fft(cols[0], bn254.omega_for_k(k), k))
+    for c, v in zip(cols, default[1]):
+        assert np.array_equal(c, v)

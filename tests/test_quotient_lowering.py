@@ -88,6 +88,16 @@ def settle(a):
     return unpack(v)
 
 
+def settle8(a):
+    assert all(x < (1 << 31) for x in a), "q_settle8: limbs must be below 2^31"
+    a = normalize29(a)
+    v = val(a)
+    assert v < 8 * P, "q_settle8: value must be below 8p"
+    if v >= 4 * P:
+        v -= 4 * P
+    return settle(unpack(v, 261))
+
+
 def mul29(a, b):
     assert all(x <= MASK + 8 for x in b[:8]), "second operand of mul29 must be normalised"
     assert val(a) * val(b) < (1 << 261) * P, "mul29: a b must be below 2^261 p"
@@ -153,6 +163,14 @@ def run_lowered(words, cols, consts, num_cols):
             st[-1] = settle(st[-1])
         if w0 & 0x200:
             st[-2] = settle(st[-2])
+        if w0 & 0x400:
+            st[-1] = normalize29(st[-1])
+        if w0 & 0x800:
+            st[-2] = normalize29(st[-2])
+        if w0 & 0x1000:
+            st[-1] = settle8(st[-1])
+        if w0 & 0x2000:
+            st[-2] = settle8(st[-2])
         if op == Q_PUSH_COL:
             st.append(unpack(mem))
         elif op == Q_PUSH_CONST:
@@ -186,7 +204,7 @@ def run_lowered(words, cols, consts, num_cols):
         elif op == K_MUL_COL:
             st[-1] = mul29(st[-1], unpack_x32(mem))
         elif op == K_FOLD_COL:
-            acc = add29(mul29(acc, unpack(consts_rp[w0 >> 12])), unpack(mem))
+            acc = add29(mul29(acc, unpack(consts_rp[w0 >> 16])), unpack(mem))
         elif op == K_NOP:
             pass
         else:

@@ -583,7 +583,7 @@ static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t l
     if (!(ctx->ntt_fixed_attr & bit)) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); ctx->ntt_fixed_attr |= bit; }
     hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp);
 }
-static bool ntt_fixed_on() { static const bool on = !(getenv("ZK_NTT_FIXED") && atoi(getenv("ZK_NTT_FIXED")) == 0); return on; }      // measurement knob
+static bool ntt_fixed_on() { const char* e = getenv("ZK_NTT_FIXED"); return !(e && atoi(e) == 0); }      // measurement knob, read per call (tests flip it inside one process)
 static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     if (!ntt_fixed_on() || !out_tw) return false;
 #define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); \

@@ -358,8 +358,8 @@ int run_program(zk_ctx* ctx, const Env& e, const Prog& g, void* d_out) {
     Concrete c;
     PK_TRY(concretise(ctx, e, g, &c));
     {   // measurement knob (results are WRONG): every operand read from ONE column -- the same instruction stream with its loads served by the caches
-        static const bool alias = getenv("ZK_QUOTIENT_ALIAS") && atoi(getenv("ZK_QUOTIENT_ALIAS")) == 1;
-        if (alias) for (auto& p : c.cols) p = c.cols[0];
+        static const int alias = getenv("ZK_QUOTIENT_ALIAS") ? atoi(getenv("ZK_QUOTIENT_ALIAS")) : 0;      // N: the class programs read N distinct columns in all
+        if (alias > 0 && ctx->prof_tag && !strcmp(ctx->prof_tag, "quotient_coset")) for (size_t i = 0; i < c.cols.size(); ++i) c.cols[i] = c.cols[i % (size_t)alias];
     }
     return zk_quotient_eval(ctx, c.words.data(), (uint32_t)(c.words.size() / 3), c.cols.data(), (uint32_t)c.cols.size(),
                             c.consts.empty() ? nullptr : c.consts.data(), (uint32_t)c.consts.size(), e.pk->k, e.pk->k, 0, d_out);

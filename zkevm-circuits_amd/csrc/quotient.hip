@@ -89,6 +89,22 @@ __device__ __forceinline__ Q29 q_settle(Q29 r) {
     for (int i = 0; i < 9; ++i) r.l[i] = neg_ ? r.l[i] : d.l[i];
     return r;
 }
+// r (limbs < 2^31, value < 8p) -> normalised representative below 2p: one more round for the values the relaxed bounds let grow past 4p
+__device__ __forceinline__ Q29 q_settle8(Q29 r) {
+    normalize29(r);
+    Q29 d;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int32_t s_ = (int32_t)r.l[i] - (int32_t)kp_norm<Fr29P>(4, i) + c;
+        d.l[i] = i < 8 ? ((uint32_t)s_ & MASK29) : (uint32_t)s_;
+        c = s_ >> 29;
+    }
+    const bool neg_ = (int32_t)d.l[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = neg_ ? r.l[i] : d.l[i];
+    return q_settle(r);
+}
 __device__ __forceinline__ Q29 q_add(const Q29& a, const Q29& b) { return q_settle(add29(a, b)); }          // a, b < 2p
 __device__ __forceinline__ Q29 q_sub(const Q29& a, const Q29& b) { return q_settle(sub29k<2>(a, b)); }      // a - b + 2p in (0, 4p)
 // x * 32 for a normalised x < 2p: limbs stay normalised, value < 64p < 2^260
@@ -106,13 +122,19 @@ enum QOp : uint32_t { Q_END = 0, Q_PUSH_COL = 1, Q_PUSH_CONST = 2, Q_ADD = 3, Q_
                       // produced by the lowering only (never part of a caller's program): the second operand comes from memory
                       K_ADD_COL = 16, K_SUB_COL = 17, K_RSUB_COL = 18, K_MUL_COL = 19, K_FOLD_COL = 20, K_NOP = 21 };
 constexpr uint32_t K_SETTLE0 = 0x100, K_SETTLE1 = 0x200;      // word 0 of a lowered instruction: settle t0 / t1 before executing
-constexpr int K_CONST_SHIFT = 12;                              // K_FOLD_COL keeps its constant index in the bits above
+constexpr uint32_t K_NORM0 = 0x400, K_NORM1 = 0x800;          // ... or only propagate its carries (limbs back below 2^29, value unchanged): a third of a settle
+constexpr uint32_t K_SETTLE0_8 = 0x1000, K_SETTLE1_8 = 0x2000; // ... or settle a value that may have reached 8p (q_settle8)
+constexpr int K_CONST_SHIFT = 16;                              // K_FOLD_COL keeps its constant index in the bits above
 
 // A program constant as the kernel reads it: the nine 29-bit limbs, unpacked on the host once per launch (the kernel used to
 // spend 27 vector instructions per constant operand on it).  The index is wave-uniform, so the limbs arrive by scalar loads
 // and stay in scalar registers (mul29_ub).  64-byte records.
 struct QC29 { uint32_t l[16]; };
 constexpr int Q_THREADS = 256;
+// how many instructions ahead of its use a memory operand is requested (1: while the previous instruction computes; 2: one more)
+#ifndef Q_PREFETCH_DIST
+#define Q_PREFETCH_DIST 1
+#endif
 constexpr int Q_MAX_STACK = 16;
 constexpr uint32_t Q_MAX_TMP = 4096;     // intermediates live in HBM, [slot][row]: 32 MiB per slot at 2^20 rows
 
@@ -153,11 +175,22 @@ __device__ __forceinline__ bool k_has_mem(uint32_t w0) {
 
 // Runs a LOWERED program (lower_program below): `prog` holds prog_len instructions followed by two END triples.
 // FULL: the grid covers the domain exactly (2^ext_k >= Q_THREADS), no lane needs masking.
-template <bool FULL>
-__global__ void __launch_bounds__(Q_THREADS)
+#ifdef Q_WAVES_PER_EU
+#define Q_OCC_ATTR __attribute__((amdgpu_waves_per_eu(Q_WAVES_PER_EU, Q_WAVES_PER_EU)))
+#else
+#define Q_OCC_ATTR
+#endif
+// ACC_MEM (round 6): the accumulator of the FOLD instructions lives in memory ([limb][row], raw limbs), not in registers.  A compiled
+// class program folds once per factor group -- 82 FOLDs in 34 185 instructions of the EVM-style program -- yet as a loop-carried
+// register value the accumulator was copied (nine v_mov) at the end of EVERY case of the interpreter's switch, whichever instruction
+// ran.  Programs that fold on most instructions (linear combinations: FOLD_COL chains) keep it in registers (ACC_MEM = false).
+// K_FIRST_FOLD marks the first fold of a program: the accumulator is zero there, nothing is read.
+constexpr uint32_t K_FIRST_FOLD = 0x4000;
+template <bool FULL, bool ACC_MEM>
+__global__ void __launch_bounds__(Q_THREADS) Q_OCC_ATTR
 k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const QC29* __restrict__ consts,
                 const QC29* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
-                Fr* __restrict__ out, Fr* tmp /* [slot][row]: the row's intermediates, written and read by its own lane */) {
+                Fr* __restrict__ out, Fr* tmp /* [slot][row]: the row's intermediates, written and read by its own lane */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     QStack st{smem};
     const uint64_t ne = 1ull << ext_k;
@@ -165,7 +198,7 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     const bool live = FULL || i < (uint32_t)ne;
     const uint32_t rot_scale = 1u << (ext_k - k), row_mask = (uint32_t)ne - 1u;
     const Q29 zero29 = unpack29<Fr29P>(Fr::zero());
-    Q29 acc = zero29;
+    Q29 acc = zero29;                         // ACC_MEM: unused (dead), the folds go through acc_mem
     // The two topmost stack elements live in registers (t0 = top, t1 = second); element j < sp - 2
     // lives in LDS slot j.
     Q29 t0 = zero29, t1 = zero29;
@@ -185,6 +218,7 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
     // for the operand that is being prefetched.  The columns are device memory: say so (global_load, vmcnt only).
     typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
     using GU4 = const U32x4 __attribute__((address_space(1)));
+    using GU1 = uint32_t __attribute__((address_space(1)));
     auto load_row = [&](uint32_t a, uint32_t row) -> Fr {
         GU4* q = (GU4*)(uintptr_t)(cols[a] + row);
         const U32x4 lo = q[0], hi = q[1];
@@ -204,21 +238,46 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         for (int q = 0; q < 9; ++q) r.l[q] = tab[j].l[q];
         return r;
     };
-    // instruction words are fetched two ahead, the memory operand one ahead: the load of instruction pc + 1 is
-    // in flight while instruction pc computes
+    auto acc_get = [&](uint32_t w0_) -> Q29 {
+        if (!ACC_MEM) return acc;
+        Q29 r = zero29;
+        if (!(w0_ & K_FIRST_FOLD) && live) {
+            GU1* q = (GU1*)(uintptr_t)(acc_mem + i);
+#pragma unroll
+            for (int l = 0; l < 9; ++l) r.l[l] = q[(uint64_t)l << ext_k];
+        }
+        return r;
+    };
+    auto acc_put = [&](const Q29& v) {
+        if (!ACC_MEM) { acc = v; return; }
+        if (live) {
+            GU1* q = (GU1*)(uintptr_t)(acc_mem + i);
+#pragma unroll
+            for (int l = 0; l < 9; ++l) q[(uint64_t)l << ext_k] = v.l[l];
+        }
+    };
+    // Instruction words are fetched two ahead, the memory operand one ahead: the load of instruction pc + 1 is in flight while
+    // instruction pc computes.  The raw operand `m` of instruction pc is unpacked into limbs FIRST, then the same registers take the
+    // load for pc + 1 (no m_cur = m_next rotation: eight register copies an iteration).
     uint32_t w0 = prog[0], w1 = prog[1], w2 = prog[2];
     uint32_t n0 = prog[3], n1 = prog[4], n2 = prog[5];
-    Fr m_cur, m_next;                          // only read by instructions that have a memory operand, which loaded them
-    if (k_has_mem(w0)) m_cur = load(w1, w2);
+    Fr m;                                      // only read by instructions that have a memory operand, which loaded it
+    if (k_has_mem(w0)) m = load(w1, w2);
     for (uint32_t pc = 0; pc < prog_len; ++pc) {
         const uint32_t f0 = prog[3 * pc + 6], f1 = prog[3 * pc + 7], f2 = prog[3 * pc + 8];
-        if (k_has_mem(n0)) m_next = load(n1, n2);
         const uint32_t op = w0 & 0xffu;
         if (op == Q_END) break;
+        Q29 mq = zero29;
+        if (k_has_mem(w0)) mq = op == K_MUL_COL ? unpack29_x32(m) : unpack29<Fr29P>(m);
+        if (k_has_mem(n0)) m = load(n1, n2);
         if (w0 & K_SETTLE0) t0 = q_settle(t0);
         if (w0 & K_SETTLE1) t1 = q_settle(t1);
+        if (w0 & K_NORM0) normalize29(t0);
+        if (w0 & K_NORM1) normalize29(t1);
+        if (w0 & K_SETTLE0_8) t0 = q_settle8(t0);
+        if (w0 & K_SETTLE1_8) t1 = q_settle8(t1);
         switch (op) {
-            case Q_PUSH_COL: push_shift(); t0 = unpack29<Fr29P>(m_cur); break;
+            case Q_PUSH_COL: push_shift(); t0 = mq; break;
             case Q_PUSH_CONST: push_shift(); t0 = cst(consts, w1); break;
             case Q_ADD: drop_to(add29(t1, t0)); break;
             case Q_SUB: { Q29 d = sub29k<2>(t1, t0); normalize29(d); drop_to(d); break; }     // the top limb of a settled subtrahend may borrow: carry it out before anyone multiplies
@@ -226,24 +285,24 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
             case Q_NEG: t0 = sub29k<2>(zero29, t0); normalize29(t0); break;
             case Q_SQUARE: t0 = mul29(t0, q_shl5(t0)); break;
             case Q_DOUBLE: t0 = add29(t0, t0); break;
-            case Q_FOLD: acc = add29(mul29_ub(acc, cst(consts_rp, w1)), t0); drop_to(t1); break;
+            case Q_FOLD: acc_put(add29(mul29_ub(acc_get(w0), cst(consts_rp, w1)), t0)); drop_to(t1); break;
             case Q_MUL_CONST: t0 = mul29_ub(t0, cst(consts_rp, w1)); break;
             case Q_ADD_CONST: t0 = add29(t0, cst(consts, w1)); break;
             case Q_TEE_TMP: if (live) stg(tmp + (((uint64_t)w1 << ext_k) + i), pack29_lt2p(t0)); break;             // parked canonical: read back as a column
-            case K_ADD_COL: t0 = add29(t0, unpack29<Fr29P>(m_cur)); break;
-            case K_SUB_COL: t0 = sub29k<2>(t0, unpack29<Fr29P>(m_cur)); break;                                  // canonical subtrahend: its top limb is below that of 2p, no borrow
-            case K_RSUB_COL: t0 = sub29k<2>(unpack29<Fr29P>(m_cur), t0); normalize29(t0); break;
-            case K_MUL_COL: t0 = mul29(t0, unpack29_x32(m_cur)); break;
-            case K_FOLD_COL: acc = add29(mul29_ub(acc, cst(consts_rp, w0 >> K_CONST_SHIFT)), unpack29<Fr29P>(m_cur)); break;
+            case K_ADD_COL: t0 = add29(t0, mq); break;
+            case K_SUB_COL: t0 = sub29k<2>(t0, mq); break;                                  // canonical subtrahend: its top limb is below that of 2p, no borrow (with K = 1 the top limb of p - b could borrow)
+            case K_RSUB_COL: t0 = sub29k<2>(mq, t0); normalize29(t0); break;
+            case K_MUL_COL: t0 = mul29(t0, mq); break;
+            case K_FOLD_COL: acc_put(add29(mul29_ub(acc_get(w0), cst(consts_rp, w0 >> K_CONST_SHIFT)), mq)); break;
             default: break;
         }
         w0 = n0; w1 = n1; w2 = n2;
         n0 = f0; n1 = f1; n2 = f2;
-        m_cur = m_next;
     }
     if (live) {
-        if (t_evals) stg(out + i, pack29_lt2p(mul29(acc, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1u)))))));
-        else { normalize29(acc); stg(out + i, reduce_lazy29(acc)); }       // acc < 6p, never settled on the way
+        Q29 a = acc_get(0);
+        if (t_evals) stg(out + i, pack29_lt2p(mul29(a, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1u)))))));
+        else { normalize29(a); stg(out + i, reduce_lazy29(a)); }       // acc < 6p, never settled on the way
     }
 }
 
@@ -344,62 +403,87 @@ static void lower_fuse(const uint32_t* prog, uint32_t len, uint32_t num_cols, st
     materialise_pending();
 }
 
-// Settle bits, prefetch hazards and stack depth of a fused program (bounds: header comment).  V in units of p, L in
-// units of 2^29; every stack entry stays within (4, 4), so q_settle (< 4p, limbs < 2^31) applies to any of them.
+// Settle / normalise bits, prefetch hazards and stack depth of a fused program (bounds: header comment).  V in units of p, L in
+// units of 2^29.  Round 6: a stack entry may grow to (8, 4) -- sums only ever need limbs below 2^31 (carries are propagated where a
+// limb bound is in the way: K_NORM, 24 instructions) and the consumers that care about the VALUE say so: the first operand of a
+// product by a memory operand takes V <= 5, by a constant anything here, the second operand of a stack product / a subtrahend / a
+// value being parked must be settled.  A value above 4p that has to be settled after all takes q_settle8 (one more conditional
+// subtraction).  The Horner steps S = S y^g + term of the compiled class programs run without a single settle that way; round 5's
+// rule (everything within (4, 4), settle on every excess: ZK_QUOTIENT_RELAXED=0) spent 8 024 settles on the 12 289 products of the
+// EVM-style class program.
 static int lower_bounds(std::vector<LowInstr>* prog_io, uint32_t num_cols, int* max_depth) {
     struct Bd { int V, L; };
     std::vector<Bd> bs;
     std::vector<LowInstr> out;
     out.reserve(prog_io->size() + 8);
     int mx = 0;
-    for (const LowInstr& in0 : *prog_io) {
-        LowInstr in = in0;
+    const char* renv = getenv("ZK_QUOTIENT_RELAXED");
+    const bool relaxed = !(renv && atoi(renv) == 0);
+    const int capV = relaxed ? 8 : 4;
+    for (size_t ii = 0; ii < prog_io->size(); ++ii) {
+        LowInstr in = (*prog_io)[ii];
         const uint32_t op = in.w0 & 0xffu;
-        auto settle0 = [&]() { in.w0 |= K_SETTLE0; bs.back() = {2, 1}; };
-        auto settle1 = [&]() { in.w0 |= K_SETTLE1; bs[bs.size() - 2] = {2, 1}; };
+        auto settle0 = [&]() { in.w0 &= ~(K_NORM0 | K_SETTLE0 | K_SETTLE0_8); in.w0 |= bs.back().V > 4 ? K_SETTLE0_8 : K_SETTLE0; bs.back() = {2, 1}; };
+        auto settle1 = [&]() { in.w0 &= ~(K_NORM1 | K_SETTLE1 | K_SETTLE1_8); in.w0 |= bs[bs.size() - 2].V > 4 ? K_SETTLE1_8 : K_SETTLE1; bs[bs.size() - 2] = {2, 1}; };
+        auto norm0 = [&]() { if (!relaxed) { settle0(); return; } if (!(in.w0 & (K_SETTLE0 | K_SETTLE0_8))) in.w0 |= K_NORM0; bs.back().L = 1; };
+        auto norm1 = [&]() { if (!relaxed) { settle1(); return; } if (!(in.w0 & (K_SETTLE1 | K_SETTLE1_8))) in.w0 |= K_NORM1; bs[bs.size() - 2].L = 1; };
+        auto settled0 = [&]() { if (bs.back().V > 2 || bs.back().L > 1) settle0(); };          // t0 must be a settled value
+        // t0 op= something of bounds (dV, dL): make room in t0
+        auto room0 = [&](int dV, int dL) {
+            if (bs.back().L + dL > 4) norm0();
+            if (bs.back().V + dV > capV) settle0();
+        };
         const size_t need = (op == Q_ADD || op == Q_SUB || op == Q_MUL) ? 2 : (op == Q_PUSH_COL || op == Q_PUSH_CONST || op == K_FOLD_COL || op == K_NOP) ? 0 : 1;
         if (bs.size() < need) return -1;
         switch (op) {
             case Q_PUSH_COL: case Q_PUSH_CONST: bs.push_back({1, 1}); break;
             case Q_ADD: {
-                if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) {
-                    if (bs.back().V > 2 || bs.back().L > 1) settle0();
-                    if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) settle1();
-                    if (bs[bs.size() - 2].V + bs.back().V > 4 || bs[bs.size() - 2].L + bs.back().L > 4) settle0();
-                }
-                const Bd r{bs[bs.size() - 2].V + bs.back().V, bs[bs.size() - 2].L + bs.back().L};
+                Bd &x = bs[bs.size() - 2], &y = bs.back();
+                if (x.L + y.L > 4) { if (y.L >= x.L) norm0(); else norm1(); }
+                if (x.L + y.L > 4) { if (y.L > 1) norm0(); else norm1(); }
+                if (x.V + y.V > capV) { if (y.V >= x.V) settle0(); else settle1(); }
+                if (x.V + y.V > capV) { if (y.V > 2) settle0(); else settle1(); }
+                if (x.V + y.V > capV || x.L + y.L > 4) return -1;
+                const Bd r{x.V + y.V, x.L + y.L};
                 bs.pop_back(); bs.back() = r;
                 break;
             }
             case Q_SUB: {
-                if (bs.back().V > 2 || bs.back().L > 1) settle0();
-                if (bs[bs.size() - 2].V + 2 > 4 || bs[bs.size() - 2].L + 2 > 4) settle1();
+                settled0();
+                if (bs[bs.size() - 2].L + 2 > 4) norm1();
+                if (bs[bs.size() - 2].V + 2 > capV) settle1();
                 const Bd r{bs[bs.size() - 2].V + 2, 1};
                 bs.pop_back(); bs.back() = r;
                 break;
             }
             case Q_MUL: {
-                if (bs.back().V > 2 || bs.back().L > 1) settle0();
+                settled0();
                 if (bs[bs.size() - 2].V * bs.back().V > 5) settle1();
                 bs.pop_back(); bs.back() = {2, 1};
                 break;
             }
-            case Q_NEG: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {3, 1}; break;       // 2p - t0 reaches 2p itself (t0 = 0): not below 2p
-            case Q_SQUARE: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {2, 1}; break;
-            case Q_DOUBLE: if (bs.back().V > 2 || bs.back().L > 2) settle0(); bs.back() = {2 * bs.back().V, 2 * bs.back().L}; break;
-            case Q_FOLD: if (bs.back().L > 3) settle0(); bs.pop_back(); break;
+            case Q_NEG: settled0(); bs.back() = {3, 1}; break;       // 2p - t0 reaches 2p itself (t0 = 0): not below 2p
+            case Q_SQUARE: settled0(); bs.back() = {2, 1}; break;
+            case Q_DOUBLE: if (bs.back().L > 2) norm0(); if (2 * bs.back().V > capV) settle0(); bs.back() = {2 * bs.back().V, 2 * bs.back().L}; break;
+            case Q_FOLD: if (bs.back().L > 3) norm0(); bs.pop_back(); break;
             case Q_MUL_CONST: bs.back() = {2, 1}; break;
-            case Q_ADD_CONST: case K_ADD_COL: if (bs.back().V + 1 > 4 || bs.back().L + 1 > 4) settle0(); bs.back() = {bs.back().V + 1, bs.back().L + 1}; break;
-            case Q_TEE_TMP: if (bs.back().V > 2 || bs.back().L > 1) settle0(); break;
-            case K_SUB_COL: if (bs.back().V + 2 > 4 || bs.back().L + 2 > 4) settle0(); bs.back() = {bs.back().V + 2, bs.back().L + 2}; break;
-            case K_RSUB_COL: if (bs.back().V > 2 || bs.back().L > 1) settle0(); bs.back() = {3, 1}; break;
-            case K_MUL_COL: bs.back() = {2, 1}; break;
+            case Q_ADD_CONST: case K_ADD_COL: room0(1, 1); bs.back() = {bs.back().V + 1, bs.back().L + 1}; break;
+            case Q_TEE_TMP: settled0(); break;
+            case K_SUB_COL: room0(2, 2); bs.back() = {bs.back().V + 2, bs.back().L + 2}; break;
+            case K_RSUB_COL: settled0(); bs.back() = {3, 1}; break;
+            case K_MUL_COL: if (bs.back().V > 5) settle0(); bs.back() = {2, 1}; break;
             case K_FOLD_COL: case K_NOP: break;
             default: return -1;
         }
         // the memory operand of an instruction is loaded while its predecessor runs: a parked intermediate must not be
         // read back by the instruction right behind the one that parks it
-        if (k_has_mem_host(in.w0) && in.a >= num_cols && !out.empty() && (out.back().w0 & 0xffu) == Q_TEE_TMP && out.back().a == in.a - num_cols) out.push_back({K_NOP, 0, 0});
+        if (k_has_mem_host(in.w0) && in.a >= num_cols) {
+            for (int back = 1; back <= Q_PREFETCH_DIST; ++back) {
+                if ((int)out.size() < back) break;
+                const LowInstr& pv = out[out.size() - back];
+                if ((pv.w0 & 0xffu) == Q_TEE_TMP && pv.a == in.a - num_cols) { for (int q = back; q <= Q_PREFETCH_DIST; ++q) out.push_back({K_NOP, 0, 0}); break; }
+            }
+        }
         out.push_back(in);
         if ((int)bs.size() > mx) mx = (int)bs.size();
     }
@@ -527,12 +611,25 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     }
     if (depth < 1) depth = 1;
     const uint32_t low_len = (uint32_t)low.size();
+    // the accumulator's home: registers for programs that fold on most instructions, memory for the rest (see the kernel)
+    uint32_t folds = 0;
+    for (LowInstr& in : low) {
+        const uint32_t o = in.w0 & 0xffu;
+        if (o == Q_FOLD || o == K_FOLD_COL) { if (!folds) in.w0 |= K_FIRST_FOLD; ++folds; }
+    }
+    static const int acc_knob = getenv("ZK_QUOTIENT_ACC_MEM") ? atoi(getenv("ZK_QUOTIENT_ACC_MEM")) : -1;      // measurement knob: 0 / 1 force the variant
+    const bool acc_in_mem = folds > 0 && (acc_knob < 0 ? (uint64_t)folds * 16 <= low_len : acc_knob == 1);
+    uint32_t* d_acc = nullptr;
+    if (acc_in_mem) {
+        d_acc = (uint32_t*)ctx->get_scratch(SC_QACC, ((size_t)9 << ext_k) * sizeof(uint32_t));
+        if (!d_acc) return ZK_ERR_OOM;
+    }
     if (getenv("ZK_QUOTIENT_TRACE") && low_len >= 64) {        // what the kernel will run: lowered instructions by opcode, settle bits, stack depth
         static const char* names[22] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "SQUARE", "DOUBLE", "FOLD", "MUL_CONST", "ADD_CONST", "TEE_TMP", "PUSH_TMP", "?", "?",
                                         "ADD_COL", "SUB_COL", "RSUB_COL", "MUL_COL", "FOLD_COL", "NOP"};
-        uint32_t hist[22] = {0}, settles = 0;
-        for (const LowInstr& in : low) { const uint32_t o = in.w0 & 0xffu; if (o < 22) ++hist[o]; settles += ((in.w0 & K_SETTLE0) ? 1 : 0) + ((in.w0 & K_SETTLE1) ? 1 : 0); }
-        fprintf(stderr, "[zk quotient] 2^%u rows, %u lowered instructions, depth %d, %u settles:", ext_k, low_len, depth, settles);
+        uint32_t hist[22] = {0}, settles = 0, norms = 0;
+        for (const LowInstr& in : low) { const uint32_t o = in.w0 & 0xffu; if (o < 22) ++hist[o]; settles += ((in.w0 & (K_SETTLE0 | K_SETTLE0_8)) ? 1 : 0) + ((in.w0 & (K_SETTLE1 | K_SETTLE1_8)) ? 1 : 0); norms += ((in.w0 & K_NORM0) ? 1 : 0) + ((in.w0 & K_NORM1) ? 1 : 0); }
+        fprintf(stderr, "[zk quotient] 2^%u rows, %u lowered instructions, depth %d, %u settles, %u carry propagations:", ext_k, low_len, depth, settles, norms);
         for (int o = 0; o < 22; ++o) if (hist[o]) fprintf(stderr, " %s %u", names[o], hist[o]);
         fprintf(stderr, "\n");
     }
@@ -546,7 +643,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     // column table = the caller's columns, then one pseudo-column per parked intermediate
     std::vector<const void*> col_tab(h_col_ptrs, h_col_ptrs + num_cols);
     for (uint32_t t = 0; t < num_tmp; ++t) col_tab.push_back(d_tmp + ((size_t)t << ext_k));
-    const size_t prog_bytes = (size_t)(low_len + 3) * 12, col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
+    const size_t prog_bytes = (size_t)(low_len + 4) * 12, col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
     const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(QC29) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
@@ -564,7 +661,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         uint32_t* hp = (uint32_t*)staging.data();
         size_t w = 0;
         for (const LowInstr& in : low) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; }
-        for (int e = 0; e < 3; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; }      // END + the two triples the kernel fetches ahead
+        for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; }      // END + the triples the kernel fetches ahead
         if (!col_tab.empty()) memcpy(staging.data() + al(prog_bytes), col_tab.data(), col_tab.size() * 8);
         char* hc = staging.data() + al(prog_bytes) + al(col_bytes);
         QC29* hq = (QC29*)hc;                                  // limb form: the R-form constants, then their R' images
@@ -577,10 +674,17 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     ZK_HIP(ctx, hipMemcpyAsync(d, staging.data(), total_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
-    const size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
+    size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
+    {   // measurement knob: pad the workgroup's LDS to this many bytes, i.e. cap the workgroups resident per CU (160 KB / pad)
+        static const long pad = getenv("ZK_QUOTIENT_LDS_PAD") ? atol(getenv("ZK_QUOTIENT_LDS_PAD")) : 0;
+        if (pad > 0 && (size_t)pad > lds && (size_t)pad <= (size_t)Q_MAX_STACK * 9 * Q_THREADS * 4) lds = (size_t)pad;
+    }
     if (!ctx->quotient_attr_set) {
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAX_STACK * 9 * Q_THREADS * 4));
+        const int lds_max = Q_MAX_STACK * 9 * Q_THREADS * 4;
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ctx->quotient_attr_set = true;
     }
     ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
@@ -598,12 +702,17 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         ops.erase(std::unique(ops.begin(), ops.end()), ops.end());
         ps.bytes = (ops.size() + tmp_moves + 1) * ne * 32;
     }
-    if (ne >= (uint64_t)Q_THREADS) {
-        hipLaunchKernelGGL(k_quotient_eval<true>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                           low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
-    } else {
-        hipLaunchKernelGGL(k_quotient_eval<false>, dim3((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), dim3(Q_THREADS), lds, ctx->stream, (const uint32_t*)d_prog,
-                           low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp);
+    {
+        const dim3 grid((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), block(Q_THREADS);
+        const bool full = ne >= (uint64_t)Q_THREADS;
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
+                               tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc);
+        };
+        if (full && acc_in_mem) launch(k_quotient_eval<true, true>);
+        else if (full) launch(k_quotient_eval<true, false>);
+        else if (acc_in_mem) launch(k_quotient_eval<false, true>);
+        else launch(k_quotient_eval<false, false>);
     }
     ZK_CHECK_LAUNCH(ctx);
     return ZK_OK;

@@ -605,4 +605,57 @@ int zk_fr_scatter_scaled(zk_ctx* ctx, const void* d_src, size_t n, const void* h
     return ZK_OK;
 }
 
+// ---- self-test of the device product routines -----------------------------------------------------------------------------------
+// The Montgomery products run as ONE asm statement each on the device (csrc/mul29_asm.hip.hpp, generated); the C forms of
+// ff29.hip.hpp stay the definition, are what the host build runs (tests/test_host_arith.py) and what the asm forms must equal bit
+// for bit at the lazy-reduction bounds every kernel relies on.  One lane = one operand set: limbs of the first operand below 2^30
+// (value below 2^258), second operand normalised, the addends of mul2add29 at their bounds; every sixteenth lane holds every
+// limb AT its bound.  Both fields (Fr: NTT / evaluator, Fq: the bucket additions).
+} // extern "C"
+namespace zk {
+__device__ __forceinline__ uint32_t st_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <class P>
+__global__ void k_selftest_products(uint32_t* bad, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F29<P> a, b, c, d, u;
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t top = i == 8;
+        a.l[i] = st_hash32(seed + tid * 41 + i) & (top ? 0x3ffffffu : 0x3fffffffu);          // limbs < 2^30, value < 2^258
+        b.l[i] = st_hash32(seed + tid * 43 + i + 100) & (top ? 0xffffffu : 0x1fffffffu);     // normalised, < 2^256
+        c.l[i] = st_hash32(seed + tid * 47 + i + 200) & (top ? 0xffffffu : 0x1fffffffu);
+        d.l[i] = st_hash32(seed + tid * 53 + i + 300) & (top ? 0xffffffu : 0x3fffffffu);     // limbs < 2^30
+        u.l[i] = st_hash32(seed + blockIdx.x * 59 + i + 400) & (top ? 0xffffffu : 0x1fffffffu);   // workgroup-uniform second factor (scalar registers)
+        if ((tid & 15) == 3 && i < 8) { a.l[i] = 0x3fffffffu; b.l[i] = 0x1fffffffu; c.l[i] = 0x1fffffffu; d.l[i] = 0x3fffffffu; }
+    }
+    F29<P> an = a;
+    for (int i = 0; i < 8; ++i) an.l[i] &= 0x1fffffffu;
+    uint32_t diff = 0;
+    auto cmp = [&](const F29<P>& x, const F29<P>& y, uint32_t bit) { for (int i = 0; i < 9; ++i) if (x.l[i] != y.l[i]) diff |= bit; };
+    cmp(mul29(a, b), mul29_c(a, b), 1u);
+    cmp(mul29_ub(a, u), mul29_ub_c(a, u), 2u);
+    cmp(sqr29(an), sqr29_c(an), 4u);
+    cmp(mul2add29(an, b, c, d), mul2add29_c(an, b, c, d), 8u);
+    // and the product against the definition: a b 2^-261 mod p through the 8 x 32 CIOS routine is covered by the NTT / MSM parity
+    // tests; here the two forms of the SAME column sums must agree in every limb
+    if (diff) { atomicAdd(bad, 1u); atomicOr(bad + 1, diff); }
+    atomicAdd(bad + 2, 1u);
+}
+}  // namespace zk
+extern "C" {
+int zk_selftest_products(zk_ctx* ctx, int field, uint32_t operand_sets, uint32_t seed, uint32_t* out3) {
+    if (!ctx) return ZK_ERR_INVALID_ARG;
+    ZK_REQUIRE(ctx, out3 && (field == ZK_FIELD_FR || field == ZK_FIELD_FQ), "bad argument");
+    uint32_t* d = (uint32_t*)ctx->get_scratch(SC_TMP, 64);
+    if (!d) return ZK_ERR_OOM;
+    ZK_HIP(ctx, hipMemsetAsync(d, 0, 12, ctx->stream));
+    const unsigned blocks = (operand_sets + 255) / 256;
+    if (blocks) {
+        if (field == ZK_FIELD_FR) hipLaunchKernelGGL(zk::k_selftest_products<Fr29P>, dim3(blocks), dim3(256), 0, ctx->stream, d, seed);
+        else hipLaunchKernelGGL(zk::k_selftest_products<Fq29P>, dim3(blocks), dim3(256), 0, ctx->stream, d, seed);
+        ZK_CHECK_LAUNCH(ctx);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(out3, d, 12, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
 }  // extern "C"
