@@ -324,6 +324,39 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
         except Exception as e:       # the headline must survive this side measurement
             pcie = {"error": repr(e)}
 
+    # ---- what ONE rank of an N-GPU run of this proof computes, measured here: rank 0 of N = 2 / 4 / 8 emulated on this GPU
+    # (zkevm-circuits_amd/sharding.EmulatedRank: own commitments, every column's transforms, the (degree class, coset) pairs the rank
+    # is dealt, everything the session replicates; the exchanges served locally, so NO communication time is in it).  A projection
+    # of the compute side of the scaling curve, not a measurement of N GPUs -- the driver's SCALE run is that.
+    projected = None
+    if world == 1 and not quick:
+        projected = {"note": "wall-clock of rank 0's share of the SAME proof sharded over N ranks, emulated on one GPU (peers' columns served from the resident witness, their commitments and "
+                             "quotient pairs replaced by stand-ins: the emulated proof is not valid); excludes every byte that would cross xGMI -- `exchange_gb_in` says how many would arrive at the rank",
+                     "rank_device_s": {}, "exchange_gb_in": {}}
+        try:
+            from zkevm_circuits_amd import sharding as shard_mod
+            for nn in (2, 4, 8):
+                owned_n = bp.owned_columns(circ, 0, nn)
+                emu = shard_mod.EmulatedRank(ctx, circ, adv_dev, 0, nn)
+                drv = bp.PhaseDriver(ctx, circ, adv_dev, rlc, owned=owned_n)
+                tt = []
+                for _ in range(2):
+                    fence()
+                    t1 = time.perf_counter()
+                    sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+                    sess.set_multiopen(1)
+                    emu.attach(sess)
+                    drv.run(sess, before_phase=emu.begin_phase)
+                    sess.finish()
+                    fence()
+                    tt.append(time.perf_counter() - t1)
+                drv.free()
+                projected["rank_device_s"][str(nn)] = round(min(tt), 4)
+                pairs = sum((1 << e_) for e_, c_ in enumerate(plan["classes"]) if c_["used"])
+                projected["exchange_gb_in"][str(nn)] = round(((circ.A - len(owned_n)) + pairs * (nn - 1) / nn) * circ.n * 32 / 1e9, 2)
+        except Exception as e:
+            projected["error"] = repr(e)
+
     # ---- rooflines of the proof's kernel classes, from this rank's events of the timed region
     n = circ.n
     ntt_ms = prof.get("ntt_pass", (0.0, 0))[0] + prof.get("ntt_last", (0.0, 0))[0]
@@ -412,7 +445,7 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
                   "witness_upload_s_outside_timing": round(t_upload, 2), "host_circuit_build_s": round(t_build, 2),
                   "msm_count": circ.A + 2 * len(circ.lookups) + (len(circ.perm_cols) + circ.degree() - 3) // (circ.degree() - 2) + (circ.degree() - 1) + 2,
                   "kernel_class_device_ms_per_proof": {k_: round(v[0] / args.steps, 2) for k_, v in prof.items() if v[1]},
-                  "pcie_inclusive": pcie, "structure_blind": blind, "degree_blind": degree_blind,
+                  "pcie_inclusive": pcie, "structure_blind": blind, "degree_blind": degree_blind, "projected_rank_device_s": projected,
                   "shape": shape, "gate_polynomials": len(circ.gates), "gate_degrees": {str(d_): sum(1 for g_ in circ.gates if g_.degree() == d_) for d_ in sorted({g_.degree() for g_ in circ.gates})},
                   "lookup_tuple_widths": sorted({len(lk.table) for lk in circ.lookups}),
                   "evaluator": {"plan": plan, "class_launches_per_proof": round(q[1] / args.steps, 1), "device_ms_per_proof": round(q[0] / args.steps, 2),

@@ -839,15 +839,19 @@ class PhaseDriver:
             self._zero = self.ctx.to_device(np.zeros((self.n, 4), dtype=np.uint64))
         return self._zero
 
-    def run(self, sess):
-        """three advice phases of `sess`; returns the challenges"""
+    def run(self, sess, before_phase=None):
+        """three advice phases of `sess`; returns the challenges.  before_phase(p): called ahead of phase p (sharding.EmulatedRank)"""
         phase_of = self.circ.advice_phase
         mine = lambda i: self.owned is None or i in self.owned
         cols = lambda ph: {i: (self.adv[i] if mine(i) else None) for i in range(self.circ.A) if phase_of[i] == ph}
+        hook = before_phase or (lambda p_: None)
+        hook(0)
         ch0 = sess.advice_phase_dev(cols(0), in_place=self.in_place)      # evm_word, keccak_input
         self._rlc(0, ch0[0], self.rlc["w"])
+        hook(1)
         ch1 = sess.advice_phase_dev(cols(1), in_place=self.in_place)      # lookup_input
         self._rlc(self.rlc["w"], ch1[0], self.rlc["t"])
+        hook(2)
         sess.advice_phase_dev(cols(2), in_place=self.in_place)
         return list(ch0) + list(ch1)
 

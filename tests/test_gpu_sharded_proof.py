@@ -26,3 +26,42 @@ def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather
     assert len(single) > 500
     for r in range(world):
         assert open(tmp_path / f"proof_{r}.bin", "rb").read() == single, f"rank {r} produced a different proof"
+
+
+@pytest.mark.parametrize("world,rank", [(2, 0), (2, 1), (4, 3), (8, 0)])
+def test_emulated_rank_runs_its_share_on_one_gpu(world, rank):
+    """sharding.EmulatedRank (what `bench.py` times for `extra.projected_rank_device_s`): rank r of N on ONE GPU with its peers'
+    columns served from the resident witness.  The session must take the owner-only hand-over (NULL for the columns of other ranks),
+    run every stage, and return a proof of the unsharded proof's length; with the peers' commitments and quotient pairs replaced by
+    stand-ins its bytes differ from the real proof (world > 1) -- it is a timing vehicle, and says so."""
+    import numpy as np
+    import zkevm_circuits_amd as z
+    from zkevm_circuits_amd import plonk, sharding
+    from plonk_fixtures import build_circuit
+    ctx = z.Context(0)
+    circ, adv, inst = build_circuit(9, seed=6, wide=True)
+    srs = ctx.srs_setup_with_s(9, np.frombuffer(plonk.fr_mont_bytes(0x5EC2E7), dtype=np.uint64).copy())
+    pk = ctx.pk_create(srs, circ.blob())
+    inst_m = [plonk.column_to_mont(c) for c in inst]
+    adv_dev = {i: ctx.to_device(plonk.column_to_mont(c)) for i, c in enumerate(adv)}
+    try:
+        sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
+        sess.set_multiopen(1)
+        sess.advice_phase_dev(dict(adv_dev))
+        real = sess.finish()
+        owned = set(range(circ.A)[rank::world])
+        emu = sharding.EmulatedRank(ctx, circ, adv_dev, rank, world)
+        sess = ctx.proof_session(pk, inst_m, bytes(range(16)))
+        sess.set_multiopen(1)
+        emu.attach(sess)
+        emu.begin_phase(0)
+        sess.advice_phase_dev({i: (adv_dev[i] if i in owned else None) for i in range(circ.A)})
+        got = sess.finish()
+        assert len(got) == len(real) and got != real
+        assert emu.phase_cols == []                        # every group of the phase went through the device gather
+    finally:
+        for b_ in adv_dev.values():
+            b_.free()
+        pk.destroy()
+        srs.destroy()
+        ctx.close()

@@ -165,7 +165,8 @@ struct zk_ctx {
 
 // RAII scope: records a HIP event pair around the enclosed launches on ctx->stream
 struct ZkProfScope {
-    static bool is_main(const char* n) { return !strcmp(n, "msm_buckets") || !strncmp(n, "ntt_", 4) || !strncmp(n, "quotient", 8); }
+    // level 2 (what bench.py's timed region runs under): every MSM class (merged and grouped bucket launches, sorts, reductions), the NTT passes, the evaluator
+    static bool is_main(const char* n) { return !strncmp(n, "msm_", 4) || !strncmp(n, "ntt_", 4) || !strncmp(n, "quotient", 8); }
     zk_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t s; uint64_t bytes = 0;
     ZkProfScope(zk_ctx* ctx, const char* n, hipStream_t on = nullptr) : c(ctx), name(n), s(on ? on : ctx->stream) {
         if (c->prof_on && (!c->prof_main_only || is_main(n))) { a = c->prof_event(); (void)hipEventRecord(a, s); }

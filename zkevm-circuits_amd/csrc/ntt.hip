@@ -578,28 +578,37 @@ static int set_lds_attr(zk_ctx* ctx) {
 
 // launchers of the fixed-structure passes: false = this digit size has no instance (the caller takes the generic kernel)
 template <int LOG_NP, bool HAS_PRE>
-static void launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
+static bool launch_pass_f(zk_ctx* ctx, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     const uint32_t bit = 1u << (2 * (LOG_NP - 7) + (HAS_PRE ? 1 : 0));          // the attribute is per device: remembered per context
-    if (!(ctx->ntt_fixed_attr & bit)) { (void)hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT); ctx->ntt_fixed_attr |= bit; }
+    if (!(ctx->ntt_fixed_attr & bit)) {
+        // a device that refuses the LDS size (not a gfx950, a lowered limit): this instance stays unused, the caller takes the generic kernel
+        if (hipFuncSetAttribute((const void*)k_ntt_pass_f<LOG_NP, HAS_PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * NTT_LDS_BYTES_PER_ELT) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ctx->ntt_fixed_attr |= bit;
+    }
     hipLaunchKernelGGL((k_ntt_pass_f<LOG_NP, HAS_PRE>), dim3(grid), dim3(threads), lds, ctx->stream, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp);
+    return true;
 }
 static bool ntt_fixed_on() { const char* e = getenv("ZK_NTT_FIXED"); return !(e && atoi(e) == 0); }      // measurement knob, read per call (tests flip it inside one process)
 static bool launch_pass_fixed(zk_ctx* ctx, int log_np, unsigned grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_m, const Fr* pre, const Fr* out_tw, uint32_t ncols, int xcd_cols, int log_grp) {
     if (!ntt_fixed_on() || !out_tw) return false;
-#define ZK_PASS_CASE(N) case N: if (pre) launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); \
-                                else launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp); return true;
+#define ZK_PASS_CASE(N) case N: return pre ? launch_pass_f<N, true>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp) \
+                                           : launch_pass_f<N, false>(ctx, grid, threads, lds, io, tw, log_t, log_m, pre, out_tw, ncols, xcd_cols, log_grp);
     switch (log_np) { ZK_PASS_CASE(7) ZK_PASS_CASE(8) ZK_PASS_CASE(9) ZK_PASS_CASE(10) ZK_PASS_CASE(11) default: return false; }      // 7, 8: the three-pass sizes (2^21 .. 2^24)
 #undef ZK_PASS_CASE
 }
 template <int LOG_NP>
-static void launch_last_f(zk_ctx* ctx, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
+static bool launch_last_f(zk_ctx* ctx, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
     const uint32_t bit = 1u << (24 + LOG_NP - 7);
-    if (!(ctx->ntt_fixed_attr & bit)) { (void)hipFuncSetAttribute((const void*)k_ntt_last_f<LOG_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT); ctx->ntt_fixed_attr |= bit; }
+    if (!(ctx->ntt_fixed_attr & bit)) {
+        if (hipFuncSetAttribute((const void*)k_ntt_last_f<LOG_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTT_TILE + 128) * NTT_LDS_BYTES_PER_ELT) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ctx->ntt_fixed_attr |= bit;
+    }
     hipLaunchKernelGGL((k_ntt_last_f<LOG_NP>), grid, dim3(threads), lds, ctx->stream, io, tw, log_t, log_n1, log_mid, xcd_remap);
+    return true;
 }
 static bool launch_last_fixed(zk_ctx* ctx, int log_np, dim3 grid, unsigned threads, size_t lds, const NttIo& io, const Tw29* tw, int log_t, int log_n1, int log_mid, int xcd_remap) {
     if (!ntt_fixed_on()) return false;
-#define ZK_LAST_CASE(N) case N: launch_last_f<N>(ctx, grid, threads, lds, io, tw, log_t, log_n1, log_mid, xcd_remap); return true;
+#define ZK_LAST_CASE(N) case N: return launch_last_f<N>(ctx, grid, threads, lds, io, tw, log_t, log_n1, log_mid, xcd_remap);
     switch (log_np) { ZK_LAST_CASE(7) ZK_LAST_CASE(8) ZK_LAST_CASE(9) ZK_LAST_CASE(10) ZK_LAST_CASE(11) default: return false; }
 #undef ZK_LAST_CASE
 }
@@ -708,7 +717,14 @@ int ntt_run_many(zk_ctx* ctx, Fr* const* d_datas, const Fr* const* d_srcs, size_
     if (P > 1) {
         // transforms on the auxiliary stream run BESIDE transforms of the main stream (coset transforms ahead of the quotient,
         // prover.hip): the intermediate buffer of a multi-pass transform is per stream
-        scratch = (Fr*)ctx->get_scratch(ctx->stream_aux && ctx->stream == ctx->stream_aux ? SC_NTT_AUX : SC_NTT, sizeof(Fr) * n * per_launch);
+        // sixteen columns per launch take 512 MiB of scratch per stream at 2^20: on a device that cannot spare it, fewer columns per launch (slower, not fatal)
+        const int slot = ctx->stream_aux && ctx->stream == ctx->stream_aux ? SC_NTT_AUX : SC_NTT;
+        for (;;) {
+            scratch = (Fr*)ctx->get_scratch(slot, sizeof(Fr) * n * per_launch);
+            if (scratch || per_launch == 1) break;
+            (void)hipGetLastError();
+            per_launch = (per_launch + 1) / 2;
+        }
         if (!scratch) return ZK_ERR_OOM;
     }
     for (size_t first = 0; first < count; first += per_launch) {

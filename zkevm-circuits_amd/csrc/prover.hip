@@ -2461,6 +2461,12 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                     if (!gbuf.p && !gbuf.alloc((size_t)pr->world * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
                     PK_TRY(comm_allgather_dev(ctx, mine_t, n * 32, gbuf.p));
                     got = (const char*)gbuf.p;
+                } else if (pr->gather_dev) {
+                    // a caller-supplied device all-gather (zk_proof_set_device_gather): device to device as well; the callback completes on return
+                    if (!gbuf.p && !gbuf.alloc((size_t)pr->world * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                    PK_TRY(zk_ctx_sync(ctx));
+                    if (pr->gather_dev(pr->gather_dev_user, mine_t, n * 32, gbuf.p)) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: device all-gather callback failed");
+                    got = (const char*)gbuf.p;
                 } else {
                     if (t < mine.size()) PK_TRY(zk_d2h(ctx, send.data(), mine_t, n * 32));
                     if (pr->gather(pr->gather_user, send.data(), n * 32, recv.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");

@@ -442,7 +442,8 @@ int msm_diff_try(zk_ctx* ctx, const zk_srs* srs, int basis, const Fr* const* d_s
         Fr* d_s = (Fr*)ctx->pool_get(s_bytes);
         char* aux = (char*)ctx->pool_get(aux_bytes);
         if (!d_s || !aux) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return ZK_OK; }
-        auto release = [&](int code) { ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return code; };
+        // error paths: kernels that read d_s / aux may still be in flight on the stream -- drain it before the blocks go back to the pool
+        auto release = [&](int code) { (void)hipStreamSynchronize(ctx->stream); ctx->pool_put(d_s, s_bytes); ctx->pool_put(aux, aux_bytes); return code; };
         Fr* d_c = (Fr*)aux;
         G1Xyzz* d_res = (G1Xyzz*)(d_c + CHUNK);
         uint32_t* d_votes = (uint32_t*)(d_res + CHUNK);

@@ -178,6 +178,62 @@ def shard_session_device(session: "binding.ProofSession", group=None):
     return cb, cb_dev
 
 
+class EmulatedRank:
+    """Rank `rank` of a `world`-rank sharded session on ONE GPU, its peers played by the local witness: what a rank of a real
+    multi-GPU run computes -- its own commitments, the transforms of every column, the (degree class, coset) pairs it is dealt,
+    everything the session replicates -- with every exchange served locally:
+      * the device all-gather of a phase's advice columns hands back the TRUE columns of the peers (all of them are resident here:
+        the lookups and the permutation argument must see a satisfied witness), device to device;
+      * the all-gather of commitments and of finished quotient pairs hands back copies of this rank's own contribution.
+    The proof that comes out is NOT valid (peers' commitments and quotient values are stand-ins); its wall-clock is this rank's
+    device time without any communication -- `bench.py`'s `extra.projected_rank_device_s`, a projection, not a measurement of N GPUs.
+    Usage: emu = EmulatedRank(ctx, circ, adv_dev, rank, world); emu.attach(sess); emu.begin_phase(p) before every advice phase p."""
+
+    def __init__(self, ctx, circ, adv_dev: dict, rank: int, world: int):
+        self.ctx, self.circ, self.adv, self.rank, self.world = ctx, circ, adv_dev, rank, world
+        self.phase_cols: List[int] = []
+        self.group = 0
+        lib = binding.lib()
+
+        def host_gather(_user, send_ptr, nbytes, recv_ptr):
+            try:
+                for q in range(world):
+                    ctypes.memmove(recv_ptr + q * nbytes, send_ptr, nbytes)
+                return 0
+            except Exception as e:
+                print(f"[zkmi355 emulated rank] gather failed: {e!r}", flush=True)
+                return 1
+
+        def dev_gather(_user, send_ptr, nbytes, recv_ptr):
+            try:
+                cols = self.phase_cols
+                for q in range(world):
+                    src = send_ptr
+                    j = self.group * world + q
+                    if cols and q != rank and j < len(cols) and self.adv.get(cols[j]) is not None:
+                        src = self.adv[cols[j]].ptr                       # the peer's column
+                    if lib.zk_d2d(ctx.h, ctypes.c_void_p(recv_ptr + q * nbytes), ctypes.c_void_p(src), ctypes.c_size_t(nbytes)) != 0:
+                        return 1
+                if cols:
+                    self.group += 1
+                    if self.group * world >= len(cols):
+                        self.phase_cols = []                                # the phase's columns are through: later calls are quotient pairs
+                ctx.sync()
+                return 0
+            except Exception as e:
+                print(f"[zkmi355 emulated rank] device gather failed: {e!r}", flush=True)
+                return 1
+        self._cb, self._cb_dev = ALLGATHER_FN(host_gather), ALLGATHER_FN(dev_gather)
+
+    def attach(self, session):
+        session.set_sharding(self.rank, self.world, self._cb)
+        session.set_device_gather(self._cb_dev)
+
+    def begin_phase(self, phase: int):
+        self.phase_cols = [i for i in range(self.circ.A) if self.circ.advice_phase[i] == phase]
+        self.group = 0
+
+
 # ---------------------------------------------------------------- one NTT over several GPUs
 ALLTOALL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
