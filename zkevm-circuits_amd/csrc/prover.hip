@@ -2328,9 +2328,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         DevBuf hpart;
         if (!hpart.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         if (late_cosets) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));          // the cosets computed beside the earlier stages are complete
-        std::unordered_map<uint32_t, const void*> part_of;
         Env part = lag;
-        part.part = &part_of;
         const Fr w_n = fr_root_of_unity(k), w_ext = fr_root_of_unity(ext_k);
         Fr g = fr_zeta();
         // Sharded session: the unit of work is a (class, coset) pair -- class e on coset r costs the transforms of the columns
@@ -2365,28 +2363,48 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             }
             for (auto& d_ : deal) std::sort(d_.begin(), d_.end(), [](const Pair& a, const Pair& b) { return a.r != b.r ? a.r < b.r : a.e < b.e; });
         }
+        // The cosets this rank works on, each with the classes active there (sharded: those of them this rank was dealt).
+        struct CosetWork { uint32_t r = 0; Fr g; std::vector<uint32_t> active; std::unordered_map<uint32_t, const void*> part_of; };
+        std::vector<std::pair<uint32_t, Fr>> rs;
         for (uint32_t r_ = 0; r_ < nparts; ++r_) {
-          // classes whose extended domain contains this coset (sharded: those of them this rank was dealt), and the columns they read
-          std::vector<uint32_t> active;
-          for (uint32_t e = 0; e <= E; ++e)
-              if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0 && (!sharded || owner(e, r_) == pr->rank)) active.push_back(e);
-          if (!active.empty()) {
-            part_of.clear();
+            bool any = false;
+            for (uint32_t e = 0; e <= E && !any; ++e) any = qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0 && (!sharded || owner(e, r_) == pr->rank);
+            if (any) rs.push_back({r_, g});
+            g = g * w_ext;
+        }
+        // ZK_QUOTIENT_OVERLAP=1 (round 6, measured and left OFF): the transforms of coset j + 1 run on the auxiliary stream WHILE the class
+        // programs of coset j run on the main one (into a second set of coset buffers: for an unsharded proof the odd cosets, which only
+        // the top class reads).  Both kernels are bound by vector issue; what each leaves to barriers / operand loads the other did not
+        // fill: EVM-style headline 2.393 s against 2.405 s, plain shape 0.989 against 0.979 (alternating A/B, profiles/r06_experiments.md).
+        const char* ov_env = getenv("ZK_QUOTIENT_OVERLAP");
+        const bool overlap = ov_env && atoi(ov_env) == 1 && rs.size() > 1 && ctx->ensure_aux();
+        std::vector<DevBuf> part_buf2(overlap ? refs.size() : 0);
+        struct EventPair { hipEvent_t e[2] = {nullptr, nullptr}; ~EventPair() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } ev_t;
+        if (overlap) for (hipEvent_t& x : ev_t.e) ZK_HIP(ctx, hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        CosetWork work[2];
+        // the columns the active classes read on coset w.r: taken from where they already are (computed ahead, the key's cache) or
+        // transformed into `bufs` on the CURRENT stream of the context
+        auto transform = [&](CosetWork& w, std::vector<DevBuf>& bufs) -> int {
+            const uint32_t r_ = w.r;
+            w.active.clear();
+            for (uint32_t e = 0; e <= E; ++e)
+                if (qc[e].used && (r_ & ((1u << (E - e)) - 1u)) == 0 && (!sharded || owner(e, r_) == pr->rank)) w.active.push_back(e);
+            w.part_of.clear();
             std::vector<const void*> bat_src;                 // the coset transforms of this round go out as one batch
             std::vector<void*> bat_dst;
             std::vector<std::pair<uint32_t, DevBuf>> fresh_slots;      // cache slots being filled: published only once they hold their coset
             for (size_t i = 0; i < refs.size(); ++i) {
                 bool needed = false;
-                for (uint32_t e : active) needed |= std::find(qc[e].refs.begin(), qc[e].refs.end(), refs[i]) != qc[e].refs.end();
+                for (uint32_t e : w.active) needed |= std::find(qc[e].refs.begin(), qc[e].refs.end(), refs[i]) != qc[e].refs.end();
                 if (!needed) continue;
-                if (const void* pre = pre_coset(refs[i], r_)) { part_of[refs[i]] = pre; continue; }
-                if (!(cache_on && of_key(refs[i])) && !part_buf[i].p && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-                void* dst = part_buf[i].p;
+                if (const void* pre = pre_coset(refs[i], r_)) { w.part_of[refs[i]] = pre; continue; }
+                if (!(cache_on && of_key(refs[i])) && !bufs[i].p && !bufs[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                void* dst = bufs[i].p;
                 DevBuf fresh;                             // a cache slot being filled: published only once it holds the coset
                 const bool cached = cache_on && of_key(refs[i]);
                 if (cached) {
                     auto it = pk->part_cache[r_].find(refs[i]);
-                    if (it != pk->part_cache[r_].end()) { part_of[refs[i]] = it->second.p; continue; }   // computed by an earlier proof
+                    if (it != pk->part_cache[r_].end()) { w.part_of[refs[i]] = it->second.p; continue; }   // computed by an earlier proof
                     // a slot lives as long as the key, not the session's pool.  When the device has no room for it: give the
                     // pool's parked blocks back and retry; if that fails too, freeze the cache (existing slots stay in use) and
                     // compute this coset into a session buffer like any witness column's -- the proof goes on, uncached.
@@ -2401,12 +2419,12 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                     }
                     if (got) dst = fresh.p;
                     else {
-                        if (!part_buf[i].p && !part_buf[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-                        dst = part_buf[i].p;
+                        if (!bufs[i].p && !bufs[i].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                        dst = bufs[i].p;
                     }
                 }
-                part_of[refs[i]] = dst;
-                if (refs[i] == colref(CT_SPECIAL, SP_X)) PK_TRY(zk_fr_powers(ctx, &w_n, &g, dst, n));   // X on the coset: g * omega^i
+                w.part_of[refs[i]] = dst;
+                if (refs[i] == colref(CT_SPECIAL, SP_X)) PK_TRY(zk_fr_powers(ctx, &w_n, &w.g, dst, n));   // X on the coset: g * omega^i
                 else {
                     const Fr* cf = (refs[i] >> 24) == CT_SPLIT_R ? ((refs[i] & 0xFFFFFFu) < rems.size() ? rems[refs[i] & 0xFFFFFFu].coeff.fr() : nullptr)
                                                                  : coeff_of(pk, refs[i], adv_coeff, inst_coeff, pz_coeff, m_coeff, phi_coeff);
@@ -2416,17 +2434,21 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 }
                 if (cached && fresh.p) fresh_slots.emplace_back(refs[i], std::move(fresh));
             }
-            PK_TRY(zk_coeff_to_coset_batch(ctx, bat_src.data(), k, &g, bat_dst.data(), bat_src.size()));
+            PK_TRY(zk_coeff_to_coset_batch(ctx, bat_src.data(), k, &w.g, bat_dst.data(), bat_src.size()));
             for (auto& fs : fresh_slots) {
                 pk->part_cache_bytes += n * 32;
                 ctx->coset_cache_bytes += n * 32;
                 pk->part_cache[r_][fs.first] = std::move(fs.second);
             }
-            trace.mark("  quotient: cosets of the columns");
-            Fr gn = g;
+            return ZK_OK;
+        };
+        auto programs = [&](CosetWork& w) -> int {
+            const uint32_t r_ = w.r;
+            part.part = &w.part_of;
+            Fr gn = w.g;
             for (uint32_t i = 0; i < k; ++i) gn = sqr(gn);
             const Fr vinv = fr_inv_host(gn - Fr::one());
-            for (uint32_t e : active) {
+            for (uint32_t e : w.active) {
                 ctx->prof_tag = "quotient_coset";
                 const int rc_q = run_program(ctx, part, qc[e].prog, hpart.p);
                 ctx->prof_tag = nullptr;
@@ -2445,9 +2467,39 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 }
                 PK_TRY(zk_fr_scatter_scaled(ctx, hpart.p, n, sharded ? &one_fr : &scale, qc[e].h.p, (size_t)1 << e, r_ >> (E - e)));
             }
+            return ZK_OK;
+        };
+        for (size_t j = 0; j < rs.size(); ++j) {
+            CosetWork& cur = work[j & 1];
+            if (j == 0) {
+                cur.r = rs[0].first; cur.g = rs[0].second;
+                PK_TRY(transform(cur, part_buf));
+                trace.mark("  quotient: cosets of the columns");
+            }
+            if (overlap && j + 1 < rs.size()) {
+                // the auxiliary stream starts behind everything the main stream holds so far -- the programs of coset j - 1, which read the
+                // buffer set the transforms below write; pooled blocks handed out now were last used there as well
+                CosetWork& nxt = work[(j + 1) & 1];
+                nxt.r = rs[j + 1].first; nxt.g = rs[j + 1].second;
+                ZK_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
+                ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
+                hipStream_t main_stream = ctx->stream;
+                ctx->stream = ctx->stream_aux;
+                const int rc_t = transform(nxt, ((j + 1) & 1) ? part_buf2 : part_buf);
+                hipError_t e_rec = rc_t ? hipSuccess : hipEventRecord(ev_t.e[(j + 1) & 1], ctx->stream_aux);
+                ctx->stream = main_stream;
+                PK_TRY(rc_t);
+                ZK_HIP(ctx, e_rec);
+            }
+            if (overlap && j > 0) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev_t.e[j & 1], 0));
+            PK_TRY(programs(cur));
             trace.mark("  quotient: program");
-          }
-            g = g * w_ext;
+            if (!overlap && j + 1 < rs.size()) {
+                CosetWork& nxt = work[(j + 1) & 1];
+                nxt.r = rs[j + 1].first; nxt.g = rs[j + 1].second;
+                PK_TRY(transform(nxt, part_buf));
+                trace.mark("  quotient: cosets of the columns");
+            }
         }
         if (sharded) {
             if (mine.size() != deal[pr->rank].size()) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: %zu pairs evaluated, %zu dealt", mine.size(), deal[pr->rank].size());
