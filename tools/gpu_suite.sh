@@ -3,5 +3,5 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 ROOT=$(pwd); O=$ROOT/gpurun_out/suite; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed" $O/pytest.log | tail -2
+timeout 3000 python -m pytest tests -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed" $O/pytest.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
