@@ -120,7 +120,7 @@ def hbm_roof(kernel, alg_bytes, ms, note, products=None, launches=None):
 
 def committed_traffic(key):
     """PMC traffic (FETCH_SIZE + WRITE_SIZE per launch) from the newest committed rocprofv3 --pmc passes under profiles/"""
-    for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
+    for tname in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             try:
@@ -155,6 +155,31 @@ def proof_algorithmic_bytes(circ, shplonk=True, uniform_random_poly=False):
         "multi-open (K10/K11): two linear combinations over the opened polynomials": 2 * 32 * n * (opened + 1),
     }
     return b
+
+
+def class_program_operands(circ):
+    """memory operands (column reads + parked values read back) and parked values written per row of every degree class's compiled
+    program, out of zk_host_quotient_plan on the circuit's constraint system (the plan zk_proof_finish follows under the knobs in force)"""
+    import ctypes
+
+    import numpy as np
+
+    from zkevm_circuits_amd import binding
+    lib = binding.lib()
+    blob = circ.cs_blob()
+    E = circ.extended_k() - circ.k
+    out = []
+    for e in range(E + 1):
+        summ = np.zeros(8 + 8 * (E + 1), dtype=np.uint32)
+        cnt = ctypes.c_uint32()
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if lib.zk_host_quotient_plan(blob, ctypes.c_size_t(len(blob)), ptr(summ), ctypes.c_size_t(summ.size), ctypes.c_uint32(e), None, ctypes.c_size_t(0), ctypes.byref(cnt)) != 0:
+            return None
+        words = np.zeros(max(3 * cnt.value, 3), dtype=np.uint32)
+        lib.zk_host_quotient_plan(blob, ctypes.c_size_t(len(blob)), ptr(summ), ctypes.c_size_t(summ.size), ctypes.c_uint32(e), ptr(words), ctypes.c_size_t(words.size), ctypes.byref(cnt))
+        ops = words[:3 * cnt.value:3]
+        out.append({"reads": int(((ops == 1) | (ops == 13)).sum()), "parks": int((ops == 12).sum()), "products": int(summ[8 + 8 * e + 2]), "used": int(summ[8 + 8 * e])})
+    return out
 
 
 def device_sync(ctx, torch):
@@ -232,14 +257,56 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
             dist.barrier()
         device_sync(ctx, torch)
 
+    # the same proof from page-locked HOST memory (what a Rust caller of create_proof holds): zk_proof_advice_phase, 33.5 GB over PCIe inside the proof
+    host = {}
+
+    def host_setup():
+        if host:
+            return
+        pinned = {}
+        for a in adv_m[:SC_SHAPE[1] - 2]:
+            if id(a) not in pinned:
+                pinned[id(a)] = ctx.host_alloc(a.shape)
+                pinned[id(a)][:] = a
+        host["pinned"] = pinned
+        host["cols"] = [pinned[id(a)] for a in adv_m[:SC_SHAPE[1] - 2]]
+        host["w"], host["t"] = ctx.host_alloc((circ.n, 4)), ctx.host_alloc((circ.n, 4))
+
+    def host_teardown():
+        if not host:
+            return
+        for a in list(host["pinned"].values()) + [host["w"], host["t"]]:
+            ctx.host_free(a)
+        host.clear()
+
+    def step_host():
+        host_cols, w_h, t_h = host["cols"], host["w"], host["t"]
+        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+        sess.set_multiopen(1)
+        ph = circ.advice_phase
+        ch0 = sess.advice_phase({i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 0})
+        driver._rlc(0, ch0[0], rlc["w"])
+        w_h[:] = adv_dev[rlc["w"]].download((circ.n, 4))          # a host caller synthesises the RLC column on the host; here it comes back from the device
+        ch1 = sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 1}, rlc["w"]: w_h})
+        driver._rlc(rlc["w"], ch1[0], rlc["t"])
+        t_h[:] = adv_dev[rlc["t"]].download((circ.n, 4))
+        sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 2}, rlc["t"]: t_h})
+        state["proof"] = sess.finish()
+
+    # record runs (tools/gpu_r6_record.sh): ZK_BENCH_KIND=host makes the TIMED proofs the host-memory kind, so that a kernel trace holds one kind only
+    timed_step = step
+    if os.environ.get("ZK_BENCH_KIND") == "host" and world == 1:
+        host_setup()
+        timed_step = step_host
+
     for _ in range(args.warmup):
-        step()
+        timed_step()
     fence()
     ctx.prof_reset()
-    ctx.prof_enable(2)           # HIP events around the roofline kernels only (NTT passes, bucket accumulation, quotient evaluator)
+    ctx.prof_enable(2)           # HIP events around the kernel classes of the proof (MSM classes, NTT passes, quotient evaluator)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        timed_step()
     fence()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
@@ -294,35 +361,20 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
     pcie = None
     if world == 1 and not quick:
         try:
-            pinned = {}
-            for a in adv_m[:SC_SHAPE[1] - 2]:
-                if id(a) not in pinned:
-                    pinned[id(a)] = ctx.host_alloc(a.shape)
-                    pinned[id(a)][:] = a
-            host_cols = [pinned[id(a)] for a in adv_m[:SC_SHAPE[1] - 2]]
-            w_h, t_h = ctx.host_alloc((circ.n, 4)), ctx.host_alloc((circ.n, 4))
+            host_setup()
             times = []
             for _ in range(2):
                 t1 = time.perf_counter()
-                sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
-                sess.set_multiopen(1)
-                ph = circ.advice_phase
-                ch0 = sess.advice_phase({i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 0})
-                driver._rlc(0, ch0[0], rlc["w"])
-                w_h[:] = adv_dev[rlc["w"]].download((circ.n, 4))          # a host caller synthesises the RLC column on the host; here it comes back from the device
-                ch1 = sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 1}, rlc["w"]: w_h})
-                driver._rlc(rlc["w"], ch1[0], rlc["t"])
-                t_h[:] = adv_dev[rlc["t"]].download((circ.n, 4))
-                sess.advice_phase({**{i: host_cols[i] for i in range(circ.A - 2) if ph[i] == 2}, rlc["t"]: t_h})
-                host_proof = sess.finish()
+                step_host()
                 times.append(time.perf_counter() - t1)
-            pcie = {"value": round(min(times), 4), "unit": "s", "same_proof_bytes": host_proof == state["proof"],
+            pcie = {"value": round(min(times), 4), "unit": "s", "same_proof_bytes": state["proof"] == proof_timed,
                     "note": "the same proof with the witness in page-locked HOST memory (zk_proof_advice_phase): 33.5 GB cross PCIe inside the proof; what a Rust caller of "
                             "create_proof pays today.  Never `value` (inputs resident in HBM)."}
-            for a in list(pinned.values()) + [w_h, t_h]:
-                ctx.host_free(a)
+            state["proof"] = proof_timed
         except Exception as e:       # the headline must survive this side measurement
             pcie = {"error": repr(e)}
+        finally:
+            host_teardown()
 
     # ---- what ONE rank of an N-GPU run of this proof computes, measured here: rank 0 of N = 2 / 4 / 8 emulated on this GPU
     # (zkevm-circuits_amd/sharding.EmulatedRank: own commitments, every column's transforms, the (degree class, coset) pairs the rank
@@ -389,8 +441,24 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
     if q[1]:
         roof_q = {"kernel": "k_quotient_eval (degree-class launches)", "bound": "hbm", "achieved": round(qb / (q[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(qb / (q[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "device_ms_per_proof": round(q[0] / args.steps, 2), "launches_timed": q[1],
+                  "avg_launch_ms": round(q[0] / q[1], 4), "algorithmic_bytes_per_launch": int(qb / q[1]),
                   "algorithmic_bytes_per_proof": int(qb / args.steps), "traffic": None,
-                  "note": "bytes = what the launches stream: 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result), counted by the library"}
+                  "note": "`achieved` counts ALGORITHMIC bytes: 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result) per launch, as the library books them -- "
+                          "every operand once.  `executed` counts what the interpreter actually loads: every memory operand of every instruction (a cell read by twenty constraints is loaded "
+                          "twenty times, thousands of instructions apart; no cache holds a coset's columns that long), and the field products it performs"}
+        ops = class_program_operands(circ) if world == 1 else None
+        if ops:
+            ex_bytes = sum((1 << e_) * (c_["reads"] + c_["parks"] + 1) * 32 * n for e_, c_ in enumerate(ops) if c_["used"])
+            ex_prod = sum((1 << e_) * c_["products"] * n for e_, c_ in enumerate(ops) if c_["used"])
+            roof_q["executed"] = {"operand_bytes_per_proof": int(ex_bytes), "achieved_gb_s": round(ex_bytes / (q[0] / args.steps * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": round(ex_bytes / (q[0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "products_per_proof": int(ex_prod), "g_products_per_s": round(ex_prod / (q[0] / args.steps * 1e-3) / 1e9, 1),
+                                  "frac_of_product_peak": round(ex_prod / (q[0] / args.steps * 1e-3) / 1e9 / MULPEAK_G, 3)}
+            roof_q["alu"] = {"unit": "G Montgomery products/s", "achieved": roof_q["executed"]["g_products_per_s"], "peak_own_routine": MULPEAK_G,
+                             "frac_own_routine": roof_q["executed"]["frac_of_product_peak"]}
+        tq, tsrc_q = committed_traffic("quotient_bytes_per_launch") if circ.k == 20 and shape == "evm" else (None, None)
+        roof_q["traffic"] = tq
+        roof_q["traffic_source"] = f"profiles/{tsrc_q}" if tq else None
     alg = proof_algorithmic_bytes(circ)
     alg_total = sum(alg.values())
     # the same sum with the two stages the degree classes shrink replaced by what this implementation executes: the transforms the
@@ -429,7 +497,8 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
                    "parallelism": "single GPU" if world == 1 else
                                   f"one proof sharded x{world}: commitments by column, quotient by (degree class, coset), 64-byte commitments and witness columns all-gathered "
                                   + ("over torch.distributed gloo callbacks (the ranks share one GPU: test box)" if shared_gpu else "over the library's RCCL communicator (xGMI)")},
-        "roofline": roof_ntt,
+        # the dominant kernel class of THIS proof by device time: the evaluator on the EVM-style shape, the NTT passes on the plain one
+        "roofline": max((r for r in (roof_ntt, roof_q) if r), key=lambda r: r.get("device_ms_per_proof", 0), default=None),
         "rooflines": [r for r in (roof_ntt, roof_msm, roof_q) if r],
         "proof_roofline": {"algorithmic_bytes": int(alg_total), "achieved": round(alg_total / per_proof / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(alg_total / per_proof / 1e9 / HBM_PEAK_GBS, 4), "by_stage_bytes": {k_: int(v) for k_, v in alg.items()},
@@ -454,6 +523,7 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
                                         "at once (csrc/class_compile.hpp); a class of index e runs on 2^e cosets"}},
     }
     out["config"]["workload"] = workload_text(shape)
+    host_teardown()
     driver.free()
     for b_ in adv_dev.values():
         b_.free()
