@@ -21,7 +21,7 @@ def test_kit_made_on_the_gpu_equals_the_oracle_made_kit(tmp_path):
     res = run("make", gpu_kit, "--gpu")
     assert res.returncode == 0, res.stdout + res.stderr
     res = run("check", gpu_kit)
-    assert res.returncode == 0 and res.stdout.count("accepted") == 24 and "REJECTED" not in res.stdout, res.stdout + res.stderr
+    assert res.returncode == 0 and res.stdout.count("accepted") == 27 and "REJECTED" not in res.stdout, res.stdout + res.stderr
     res = run("make", cpu_kit)
     assert res.returncode == 0, res.stdout + res.stderr
     cases = sorted(os.listdir(cpu_kit))

@@ -37,7 +37,7 @@ def test_kit_round_trip_from_files_only(tmp_path):
     res = run("make", kit)
     assert res.returncode == 0, res.stdout + res.stderr
     res = run("check", kit)
-    assert res.returncode == 0 and res.stdout.count("accepted") == 24 and "REJECTED" not in res.stdout, res.stdout + res.stderr     # 8 cases x (SHPLONK, GWC, Poseidon + SHPLONK)
+    assert res.returncode == 0 and res.stdout.count("accepted") == 27 and "REJECTED" not in res.stdout, res.stdout + res.stderr     # 9 cases x (SHPLONK, GWC, Poseidon + SHPLONK)
     assert run("prove", kit).returncode == 1              # no vk_repr.hex yet: the Rust `repr` step has not run
     # stand in for the Rust step: any field element will do as "upstream's vk.transcript_repr" for the mechanics
     for case in os.listdir(kit):
@@ -45,7 +45,7 @@ def test_kit_round_trip_from_files_only(tmp_path):
     res = run("prove", kit)
     assert res.returncode == 0, res.stdout + res.stderr
     res = run("check", kit)
-    assert res.returncode == 0 and res.stdout.count("accepted") == 40, res.stdout + res.stderr
+    assert res.returncode == 0 and res.stdout.count("accepted") == 45, res.stdout + res.stderr
     # a proof made under one repr must not verify under another (the repr is absorbed first)
     d = os.path.join(kit, "plain_k6")
     os.replace(os.path.join(d, "selfcheck_shplonk.bin"), os.path.join(d, "proof_shplonk.bin"))

@@ -106,7 +106,7 @@ def three_phase_case(k=6):
 
 
 def cases():
-    from plonk_fixtures import build_circuit, build_multi_lookup_circuit, build_rotation_circuit
+    from plonk_fixtures import build_circuit, build_evm_circuit, build_multi_lookup_circuit, build_rotation_circuit
 
     def static(build):
         circ, adv, inst = build
@@ -118,6 +118,7 @@ def cases():
         "lookup_1x_k6": static(build_multi_lookup_circuit(6, 1, 1, 2, 3)),        # mv-lookup, one input tuple of degree 2
         "lookup_2x_k6": static(build_multi_lookup_circuit(6, 1, 2, 1, 3)),        # two tuples merged into one argument
         "lookup_5x_k7": static(build_multi_lookup_circuit(7, 1, 5, 1, 9)),        # five tuples, degree 9: chunk_lookups splits and packs
+        "evm_style_k7": static(build_evm_circuit(7, seed=7, states=6, per_state=16)),   # round 6: the EVM-style shape of the bench -- 113 gates q_usable * q_step * state_selector * (constraint * condition) of degree <= 9 at rotations 0 / 1 / 2, a 4-column lookup
         "two_phase_k6": two_phase_case(6),                                        # second-phase columns behind two challenges
         "three_phase_k6": three_phase_case(6),                                    # the SuperCircuit's three phases and three challenges, with a two-column lookup and a copy constraint
     }
