@@ -141,9 +141,11 @@ if "k_msm_buckets" in per and "k_ntt_pass" in per:
                     "ntt_bytes_per_transform_note": "FETCH x 2 (gfx950 streaming-read correction) + WRITE of k_ntt_pass and k_ntt_last, per column"})
 if qf["launches"]:
     coset_launches = ev["class_launches_per_proof"]
-    traffic["quotient_bytes_per_launch"] = int((2 * qf["sum"] + qw["sum"]) * KB / qf["launches"])
-    traffic["quotient_note"] = (f"FETCH x 2 + WRITE of every k_quotient_eval launch of one EVM-style headline proof ({qf['launches']} launches: {coset_launches:.0f} class programs and the proof's small programs), "
-                                "divided by the launches -- an average over very different programs; the class programs' own figure is `rooflines[..].executed`")
+    traffic["quotient_bytes_per_launch"] = int((2 * qf["sum"] + qw["sum"]) * KB / max(coset_launches, 1))
+    traffic["quotient_bytes_per_proof"] = int((2 * qf["sum"] + qw["sum"]) * KB)
+    traffic["quotient_note"] = (f"FETCH x 2 (the guide's correction for 16-byte-per-lane streaming reads) + WRITE of every k_quotient_eval launch of ONE EVM-style headline proof ({qf['launches']} launches), "
+                                f"divided by the {coset_launches:.0f} degree-class launches that `roofline.avg_launch_ms` averages over (the other launches are the proof's compressions and linear "
+                                "combinations: a percent of the bytes)")
 traffic["proof_traffic_bytes"] = {"fetch_raw": int(tot_f * KB), "fetch_x2": int(2 * tot_f * KB), "write": int(tot_w * KB),
                                   "note": "all proving kernels of ONE EVM-style headline proof (circuit construction excluded); FETCH_SIZE raw and doubled (the guide's correction for wide streaming reads), WRITE_SIZE"}
 json.dump(traffic, open(f"profiles/traffic_{tag}.json", "w"), indent=1)

@@ -2598,7 +2598,19 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             ptrs[i] = evals[i].poly;
         }
         std::vector<F4> vals(evals.size());
-        PK_TRY(zk_poly_eval_pairs(ctx, ptrs.data(), pidx.data(), evals.size(), points.data(), points.size(), n, vals.data()));
+        if (sharded) {
+            // sharded session: pair i is evaluated by rank i mod world; the 32-byte values are all-gathered (every rank holds every
+            // coefficient form, so which rank evaluates what is free to choose)
+            const size_t per = (evals.size() + pr->world - 1) / pr->world;
+            std::vector<const void*> my_ptrs;
+            std::vector<uint32_t> my_pidx;
+            for (size_t i = pr->rank; i < evals.size(); i += pr->world) { my_ptrs.push_back(ptrs[i]); my_pidx.push_back(pidx[i]); }
+            std::vector<F4> local(per, host::fr_zero()), all(per * pr->world);
+            if (!my_ptrs.empty()) PK_TRY(zk_poly_eval_pairs(ctx, my_ptrs.data(), my_pidx.data(), my_ptrs.size(), points.data(), points.size(), n, local.data()));
+            if (pr->gather(pr->gather_user, local.data(), per * sizeof(F4), all.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+            for (size_t i = 0; i < evals.size(); ++i) vals[i] = all[(i % pr->world) * per + i / pr->world];
+        } else
+            PK_TRY(zk_poly_eval_pairs(ctx, ptrs.data(), pidx.data(), evals.size(), points.data(), points.size(), n, vals.data()));
         for (size_t i = 0; i < evals.size(); ++i) evals[i].eval = vals[i];
         for (const Open& o : evals) tr.write_scalar(o.eval);
     }
