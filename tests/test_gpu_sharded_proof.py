@@ -15,11 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-@pytest.mark.parametrize("world,k,multiopen,devgather", [(2, 7, 0, 0), (3, 8, 1, 0), (2, 7, 1, 1), (3, 7, 0, 1), (2, 11, 1, 0), (3, 12, 0, 1)])
-def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather):
+@pytest.mark.parametrize("world,k,multiopen,devgather,knobs", [(2, 7, 0, 0, {}), (3, 8, 1, 0, {}), (2, 7, 1, 1, {}), (3, 7, 0, 1, {}), (2, 11, 1, 0, {}), (3, 12, 0, 1, {}),
+                                                                (3, 8, 1, 1, {"ZK_QUOTIENT_COSTGATE": "0"}), (2, 8, 1, 0, {"ZK_QUOTIENT_DAG": "0"})])
+def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather, knobs):
+    """knobs: ZK_QUOTIENT_COSTGATE=0 forces the additive split (remainder polynomials travelling between degree classes, (class, coset)
+    pairs of three classes dealt over the ranks); ZK_QUOTIENT_DAG=0 the class programs as round 5 assembled them"""
     from _launch import run_ranks
     # devgather: the advice columns are uploaded by their owning rank only and all-gathered between devices
-    env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1", ZK_TEST_DEVGATHER=str(devgather))
+    env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1", ZK_TEST_DEVGATHER=str(devgather), **knobs)
     res = run_ranks(world, os.path.join(HERE, "_sharded_proof_worker.py"), [tmp_path, k, multiopen], env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     single = open(tmp_path / "proof_single.bin", "rb").read()

@@ -270,12 +270,14 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         Q29 mq = zero29;
         if (k_has_mem(w0)) mq = op == K_MUL_COL ? unpack29_x32(m) : unpack29<Fr29P>(m);
         if (k_has_mem(n0)) m = load(n1, n2);
-        if (w0 & K_SETTLE0) t0 = q_settle(t0);
-        if (w0 & K_SETTLE1) t1 = q_settle(t1);
-        if (w0 & K_NORM0) normalize29(t0);
-        if (w0 & K_NORM1) normalize29(t1);
-        if (w0 & K_SETTLE0_8) t0 = q_settle8(t0);
-        if (w0 & K_SETTLE1_8) t1 = q_settle8(t1);
+        if (w0 & (K_SETTLE0 | K_SETTLE1 | K_NORM0 | K_NORM1 | K_SETTLE0_8 | K_SETTLE1_8)) {        // one test on the common path (three instructions in four carry no flag)
+            if (w0 & K_SETTLE0) t0 = q_settle(t0);
+            if (w0 & K_SETTLE1) t1 = q_settle(t1);
+            if (w0 & K_NORM0) normalize29(t0);
+            if (w0 & K_NORM1) normalize29(t1);
+            if (w0 & K_SETTLE0_8) t0 = q_settle8(t0);
+            if (w0 & K_SETTLE1_8) t1 = q_settle8(t1);
+        }
         switch (op) {
             case Q_PUSH_COL: push_shift(); t0 = mq; break;
             case Q_PUSH_CONST: push_shift(); t0 = cst(consts, w1); break;
