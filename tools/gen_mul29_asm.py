@@ -73,6 +73,59 @@ def product(kind):
     return lines, ops
 
 
+def product_inplace(kind, on):
+    """The 'vv' / 'vs' product with the RESULT IN THE REGISTERS OF ONE FACTOR (round 6, the evaluator's interpreter): limb j of that factor is
+    last read in column j + 8 and result limb j is written in column j + 9, so the result can take its place -- x <- x * y without a
+    copy at the end, which is what lets an interpreter keep its top-of-stack in FIXED registers across the cases of its switch.  The
+    Montgomery multipliers m_j (alive from column j to j + 8) get nine scratch registers.  Same column sums in the same order.
+    Operands: 0..8 = x (in / out), 9..17 = scratch, then the other factor, the modulus, INV, MASK.  on = 'a' or 'b': which factor x is."""
+    x = list(range(9))
+    m = list(range(9, 18))
+    o = list(range(18, 27))
+    a, b = (x, o) if on == "a" else (o, x)
+    M = list(range(27, 36))
+    INV, MASK = 36, 37
+    lines = []
+    first = True
+    def mad(p, q):
+        nonlocal first
+        src2 = "0" if first else ACC
+        first = False
+        lines.append(f"v_mad_u64_u32 {ACC}, vcc, %{p}, %{q}, {src2}")
+    for k in range(17):
+        lo, hi = (0, k) if k < 9 else (k - 8, 8)
+        for i in range(lo, hi + 1):
+            mad(a[i], b[k - i])
+        for i in range(lo, (k - 1 if k < 9 else 8) + 1):
+            mad(m[i], M[k - i])
+        if k < 9:
+            lines.append(f"v_mul_lo_u32 %{m[k]}, {LO}, %{INV}")
+            lines.append(f"v_and_b32 %{m[k]}, %{MASK}, %{m[k]}")
+            mad(m[k], M[0])
+        else:
+            lines.append(f"v_and_b32 %{x[k - 9]}, %{MASK}, {LO}")
+        lines.append(f"v_lshrrev_b64 {ACC}, 29, {ACC}")
+    lines.append(f"v_mov_b32 %{x[8]}, {LO}")
+    return lines
+
+
+def emit_inplace(name, kind, on):
+    lines = product_inplace(kind, on)
+    body = "\\n\\t\"\n        \"".join(lines)
+    oc = "s" if kind == "vs" else "v"
+    out = []
+    out.append(f"template <class P>\n__device__ __forceinline__ void {name}(F29<P>& x, const F29<P>& y) {{")
+    out.append("    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;")
+    out.append(f"    asm(\"{body}\"")
+    out.append("        : " + ", ".join(f"\"+v\"(x.l[{i}])" for i in range(9)) + ",")
+    out.append("          " + ", ".join(f"\"=&v\"(m{i})" for i in range(9)))
+    out.append("        : " + ", ".join(f"\"{oc}\"(y.l[{i}])" for i in range(9)) + ",")
+    out.append("          " + ", ".join(f"\"s\"(P::M({i}))" for i in range(9)) + ", \"s\"(P::INV), \"s\"(MASK29)")
+    out.append(f"        : \"vcc\", \"v{AL}\", \"v{AH}\");")
+    out.append("}")
+    return "\n".join(out)
+
+
 def emit(name, kind, sig, ins):
     lines, ops = product(kind)
     body = "\\n\\t\"\n        \"".join(lines)
@@ -105,6 +158,16 @@ def main():
     print("template <class P>\n__device__ __forceinline__ F29<P> sqr29_asm(const F29<P>& a) {\n    uint32_t a2[9];\n#pragma unroll\n    for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;\n    return sqr29_asm_<P>(a, a2);\n}")
     print()
     print(emit("mul2add29_asm", "2", "const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d", [vlist("a.l"), vlist("b.l"), vlist("c.l"), vlist("d.l")]))
+    print()
+    print("// In-place forms (the evaluator's interpreter, csrc/quotient.hip): the result takes the registers of one factor.")
+    print("// x <- mul29(x, y): x is the FIRST factor (limbs below 2^31), y normalised")
+    print(emit_inplace("mul29_ipa_asm", "vv", "a"))
+    print()
+    print("// x <- mul29(y, x): x is the SECOND factor (normalised), y the first")
+    print(emit_inplace("mul29_ipb_asm", "vv", "b"))
+    print()
+    print("// x <- mul29_ub(x, y): y wave-uniform, in scalar registers")
+    print(emit_inplace("mul29_ub_ipa_asm", "vs", "a"))
 
 
 if __name__ == "__main__":

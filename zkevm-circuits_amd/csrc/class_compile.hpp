@@ -282,11 +282,13 @@ static bool compile_class(const std::vector<ClassTerm>& terms, uint32_t K, Prog&
     cc.count_uses(root);
     cc.prod_memo.assign(cc.nd.size(), -1);
     cc.no_park.assign(cc.nd.size(), 0);
-    // Parking pays when the value is read back soon or cost more than a product to make: a value of ONE product (cell * 256, a * b)
-    // that is read again thousands of instructions later would hold 32 B x rows of the parking area all that time to save ~150
-    // instructions.  So: emit, measure every parked value's span, and emit again without the cheap long-lived ones; if more than
-    // CLASS_MAX_LIVE values are still alive at once, raise the price of admission and repeat.
+    // Parking pays by (uses - 1) x (products the value cost): tau = t + beta of a lookup table is ONE product and is read by every
+    // lookup into the table -- parked; cell * 256 read again once, thousands of instructions later, would hold 32 B x rows of the
+    // parking area all that time to save one product -- recomputed.  So: emit, measure every parked value's span, emit again without
+    // the long-lived values whose benefit is below the price of admission; the price starts at one product and doubles until at most
+    // CLASS_MAX_LIVE values are alive at once.
     constexpr uint32_t CLASS_MAX_LIVE = 64;
+    uint64_t price = 1;
     for (uint32_t round = 0;; ++round) {
         cc.out.clear();
         cc.stats.parked = 0;
@@ -301,14 +303,17 @@ static bool compile_class(const std::vector<ClassTerm>& terms, uint32_t K, Prog&
             else if (cc.out[i].op == Q_PUSH_TMP) last_read[cc.out[i].a] = i;
         }
         cc.assign_slots();
-        if (round >= 6) break;
-        const uint32_t price = round + 1;                       // products a value must have cost to stay parked over a long span
-        const size_t span_max = 256u >> std::min(round, 4u);
+        if (round >= 24) break;
+        if (round > 0 && cc.stats.max_live <= CLASS_MAX_LIVE) break;
+        const size_t span_max = round < 20 ? 256 : 0;               // the last rounds evict whatever is still in the way
         bool changed = false;
-        if (round == 0 || cc.stats.max_live > CLASS_MAX_LIVE)
-            for (uint32_t sl = 0; sl < node_of.size(); ++sl)
-                if (node_of[sl] >= 0 && cc.tree_cost(node_of[sl]) <= price && last_read[sl] - def_at[sl] > span_max) { cc.no_park[node_of[sl]] = 1; changed = true; }
-        if (!changed) break;
+        for (uint32_t sl = 0; sl < node_of.size(); ++sl) {
+            if (node_of[sl] < 0 || last_read[sl] - def_at[sl] <= span_max) continue;
+            const uint64_t benefit = (uint64_t)(cc.uses[node_of[sl]] - 1) * cc.tree_cost(node_of[sl]);
+            if (benefit <= price) { cc.no_park[node_of[sl]] = 1; changed = true; }
+        }
+        if (!changed && cc.stats.max_live <= CLASS_MAX_LIVE) break;
+        price *= 2;
     }
     int sp = 0, mx = 0;
     for (const Instr& in : cc.out) {

@@ -517,6 +517,33 @@ __host__ __device__ __forceinline__ F29<P> mul2add29(const F29<P>& a, const F29<
 template <class P>
 __host__ __device__ __forceinline__ F29<P> sqr29(const F29<P>& a) { ZK_MUL29_DISPATCH(sqr29, a); }
 #undef ZK_MUL29_DISPATCH
+// In-place forms (round 6; the evaluator's interpreter keeps its top of stack in fixed registers): on the device the result is
+// written over the named factor's registers by the asm statement itself -- no copy, no phi at the join of an interpreter's switch.
+//   mul29_ipa(x, y): x <- mul29(x, y)      mul29_ipb(x, y): x <- mul29(y, x)      mul29_ub_ipa(x, y): x <- mul29_ub(x, y)
+template <class P>
+__host__ __device__ __forceinline__ void mul29_ipa(F29<P>& x, const F29<P>& y) {
+#if ZK_MUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    mul29_ipa_asm<P>(x, y);
+#else
+    x = mul29_c<P>(x, y);
+#endif
+}
+template <class P>
+__host__ __device__ __forceinline__ void mul29_ipb(F29<P>& x, const F29<P>& y) {
+#if ZK_MUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    mul29_ipb_asm<P>(x, y);
+#else
+    x = mul29_c<P>(y, x);
+#endif
+}
+template <class P>
+__host__ __device__ __forceinline__ void mul29_ub_ipa(F29<P>& x, const F29<P>& y) {
+#if ZK_MUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    mul29_ub_ipa_asm<P>(x, y);
+#else
+    x = mul29_ub_c<P>(x, y);
+#endif
+}
 
 // a^(m-2) for a canonical 8 x 32 element in R = 2^256 Montgomery form; result in the same form.
 // The 254-step exponentiation runs on 29-bit limbs (R' domain): its dependent chain is what a

@@ -130,7 +130,10 @@ constexpr int K_CONST_SHIFT = 16;                              // K_FOLD_COL kee
 // spend 27 vector instructions per constant operand on it).  The index is wave-uniform, so the limbs arrive by scalar loads
 // and stay in scalar registers (mul29_ub).  64-byte records.
 struct QC29 { uint32_t l[16]; };
-constexpr int Q_THREADS = 256;
+#ifndef Q_THREADS_N
+#define Q_THREADS_N 256
+#endif
+constexpr int Q_THREADS = Q_THREADS_N;      // lanes per workgroup (no cooperation between waves: the size only sets the granularity of the LDS allocation)
 // how many instructions ahead of its use a memory operand is requested (1: while the previous instruction computes; 2: one more)
 #ifndef Q_PREFETCH_DIST
 #define Q_PREFETCH_DIST 1
@@ -305,6 +308,289 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
         Q29 a = acc_get(0);
         if (t_evals) stg(out + i, pack29_lt2p(mul29(a, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1u)))))));
         else { normalize29(a); stg(out + i, reduce_lazy29(a)); }       // acc < 6p, never settled on the way
+    }
+}
+
+// ---- the interpreter with fixed register roles (round 6, second half) ----------------------------------------------------------
+// k_quotient_eval above keeps the two topmost stack entries in registers and lets every case of its switch produce NEW values for
+// them: the ISA carries 18 + 18 v_mov per interpreted instruction (the phi copies of t0 and t1 at the join, whichever case ran) on top
+// of the rotations t1 = t0 of a push -- 1.3 M of the 5.3 M vector instructions a wave spends on the EVM-style class program.  Here
+//   * ONE stack entry lives in registers (t0); every deeper entry is in LDS (a binary stack operation reads its other operand from
+//     there: nine ds_read instead of eighteen v_mov);
+//   * every operation UPDATES t0 IN PLACE -- the products through asm statements whose result takes the first factor's registers
+//     (mul29_ipa / mul29_ub_ipa / mul29_ipb: limb j of the factor is last read one column before result limb j is written), sums and
+//     differences limb by limb -- so the join of the switch has nothing to copy;
+//   * the second operand B (a memory operand unpacked on arrival, or the stack entry below the top) has its own nine registers and
+//     dies with the instruction;
+//   * memory operands are unpacked with v_alignbit (16 / 17 instructions instead of 27).
+// Same instruction set, same lowering, same bounds (header comment); bit-identical results.  ZK_QUOTIENT_KERNEL=1 runs the older kernel.
+__device__ __forceinline__ void q_unpack_to(Q29& r, const Fr& a) {
+    r.l[0] = a.l[0] & MASK29;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        r.l[i] = __builtin_amdgcn_alignbit(a.l[w + 1], a.l[w], sh) & MASK29;
+    }
+    r.l[8] = a.l[7] >> 8;
+}
+__device__ __forceinline__ void q_unpack_x32_to(Q29& r, const Fr& a) {       // limbs of 32 * a
+    r.l[0] = (a.l[0] << 5) & MASK29;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const int bit = 29 * i - 5, w = bit >> 5, sh = bit & 31;
+        r.l[i] = __builtin_amdgcn_alignbit(a.l[w + 1], a.l[w], sh) & MASK29;
+    }
+    r.l[8] = a.l[7] >> 3;
+}
+__device__ __forceinline__ void q_shl5_ip(Q29& x) {                          // x <- 32 x (normalised x < 2p), top down so that no limb is read after it is written
+    x.l[8] = (x.l[8] << 5) | (x.l[7] >> 24);
+#pragma unroll
+    for (int i = 7; i >= 1; --i) x.l[i] = ((x.l[i] << 5) & MASK29) | (x.l[i - 1] >> 24);
+    x.l[0] = (x.l[0] << 5) & MASK29;
+}
+__device__ __forceinline__ void q_settle_ip(Q29& r) {
+    normalize29(r);
+    uint32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int32_t s_ = (int32_t)r.l[i] - (int32_t)kp_norm<Fr29P>(2, i) + c;
+        d[i] = i < 8 ? ((uint32_t)s_ & MASK29) : (uint32_t)s_;
+        c = s_ >> 29;
+    }
+    const bool neg_ = (int32_t)d[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = neg_ ? r.l[i] : d[i];
+}
+__device__ __forceinline__ void q_settle8_ip(Q29& r) {
+    normalize29(r);
+    uint32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int32_t s_ = (int32_t)r.l[i] - (int32_t)kp_norm<Fr29P>(4, i) + c;
+        d[i] = i < 8 ? ((uint32_t)s_ & MASK29) : (uint32_t)s_;
+        c = s_ >> 29;
+    }
+    const bool neg_ = (int32_t)d[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = neg_ ? r.l[i] : d[i];
+    q_settle_ip(r);
+}
+
+// What an instruction does, as one bit per step of the interpreter's loop body (word 3 of the 4-word instructions k_quotient_eval2 reads; made by
+// q_class_mask on the host).  The loop body is a flat sequence of `if (mask & bit) { step }`: every step updates its registers in place and the
+// only joins are those of single-armed ifs, which the register coalescer resolves without copies -- a `switch (op)` does not survive the
+// compiler (cases merged and re-split around shared tails, phi copies of the whole top-of-stack at every join), and tests on separate bits of a
+// word cannot be threaded into one another the way comparisons of one opcode are.
+enum QClass : uint32_t {
+    C_SPILL = 1u << 0,       // make room on top: PUSH_COL, PUSH_CONST
+    C_UNPACK_T = 1u << 1,    // t0 <- memory operand                       PUSH_COL
+    C_UNPACK_B = 1u << 2,    // B <- memory operand                        ADD_COL SUB_COL RSUB_COL FOLD_COL
+    C_UNPACK_B32 = 1u << 3,  // B <- 32 x memory operand                   MUL_COL
+    C_POP_B = 1u << 4,       // B <- the entry below the top               ADD SUB MUL
+    C_HASMEM = 1u << 5,      // the instruction has a memory operand (tested on the NEXT instruction: its load is issued one instruction early)
+    C_FLAGS = 1u << 6,       // any settle / carry-propagation request in word 0
+    C_MULV = 1u << 7,        // t0 <- t0 * B                               MUL_COL
+    C_MULC = 1u << 8,        // t0 <- t0 * const                           MUL_CONST
+    C_ADDV = 1u << 9,        // t0 <- t0 + B                               ADD ADD_COL
+    C_SUBV = 1u << 10,       // t0 <- t0 - B                               SUB_COL
+    C_FOLDC = 1u << 11,      // acc <- acc * const + B                     FOLD_COL
+    C_RARE = 1u << 12,       // any of the steps below
+    C_PUSHC = 1u << 13,      // t0 <- const                                PUSH_CONST
+    C_ADDC = 1u << 14,       // t0 <- t0 + const                           ADD_CONST
+    C_RSUB = 1u << 15,       // t0 <- B - t0                               SUB RSUB_COL
+    C_MULS = 1u << 16,       // t0 <- B * t0 (stack product)               MUL
+    C_NEG = 1u << 17, C_SQ = 1u << 18, C_DBL = 1u << 19, C_TEE = 1u << 20,
+    C_FOLD = 1u << 21,       // acc <- acc * const + t0, pop               FOLD
+};
+static uint32_t q_class_mask(uint32_t w0) {
+    uint32_t m = 0;
+    switch (w0 & 0xffu) {
+        case Q_PUSH_COL: m = C_SPILL | C_UNPACK_T | C_HASMEM; break;
+        case Q_PUSH_CONST: m = C_SPILL | C_RARE | C_PUSHC; break;
+        case Q_ADD: m = C_POP_B | C_ADDV; break;
+        case Q_SUB: m = C_POP_B | C_RARE | C_RSUB; break;
+        case Q_MUL: m = C_POP_B | C_RARE | C_MULS; break;
+        case Q_NEG: m = C_RARE | C_NEG; break;
+        case Q_SQUARE: m = C_RARE | C_SQ; break;
+        case Q_DOUBLE: m = C_RARE | C_DBL; break;
+        case Q_FOLD: m = C_RARE | C_FOLD; break;
+        case Q_MUL_CONST: m = C_MULC; break;
+        case Q_ADD_CONST: m = C_RARE | C_ADDC; break;
+        case Q_TEE_TMP: m = C_RARE | C_TEE; break;
+        case K_ADD_COL: m = C_UNPACK_B | C_HASMEM | C_ADDV; break;
+        case K_SUB_COL: m = C_UNPACK_B | C_HASMEM | C_SUBV; break;
+        case K_RSUB_COL: m = C_UNPACK_B | C_HASMEM | C_RARE | C_RSUB; break;
+        case K_MUL_COL: m = C_UNPACK_B32 | C_HASMEM | C_MULV; break;
+        case K_FOLD_COL: m = C_UNPACK_B | C_HASMEM | C_FOLDC; break;
+        default: break;            // K_NOP, Q_END
+    }
+    if (w0 & (K_SETTLE0 | K_SETTLE1 | K_NORM0 | K_NORM1 | K_SETTLE0_8 | K_SETTLE1_8)) m |= C_FLAGS;
+    return m;
+}
+
+// `prog`: 4-word instructions (word 0: opcode + settle bits [+ constant of FOLD_COL], 1 / 2: operands, 3: class mask), prog_len of them
+// followed by END quadruples for the fetch-ahead.
+template <bool FULL, bool ACC_MEM>
+__global__ void __launch_bounds__(Q_THREADS) Q_OCC_ATTR
+k_quotient_eval2(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const QC29* __restrict__ consts,
+                 const QC29* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
+                 Fr* __restrict__ out, Fr* tmp /* [slot][row] */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // stack entry j < sp - 1 lives in LDS slot j ([slot][limb][lane]); entry sp - 1 is t0.  ONE address register (slot and lane; made opaque so
+    // that the compiler does not split it into nine loop-invariant lane addresses + nine adds per access), the limb in the instruction's offset field.
+    auto st_addr = [&](int slot) -> uint32_t {
+        uint32_t a = (uint32_t)slot * (9u * Q_THREADS * 4u) + threadIdx.x * 4u;
+        asm volatile("" : "+v"(a));
+        return a;
+    };
+    auto st_put = [&](int slot, const Q29& v) {
+        const uint32_t a = st_addr(slot);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) *(uint32_t*)((char*)smem + a + q * (Q_THREADS * 4)) = v.l[q];
+    };
+    auto st_get = [&](int slot, Q29& v) {
+        const uint32_t a = st_addr(slot);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v.l[q] = *(const uint32_t*)((const char*)smem + a + q * (Q_THREADS * 4));
+    };
+    const uint64_t ne = 1ull << ext_k;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = FULL || i < (uint32_t)ne;
+    const uint32_t rot_scale = 1u << (ext_k - k), row_mask = (uint32_t)ne - 1u;
+    Q29 t0, acc, B;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { t0.l[q] = 0; acc.l[q] = 0; B.l[q] = 0; }        // acc: registers only when !ACC_MEM
+    int sp = 0;
+    typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+    using GU4 = const U32x4 __attribute__((address_space(1)));
+    using GU1 = uint32_t __attribute__((address_space(1)));
+    // The raw memory operand stays in the two 4-register tuples the loads write (unpacked from there: no copies between the load and its use)
+    struct Raw { U32x4 lo, hi; };
+    auto load = [&](uint32_t a, uint32_t b, Raw& r) {
+        const uint32_t row = (i + b * rot_scale) & row_mask;          // b = the rotation as a two's complement word: wraps like the domain
+        if (FULL || live) {
+            GU4* q = (GU4*)(uintptr_t)(cols[a] + row);
+            r.lo = q[0]; r.hi = q[1];
+        }
+    };
+    auto raw_fr = [](Raw& r) -> Fr {        // opaque: each unpack site unpacks for itself (the compiler otherwise unpacks on EVERY instruction and copies)
+        asm volatile("" : "+v"(r.lo), "+v"(r.hi));
+        Fr x;
+        x.l[0] = r.lo.x; x.l[1] = r.lo.y; x.l[2] = r.lo.z; x.l[3] = r.lo.w;
+        x.l[4] = r.hi.x; x.l[5] = r.hi.y; x.l[6] = r.hi.z; x.l[7] = r.hi.w;
+        return x;
+    };
+    auto cst = [&](const QC29* __restrict__ tab, uint32_t j) -> Q29 {       // wave-uniform index: scalar loads, the limbs stay in scalar registers
+        Q29 r;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) r.l[q] = tab[j].l[q];
+        return r;
+    };
+    // acc <- acc * c + v  (v: limbs below 3 x 2^29)
+    auto fold = [&](uint32_t w0_, const Q29& c, const Q29& v) {
+        if (!ACC_MEM) {
+            mul29_ub_ipa(acc, c);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc.l[q] += v.l[q];
+            return;
+        }
+        Q29 a;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) a.l[q] = 0;
+        uint32_t ii = i;
+        asm volatile("" : "+v"(ii));              // the nine limb addresses are made here, not kept in eighteen registers across the loop
+        GU1* qa = (GU1*)(uintptr_t)(acc_mem + ii);
+        if (!(w0_ & K_FIRST_FOLD) && live) {
+#pragma unroll
+            for (int l = 0; l < 9; ++l) a.l[l] = qa[(uint64_t)l << ext_k];
+        }
+        mul29_ub_ipa(a, c);
+        if (live) {
+#pragma unroll
+            for (int l = 0; l < 9; ++l) qa[(uint64_t)l << ext_k] = a.l[l] + v.l[l];
+        }
+    };
+    uint32_t w0 = prog[0], w1 = prog[1], w2 = prog[2], w3 = prog[3];
+    uint32_t n0 = prog[4], n1 = prog[5], n2 = prog[6], n3 = prog[7];
+    Raw m;
+    m.lo = U32x4{0, 0, 0, 0}; m.hi = U32x4{0, 0, 0, 0};
+    if (w3 & C_HASMEM) load(w1, w2, m);
+    for (uint32_t pc = 0; pc < prog_len; ++pc) {
+        const uint32_t f0 = prog[4 * pc + 8], f1 = prog[4 * pc + 9], f2 = prog[4 * pc + 10], f3 = prog[4 * pc + 11];
+        if ((w0 & 0xffu) == Q_END) break;
+        // 1. operands: a memory operand leaves its raw registers (which then take the load for instruction pc + 1), a binary stack operation
+        //    takes the entry below the top
+        if (w3 & C_SPILL) { if (sp >= 1) st_put(sp - 1, t0); ++sp; }
+        if (w3 & C_UNPACK_T) q_unpack_to(t0, raw_fr(m));
+        if (w3 & C_UNPACK_B) q_unpack_to(B, raw_fr(m));
+        if (w3 & C_UNPACK_B32) q_unpack_x32_to(B, raw_fr(m));
+        if (w3 & C_POP_B) { st_get(sp - 2, B); --sp; }
+        if (n3 & C_HASMEM) load(n1, n2, m);
+        // 2. settle / carry-propagation requests of the lowering (bit 0: the top, bit 1: the entry below it = B)
+        if (w3 & C_FLAGS) {
+            if (w0 & K_SETTLE0) q_settle_ip(t0);
+            if (w0 & K_SETTLE1) q_settle_ip(B);
+            if (w0 & K_NORM0) normalize29(t0);
+            if (w0 & K_NORM1) normalize29(B);
+            if (w0 & K_SETTLE0_8) q_settle8_ip(t0);
+            if (w0 & K_SETTLE1_8) q_settle8_ip(B);
+        }
+        // 3. the operation, on t0 in place
+        if (w3 & C_MULV) mul29_ipa(t0, B);
+        if (w3 & C_MULC) mul29_ub_ipa(t0, cst(consts_rp, w1));
+        if (w3 & C_ADDV) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t0.l[q] += B.l[q];
+        }
+        if (w3 & C_SUBV) {                                                  // canonical subtrahend: its top limb is below that of 2p, no borrow
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t0.l[q] = t0.l[q] + kp_balanced<Fr29P>(2, q) - B.l[q];
+        }
+        if (w3 & C_FOLDC) fold(w0, cst(consts_rp, w0 >> K_CONST_SHIFT), B);
+        if (w3 & C_RARE) {
+            if (w3 & C_PUSHC) {
+                const Q29 c = cst(consts, w1);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t0.l[q] = c.l[q];
+            }
+            if (w3 & C_ADDC) {
+                const Q29 c = cst(consts, w1);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t0.l[q] += c.l[q];
+            }
+            if (w3 & C_RSUB) {                                              // B - t0 (t0 settled): carry the borrow of the top limb out before anyone multiplies
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t0.l[q] = B.l[q] + kp_balanced<Fr29P>(2, q) - t0.l[q];
+                normalize29(t0);
+            }
+            if (w3 & C_MULS) { q_shl5_ip(t0); mul29_ipb(t0, B); }            // t0 <- mul29(B, 32 t0)
+            if (w3 & C_NEG) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t0.l[q] = kp_balanced<Fr29P>(2, q) - t0.l[q];
+                normalize29(t0);
+            }
+            if (w3 & C_SQ) { Q29 s2 = t0; q_shl5_ip(s2); mul29_ipa(t0, s2); }
+            if (w3 & C_DBL) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t0.l[q] <<= 1;
+            }
+            if (w3 & C_TEE) { if (live) stg(tmp + (((uint64_t)w1 << ext_k) + i), pack29_lt2p(t0)); }
+            if (w3 & C_FOLD) { fold(w0, cst(consts_rp, w1), t0); --sp; if (sp >= 1) st_get(sp - 1, t0); }
+        }
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+        n0 = f0; n1 = f1; n2 = f2; n3 = f3;
+    }
+    if (live) {
+        Q29 a = acc;
+        if (ACC_MEM) {
+            GU1* qa = (GU1*)(uintptr_t)(acc_mem + i);
+#pragma unroll
+            for (int l = 0; l < 9; ++l) a.l[l] = qa[(uint64_t)l << ext_k];
+        }
+        if (t_evals) stg(out + i, pack29_lt2p(mul29(a, unpack29<Fr29P>(ldg(t_evals + (i & (rot_scale - 1u)))))));
+        else { normalize29(a); stg(out + i, reduce_lazy29(a)); }
     }
 }
 
@@ -645,7 +931,9 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     // column table = the caller's columns, then one pseudo-column per parked intermediate
     std::vector<const void*> col_tab(h_col_ptrs, h_col_ptrs + num_cols);
     for (uint32_t t = 0; t < num_tmp; ++t) col_tab.push_back(d_tmp + ((size_t)t << ext_k));
-    const size_t prog_bytes = (size_t)(low_len + 4) * 12, col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
+    static const int kernel_knob = getenv("ZK_QUOTIENT_KERNEL") ? atoi(getenv("ZK_QUOTIENT_KERNEL")) : 2;       // 2: fixed register roles (k_quotient_eval2: one stack entry in registers, 4-word instructions); 1: round 5's kernel
+    const bool v2 = kernel_knob != 1;
+    const size_t prog_bytes = (size_t)(low_len + 4) * (v2 ? 16 : 12), col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
     const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(QC29) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
@@ -662,8 +950,8 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     {
         uint32_t* hp = (uint32_t*)staging.data();
         size_t w = 0;
-        for (const LowInstr& in : low) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; }
-        for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; }      // END + the triples the kernel fetches ahead
+        for (const LowInstr& in : low) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; if (v2) hp[w++] = q_class_mask(in.w0); }
+        for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; if (v2) hp[w++] = 0; }      // END + the instructions the kernel fetches ahead
         if (!col_tab.empty()) memcpy(staging.data() + al(prog_bytes), col_tab.data(), col_tab.size() * 8);
         char* hc = staging.data() + al(prog_bytes) + al(col_bytes);
         QC29* hq = (QC29*)hc;                                  // limb form: the R-form constants, then their R' images
@@ -676,7 +964,7 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     ZK_HIP(ctx, hipMemcpyAsync(d, staging.data(), total_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
     const uint64_t ne = 1ull << ext_k;
-    size_t lds = (size_t)(depth > 2 ? depth - 2 : 1) * 9 * Q_THREADS * 4;    // the two topmost elements are in registers
+    size_t lds = (size_t)(v2 ? (depth > 1 ? depth - 1 : 1) : (depth > 2 ? depth - 2 : 1)) * 9 * Q_THREADS * 4;    // the topmost element(s) are in registers
     {   // measurement knob: pad the workgroup's LDS to this many bytes, i.e. cap the workgroups resident per CU (160 KB / pad)
         static const long pad = getenv("ZK_QUOTIENT_LDS_PAD") ? atol(getenv("ZK_QUOTIENT_LDS_PAD")) : 0;
         if (pad > 0 && (size_t)pad > lds && (size_t)pad <= (size_t)Q_MAX_STACK * 9 * Q_THREADS * 4) lds = (size_t)pad;
@@ -687,6 +975,10 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_quotient_eval2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ctx->quotient_attr_set = true;
     }
     ZkProfScope ps(ctx, ctx->prof_tag ? ctx->prof_tag : "quotient_eval");
@@ -711,7 +1003,11 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
             hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
                                tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc);
         };
-        if (full && acc_in_mem) launch(k_quotient_eval<true, true>);
+        if (v2 && full && acc_in_mem) launch(k_quotient_eval2<true, true>);
+        else if (v2 && full) launch(k_quotient_eval2<true, false>);
+        else if (v2 && acc_in_mem) launch(k_quotient_eval2<false, true>);
+        else if (v2) launch(k_quotient_eval2<false, false>);
+        else if (full && acc_in_mem) launch(k_quotient_eval<true, true>);
         else if (full) launch(k_quotient_eval<true, false>);
         else if (acc_in_mem) launch(k_quotient_eval<false, true>);
         else launch(k_quotient_eval<false, false>);
