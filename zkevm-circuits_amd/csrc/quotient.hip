@@ -436,7 +436,7 @@ template <bool FULL, bool ACC_MEM>
 __global__ void __launch_bounds__(Q_THREADS) Q_OCC_ATTR
 k_quotient_eval2(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const QC29* __restrict__ consts,
                  const QC29* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
-                 Fr* __restrict__ out, Fr* tmp /* [slot][row] */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */) {
+                 Fr* __restrict__ out, Fr* tmp /* [slot][row] */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */, uint32_t tile_alias /* measurement only, see the launch */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // stack entry j < sp - 1 lives in LDS slot j ([slot][limb][lane]); entry sp - 1 is t0.  ONE address register (slot and lane; made opaque so
     // that the compiler does not split it into nine loop-invariant lane addresses + nine adds per access), the limb in the instruction's offset field.
@@ -456,7 +456,9 @@ k_quotient_eval2(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr*
         for (int q = 0; q < 9; ++q) v.l[q] = *(const uint32_t*)((const char*)smem + a + q * (Q_THREADS * 4));
     };
     const uint64_t ne = 1ull << ext_k;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t blk = blockIdx.x;
+    if (tile_alias) { const uint32_t xcd = blk & 7u, j = blk >> 3; blk = ((j >> tile_alias) << 3) | xcd; }       // 2^tile_alias consecutive workgroups of an XCD share one row tile (results wrong)
+    const uint32_t i = blk * blockDim.x + threadIdx.x;
     const bool live = FULL || i < (uint32_t)ne;
     const uint32_t rot_scale = 1u << (ext_k - k), row_mask = (uint32_t)ne - 1u;
     Q29 t0, acc, B;
@@ -1003,10 +1005,17 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
             hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
                                tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc);
         };
-        if (v2 && full && acc_in_mem) launch(k_quotient_eval2<true, true>);
-        else if (v2 && full) launch(k_quotient_eval2<true, false>);
-        else if (v2 && acc_in_mem) launch(k_quotient_eval2<false, true>);
-        else if (v2) launch(k_quotient_eval2<false, false>);
+        // measurement knob (results WRONG): 2^a consecutive workgroups of an XCD evaluate the same row tile -- the operand working set of the resident waves shrinks by
+        // 2^a while every wave does what it did: what the launch would take if the slices of a sliced program shared their rows' operands through the L2
+        static const uint32_t tile_alias = getenv("ZK_QUOTIENT_TILE_ALIAS") ? (uint32_t)atoi(getenv("ZK_QUOTIENT_TILE_ALIAS")) : 0;
+        auto launch2 = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
+                               tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc, tile_alias);
+        };
+        if (v2 && full && acc_in_mem) launch2(k_quotient_eval2<true, true>);
+        else if (v2 && full) launch2(k_quotient_eval2<true, false>);
+        else if (v2 && acc_in_mem) launch2(k_quotient_eval2<false, true>);
+        else if (v2) launch2(k_quotient_eval2<false, false>);
         else if (full && acc_in_mem) launch(k_quotient_eval<true, true>);
         else if (full) launch(k_quotient_eval<true, false>);
         else if (acc_in_mem) launch(k_quotient_eval<false, true>);
