@@ -179,6 +179,13 @@ int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr,
  * sequence.  out_words may be NULL (sizes only).  For tests and for inspecting what a key's gates compile to. */
 int zk_host_quotient_lower(const uint32_t* program, uint32_t num_instr, uint32_t num_cols, int fuse, uint32_t* out_words, size_t cap_words,
                            uint32_t* out_instr, int* out_depth);
+/* Host only (no device): where zk_quotient_eval would cut `program` into slices for 2^ext_k rows (round 6: a large sum of terms
+ * acc = acc * c_f + term_f whose operands are read many times is evaluated slice by slice over the same rows at the same time so
+ * that the slices find each other's operands in the caches; cuts only at top-level FOLDs that no parked intermediate is alive
+ * across).  out_cuts receives the first instruction of every slice and the end of the program (*out_count entries; 0 = the program
+ * runs in one piece).  ZK_QUOTIENT_SLICES=0 / N turns the slicing off / asks for N slices.  No counterpart in halo2's evaluate_h
+ * (plonk/evaluation.rs, external crate), which walks one row at a time on the CPU.                                              */
+int zk_host_quotient_slices(const uint32_t* program, uint32_t num_instr, uint32_t ext_k, uint32_t* out_cuts, size_t cap, uint32_t* out_count);
 
 /* Host only, for tests: how the prover distributes constraint programs over its degree classes when the programs share
  * intermediates (TEE_TMP in one constraint, PUSH_TMP in a later one -- halo2's GraphEvaluator intermediates as exported): a

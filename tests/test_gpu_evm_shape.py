@@ -25,7 +25,7 @@ from zkevm_circuits_amd import plonk  # noqa: E402
 pytestmark = pytest.mark.gpu
 S_SECRET = 0x5EC2E7
 KNOBS = ({"ZK_QUOTIENT_DAG": "0"}, {"ZK_QUOTIENT_SPLIT": "0", "ZK_QUOTIENT_ADDSPLIT": "0"}, {"ZK_QUOTIENT_COSTGATE": "0"}, {"ZK_QUOTIENT_COSTGATE": "0", "ZK_QUOTIENT_DAG": "0"},
-         {"ZK_QUOTIENT_DAG": "0", "ZK_QUOTIENT_GROUP": "0"})
+         {"ZK_QUOTIENT_DAG": "0", "ZK_QUOTIENT_GROUP": "0"}, {"ZK_QUOTIENT_KERNEL": "1"})
 
 
 class env:
@@ -134,6 +134,10 @@ def test_the_benched_evm_configuration_at_k20(ctx, cref):
         with env({"ZK_QUOTIENT_SPLIT": "0", "ZK_QUOTIENT_ADDSPLIT": "0"}):       # degree classes off: every column on all 8 cosets, one class
             assert resident() == proof
         with env({"ZK_QUOTIENT_DAG": "0"}):                                        # the exported trees, as round 5 assembled them
+            assert resident() == proof
+        with env({"ZK_QUOTIENT_SLICES": "0"}):                                     # class programs in one piece (by default the large ones are cut into slices that share their rows' operands)
+            assert resident() == proof
+        with env({"ZK_QUOTIENT_KERNEL": "1"}):                                     # round 5's interpreter
             assert resident() == proof
     finally:
         driver.free()

@@ -40,6 +40,33 @@ def _run_oracle(prog, cols, consts, k, ext_k, divide):
     return out
 
 
+def _run_oracle_rows(prog, cols, consts, k, ext_k, divide, rows):
+    """_run_oracle on a sample of rows (the sliced-program tests run at sizes where every row in Python would take minutes)"""
+    ne, scale = 1 << ext_k, 1 << (ext_k - k)
+    tev = None
+    if divide:
+        zn, step = pow(b.FR_ZETA, 1 << k, R), pow(b.omega_for_k(ext_k), 1 << k, R)
+        tev = [b.fr_inv((zn * pow(step, j, R) - 1) % R) for j in range(scale)]
+    out = []
+    for i in rows:
+        st, acc, tmp = [], 0, {}
+        for op, a, bb in prog:
+            if op == 1:
+                rot = bb if bb < (1 << 31) else bb - (1 << 32)
+                st.append(cols[a][(i + rot * scale) % ne])
+            elif op == 2: st.append(consts[a])
+            elif op == 3: y = st.pop(); st[-1] = (st[-1] + y) % R
+            elif op == 4: y = st.pop(); st[-1] = (st[-1] - y) % R
+            elif op == 5: y = st.pop(); st[-1] = st[-1] * y % R
+            elif op == 9: acc = (acc * consts[a] + st.pop()) % R
+            elif op == 10: st[-1] = st[-1] * consts[a] % R
+            elif op == 12: tmp[a] = st[-1]
+            elif op == 13: st.append(tmp[a])
+            else: raise AssertionError(op)
+        out.append(acc * tev[i % scale] % R if divide else acc)
+    return out
+
+
 @pytest.mark.parametrize("k,ext_k,divide", [(4, 4, False), (5, 7, True), (8, 10, True), (10, 10, False)])
 def test_program_matches_oracle(zk, ctx, cref, k, ext_k, divide):
     rng = random.Random(100 * k + ext_k)
@@ -128,3 +155,36 @@ def test_intermediates_shared_between_gates(zk, ctx, cref, k, ext_k):
                      ([(zk.Q_PUSH_COL, 0, 0), (zk.Q_TEE_TMP, 1 << 20, 0), (zk.Q_FOLD, 0, 0)], "bad TEE_TMP")):
         with pytest.raises(zk.ZkError, match=msg):
             ctx.quotient_eval(np.array(bad, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out, False)
+
+
+@pytest.mark.parametrize("k,ext_k,divide,slices", [(11, 11, False, 2), (11, 12, True, 3), (11, 12, True, 64), (12, 12, False, 5)])
+def test_sliced_program_matches_oracle(zk, ctx, cref, k, ext_k, divide, slices, monkeypatch):
+    """Round 6: a sum of terms cut into slices (ZK_QUOTIENT_SLICES forces the count; each slice evaluated from acc = 0 by its own workgroups over the same
+    rows, partial sums put together with the products of the slices' fold constants).  Parked intermediates block the cuts they are alive across and are
+    renumbered per slice; fold constants differ per term."""
+    rng = random.Random(7 * k + ext_k + slices)
+    ne, ncols = 1 << ext_k, 6
+    cols = [[rng.randrange(R) for _ in range(ne)] for _ in range(ncols)]
+    consts = [rng.randrange(R) for _ in range(6)]
+    M32 = 1 << 32
+    prog = []
+    for t in range(40):
+        a, b_, c = rng.randrange(ncols), rng.randrange(ncols), rng.randrange(ncols)
+        prog += [(zk.Q_PUSH_COL, a, 0), (zk.Q_PUSH_COL, b_, rng.choice([0, 1, (-1) % M32])), (zk.Q_MUL, 0, 0)]
+        if t % 7 == 2:      # park a product, read it back in this term and in the next two (no cut in between)
+            prog += [(zk.Q_TEE_TMP, t % 3, 0)]
+        if t % 7 in (3, 4):
+            prog += [(zk.Q_PUSH_TMP, (t - (t % 7 - 2)) % 3, 0), (zk.Q_ADD, 0, 0)]
+        prog += [(zk.Q_PUSH_COL, c, 0), (zk.Q_SUB, 0, 0), (zk.Q_MUL_CONST, rng.randrange(6), 0), (zk.Q_FOLD, rng.randrange(6), 0)]
+    monkeypatch.setenv("ZK_QUOTIENT_SLICES", str(slices))
+    dcols = [ctx.to_device(cref.to_mont(c)) for c in cols]
+    out = ctx.alloc(ne * 32)
+    ctx.quotient_eval(np.array(prog, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out, divide)
+    got = cref.from_mont(out.download((ne, 4)))
+    monkeypatch.setenv("ZK_QUOTIENT_SLICES", "0")
+    out2 = ctx.alloc(ne * 32)
+    ctx.quotient_eval(np.array(prog, dtype=np.uint32), [d.ptr for d in dcols], cref.to_mont(consts), k, ext_k, out2, divide)
+    assert got == cref.from_mont(out2.download((ne, 4)))
+    sample = list(range(0, ne, max(1, ne // 64)))
+    want = _run_oracle_rows(prog, cols, consts, k, ext_k, divide, sample)
+    assert [got[i] for i in sample] == want

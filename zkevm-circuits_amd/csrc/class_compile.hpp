@@ -178,6 +178,22 @@ struct ClassCompiler {
     std::vector<uint32_t> uses;
     std::vector<int32_t> vslot;          // node -> virtual slot once parked
     Prog out;
+    // Chunked emission (round 6, for the sliced launches of csrc/quotient.hip: plan_slices): a parked value is only visible inside the top-level term that
+    // parked it -- the next term recomputes (and, if it reads the value twice itself, parks) it again.  Every top-level FOLD is then a point where nothing
+    // parked is alive, i.e. where the evaluator may cut the program into slices that run side by side.  `uses` are counted per term for the same reason.
+    bool chunked = false;
+    void count_uses_from(const std::vector<int32_t>& roots) {
+        uses.assign(nd.size(), 0);
+        std::vector<int32_t> work(roots);
+        while (!work.empty()) {
+            const int32_t v = work.back();
+            work.pop_back();
+            if (uses[v]++) continue;
+            const Node& n = nd[v];
+            if (n.op == OP_HSUM) for (const Item& it : hs[n.a]) work.push_back(it.node);
+            else { if (n.x >= 0) work.push_back(n.x); if (n.y >= 0) work.push_back(n.y); }
+        }
+    }
     void count_uses(int32_t root) {
         uses.assign(nd.size(), 0);
         std::vector<int32_t> work{root};
@@ -213,6 +229,12 @@ struct ClassCompiler {
                     bool first = true;
                     while (i < items.size()) {
                         size_t j = i;
+                        if (chunked) {
+                            std::vector<int32_t> roots;
+                            for (size_t q = i; q < items.size() && items[q].idx == items[i].idx; ++q) roots.push_back(items[q].node);
+                            count_uses_from(roots);
+                            std::fill(vslot.begin(), vslot.end(), -1);
+                        }
                         while (j < items.size() && items[j].idx == items[i].idx) { emit(items[j].node, false); if (j > i) out.push_back({Q_ADD, 0, 0}); ++j; }
                         out.push_back({Q_FOLD, first ? C_ONE : C_YPOW0 + (items[i].idx - prev), 0});
                         prev = items[i].idx;
@@ -280,6 +302,10 @@ static bool compile_class(const std::vector<ClassTerm>& terms, uint32_t K, Prog&
         root = cc.fresh(ClassCompiler::OP_HSUM, (uint32_t)cc.hs.size() - 1, 0, -1, -1);
     }
     cc.count_uses(root);
+    {   // large programs are emitted term by term so that the evaluator can slice them (ZK_QUOTIENT_CHUNK=0: one parking scope for the whole class)
+        const char* e = getenv("ZK_QUOTIENT_CHUNK");
+        cc.chunked = e ? atoi(e) != 0 : cc.nd.size() >= 4096;
+    }
     cc.prod_memo.assign(cc.nd.size(), -1);
     cc.no_park.assign(cc.nd.size(), 0);
     // Parking pays by (uses - 1) x (products the value cost): tau = t + beta of a lookup table is ONE product and is read by every

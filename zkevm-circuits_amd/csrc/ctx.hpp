@@ -33,7 +33,7 @@ struct zk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
     // scratch arenas, grown on demand (never shrunk): index = purpose
-    zk::Scratch scratch[18];
+    zk::Scratch scratch[19];
     // side stream + events for pipelining consecutive MSMs (msm.hip): created on first use
     hipStream_t stream2 = nullptr, stream2b = nullptr, stream2c = nullptr;
     std::vector<hipStream_t> owned_streams;      // every stream zk_ctx_create made (roles may share one; 'd' entries of the layout have no role at all)
@@ -212,7 +212,7 @@ struct zk_srs {
     } while (0)
 
 namespace zk {
-enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14, SC_MSM_TAILS = 15, SC_NTT_AUX = 16, SC_QACC = 17 };
+enum ScratchSlot { SC_NTT = 0, SC_MSM_KEYS = 1, SC_MSM_BUCKETS = 2, SC_MSM_MISC = 3, SC_POLY = 4, SC_POLY2 = 5, SC_TMP = 6, SC_TMP2 = 7, SC_MSM_BUCKETS2 = 8, SC_MSM_RESULTS = 9, SC_QTMP = 10, SC_COMM = 11, SC_MSM_BUCKETS3 = 12, SC_MSM_BUCKETS4 = 13, SC_MSM_DESC = 14, SC_MSM_TAILS = 15, SC_NTT_AUX = 16, SC_QACC = 17, SC_QSLICE = 18 };
 
 // host-side field helpers (slow path, used for constants / tables only)
 Fr fr_from_u64(uint64_t v);

@@ -55,6 +55,7 @@
 //                  constant, so it is never settled: L_t <= 3
 #include "ctx.hpp"
 #include "ff29.hip.hpp"
+#include <unordered_map>
 
 namespace zk {
 
@@ -436,7 +437,8 @@ template <bool FULL, bool ACC_MEM>
 __global__ void __launch_bounds__(Q_THREADS) Q_OCC_ATTR
 k_quotient_eval2(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* const* __restrict__ cols, const QC29* __restrict__ consts,
                  const QC29* __restrict__ consts_rp /* the same constants in R' form */, const Fr* __restrict__ t_evals /* R' form */, uint32_t ext_k, uint32_t k,
-                 Fr* __restrict__ out, Fr* tmp /* [slot][row] */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */, uint32_t tile_alias /* measurement only, see the launch */) {
+                 Fr* __restrict__ out, Fr* tmp /* [slot][row] */, uint32_t* acc_mem /* ACC_MEM: [limb][row] */, uint32_t tile_alias /* measurement only, see the launch */,
+                 const uint32_t* __restrict__ slice_tab /* per slice: first word of its instructions, their number */, uint32_t num_slices /* 0: one program for every workgroup */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // stack entry j < sp - 1 lives in LDS slot j ([slot][limb][lane]); entry sp - 1 is t0.  ONE address register (slot and lane; made opaque so
     // that the compiler does not split it into nine loop-invariant lane addresses + nine adds per access), the limb in the instruction's offset field.
@@ -458,6 +460,15 @@ k_quotient_eval2(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr*
     const uint64_t ne = 1ull << ext_k;
     uint32_t blk = blockIdx.x;
     if (tile_alias) { const uint32_t xcd = blk & 7u, j = blk >> 3; blk = ((j >> tile_alias) << 3) | xcd; }       // 2^tile_alias consecutive workgroups of an XCD share one row tile (results wrong)
+    if (num_slices) {
+        // A sliced program (see zk_quotient_eval): workgroup ids go round the XCDs, so ids 8 j + x, j = t S ... t S + S - 1, are S workgroups that start
+        // together on XCD x -- they take the S slices of ONE row tile and find each other's operands in that XCD's L2 / the Infinity Cache.
+        const uint32_t xcd = blk & 7u, j = blk >> 3, sl = j % num_slices;
+        blk = ((j / num_slices) << 3) | xcd;
+        prog += slice_tab[2 * sl];
+        prog_len = slice_tab[2 * sl + 1];
+        out += (size_t)sl << ext_k;
+    }
     const uint32_t i = blk * blockDim.x + threadIdx.x;
     const bool live = FULL || i < (uint32_t)ne;
     const uint32_t rot_scale = 1u << (ext_k - k), row_mask = (uint32_t)ne - 1u;
@@ -870,6 +881,88 @@ extern "C" int zk_host_quotient_lower(const uint32_t* h_program, uint32_t num_in
     return ZK_OK;
 }
 
+// ---- slicing a large program for the caches (round 6) --------------------------------------------------------------------------
+// A class program of the EVM-style constraint system reads each of its operands ~70 times per row, hundreds of instructions apart, and the
+// rows of the ~5 000 resident waves x their few hundred columns are gigabytes: every read goes to HBM (5 TB/s of operand loads for 5 KB of
+// distinct operands per row).  Made to evaluate ONE row tile with four to sixteen workgroups at a time (ZK_QUOTIENT_TILE_ALIAS) the same
+// launch takes 116 ... 107 ms instead of 139: with a sixteenth of the rows in flight their operands stay in the Infinity Cache.  So a program
+// that is a top-level sum  acc = acc * c_f + term_f  is cut at fold boundaries into S slices, slice s is evaluated from acc = 0 by its own
+// workgroup over the same rows at the same time (k_quotient_eval2: slice_tab), and
+//      acc_out(slice s) = acc_in * prod_{f in s} c_f + P_s
+// puts the partial sums P_s together afterwards (an S-term FOLD_COL chain through this same function).  A cut is only made where no parked
+// intermediate is alive; parking slots are renumbered per slice (slices run concurrently).  ZK_QUOTIENT_SLICES=0 turns it off, =N asks for N.
+struct SlicePlan { std::vector<uint32_t> cut; };       // cut[s] .. cut[s + 1]: the caller's instructions of slice s
+static bool plan_slices(const uint32_t* prog, uint32_t len, uint32_t ext_k, SlicePlan* out) {
+    const int knob = getenv("ZK_QUOTIENT_SLICES") ? atoi(getenv("ZK_QUOTIENT_SLICES")) : -1;        // read per call: the tests flip it
+    if (knob == 0 || (knob < 0 && (len < 2048 || ext_k < 16)) || ext_k < 11) return false;     // a forced count (tests) slices small programs too
+    std::vector<uint32_t> bpos;           // instruction index behind a top-level FOLD
+    std::vector<uint64_t> bcost;          // cost of everything in front of it
+    std::vector<int32_t> blocked(len + 2, 0);
+    std::vector<uint32_t> last_tee;
+    std::vector<uint64_t> ops;
+    std::vector<uint32_t> colset;
+    uint64_t cost = 0, reads = 0;
+    int sp = 0;
+    uint32_t n = 0;
+    for (; n < len && prog[3 * n] != Q_END; ++n) {
+        const uint32_t op = prog[3 * n], a = prog[3 * n + 1];
+        switch (op) {
+            case Q_PUSH_COL: ++sp; cost += 3; ++reads; ops.push_back(((uint64_t)a << 32) | prog[3 * n + 2]); colset.push_back(a); break;
+            case Q_PUSH_CONST: ++sp; cost += 1; break;
+            case Q_PUSH_TMP:
+                ++sp; cost += 3;
+                if (a < last_tee.size()) { ++blocked[last_tee[a] + 1]; --blocked[n + 1]; }       // no cut between the parking and this read
+                break;
+            case Q_TEE_TMP: if (a >= last_tee.size()) last_tee.resize(a + 1, 0); last_tee[a] = n; cost += 4; break;
+            case Q_ADD: case Q_SUB: --sp; cost += 1; break;
+            case Q_MUL: --sp; cost += 24; break;
+            case Q_SQUARE: case Q_MUL_CONST: cost += 24; break;
+            case Q_FOLD: --sp; cost += 24; if (sp == 0) { bpos.push_back(n + 1); bcost.push_back(cost); } break;
+            default: cost += 1; break;
+        }
+    }
+    if (bpos.size() < 2 || bpos.back() != n) return false;          // not a sum of terms (or something trails the last fold)
+    std::sort(ops.begin(), ops.end()); ops.erase(std::unique(ops.begin(), ops.end()), ops.end());
+    std::sort(colset.begin(), colset.end()); colset.erase(std::unique(colset.begin(), colset.end()), colset.end());
+    if (knob < 0 && reads < 4 * ops.size()) return false;           // operands read once or twice: nothing to keep in a cache
+    // slices wanted: the operands of the rows in flight (~5 000 waves x 64) should be well inside the 256 MiB Infinity Cache
+    const uint64_t rows_in_flight = std::min<uint64_t>(1ull << ext_k, 327680);
+    const uint64_t ws = colset.size() * 32ull * rows_in_flight;
+    uint32_t want = knob > 0 ? (uint32_t)knob : (uint32_t)std::min<uint64_t>(64, (ws + (96ull << 20) - 1) / (96ull << 20));
+    if (want < 2) return false;
+    // cuts at unblocked boundaries, by cost
+    std::vector<char> ok(bpos.size(), 1);
+    {
+        int32_t run = 0;
+        size_t b = 0;
+        for (uint32_t q = 0; q <= n && b < bpos.size(); ++q) {
+            run += blocked[q];
+            if (bpos[b] == q) { ok[b] = run == 0; ++b; }
+        }
+    }
+    out->cut.assign(1, 0);
+    uint32_t made = 1;
+    for (size_t b = 0; b + 1 < bpos.size() && made < want; ++b) {
+        if (!ok[b]) continue;
+        if (bcost[b] * want >= cost * made) { out->cut.push_back(bpos[b]); ++made; }
+    }
+    out->cut.push_back(n);
+    return out->cut.size() > 2;
+}
+
+extern "C" int zk_host_quotient_slices(const uint32_t* program, uint32_t num_instr, uint32_t ext_k, uint32_t* out_cuts, size_t cap, uint32_t* out_count) {
+    if (!program || !out_count) return ZK_ERR_INVALID_ARG;
+    SlicePlan plan;
+    *out_count = 0;
+    if (!plan_slices(program, num_instr, ext_k, &plan)) return ZK_OK;
+    *out_count = (uint32_t)plan.cut.size();
+    if (out_cuts) {
+        if (cap < plan.cut.size()) return ZK_ERR_INVALID_ARG;
+        for (size_t i = 0; i < plan.cut.size(); ++i) out_cuts[i] = plan.cut[i];
+    }
+    return ZK_OK;
+}
+
 extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t num_instr, const void* const* h_col_ptrs, uint32_t num_cols,
                                 const void* h_consts, uint32_t num_consts, uint32_t k, uint32_t ext_k, int divide_by_vanishing, void* d_out) {
     if (!ctx) return ZK_ERR_INVALID_ARG;
@@ -879,15 +972,49 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     uint32_t num_tmp = 0;
     int rc = validate_program(ctx, h_program, num_instr, num_cols, num_consts, &depth, &num_tmp);
     if (rc) return rc;
-    Fr* d_tmp = nullptr;
-    if (num_tmp) {
-        d_tmp = (Fr*)ctx->get_scratch(SC_QTMP, ((size_t)num_tmp << ext_k) * sizeof(Fr));
-        if (!d_tmp) return ZK_ERR_OOM;
-    }
+    const int kernel_knob = getenv("ZK_QUOTIENT_KERNEL") ? atoi(getenv("ZK_QUOTIENT_KERNEL")) : 2;       // 2: fixed register roles (k_quotient_eval2: one stack entry in registers, 4-word instructions); 1: round 5's kernel
+    const bool v2 = kernel_knob != 1;
+    const uint64_t ne = 1ull << ext_k;
+    // a large sum of terms whose operands are read many times is cut into slices that share their rows' operands through the caches (plan_slices)
+    SlicePlan plan;
+    const bool sliced = v2 && ((ne / Q_THREADS) & 7) == 0 && plan_slices(h_program, num_instr, ext_k, &plan);
+    const uint32_t S = sliced ? (uint32_t)plan.cut.size() - 1 : 1;
     // lower the program for the kernel (memory operands, settle bits, prefetch hazards); ZK_QUOTIENT_FUSE=0 keeps the
     // caller's instruction sequence (measurement knob: only the bounds pass runs)
-    std::vector<LowInstr> low;
-    {
+    std::vector<std::vector<LowInstr>> lows(S);
+    std::vector<Fr> slice_k;                  // sliced: the product of a slice's fold constants (what the accumulator coming in is multiplied by)
+    if (sliced) {
+        uint32_t next_slot = 0;
+        int dmax = 0;
+        slice_k.assign(S, Fr::one());
+        for (uint32_t sl = 0; sl < S; ++sl) {
+            std::vector<uint32_t> sub(h_program + 3 * plan.cut[sl], h_program + 3 * plan.cut[sl + 1]);
+            std::unordered_map<uint32_t, uint32_t> slot_of;        // parking slots of this slice -> its own range (slices run at the same time)
+            int spd = 0;
+            for (size_t q = 0; q < sub.size() / 3; ++q) {
+                const uint32_t op = sub[3 * q];
+                if (op == Q_TEE_TMP || op == Q_PUSH_TMP) {
+                    auto it = slot_of.find(sub[3 * q + 1]);
+                    if (it == slot_of.end()) {
+                        if (op == Q_PUSH_TMP) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: slice %u reads an intermediate parked outside it", sl);
+                        it = slot_of.emplace(sub[3 * q + 1], next_slot++).first;
+                    }
+                    sub[3 * q + 1] = it->second;
+                }
+                if (op == Q_PUSH_COL || op == Q_PUSH_CONST || op == Q_PUSH_TMP) ++spd;
+                else if (op == Q_ADD || op == Q_SUB || op == Q_MUL) --spd;
+                else if (op == Q_FOLD) { --spd; if (spd == 0) slice_k[sl] = slice_k[sl] * ((const Fr*)h_consts)[sub[3 * q + 1]]; }
+            }
+            sub.push_back(Q_END); sub.push_back(0); sub.push_back(0);
+            lower_fuse(sub.data(), (uint32_t)(sub.size() / 3), num_cols, &lows[sl]);
+            int dsl = 0;
+            if (lower_bounds(&lows[sl], num_cols, &dsl)) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: lowering failed");
+            dmax = std::max(dmax, dsl);
+        }
+        depth = dmax;
+        num_tmp = next_slot;
+    } else {
+        std::vector<LowInstr>& low = lows[0];
         const char* env = getenv("ZK_QUOTIENT_FUSE");
         if (env && atoi(env) == 0) {
             for (uint32_t pc = 0; pc < num_instr && h_program[3 * pc] != Q_END; ++pc) {
@@ -897,46 +1024,72 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
             }
         } else lower_fuse(h_program, num_instr, num_cols, &low);
         if (lower_bounds(&low, num_cols, &depth)) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient program: lowering failed");
-        if (depth > Q_MAX_STACK) return ctx->fail(ZK_ERR_UNSUPPORTED, "quotient program: stack deeper than %d", Q_MAX_STACK);
     }
+    if (depth > Q_MAX_STACK) return ctx->fail(ZK_ERR_UNSUPPORTED, "quotient program: stack deeper than %d", Q_MAX_STACK);
     if (depth < 1) depth = 1;
-    const uint32_t low_len = (uint32_t)low.size();
-    // the accumulator's home: registers for programs that fold on most instructions, memory for the rest (see the kernel)
+    Fr* d_tmp = nullptr;
+    if (num_tmp) {
+        d_tmp = (Fr*)ctx->get_scratch(SC_QTMP, ((size_t)num_tmp << ext_k) * sizeof(Fr));
+        if (!d_tmp) return ZK_ERR_OOM;
+    }
+    uint32_t low_len = 0;
+    // the accumulator's home: registers for programs that fold on most instructions (and for slices), memory for the rest (see the kernel)
     uint32_t folds = 0;
-    for (LowInstr& in : low) {
-        const uint32_t o = in.w0 & 0xffu;
-        if (o == Q_FOLD || o == K_FOLD_COL) { if (!folds) in.w0 |= K_FIRST_FOLD; ++folds; }
+    for (std::vector<LowInstr>& low : lows) {
+        bool first = true;
+        for (LowInstr& in : low) {
+            const uint32_t o = in.w0 & 0xffu;
+            if (o == Q_FOLD || o == K_FOLD_COL) { if (first) in.w0 |= K_FIRST_FOLD; first = false; ++folds; }
+        }
+        low_len += (uint32_t)low.size();
     }
     static const int acc_knob = getenv("ZK_QUOTIENT_ACC_MEM") ? atoi(getenv("ZK_QUOTIENT_ACC_MEM")) : -1;      // measurement knob: 0 / 1 force the variant
-    const bool acc_in_mem = folds > 0 && (acc_knob < 0 ? (uint64_t)folds * 16 <= low_len : acc_knob == 1);
+    const bool acc_in_mem = !sliced && folds > 0 && (acc_knob < 0 ? (uint64_t)folds * 16 <= low_len : acc_knob == 1);
     uint32_t* d_acc = nullptr;
     if (acc_in_mem) {
         d_acc = (uint32_t*)ctx->get_scratch(SC_QACC, ((size_t)9 << ext_k) * sizeof(uint32_t));
         if (!d_acc) return ZK_ERR_OOM;
     }
+    Fr* d_part = nullptr;                     // sliced: the slices' sums, [slice][row]
+    if (sliced) {
+        d_part = (Fr*)ctx->get_scratch(SC_QSLICE, ((size_t)S << ext_k) * sizeof(Fr));
+        if (!d_part) return ZK_ERR_OOM;
+    }
     if (getenv("ZK_QUOTIENT_TRACE") && low_len >= 64) {        // what the kernel will run: lowered instructions by opcode, settle bits, stack depth
         static const char* names[22] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "SQUARE", "DOUBLE", "FOLD", "MUL_CONST", "ADD_CONST", "TEE_TMP", "PUSH_TMP", "?", "?",
                                         "ADD_COL", "SUB_COL", "RSUB_COL", "MUL_COL", "FOLD_COL", "NOP"};
         uint32_t hist[22] = {0}, settles = 0, norms = 0;
-        for (const LowInstr& in : low) { const uint32_t o = in.w0 & 0xffu; if (o < 22) ++hist[o]; settles += ((in.w0 & (K_SETTLE0 | K_SETTLE0_8)) ? 1 : 0) + ((in.w0 & (K_SETTLE1 | K_SETTLE1_8)) ? 1 : 0); norms += ((in.w0 & K_NORM0) ? 1 : 0) + ((in.w0 & K_NORM1) ? 1 : 0); }
-        fprintf(stderr, "[zk quotient] 2^%u rows, %u lowered instructions, depth %d, %u settles, %u carry propagations:", ext_k, low_len, depth, settles, norms);
+        for (const std::vector<LowInstr>& low : lows) for (const LowInstr& in : low) { const uint32_t o = in.w0 & 0xffu; if (o < 22) ++hist[o]; settles += ((in.w0 & (K_SETTLE0 | K_SETTLE0_8)) ? 1 : 0) + ((in.w0 & (K_SETTLE1 | K_SETTLE1_8)) ? 1 : 0); norms += ((in.w0 & K_NORM0) ? 1 : 0) + ((in.w0 & K_NORM1) ? 1 : 0); }
+        fprintf(stderr, "[zk quotient] 2^%u rows, %u lowered instructions%s, depth %d, %u settles, %u carry propagations:", ext_k, low_len, sliced ? (" in " + std::to_string(S) + " slices").c_str() : "", depth, settles, norms);
         for (int o = 0; o < 22; ++o) if (hist[o]) fprintf(stderr, " %s %u", names[o], hist[o]);
+        if (sliced) { fprintf(stderr, "; slice lengths"); for (const std::vector<LowInstr>& low : lows) fprintf(stderr, " %zu", low.size()); fprintf(stderr, "; %u parking slots", num_tmp); }
         fprintf(stderr, "\n");
     }
     std::vector<Fr> tev;
     if (divide_by_vanishing) vanishing_inverses(k, ext_k, &tev);
     // constants that multiply (MUL_CONST, FOLD) and the vanishing inverses go to the device in R' = 2^261 form too: x 32
     auto times32 = [](Fr x) { for (int j = 0; j < 5; ++j) x = dbl(x); return x; };
-    std::vector<Fr> consts_rp((const Fr*)h_consts, (const Fr*)h_consts + num_consts);
+    std::vector<Fr> consts_r((const Fr*)h_consts, (const Fr*)h_consts + num_consts);
+    if (sliced) consts_r.insert(consts_r.end(), slice_k.begin(), slice_k.end());      // constants num_consts + s: what the accumulator coming into slice s is multiplied by
+    const uint32_t nc_all = (uint32_t)consts_r.size();
+    std::vector<Fr> consts_rp(consts_r);
     for (Fr& c : consts_rp) c = times32(c);
     for (Fr& t : tev) t = times32(t);
     // column table = the caller's columns, then one pseudo-column per parked intermediate
     std::vector<const void*> col_tab(h_col_ptrs, h_col_ptrs + num_cols);
     for (uint32_t t = 0; t < num_tmp; ++t) col_tab.push_back(d_tmp + ((size_t)t << ext_k));
-    static const int kernel_knob = getenv("ZK_QUOTIENT_KERNEL") ? atoi(getenv("ZK_QUOTIENT_KERNEL")) : 2;       // 2: fixed register roles (k_quotient_eval2: one stack entry in registers, 4-word instructions); 1: round 5's kernel
-    const bool v2 = kernel_knob != 1;
-    const size_t prog_bytes = (size_t)(low_len + 4) * (v2 ? 16 : 12), col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
-    const size_t const_bytes = (size_t)(num_consts ? num_consts : 1) * sizeof(QC29) * 2, tev_bytes = tev.size() * sizeof(Fr);
+    // sliced: the partial sums are columns num_cols + num_tmp + s of a last little program, acc = acc * k_s + P_s over the slices (and the vanishing division the
+    // caller asked for), which rides in the same upload and is launched right behind the slices: no second call, no host synchronisation in between
+    std::vector<LowInstr> comb;
+    if (sliced) {
+        if (nc_all >= (1u << (32 - K_CONST_SHIFT))) return ctx->fail(ZK_ERR_UNSUPPORTED, "quotient program: too many constants for a sliced launch");
+        for (uint32_t sl = 0; sl < S; ++sl) {
+            col_tab.push_back(d_part + ((size_t)sl << ext_k));
+            comb.push_back({K_FOLD_COL | ((num_consts + sl) << K_CONST_SHIFT) | (sl ? 0u : K_FIRST_FOLD), num_cols + num_tmp + sl, 0});
+        }
+    }
+    const size_t prog_bytes = (size_t)(low_len + 4 * S + comb.size() + 4) * (v2 ? 16 : 12) + (sliced ? S * 8 : 0), col_bytes = (col_tab.size() ? col_tab.size() : 1) * 8;
+    const size_t const_bytes = (size_t)(nc_all ? nc_all : 1) * sizeof(QC29) * 2, tev_bytes = tev.size() * sizeof(Fr);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* d = (char*)ctx->get_scratch(SC_POLY, al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes) + 256);
     if (!d) return ZK_ERR_OOM;
@@ -949,23 +1102,34 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
     // SuperCircuit-shape proof at ~8 us of device time apiece
     const size_t total_bytes = al(prog_bytes) + al(col_bytes) + al(const_bytes) + al(tev_bytes);
     std::vector<char> staging(total_bytes, 0);
+    std::vector<uint32_t> slice_tab(2 * S);
+    size_t slice_tab_at = 0, comb_at = 0;
     {
         uint32_t* hp = (uint32_t*)staging.data();
         size_t w = 0;
-        for (const LowInstr& in : low) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; if (v2) hp[w++] = q_class_mask(in.w0); }
-        for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; if (v2) hp[w++] = 0; }      // END + the instructions the kernel fetches ahead
+        for (uint32_t sl = 0; sl < S; ++sl) {
+            slice_tab[2 * sl] = (uint32_t)w; slice_tab[2 * sl + 1] = (uint32_t)lows[sl].size() + 1;
+            for (const LowInstr& in : lows[sl]) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; if (v2) hp[w++] = q_class_mask(in.w0); }
+            for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; if (v2) hp[w++] = 0; }      // END + the instructions the kernel fetches ahead
+        }
+        comb_at = w;
+        if (sliced) {
+            for (const LowInstr& in : comb) { hp[w++] = in.w0; hp[w++] = in.a; hp[w++] = in.b; hp[w++] = q_class_mask(in.w0); }
+            for (int e = 0; e < 4; ++e) { hp[w++] = Q_END; hp[w++] = 0; hp[w++] = 0; hp[w++] = 0; }
+        }
+        slice_tab_at = w;
+        if (sliced) for (uint32_t q = 0; q < 2 * S; ++q) hp[w++] = slice_tab[q];
         if (!col_tab.empty()) memcpy(staging.data() + al(prog_bytes), col_tab.data(), col_tab.size() * 8);
         char* hc = staging.data() + al(prog_bytes) + al(col_bytes);
         QC29* hq = (QC29*)hc;                                  // limb form: the R-form constants, then their R' images
-        for (uint32_t j = 0; j < num_consts; ++j) {
-            const Q29 a = unpack29<Fr29P>(((const Fr*)h_consts)[j]), b = unpack29<Fr29P>(consts_rp[j]);
-            for (int q = 0; q < 9; ++q) { hq[j].l[q] = a.l[q]; hq[num_consts + j].l[q] = b.l[q]; }
+        for (uint32_t j = 0; j < nc_all; ++j) {
+            const Q29 a = unpack29<Fr29P>(consts_r[j]), b = unpack29<Fr29P>(consts_rp[j]);
+            for (int q = 0; q < 9; ++q) { hq[j].l[q] = a.l[q]; hq[nc_all + j].l[q] = b.l[q]; }
         }
         if (!tev.empty()) memcpy(staging.data() + al(prog_bytes) + al(col_bytes) + al(const_bytes), tev.data(), tev_bytes);
     }
     ZK_HIP(ctx, hipMemcpyAsync(d, staging.data(), total_bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors are stack-owned
-    const uint64_t ne = 1ull << ext_k;
     size_t lds = (size_t)(v2 ? (depth > 1 ? depth - 1 : 1) : (depth > 2 ? depth - 2 : 1)) * 9 * Q_THREADS * 4;    // the topmost element(s) are in registers
     {   // measurement knob: pad the workgroup's LDS to this many bytes, i.e. cap the workgroups resident per CU (160 KB / pad)
         static const long pad = getenv("ZK_QUOTIENT_LDS_PAD") ? atol(getenv("ZK_QUOTIENT_LDS_PAD")) : 0;
@@ -999,18 +1163,19 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         ps.bytes = (ops.size() + tmp_moves + 1) * ne * 32;
     }
     {
-        const dim3 grid((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), block(Q_THREADS);
+        const dim3 grid((unsigned)((ne + Q_THREADS - 1) / Q_THREADS) * S), block(Q_THREADS);
         const bool full = ne >= (uint64_t)Q_THREADS;
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
+            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + nc_all),
                                tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc);
         };
         // measurement knob (results WRONG): 2^a consecutive workgroups of an XCD evaluate the same row tile -- the operand working set of the resident waves shrinks by
         // 2^a while every wave does what it did: what the launch would take if the slices of a sliced program shared their rows' operands through the L2
         static const uint32_t tile_alias = getenv("ZK_QUOTIENT_TILE_ALIAS") ? (uint32_t)atoi(getenv("ZK_QUOTIENT_TILE_ALIAS")) : 0;
         auto launch2 = [&](auto kern) {
-            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + num_consts),
-                               tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, d_acc, tile_alias);
+            hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, (const uint32_t*)d_prog, low_len + 1, (const Fr* const*)d_cols, (const QC29*)d_consts, (const QC29*)(d_consts + nc_all),
+                               tev.empty() || sliced ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, sliced ? d_part : (Fr*)d_out, d_tmp, d_acc, sliced ? 0u : tile_alias,
+                               (const uint32_t*)d_prog + slice_tab_at, sliced ? S : 0u);
         };
         if (v2 && full && acc_in_mem) launch2(k_quotient_eval2<true, true>);
         else if (v2 && full) launch2(k_quotient_eval2<true, false>);
@@ -1022,6 +1187,12 @@ extern "C" int zk_quotient_eval(zk_ctx* ctx, const uint32_t* h_program, uint32_t
         else launch(k_quotient_eval<false, false>);
     }
     ZK_CHECK_LAUNCH(ctx);
+    if (sliced) {
+        const dim3 grid((unsigned)((ne + Q_THREADS - 1) / Q_THREADS)), block(Q_THREADS);
+        hipLaunchKernelGGL((k_quotient_eval2<true, false>), grid, block, (size_t)9 * Q_THREADS * 4, ctx->stream, (const uint32_t*)d_prog + comb_at, S + 1, (const Fr* const*)d_cols, (const QC29*)d_consts,
+                           (const QC29*)(d_consts + nc_all), tev.empty() ? (const Fr*)nullptr : (const Fr*)d_tev, ext_k, k, (Fr*)d_out, d_tmp, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
+        ZK_CHECK_LAUNCH(ctx);
+    }
     return ZK_OK;
 }
 
