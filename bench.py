@@ -445,7 +445,8 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
                   "algorithmic_bytes_per_proof": int(qb / args.steps), "traffic": None,
                   "note": "`achieved` counts ALGORITHMIC bytes: 32 B x rows x (distinct (column, rotation) operands + parked intermediates + 1 result) per launch, as the library books them -- "
                           "every operand once.  `executed` counts what the interpreter actually loads: every memory operand of every instruction (a cell read by twenty constraints is loaded "
-                          "twenty times, thousands of instructions apart; no cache holds a coset's columns that long), and the field products it performs"}
+                          "twenty times, hundreds of instructions apart), and the field products it performs.  Since the second half of round 6 the large class programs run in slices that share "
+                          "their rows' operands through the caches: `traffic` (counters, per launch) is a quarter of the executed loads"}
         ops = class_program_operands(circ) if world == 1 else None
         if ops:
             ex_bytes = sum((1 << e_) * (c_["reads"] + c_["parks"] + 1) * 32 * n for e_, c_ in enumerate(ops) if c_["used"])

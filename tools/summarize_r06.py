@@ -124,13 +124,14 @@ qf = fetch_p.get(("k_quotient_eval", "FETCH_SIZE"), {"sum": 0, "launches": 0})
 qw = write_p.get(("k_quotient_eval", "WRITE_SIZE"), {"sum": 0, "launches": 0})
 ev = bench["extra"]["evaluator"]
 q_exec = None
+fetched_share = lambda loaded: 100.0 * 2 * qf["sum"] * KB / loaded            # FETCH_SIZE is in KB; doubled as the guide prescribes
 for r in bench["rooflines"]:
     if "k_quotient_eval" in r["kernel"]:
         q_exec = r.get("executed")
 lines += ["", f"All proving kernels of the proof: FETCH {tot_f / KB / KB:.1f} GiB (x2: {2 * tot_f / KB / KB:.1f}), WRITE {tot_w / KB / KB:.1f} GiB; "
           f"the line's `proof_roofline.algorithmic_bytes` = {bench['proof_roofline']['algorithmic_bytes'] / 2**30:.1f} GiB (halo2's full-extended-domain counts).",
           f"The evaluator (all launches of the proof, compressions and linear combinations included): FETCH {qf['sum'] / KB / KB:.1f} GiB raw = {2 * qf['sum'] / KB / KB:.1f} GiB corrected, WRITE {qw['sum'] / KB / KB:.1f} GiB"
-          + (f"; the class programs alone execute {q_exec['operand_bytes_per_proof'] / 2**30:.1f} GiB of operand loads per proof (`rooflines[..].executed`): what is fetched is what is loaded -- no reuse out of the caches." if q_exec else ".")]
+          + (f"; the class programs alone execute {q_exec['operand_bytes_per_proof'] / 2**30:.1f} GiB of operand loads per proof (`rooflines[..].executed`): {fetched_share(q_exec['operand_bytes_per_proof']):.0f} % of what the interpreter loads is fetched from beyond the L2 -- the first record run of the round read 88 % (every load a miss); the slices of a sliced class program (csrc/quotient.hip: plan_slices) find each other's operands in the caches." if q_exec else ".")]
 open(f"profiles/{tag}_pmc_traffic.md", "w").write("\n".join(lines) + "\n")
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/gpu_r6_record.sh; profiles/r06_pmc_traffic.md"}
 if "k_msm_buckets" in per and "k_ntt_pass" in per:
