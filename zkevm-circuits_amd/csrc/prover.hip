@@ -1037,23 +1037,33 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
             // commits them, and the ranks then exchange the columns group by group over the fabric.
             for (size_t c_ = pr->rank; c_ < total; c_ += sg.world) sg.own.push_back(c_);
             PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg, mine_narrow.data()));
-            DevBuf gbuf, zero;
-            if (!gbuf.alloc((size_t)sg.world * n * 32) || !zero.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            ZK_HIP(ctx, hipMemsetAsync(zero.p, 0, n * 32, ctx->stream));
+            // The exchange goes SEVERAL groups of `world` columns at a time (ZK_SHARD_EXCHANGE_GROUPS, default 16): this rank's columns of the chunk are packed into one
+            // send buffer and ONE all-gather moves world x 16 columns -- fewer, larger collectives (a collective per column group was 125 host-synchronised rounds of
+            // 32 MB per rank at eight ranks; RCCL over point-to-point xGMI wants its messages large).
+            static const size_t xg_knob = getenv("ZK_SHARD_EXCHANGE_GROUPS") ? (size_t)atol(getenv("ZK_SHARD_EXCHANGE_GROUPS")) : 16;
+            const size_t groups_total = (total + sg.world - 1) / sg.world, XG = std::max<size_t>(1, std::min(xg_knob, groups_total));
+            DevBuf gbuf, sbuf;
+            if (!gbuf.alloc((size_t)sg.world * XG * n * 32) || !sbuf.alloc(XG * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
             // the transforms of this rank's own columns still run on the auxiliary stream and share the NTT
             // scratch with the ones enqueued below on the main stream: finish them first
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
-            for (size_t grp = 0; grp * sg.world < total; ++grp) {
-                const size_t mine_c = grp * sg.world + pr->rank;
-                PK_TRY(zk_ctx_sync(ctx));                                  // own column uploaded, previous copies out of gbuf done
-                if (pr->gather_dev(pr->gather_dev_user, mine_c < total ? sg.dst[mine_c] : zero.p, n * 32, gbuf.p))
-                    return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: device all-gather callback failed");
-                for (uint32_t q_ = 0; q_ < sg.world; ++q_) {
-                    const size_t c_ = grp * sg.world + q_;
-                    if (q_ == pr->rank || c_ >= total) continue;
-                    ZK_HIP(ctx, hipMemcpyAsync(sg.dst[c_], (char*)gbuf.p + (size_t)q_ * n * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-                    PK_TRY(to_coeff(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
+            for (size_t grp0 = 0; grp0 < groups_total; grp0 += XG) {
+                const size_t gcnt = std::min(XG, groups_total - grp0);
+                for (size_t g = 0; g < gcnt; ++g) {
+                    const size_t mine_c = (grp0 + g) * sg.world + pr->rank;
+                    if (mine_c < total) ZK_HIP(ctx, hipMemcpyAsync((char*)sbuf.p + g * n * 32, sg.dst[mine_c], n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                    else ZK_HIP(ctx, hipMemsetAsync((char*)sbuf.p + g * n * 32, 0, n * 32, ctx->stream));
                 }
+                PK_TRY(zk_ctx_sync(ctx));                                  // own columns uploaded and packed, previous copies out of gbuf done
+                if (pr->gather_dev(pr->gather_dev_user, sbuf.p, gcnt * n * 32, gbuf.p))
+                    return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: device all-gather callback failed");
+                for (size_t g = 0; g < gcnt; ++g)
+                    for (uint32_t q_ = 0; q_ < sg.world; ++q_) {
+                        const size_t c_ = (grp0 + g) * sg.world + q_;
+                        if (q_ == pr->rank || c_ >= total) continue;
+                        ZK_HIP(ctx, hipMemcpyAsync(sg.dst[c_], (char*)gbuf.p + ((size_t)q_ * gcnt + g) * n * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                        PK_TRY(to_coeff(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
+                    }
             }
         } else {
             PK_TRY(commit_batch_staged(ctx, pk->srs, 1, mine.data(), mine.size(), n, local.data(), stage, &sg, mine_narrow.data()));   // MSM j reads group j of `world` columns
@@ -2007,25 +2017,72 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
     // of commits.  The unusable rows of m stay zero, as upstream leaves them.
     std::vector<std::vector<DevBuf>> lk_f(pk->L);
     std::vector<DevBuf> lk_t(pk->L), lk_m(pk->L), lk_phi(pk->L);
-    std::vector<uint8_t> same_table(pk->L, 0);            // lookup l reads the table of lookup l - 1 (lk_t lives at table_owner[l])
+    std::vector<uint8_t> same_table(pk->L, 0);            // lookup l reads the table of the lookup this rank worked on before it (lk_t lives at table_owner[l])
     std::vector<uint32_t> table_owner(pk->L, 0);
+    // Sharded sessions (round 6): the lookup arguments are split over the ranks like their commitments -- rank r compresses the tuples, counts the multiplicities and forms the
+    // running sum of arguments r, r + world, ... only; the Lagrange forms of m and phi (what the additive split's remainders, the coefficient forms and with them every later
+    // stage read) are all-gathered device to device behind each of the two rounds.  The blinding rows are drawn for every argument on every rank (one RNG sequence).
+    // ZK_SHARD_LOOKUPS=0: every rank works on every argument, as before.
+    const bool shard_args = pr->world > 1 && pr->gather && pk->L >= pr->world && !(getenv("ZK_SHARD_LOOKUPS") && atoi(getenv("ZK_SHARD_LOOKUPS")) == 0);
+    std::vector<uint32_t> act;                             // the arguments this rank works on, in order
+    for (uint32_t l = 0; l < pk->L; ++l) if (!shard_args || l % pr->world == pr->rank) act.push_back(l);
+    // all-gather of columns owned round-robin (column l by rank l % world): a rank's columns packed into one send buffer, several groups of `world` per exchange
+    auto exchange_owned = [&](std::vector<DevBuf>& cols) -> int {
+        const size_t total = cols.size(), W = pr->world, groups_total = (total + W - 1) / W;
+        static const size_t xg_knob = getenv("ZK_SHARD_EXCHANGE_GROUPS") ? (size_t)atol(getenv("ZK_SHARD_EXCHANGE_GROUPS")) : 16;
+        const size_t XG = std::max<size_t>(1, std::min(xg_knob, groups_total));
+        DevBuf gbuf, sbuf;
+        if (!gbuf.alloc(W * XG * n * 32) || !sbuf.alloc(XG * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+        std::vector<uint8_t> hs, hr;
+        for (size_t grp0 = 0; grp0 < groups_total; grp0 += XG) {
+            const size_t gcnt = std::min(XG, groups_total - grp0);
+            for (size_t g = 0; g < gcnt; ++g) {
+                const size_t mine_c = (grp0 + g) * W + pr->rank;
+                if (mine_c < total) ZK_HIP(ctx, hipMemcpyAsync((char*)sbuf.p + g * n * 32, cols[mine_c].p, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                else ZK_HIP(ctx, hipMemsetAsync((char*)sbuf.p + g * n * 32, 0, n * 32, ctx->stream));
+            }
+            if (pr->gather_dev) {
+                PK_TRY(zk_ctx_sync(ctx));
+                if (pr->gather_dev(pr->gather_dev_user, sbuf.p, gcnt * n * 32, gbuf.p)) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: device all-gather callback failed");
+            } else {
+                hs.resize(gcnt * n * 32); hr.resize(W * gcnt * n * 32);
+                PK_TRY(zk_d2h(ctx, hs.data(), sbuf.p, hs.size()));
+                if (pr->gather(pr->gather_user, hs.data(), hs.size(), hr.data())) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: all-gather callback failed");
+                PK_TRY(zk_h2d(ctx, gbuf.p, hr.data(), hr.size()));
+            }
+            for (size_t g = 0; g < gcnt; ++g)
+                for (uint32_t q_ = 0; q_ < W; ++q_) {
+                    const size_t c_ = (grp0 + g) * W + q_;
+                    if (q_ == pr->rank || c_ >= total) continue;
+                    ZK_HIP(ctx, hipMemcpyAsync(cols[c_].p, (char*)gbuf.p + ((size_t)q_ * gcnt + g) * n * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+            PK_TRY(zk_ctx_sync(ctx));                      // gbuf / sbuf are reused by the next chunk (and freed at the end)
+        }
+        return ZK_OK;
+    };
     if (pk->L) {
         Prog prev_table;
         DevBuf status;
         if (!status.alloc((size_t)pk->L * 4)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         ZK_HIP(ctx, hipMemsetAsync(status.p, 0xFF, (size_t)pk->L * 4, ctx->stream));
         std::vector<const void*> mptrs(pk->L);
-        for (uint32_t l = 0; l < pk->L; ++l) {
+        for (uint32_t l = 0; l < pk->L; ++l) {            // every m exists on every rank (the ones of other ranks arrive below)
+            if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            mptrs[l] = lk_m[l].p;
+        }
+        uint32_t prev_l = 0;
+        bool have_prev = false;
+        for (const uint32_t l : act) {
             const auto& lk = pk->lookups[l];
             PB pt;
             push_compressed(pt, lk.tables); pt.fold(C_ONE);
             // consecutive arguments into the same table (chunk_lookups() splits a table's inputs over as many arguments as the
             // degree bound needs; the EVM circuit's 80-odd lookups go into a dozen tables): one compressed table, one hash
             static const bool share_tables = !(getenv("ZK_LOOKUP_SHARE") && atoi(getenv("ZK_LOOKUP_SHARE")) == 0);      // measurement knob
-            same_table[l] = share_tables && l > 0 && pt.g.size() == prev_table.size() && memcmp(pt.g.data(), prev_table.data(), pt.g.size() * sizeof(Instr)) == 0;
-            table_owner[l] = same_table[l] ? table_owner[l - 1] : l;
+            same_table[l] = share_tables && have_prev && pt.g.size() == prev_table.size() && memcmp(pt.g.data(), prev_table.data(), pt.g.size() * sizeof(Instr)) == 0;
+            table_owner[l] = same_table[l] ? table_owner[prev_l] : l;
             prev_table = pt.g;
-            if (!lk_m[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            prev_l = l; have_prev = true;
             if (!same_table[l]) {
                 if (!lk_t[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
                 PK_TRY(run_program(ctx, lag, pt.g, lk_t[l].p));
@@ -2040,7 +2097,6 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 fptrs.push_back(lk_f[l][a].fr());
             }
             PK_TRY(lookup_multiplicities_enqueue(ctx, fptrs.data(), fptrs.size(), lk_t[table_owner[l]].fr(), pk->u, lk_m[l].fr(), n, (uint32_t*)status.p + l, same_table[l]));
-            mptrs[l] = lk_m[l].p;
         }
         std::vector<uint32_t> st(pk->L);
         PK_TRY(zk_d2h(ctx, st.data(), status.p, (size_t)pk->L * 4));
@@ -2050,6 +2106,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         std::vector<G1Affine> coms(pk->L);
         PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, mptrs.data(), pk->L, n, coms.data(), 1));      // multiplicities are small counts
         for (const G1Affine& com : coms) tr.write_point(com);
+        if (shard_args) PK_TRY(exchange_owned(lk_m));
     }
     trace.mark("lookup m");
     lag.lk_m = &lk_m;
@@ -2119,26 +2176,35 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         DevBuf g, closing_d;
         if (!g.alloc(n * 32) || !closing_d.alloc((size_t)pk->L * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
         std::vector<F4> blind((size_t)pk->L * pk->bf);
+        for (size_t q = 0; q < blind.size(); ++q) blind[q] = rng.next_fr();            // argument by argument, row by row: the order they were always drawn in, on every rank
         std::vector<const void*> pptrs(pk->L);
+        for (uint32_t l = 0; l < pk->L; ++l) {            // every phi exists on every rank (the ones of other ranks arrive below)
+            if (!lk_phi[l].alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            pptrs[l] = lk_phi[l].p;
+        }
+        ZK_HIP(ctx, hipMemsetAsync(closing_d.p, 0, (size_t)pk->L * 32, ctx->stream));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         const size_t max_slots = std::max<size_t>(4, (free_b + ctx->pool_bytes) / 4 / (n * 32));
-        for (uint32_t l0 = 0; l0 < pk->L;) {
-            // arguments [l0, l1) share one inversion; an argument is never separated from the owner of its table
+        const size_t NA = act.size();
+        for (size_t j0 = 0; j0 < NA;) {
+            // arguments act[j0 .. j1) share one inversion; an argument is never separated from the owner of its table
             size_t slots = 0;
-            uint32_t l1 = l0;
-            while (l1 < pk->L) {
-                const size_t need = lk_f[l1].size() + (same_table[l1] && l1 > l0 ? 0 : 1);
-                if (l1 > l0 && slots + need > max_slots && !same_table[l1]) break;
+            size_t j1 = j0;
+            while (j1 < NA) {
+                const uint32_t l1 = act[j1];
+                const size_t need = lk_f[l1].size() + (same_table[l1] && j1 > j0 ? 0 : 1);
+                if (j1 > j0 && slots + need > max_slots && !same_table[l1]) break;
                 slot0[l1] = slots;
-                tslot[l1] = (same_table[l1] && l1 > l0) ? tslot[l1 - 1] : slots;
+                tslot[l1] = (same_table[l1] && j1 > j0) ? tslot[act[j1 - 1]] : slots;
                 nslots[l1] = need;
                 slots += need;
-                ++l1;
+                ++j1;
             }
             DevBuf inv;
             if (!inv.alloc(slots * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            for (uint32_t l = l0; l < l1; ++l) {
+            for (size_t j = j0; j < j1; ++j) {
+                const uint32_t l = act[j];
                 const size_t N = lk_f[l].size();
                 Env e2 = lag;
                 std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
@@ -2154,9 +2220,9 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 }
             }
             PK_TRY(zk_fr_batch_invert(ctx, inv.p, slots * n));
-            for (uint32_t l = l0; l < l1; ++l) {
-                DevBuf phi;
-                if (!phi.alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            for (size_t j = j0; j < j1; ++j) {
+                const uint32_t l = act[j];
+                DevBuf& phi = lk_phi[l];
                 const size_t N = lk_f[l].size();
                 const bool own_t = tslot[l] == slot0[l];
                 const char* inv_t = (const char*)inv.p + tslot[l] * n * 32;
@@ -2167,14 +2233,11 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
                 for (size_t a = 1; a < N; ++a) PK_TRY(zk_field_vec_op(ctx, ZK_FIELD_FR, ZK_OP_ADD, g.p, inv_f + a * n * 32, g.p, n));
                 PK_TRY(zk_fr_prefix_sum(ctx, g.p, phi.p, n));                       // phi[0] = 0, phi[i+1] = phi[i] + g[i]
                 ZK_HIP(ctx, hipMemcpyAsync((char*)closing_d.p + (size_t)l * 32, (char*)phi.p + (size_t)pk->u * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
-                for (uint32_t i = 0; i < pk->bf; ++i) blind[(size_t)l * pk->bf + i] = rng.next_fr();
                 ZK_HIP(ctx, hipMemcpyAsync((char*)phi.p + (n - pk->bf) * 32, blind.data() + (size_t)l * pk->bf, (size_t)pk->bf * 32, hipMemcpyHostToDevice, ctx->stream));
                 lk_f[l].clear();                                                    // f, t are not needed again (the quotient recomputes them on its cosets)
-                if (l + 1 == pk->L || !same_table[l + 1]) lk_t[table_owner[l]].release();      // the table's last reader
-                pptrs[l] = phi.p;
-                lk_phi[l] = std::move(phi);
+                if (j + 1 == NA || !same_table[act[j + 1]]) lk_t[table_owner[l]].release();      // the table's last reader
             }
-            l0 = l1;
+            j0 = j1;
         }
         std::vector<F4> closing(pk->L);
         PK_TRY(zk_d2h(ctx, closing.data(), closing_d.p, (size_t)pk->L * 32));
@@ -2184,6 +2247,7 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
         std::vector<G1Affine> coms(pk->L);
         PK_TRY(sharded_commit(ctx, pr.get(), srs, 1, pptrs.data(), pk->L, n, coms.data(), 3));      // running sums: mostly equal increments (runs.hip)
         for (const G1Affine& com : coms) tr.write_point(com);
+        if (shard_args) PK_TRY(exchange_owned(lk_phi));
     }
     trace.mark("lookup phi");
     // ---- vanishing argument: the "random" polynomial.  In the reference's own proof it is the CONSTANT 1: the commitment in

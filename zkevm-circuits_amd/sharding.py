@@ -207,15 +207,19 @@ class EmulatedRank:
         def dev_gather(_user, send_ptr, nbytes, recv_ptr):
             try:
                 cols = self.phase_cols
+                colbytes = (1 << self.circ.k) * 32
+                per = nbytes // colbytes if cols else 1                     # a phase's columns travel several groups of `world` at a time (ZK_SHARD_EXCHANGE_GROUPS)
+                blk = colbytes if cols else nbytes
                 for q in range(world):
-                    src = send_ptr
-                    j = self.group * world + q
-                    if cols and q != rank and j < len(cols) and self.adv.get(cols[j]) is not None:
-                        src = self.adv[cols[j]].ptr                       # the peer's column
-                    if lib.zk_d2d(ctx.h, ctypes.c_void_p(recv_ptr + q * nbytes), ctypes.c_void_p(src), ctypes.c_size_t(nbytes)) != 0:
-                        return 1
+                    for g in range(per):
+                        src = send_ptr + g * blk
+                        j = (self.group + g) * world + q
+                        if cols and q != rank and j < len(cols) and self.adv.get(cols[j]) is not None:
+                            src = self.adv[cols[j]].ptr                   # the peer's column
+                        if lib.zk_d2d(ctx.h, ctypes.c_void_p(recv_ptr + (q * per + g) * blk), ctypes.c_void_p(src), ctypes.c_size_t(blk)) != 0:
+                            return 1
                 if cols:
-                    self.group += 1
+                    self.group += per
                     if self.group * world >= len(cols):
                         self.phase_cols = []                                # the phase's columns are through: later calls are quotient pairs
                 ctx.sync()
