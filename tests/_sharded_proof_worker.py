@@ -26,7 +26,11 @@ def main():
     dist.init_process_group(backend=os.environ.get("ZK_TEST_BACKEND", "gloo"), timeout=datetime.timedelta(seconds=150))      # a collective that never completes is an error, not a wait
     rank, world = dist.get_rank(), dist.get_world_size()
     ctx = z.Context(int(os.environ.get("ZK_TEST_DEVICE", "0")))
-    circ, adv, inst = build_circuit(k, seed=5, wide=True)
+    if os.environ.get("ZK_TEST_CIRCUIT") == "lookups":      # several lookup arguments, consecutive ones into ONE table (arguments are split over the ranks: round 6)
+        from plonk_fixtures import build_multi_lookup_circuit
+        circ, adv, inst = build_multi_lookup_circuit(k, seed=5, n_inputs=7, gate_degree=3)
+    else:
+        circ, adv, inst = build_circuit(k, seed=5, wide=True)
     s_mont = np.frombuffer(plonk.fr_mont_bytes(0x5EC2E7), dtype=np.uint64).copy()
     srs = ctx.srs_setup_with_s(k, s_mont)
     pk = ctx.pk_create(srs, circ.blob())
