@@ -383,7 +383,7 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
     projected = None
     if world == 1 and not quick:
         projected = {"note": "wall-clock of rank 0's share of the SAME proof sharded over N ranks, emulated on one GPU (peers' columns served from the resident witness, their commitments and "
-                             "quotient pairs replaced by stand-ins: the emulated proof is not valid); excludes every byte that would cross xGMI -- `exchange_gb_in` says how many would arrive at the rank",
+                             "quotient pairs and lookup columns replaced by stand-ins: the emulated proof is not valid); excludes every byte that would cross xGMI -- `exchange_gb_in` says how many would arrive at the rank",
                      "rank_device_s": {}, "exchange_gb_in": {}}
         try:
             from zkevm_circuits_amd import sharding as shard_mod
@@ -405,7 +405,8 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
                 drv.free()
                 projected["rank_device_s"][str(nn)] = round(min(tt), 4)
                 pairs = sum((1 << e_) for e_, c_ in enumerate(plan["classes"]) if c_["used"])
-                projected["exchange_gb_in"][str(nn)] = round(((circ.A - len(owned_n)) + pairs * (nn - 1) / nn) * circ.n * 32 / 1e9, 2)
+                lk_cols = 2 * len(circ.lookups) * (nn - 1) / nn if len(circ.lookups) >= nn else 0       # m and phi of the other ranks' lookup arguments (round 6: arguments split over the ranks)
+                projected["exchange_gb_in"][str(nn)] = round(((circ.A - len(owned_n)) + pairs * (nn - 1) / nn + lk_cols) * circ.n * 32 / 1e9, 2)
         except Exception as e:
             projected["error"] = repr(e)
 
