@@ -44,6 +44,11 @@
 // Results are bit-identical to the plain evaluation: every step is exact arithmetic mod p and the
 // value written is the canonical representative.
 //
+// Round 6: two kernels run a lowered program -- k_quotient_eval2 (the default: one stack entry in registers, in-place products, the loop
+// body a flat chain of single-armed ifs over a host-made class mask) and k_quotient_eval (round 5's, ZK_QUOTIENT_KERNEL=1), bit-identical.
+// A large program that is a sum of terms and reads its operands many times is cut into slices that run side by side over the same rows
+// and find each other's operands in the caches (plan_slices near the end of this file).
+//
 // Bounds (V = value bound in units of p, L = limb bound in units of 2^29; settled = (2, 1); a column,
 // constant or parked intermediate is canonical = (1, 1)):
 //   mul29(a, b)    needs b normalised, limbs of a < 2^31.2 (L <= 4), a * b < 2^261 p  (V_a V_b < 168);
@@ -320,7 +325,7 @@ k_quotient_eval(const uint32_t* __restrict__ prog, uint32_t prog_len, const Fr* 
 //     there: nine ds_read instead of eighteen v_mov);
 //   * every operation UPDATES t0 IN PLACE -- the products through asm statements whose result takes the first factor's registers
 //     (mul29_ipa / mul29_ub_ipa / mul29_ipb: limb j of the factor is last read one column before result limb j is written), sums and
-//     differences limb by limb -- so the join of the switch has nothing to copy;
+//     differences limb by limb -- and the loop body is a flat chain of single-armed ifs over a class mask (QClass below), so its joins have nothing to copy;
 //   * the second operand B (a memory operand unpacked on arrival, or the stack entry below the top) has its own nine registers and
 //     dies with the instruction;
 //   * memory operands are unpacked with v_alignbit (16 / 17 instructions instead of 27).
