@@ -142,6 +142,47 @@ def test_evm_style_constraints_share_their_selector_products(zk):
         assert run_compiled(prog, cols, consts, y) == want
 
 
+@pytest.mark.parametrize("chunk", ["1", "0"])
+def test_chunked_emission_keeps_the_value_and_frees_every_fold_boundary(zk, chunk, monkeypatch):
+    """Round 6, second half: large class programs are emitted term by term (ClassCompiler::chunked, forced here by ZK_QUOTIENT_CHUNK=1 on a small one) so that
+    no parked value is alive across a top-level FOLD -- the evaluator may then cut the program into slices there (tests/test_quotient_slices.py).  The value
+    stays the weighted sum of the terms; with one parking scope for the whole class (ZK_QUOTIENT_CHUNK=0) some boundaries are crossed by parked values."""
+    monkeypatch.setenv("ZK_QUOTIENT_CHUNK", chunk)
+    c, spec, terms = evm_terms(states=6, per_state=16)
+    cons = list(range(len(terms)))
+    K = len(terms)
+    prog, last, st = compile_class(zk, terms, cons, K)
+    rng = random.Random(11)
+    consts = [c_ % R for c_ in c.consts]
+    cols = {}
+    for p in terms:
+        for op, a, b in p:
+            if op == PUSH_COL: cols.setdefault((a, b), rng.randrange(R))
+    y = rng.randrange(R)
+    want = sum(pow(y, last - i, R) * evaluate_rot(p, cols, consts) for p, i in zip(terms, cons)) % R
+    assert run_compiled(prog, cols, consts, y) == want
+    # top-level folds and the parked values alive across them
+    sp, alive_from, crossed, folds = 0, {}, 0, 0
+    last_read = {}
+    for pc, (op, a, b) in enumerate(prog):
+        if op == PUSH_TMP: last_read[(a, alive_from[a])] = pc
+        if op == TEE: alive_from[a] = pc
+    spans = [(t, u) for (slot, t), u in last_read.items()]
+    for pc, (op, a, b) in enumerate(prog):
+        if op in (PUSH_COL, PUSH_CONST, PUSH_TMP): sp += 1
+        elif op in (ADD, SUB, MUL): sp -= 1
+        elif op == FOLD:
+            sp -= 1
+            if sp == 0:
+                folds += 1
+                crossed += any(t < pc + 1 <= u for t, u in spans)
+    assert folds >= 6
+    if chunk == "1":
+        assert crossed == 0
+    else:
+        assert crossed > 0            # what made the compiled EVM-style program unsliceable before
+
+
 def evaluate_rot(prog, cols, consts):
     st = []
     for op, a, b in prog:
