@@ -256,6 +256,7 @@ int mock_probe_enqueue(zk_ctx* ctx, const Fr* d_inputs, const Fr* d_table, const
                        uint32_t kind, uint32_t index, uint32_t sub, MockFail* d_out, uint32_t cap, uint32_t* d_counter);
 int mock_perm_enqueue(zk_ctx* ctx, const Fr* const* d_sigma, const Fr* const* d_cols, const Fr* d_ids, const uint32_t* d_slots, uint32_t mask, uint32_t num_cols, uint32_t k,
                       uint32_t kind, MockFail* d_out, uint32_t cap, uint32_t* d_counter);
+int fr_add_const_many(zk_ctx* ctx, const void* const* d_src, void* const* d_dst, size_t count, const void* h_k, size_t n);   // vec.hip: dst[c] = src[c] + k, any number of columns, no upload / sync
 int g_to_lagrange(zk_ctx* ctx, const G1Affine* d_g, uint32_t k, G1Affine* d_out);   // ecntt.hip: inverse FFT over G1
 bool comm_ready(const zk_ctx* ctx);                                                              // comm.hip: in-library RCCL collectives
 int comm_allgather_dev(zk_ctx* ctx, const void* d_send, size_t bytes, void* d_recv);             // stream-ordered, no host sync

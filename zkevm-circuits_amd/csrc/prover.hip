@@ -2203,21 +2203,20 @@ int zk_proof_finish(zk_ctx* ctx, zk_proof* pr_raw, void* h_proof, size_t proof_c
             }
             DevBuf inv;
             if (!inv.alloc(slots * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
-            for (size_t j = j0; j < j1; ++j) {
-                const uint32_t l = act[j];
-                const size_t N = lk_f[l].size();
-                Env e2 = lag;
-                std::vector<DevBuf> ft(N + 1);       // scratch references: CT_LK_PHI slot 0 = t, slot 1 + a = f_a
-                ft[0].borrow(lk_t[table_owner[l]].p);
-                for (size_t a = 0; a < N; ++a) ft[1 + a].borrow(lk_f[l][a].p);
-                e2.lk_phi = &ft;
-                const bool own_t = tslot[l] == slot0[l];
-                for (size_t a = own_t ? 0 : 1; a <= N; ++a) {
-                    PB pb;
-                    pb.col(CT_LK_PHI, (uint32_t)a).addc(C_BETA).fold(C_ONE);
-                    const size_t slot = a == 0 ? tslot[l] : slot0[l] + (own_t ? a : a - 1);
-                    PK_TRY(run_program(ctx, e2, pb.g, (char*)inv.p + slot * n * 32));
+            {   // t + beta and every f_a + beta of the batch, into their slots: ONE kind of launch for all of them (fr_add_const_many; each used to be a program of its own)
+                std::vector<const void*> asrc;
+                std::vector<void*> adst;
+                for (size_t j = j0; j < j1; ++j) {
+                    const uint32_t l = act[j];
+                    const size_t N = lk_f[l].size();
+                    const bool own_t = tslot[l] == slot0[l];
+                    for (size_t a = own_t ? 0 : 1; a <= N; ++a) {
+                        const size_t slot = a == 0 ? tslot[l] : slot0[l] + (own_t ? a : a - 1);
+                        asrc.push_back(a == 0 ? lk_t[table_owner[l]].p : lk_f[l][a - 1].p);
+                        adst.push_back((char*)inv.p + slot * n * 32);
+                    }
                 }
+                PK_TRY(fr_add_const_many(ctx, asrc.data(), adst.data(), asrc.size(), &lag.beta, n));
             }
             PK_TRY(zk_fr_batch_invert(ctx, inv.p, slots * n));
             for (size_t j = j0; j < j1; ++j) {

@@ -394,6 +394,28 @@ __global__ void __launch_bounds__(256) k_fr_random(ChaChaKey key, uint32_t s_lo,
     stg(out + i, Fr::r2() * lo + (Fr::r2() * hi) * Fr::r2());
 }
 #undef ZK_CHACHA_QR
+
+// dst[c][i] = src[c][i] + k for up to 64 columns per launch (the pointers travel as kernel arguments: no table upload, no host
+// synchronisation).  The logUp sums add beta to every compressed table and input column of a proof before ONE batch inversion: as
+// one two-instruction program per column through zk_quotient_eval that was ~400 uploads + stream synchronisations per proof.
+struct AddConstBatch { const Fr* src[64]; Fr* dst[64]; };
+__global__ void __launch_bounds__(256) k_add_const_many(AddConstBatch b, Fr k, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) stg(b.dst[blockIdx.y] + i, ldg(b.src[blockIdx.y] + i) + k);
+}
+int fr_add_const_many(zk_ctx* ctx, const void* const* d_src, void* const* d_dst, size_t count, const void* h_k, size_t n) {
+    Fr k;
+    memcpy(&k, h_k, sizeof k);
+    for (size_t c0 = 0; c0 < count; c0 += 64) {
+        AddConstBatch b;
+        const size_t cnt = std::min<size_t>(64, count - c0);
+        for (size_t c = 0; c < cnt; ++c) { b.src[c] = (const Fr*)d_src[c0 + c]; b.dst[c] = (Fr*)d_dst[c0 + c]; }
+        for (size_t c = cnt; c < 64; ++c) { b.src[c] = nullptr; b.dst[c] = nullptr; }
+        hipLaunchKernelGGL(k_add_const_many, dim3((unsigned)((n + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream, b, k, (uint64_t)n);
+    }
+    ZK_CHECK_LAUNCH(ctx);
+    return ZK_OK;
+}
 }  // namespace zk
 
 using namespace zk;
