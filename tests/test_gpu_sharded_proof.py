@@ -19,13 +19,14 @@ sys.path.insert(0, HERE)
                                                                 (3, 8, 1, 1, {"ZK_QUOTIENT_COSTGATE": "0"}), (2, 8, 1, 0, {"ZK_QUOTIENT_DAG": "0"}),
                                                                 (3, 8, 1, 1, {"ZK_SHARD_EXCHANGE_GROUPS": "1"}), (2, 8, 0, 1, {"ZK_SHARD_EXCHANGE_GROUPS": "3"}),
                                                                 (2, 8, 1, 1, {"ZK_TEST_CIRCUIT": "lookups"}), (3, 8, 0, 0, {"ZK_TEST_CIRCUIT": "lookups"}), (3, 9, 1, 1, {"ZK_TEST_CIRCUIT": "lookups", "ZK_SHARD_EXCHANGE_GROUPS": "1"}),
-                                                                (2, 8, 1, 1, {"ZK_TEST_CIRCUIT": "lookups", "ZK_SHARD_LOOKUPS": "0"})])
+                                                                (2, 8, 1, 1, {"ZK_TEST_CIRCUIT": "lookups", "ZK_SHARD_LOOKUPS": "0"}), (3, 8, 1, 1, {"ZK_TEST_CIRCUIT": "lookups", "ZK_SHARD_COEFF": "0"}), (2, 7, 0, 1, {"ZK_SHARD_COEFF": "0"})])
 def test_sharded_session_matches_single(tmp_path, world, k, multiopen, devgather, knobs):
     """knobs: ZK_QUOTIENT_COSTGATE=0 forces the additive split (remainder polynomials travelling between degree classes, (class, coset)
     pairs of three classes dealt over the ranks); ZK_QUOTIENT_DAG=0 the class programs as round 5 assembled them; ZK_SHARD_EXCHANGE_GROUPS: how many
     groups of `world` advice columns one device all-gather moves (default 16: here every column of a phase in one exchange; 1: a collective per group; 3: a ragged last chunk);
     ZK_TEST_CIRCUIT=lookups: five lookup arguments, consecutive ones into one table -- the arguments are split over the ranks (each rank compresses, counts and sums its own,
-    m and phi all-gathered device to device or through the host), ZK_SHARD_LOOKUPS=0 keeps them replicated"""
+    m and phi all-gathered device to device or through the host), ZK_SHARD_LOOKUPS=0 keeps them replicated; in the device-gather cases the owner ships the COEFFICIENT form
+    of every advice column that no lookup, permutation or remainder program reads (no inverse transform on the peers), ZK_SHARD_COEFF=0 ships Lagrange values for all"""
     from _launch import run_ranks
     # devgather: the advice columns are uploaded by their owning rank only and all-gathered between devices
     env = dict(os.environ, ZK_TEST_BACKEND="gloo", OMP_NUM_THREADS="1", ZK_TEST_DEVGATHER=str(devgather), **knobs)

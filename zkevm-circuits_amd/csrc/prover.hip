@@ -192,6 +192,7 @@ struct zk_proof {
     int vanishing_random = ZK_VANISHING_ONE;
     bool advice_on_device = false;            // the witness came as device buffers (zk_proof_advice_phase_dev)
     bool advice_in_place = false;             // the Lagrange forms of the advice columns are the caller's device buffers (zk_proof_advice_phase_dev, IN_PLACE)
+    bool lag_partial = false;                 // sharded session: some advice columns of other ranks arrived in coefficient form only (nothing on this side of the boundary reads their Lagrange form)
     // multi-GPU sharding (one process per GPU, every rank runs the same session on the same inputs):
     // commitments and quotient cosets are split over the ranks, results exchanged through `gather`
     std::vector<F4> absorbed;                // what zk_proof_begin fed the transcript (replayed into an external one)
@@ -835,6 +836,7 @@ int zk_proof_begin_instances(zk_ctx* ctx, const zk_pk* pk, const void* const* h_
 // in challenge-index order).  When h_challenges is given, *num_challenges holds its capacity (in
 // challenges) on entry; on return it holds how many the phase produced.
 static int plan_advice_cosets(zk_ctx* ctx, zk_proof* pr);
+static int advice_lagrange_readers(zk_ctx* ctx, const zk_pk* pk, std::vector<uint8_t>* need);
 static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges, bool dev_src, bool in_place);
 int zk_proof_advice_phase(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_index, const void* const* h_cols, uint32_t ncols, void* h_challenges, uint32_t* num_challenges) {
     return advice_phase_impl(ctx, pr, col_index, h_cols, ncols, h_challenges, num_challenges, false, false);
@@ -1044,15 +1046,32 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
             const size_t groups_total = (total + sg.world - 1) / sg.world, XG = std::max<size_t>(1, std::min(xg_knob, groups_total));
             DevBuf gbuf, sbuf;
             if (!gbuf.alloc((size_t)sg.world * XG * n * 32) || !sbuf.alloc(XG * n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+            // the last own column of the phase has not been transformed yet (the staging callback transforms column i - 1 when it uploads column i; the auxiliary
+            // stream already waits for its upload): the exchange below may ship its coefficient form
+            for (size_t c_ : sg.own) if (!sg.coeff[c_]->p) PK_TRY(to_coeff_aux(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
             // the transforms of this rank's own columns still run on the auxiliary stream and share the NTT
             // scratch with the ones enqueued below on the main stream: finish them first
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+            // WHAT travels (round 6): the owner has transformed its column already, and a column that no program over the Lagrange domain reads on this side of the
+            // boundary -- no lookup tuple, not a permutation column, no remainder of the additive split: on the EVM-style shape 544 of 1000 -- is needed by its peers in
+            // coefficient form only (cosets, evaluations, multi-open).  It is shipped in THAT form: same bytes, no inverse transform on the seven other ranks.
+            // ZK_SHARD_COEFF=0 ships every column as Lagrange values (and every rank transforms every column), as before.
+            std::vector<uint8_t> need_lag;
+            PK_TRY(advice_lagrange_readers(ctx, pk, &need_lag));
+            static const bool ship_coeff = !(getenv("ZK_SHARD_COEFF") && atoi(getenv("ZK_SHARD_COEFF")) == 0);
+            auto as_coeff = [&](size_t c_) { return ship_coeff && !need_lag[sg.col[c_]]; };
             for (size_t grp0 = 0; grp0 < groups_total; grp0 += XG) {
                 const size_t gcnt = std::min(XG, groups_total - grp0);
                 for (size_t g = 0; g < gcnt; ++g) {
                     const size_t mine_c = (grp0 + g) * sg.world + pr->rank;
-                    if (mine_c < total) ZK_HIP(ctx, hipMemcpyAsync((char*)sbuf.p + g * n * 32, sg.dst[mine_c], n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-                    else ZK_HIP(ctx, hipMemsetAsync((char*)sbuf.p + g * n * 32, 0, n * 32, ctx->stream));
+                    if (mine_c < total) {
+                        const void* src_ = sg.dst[mine_c];
+                        if (as_coeff(mine_c)) {
+                            if (!sg.coeff[mine_c]->p) return ctx->fail(ZK_ERR_INVALID_ARG, "sharded session: the coefficient form of an own column is missing at the exchange");
+                            src_ = sg.coeff[mine_c]->p;
+                        }
+                        ZK_HIP(ctx, hipMemcpyAsync((char*)sbuf.p + g * n * 32, src_, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                    } else ZK_HIP(ctx, hipMemsetAsync((char*)sbuf.p + g * n * 32, 0, n * 32, ctx->stream));
                 }
                 PK_TRY(zk_ctx_sync(ctx));                                  // own columns uploaded and packed, previous copies out of gbuf done
                 if (pr->gather_dev(pr->gather_dev_user, sbuf.p, gcnt * n * 32, gbuf.p))
@@ -1061,8 +1080,16 @@ static int advice_phase_impl(zk_ctx* ctx, zk_proof* pr, const uint32_t* col_inde
                     for (uint32_t q_ = 0; q_ < sg.world; ++q_) {
                         const size_t c_ = (grp0 + g) * sg.world + q_;
                         if (q_ == pr->rank || c_ >= total) continue;
-                        ZK_HIP(ctx, hipMemcpyAsync(sg.dst[c_], (char*)gbuf.p + ((size_t)q_ * gcnt + g) * n * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-                        PK_TRY(to_coeff(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
+                        const char* got = (const char*)gbuf.p + ((size_t)q_ * gcnt + g) * n * 32;
+                        if (as_coeff(c_)) {
+                            if (!sg.coeff[c_]->alloc(n * 32)) return ctx->fail(ZK_ERR_OOM, "prover: alloc failed");
+                            ZK_HIP(ctx, hipMemcpyAsync(sg.coeff[c_]->p, got, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                            sg.lag[c_]->release();                   // nobody reads the Lagrange form of this column here
+                            pr->lag_partial = true;
+                        } else {
+                            ZK_HIP(ctx, hipMemcpyAsync(sg.dst[c_], got, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                            PK_TRY(to_coeff(ctx, pk, *sg.lag[c_], sg.coeff[c_]));
+                        }
                     }
             }
         } else {
@@ -1698,6 +1725,27 @@ static int advice_coset_plan(zk_ctx* ctx, const zk_pk* pk, bool sharded, std::ve
         for (const auto& kv : key_mask) cnt += (size_t)__builtin_popcount(kv.second);
         *key_slots = cnt;
     }
+    return ZK_OK;
+}
+
+// Which advice columns some program over the LAGRANGE domain reads inside a session: the tuples of the lookup arguments, the permutation argument's columns, the
+// remainder polynomials of the additive split (quotient plan of the key).  Everything else -- gates only -- is read through coefficient forms (cosets, evaluations).
+static int advice_lagrange_readers(zk_ctx* ctx, const zk_pk* pk, std::vector<uint8_t>* need) {
+    need->assign(pk->A, 0);
+    auto scan = [&](const Prog& g) {
+        for (const Instr& in : g)
+            if (in.op == Q_PUSH_COL && (in.a >> 24) == CT_ADVICE && (in.a & 0xFFFFFFu) < pk->A) (*need)[in.a & 0xFFFFFFu] = 1;
+    };
+    for (const auto& lk : pk->lookups) {
+        for (const Prog& g : lk.tables) scan(g);
+        for (const auto& tuple : lk.inputs) for (const Prog& g : tuple) scan(g);
+    }
+    for (const auto& pc : pk->perm_cols) if (pc.first == CT_ADVICE && pc.second < pk->A) (*need)[pc.second] = 1;
+    std::shared_ptr<const QuotientPlan> qplan;
+    std::string err;
+    const int rc = quotient_plan(pk, &qplan, &err);
+    if (rc) return ctx->fail(rc, "%s", err.c_str());
+    for (const QPlanRem& r : qplan->rems) scan(r.prog);
     return ZK_OK;
 }
 
@@ -3213,6 +3261,7 @@ int zk_proof_mock_verify(zk_ctx* ctx, zk_proof* pr, const uint32_t* gate_rows, s
     if (pr->phase < pk->num_phases) return ctx->fail(ZK_ERR_INVALID_ARG, "mock verify: %u of the session's %u advice phases are committed", pr->phase, pk->num_phases);
     PoolScope pool(ctx);
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // uploads and transforms of the last phase (copy / auxiliary streams are joined by the phase itself)
+    if (pr->lag_partial) return ctx->fail(ZK_ERR_UNSUPPORTED, "mock verify: this rank of a sharded session holds some advice columns in coefficient form only (ZK_SHARD_COEFF=0 ships Lagrange values)");
     Env lag{};
     lag.pk = pk;
     lag.advice = &pr->adv_lag;
