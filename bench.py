@@ -382,28 +382,35 @@ def headline(args, torch, rank=0, world=1, dist=None, local_rank=0, shared_gpu=F
     # of the compute side of the scaling curve, not a measurement of N GPUs -- the driver's SCALE run is that.
     projected = None
     if world == 1 and (not quick if project is None else project):
-        projected = {"note": "wall-clock of rank 0's share of the SAME proof sharded over N ranks, emulated on one GPU (peers' columns served from the resident witness, their commitments and "
+        projected = {"note": "wall-clock of the SLOWEST rank's share (every rank emulated in turn: `by_rank_s`) of the SAME proof sharded over N ranks, emulated on one GPU (peers' columns served from the resident witness, their commitments and "
                              "quotient pairs and lookup columns replaced by stand-ins: the emulated proof is not valid); excludes every byte that would cross xGMI -- `exchange_gb_in` says how many would arrive at the rank",
                      "rank_device_s": {}, "exchange_gb_in": {}}
         try:
             from zkevm_circuits_amd import sharding as shard_mod
+            projected["by_rank_s"] = {}
             for nn in (2, 4, 8):
+                # EVERY rank of the N is emulated in turn (the (class, coset) pairs are dealt by cost: which rank is the busiest depends on the deal); `rank_device_s` is the slowest
+                per_rank = []
+                for rr in range(nn):
+                    owned_n = bp.owned_columns(circ, rr, nn)
+                    emu = shard_mod.EmulatedRank(ctx, circ, adv_dev, rr, nn)
+                    drv = bp.PhaseDriver(ctx, circ, adv_dev, rlc, owned=owned_n)
+                    tt = []
+                    for _ in range(2 if rr == 0 else 1):                     # the first run of an N also fills what the key caches per sharded layout
+                        fence()
+                        t1 = time.perf_counter()
+                        sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
+                        sess.set_multiopen(1)
+                        emu.attach(sess)
+                        drv.run(sess, before_phase=emu.begin_phase)
+                        sess.finish()
+                        fence()
+                        tt.append(time.perf_counter() - t1)
+                    drv.free()
+                    per_rank.append(round(min(tt), 4))
+                projected["by_rank_s"][str(nn)] = per_rank
+                projected["rank_device_s"][str(nn)] = max(per_rank)
                 owned_n = bp.owned_columns(circ, 0, nn)
-                emu = shard_mod.EmulatedRank(ctx, circ, adv_dev, 0, nn)
-                drv = bp.PhaseDriver(ctx, circ, adv_dev, rlc, owned=owned_n)
-                tt = []
-                for _ in range(2):
-                    fence()
-                    t1 = time.perf_counter()
-                    sess = ctx.proof_session(pk, inst_m, bytes(16), instance_slices=True)
-                    sess.set_multiopen(1)
-                    emu.attach(sess)
-                    drv.run(sess, before_phase=emu.begin_phase)
-                    sess.finish()
-                    fence()
-                    tt.append(time.perf_counter() - t1)
-                drv.free()
-                projected["rank_device_s"][str(nn)] = round(min(tt), 4)
                 pairs = sum((1 << e_) for e_, c_ in enumerate(plan["classes"]) if c_["used"])
                 lk_cols = 2 * len(circ.lookups) * (nn - 1) / nn if len(circ.lookups) >= nn else 0       # m and phi of the other ranks' lookup arguments (round 6: arguments split over the ranks)
                 projected["exchange_gb_in"][str(nn)] = round(((circ.A - len(owned_n)) + pairs * (nn - 1) / nn + lk_cols) * circ.n * 32 / 1e9, 2)
