@@ -4,9 +4,10 @@
 # FETCH_SIZE, WRITE_SIZE of the MSM / NTT section and of one headline proof, and the issue counters of one whole proof.
 # tools/summarize_r06.py turns gpurun_out/r6rec/ into profiles/r06_*.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); O=$ROOT/gpurun_out/r6rec; rm -rf $O; mkdir -p $O
+ROOT=$(pwd); O=$ROOT/gpurun_out/r6rec; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python bench.py > $O/bench_full.json 2> $O/bench_full.err; echo "bench rc=$? t=${SECONDS}"
+# SKIP_BENCH=1: traces and counters only (the bench line of tools/gpu_r6_bench_only.sh stays)
+if [ "$SKIP_BENCH" != 1 ]; then rm -rf $O; mkdir -p $O; timeout 1500 python bench.py > $O/bench_full.json 2> $O/bench_full.err; echo "bench rc=$? t=${SECONDS}"; else rm -rf $O/prof_* $O/pmc_*; fi
 cd /tmp
 Q="--no-cpu-baseline --no-proof --no-msm-ntt --no-verify"
 trace() {  # name, env...
